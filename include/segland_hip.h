@@ -1,0 +1,213 @@
+/* segland_hip.h -- C ABI of libsegland_hip.so: the MI355X (gfx950) kernels under SegLand's PSPNet-POP hot path.
+ *
+ * The reference (LiZhuoHong/SegLand) is pure Python/PyTorch: it has no FFI.  Its "plugin surface" for this path is
+ * the nn.Module API of networks/pspnet_pop.py (kept by segland_amd/networks/pspnet_pop.py); this header is the new
+ * boundary UNDER that module: one entry point per ATen op group the path executes.  Each entry cites
+ * the reference call site(s) it replaces.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  Every device buffer is owned by the caller (PyTorch's allocator); the library
+ *    never allocates or frees device memory and keeps no state besides its loaded code object.
+ *  - Activations are NHWC ([B][H][W][C], C contiguous) in `dtype` (SL_F32 or SL_BF16); statistics, BN coefficients,
+ *    logits, losses and weight gradients are float.  Weights are consumed in the GEMM layouts produced by
+ *    sl_weight_prep (K-contiguous); master weights / gradients stay in PyTorch's OIHW float layout.
+ *  - All launches are asynchronous on `stream` (a hipStream_t passed as void*); no hidden synchronisation.
+ *  - Return value: 0 on success, negative SL_E* for a bad argument, positive hipError_t for a runtime failure.
+ *    sl_last_error_string() describes the last failure on the calling thread.
+ */
+#ifndef SEGLAND_HIP_H
+#define SEGLAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL_F32 0
+#define SL_BF16 1
+
+#define SL_EINVAL (-1)      /* bad descriptor / unsupported shape */
+#define SL_EWORKSPACE (-2)  /* workspace too small */
+
+typedef void* sl_stream_t;
+
+int sl_version(void);
+const char* sl_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------------ convolution
+ * nn.Conv2d call sites: networks/backbones/resnet.py:44-49,109-110 (Bottleneck 1x1/3x3, stride 1/2, dilation 1/2/4),
+ * networks/pspnet_pop.py:19,22,27 (PPM 3x3 4096->512, 1x1 +bias, stage 1x1), :47-51 (classifier 1x1 512->512).
+ * Implicit GEMM on MFMA: rows = output pixels, cols = Cout, K = KH*KW*Cin.  The input may be a virtual channel
+ * concat [x (C1 channels) | x2 (Cin-C1 channels)] (torch.cat at pspnet_pop.py:33-34 is never materialised).
+ * Requirements: Cin, C1, Cin-C1 multiples of 64 (bf16) / 32 (f32); Cout multiple of 64. */
+typedef struct SlConvDesc {
+  int dtype;             /* SL_F32 | SL_BF16 : x, x2, w, y */
+  int B, H, W;           /* input  [B][H][W][Cin]  */
+  int Cin, Cout;
+  int KH, KW, stride, pad, dil;
+  int Ho, Wo;            /* output [B][Ho][Wo][Cout] */
+  int C1;                /* channels read from x; the remaining Cin-C1 come from x2 (C1 == Cin: x2 unused) */
+} SlConvDesc;
+
+/* number of row-blocks of the forward kernel == rows of the BN partial-statistics buffer */
+int sl_conv2d_stat_rows(const SlConvDesc* d);
+
+/* y = conv(x|x2, w) (+bias) (relu).  w: [Cout][KH][KW][Cin] dtype.  bias: float[Cout] or NULL.
+ * stat_partial: NULL or float[stat_rows][2][Cout] receiving per-row-block (sum, sum of squares) of the fp32
+ * accumulators per output channel (train-mode BatchNorm statistics, F.batch_norm at resnet.py:45-50). */
+int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias, int relu,
+                  void* y, float* stat_partial, sl_stream_t stream);
+
+/* dx = conv_transpose(dy, w) (+addend) (masked by mask_src > 0).  wt: [Cin][KH][KW][Cout] dtype (sl_weight_prep).
+ * dx: [B][H][W][Cin] (all Cin channels, also for a virtual concat).  addend / mask_src: NULL or [B][H][W][Cin]. */
+int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const void* mask_src,
+                       void* dx, sl_stream_t stream);
+
+/* dw (float, OIHW [Cout][Cin][KH][KW]) = sum over pixels of dy (x) x.  Deterministic split-K through `workspace`. */
+size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);
+int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
+                         void* workspace, size_t workspace_bytes, sl_stream_t stream);
+
+/* OIHW float master weight -> w_fwd [Cout][KH][KW][Cin] and/or w_bwd [Cin][KH][KW][Cout] in dtype (either may be NULL) */
+int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,
+                   sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ batch norm
+ * nn.BatchNorm2d call sites: resnet.py:45,48,50,88,111; pspnet_pop.py:20,28 (eps 1e-5, momentum 0.1). */
+
+/* Train mode: reduce the conv kernel's partials to mean / biased var, update running stats (unbiased var),
+ * emit mean, invstd and the affine pair scale = gamma*invstd, shift = beta - mean*scale. */
+int sl_bn_finalize_train(const float* stat_partial, int stat_rows, int C, long long count, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         float* mean, float* invstd, float* scale, float* shift, sl_stream_t stream);
+/* Eval mode: scale/shift (and mean/invstd) from the running statistics. */
+int sl_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
+                        sl_stream_t stream);
+/* y = x*scale[c] + shift[c] (+ residual) (relu)   -- BN affine + `out += residual` + ReLU of resnet.py:60-76 */
+int sl_bn_act_fwd(int dtype, const void* x, const float* scale, const float* shift, const void* residual, int relu,
+                  void* y, long long rows, int C, sl_stream_t stream);
+/* Backward, step 1: partial[blk][0][c] = sum g, partial[blk][1][c] = sum g*xhat with g = dy * (y > 0 if y) and
+ * xhat = (x - mean)*invstd.  Returns the number of partial rows through *nblk (buffer: float[nblk][2][C]). */
+int sl_bn_bwd_reduce_rows(long long rows, int C);
+int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                     float* partial, long long rows, int C, sl_stream_t stream);
+/* step 2: dgamma = S2, dbeta = S1 and the per-channel coefficients of dx = cA*g + cB*(x-mean) + cC.
+ * train != 0: batch-statistics backward; train == 0: frozen statistics (dx = scale*g). */
+int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, const float* gamma, const float* mean,
+                       const float* invstd, int train, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
+                       sl_stream_t stream);
+/* step 3: dx = cA*g + cB*(x-mean) + cC; if dres != NULL also dres = g (the residual-branch gradient). */
+int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* cA, const float* cB,
+                    const float* cC, const float* mean, void* dx, void* dres, long long rows, int C,
+                    sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ stem
+ * resnet.py:86-90,124-125: conv 7x7 s2 p3 3->64 on the NCHW float image, BN, ReLU, maxpool 3x3 s2 p1. */
+int sl_stem_conv_stat_rows(int B, int H, int W);
+int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w_oihw, void* y, float* stat_partial, int B, int H,
+                     int W, sl_stream_t stream);                              /* y: [B][H/2][W/2][64] */
+/* pooled: [B][Hc/2][Wc/2][64]; argmax (nullable): uint8 window position ky*3+kx of the FIRST maximum in ATen's
+ * scan order, same shape as pooled (needed by the backward). */
+int sl_stem_bn_relu_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* pooled,
+                             uint8_t* argmax, int B, int Hc, int Wc, sl_stream_t stream);
+/* g0 = maxpool_bwd(dpooled) masked by relu'(bn(c0)) */
+int sl_stem_pool_relu_bwd(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale,
+                          const float* shift, void* g0, int B, int Hc, int Wc, sl_stream_t stream);
+size_t sl_stem_conv_bwd_weight_workspace(int B, int H, int W);
+int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const void* dc0, float* dw_oihw, void* workspace,
+                            size_t workspace_bytes, int B, int H, int W, sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ pyramid pooling
+ * pspnet_pop.py:26 AdaptiveAvgPool2d(1,2,3,6) (bins [floor(i*H/s), ceil((i+1)*H/s))) and :33 bilinear
+ * (align_corners=False) upsampling of the four stage outputs.  Level l has s_l*s_l cells; the pooled / stage tensors
+ * are stored level after level as rows [sum_l B*s_l^2][C], level-major then (b, i, j). */
+typedef struct SlPpmDesc {
+  int dtype;
+  int B, H, W, C;        /* feature map x4 [B][H][W][C] */
+  int nlevels;           /* <= 4 */
+  int sizes[4];
+} SlPpmDesc;
+size_t sl_ppm_workspace(const SlPpmDesc* d);
+int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, void* pooled, void* workspace, size_t workspace_bytes,
+                    sl_stream_t stream);
+/* dx[b,y,x,c] = dcat[b,y,x, cat_off + c] + sum over levels/bins covering (y,x) of dpooled/bin_area.
+ * dcat has row pitch cat_pitch channels (the dgrad of the virtual concat). */
+int sl_ppm_pool_bwd(const SlPpmDesc* d, const void* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
+                    sl_stream_t stream);
+/* priors[b,y,x, l*Cs + c] = bilinear(stage_l)[b,y,x,c]; stage rows as above with Cs channels */
+int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const void* stage, void* priors, sl_stream_t stream);
+int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, void* dstage, void* workspace,
+                        size_t workspace_bytes, sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ POP head
+ * pspnet_pop.py:95-121 orthogonal_decompose + :178-182 / :210-219 classifier on the components, evaluated in the
+ * exactly equivalent collapsed form: for a class k with unit prototype s_k and p = s_k.q,
+ * MLP(p*s_k) = max(p,0)*MLP(s_k) + max(-p,0)*MLP(-s_k) because the MLP is bias-free and ReLU is positively
+ * homogeneous; only the residual (background) feature needs the per-pixel MLP. */
+/* proj[r][k] = S[k].q[r];  bg[r] = q[r] - sum_k proj[r][k] S[k].   S: float[Kt][C], already L2-normalised. */
+int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, float* proj, void* bg, long long R,
+                         int C, sl_stream_t stream);
+/* rows of +S and -S appended to an MLP input matrix: dst[2*Kt][C] = [S ; -S] in dtype */
+int sl_pop_proto_rows(int dtype, const float* S, int Kt, int C, void* dst, sl_stream_t stream);
+/* z[r] = h[r] . w   (classifier.4, Cout = 1; h is the post-ReLU activation) */
+int sl_rowdot_fwd(int dtype, const void* h, const float* w, float* z, long long R, int C, sl_stream_t stream);
+/* dh[r][c] = dz[r]*w[c]*(h[r][c] > 0);  partial[blk][c] = sum_r dz[r]*h[r][c]  (float[nblk][C]) */
+int sl_rowdot_bwd_rows(long long R, int C);
+int sl_rowdot_bwd(int dtype, const void* h, const float* w, const float* dz, void* dh, float* partial, long long R,
+                  int C, sl_stream_t stream);
+/* out[c] = sum_blk partial[blk][c] */
+int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream);
+/* preds NCHW float [B][1+Kt][N]: channel 0 = z_bg[r], channel 1+k = a[k]*max(p,0) + b[k]*max(-p,0) */
+int sl_pop_combine_fwd(const float* proj, const float* z_bg, const float* a, const float* b, int Kt, float* preds,
+                       int B, int N, sl_stream_t stream);
+/* dz_bg[r], dproj[r][k] = dpred*(a[k]*[p>0] - b[k]*[p<0]),  dab_partial[blk][2*Kt] = partial sums of
+ * (dpred*max(p,0), dpred*max(-p,0)) */
+int sl_pop_combine_bwd_rows(int B, int N);
+int sl_pop_combine_bwd(const float* dpreds, const float* proj, const float* a, const float* b, int Kt, float* dz_bg,
+                       float* dproj, float* dab_partial, int B, int N, sl_stream_t stream);
+/* t[r][k] = dproj[r][k] - dg[r].S[k];  dq[r] = dg[r] + sum_k t[r][k] S[k];
+ * dS_partial[blk][k][c] = sum_r t[r][k] q[r][c] - proj[r][k] dg[r][c] */
+int sl_pop_decompose_bwd_rows(long long R);
+int sl_pop_decompose_bwd(int dtype, const void* dg, const void* feats, const float* S, const float* proj,
+                         const float* dproj, int Kt, void* dq, float* dS_partial, long long R, int C,
+                         sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ loss
+ * loss/criterion.py:51-52: F.interpolate(bilinear, align_corners=True) to the label size fused with
+ * CrossEntropyLoss(ignore_index, mean); the H x W logits are never written. */
+int sl_upsample_ce_rows(int B, int H, int W);
+/* partial[blk][2] = (sum of pixel losses, number of valid pixels) */
+int sl_upsample_ce_fwd(const float* logits, const int64_t* target, int B, int K, int h, int w, int H, int W,
+                       int ignore_index, float* partial, sl_stream_t stream);
+int sl_upsample_ce_finalize(const float* partial, int nblk, float* loss_and_count, sl_stream_t stream);
+/* dlogits[b][k][i][j] = gscale/nvalid * sum over pixels of weight * (softmax - onehot); loss_and_count from fwd */
+int sl_upsample_ce_bwd(const float* logits, const int64_t* target, const float* loss_and_count, const float* gscale,
+                       int B, int K, int h, int w, int H, int W, int ignore_index, float* dlogits, sl_stream_t stream);
+/* pspnet_pop.py:221-231: argmax of the upsampled (align_corners=True) [K2][h][w] logits of tile b, ids > 0 shifted
+ * by n_base, written into mask[b] where mask == 0 (in place, int64). */
+int sl_pseudo_label(const float* logits, int K2, int h, int w, int64_t* mask, int B, int H, int W, int n_base,
+                    sl_stream_t stream);
+/* argmax over channels of the upsampled (align_corners=True) logits -> uint8 labels (eval_base.py:168-169) */
+int sl_upsample_argmax(const float* logits, int B, int K, int h, int w, int H, int W, uint8_t* labels,
+                       sl_stream_t stream);
+/* utils/pyt_utils.py:293-305 intersectionAndUnionGPU: hist[0..K) inter, [K..2K) pred area, [2K..3K) target area
+ * (int64 counts; caller zeroes hist). */
+int sl_iou_hist(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* hist,
+                sl_stream_t stream);
+/* networks/pspnet.py:7-15 masked_average_pooling (dead code upstream; prototype-init utility here):
+ * proto[c] = mean_b( sum_hw f*m / (sum_hw m + 1e-5) ), m = bilinear(mask, align_corners=True) at feature size.
+ * feature: NHWC dtype [B][h][w][C]; mask: float [B][H][W]. */
+int sl_masked_avg_pool(int dtype, const void* feature, const float* mask, int B, int h, int w, int C, int H, int W,
+                       float* proto, sl_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ utilities */
+/* NHWC dtype <-> NCHW float (module boundary / tests) */
+int sl_nhwc_to_nchw_f32(int dtype, const void* src, float* dst, int B, int H, int W, int C, sl_stream_t stream);
+int sl_nchw_f32_to_nhwc(int dtype, const float* src, void* dst, int B, int H, int W, int C, sl_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,79 @@
+// Shared device/host helpers for libsegland_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/segland_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// 16-byte vector of T <-> floats
+template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y); out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
+  return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
+  uint4 r;
+  r.x = (unsigned)f2bf(in[0]) | ((unsigned)f2bf(in[1]) << 16);
+  r.y = (unsigned)f2bf(in[2]) | ((unsigned)f2bf(in[3]) << 16);
+  r.z = (unsigned)f2bf(in[4]) | ((unsigned)f2bf(in[5]) << 16);
+  r.w = (unsigned)f2bf(in[6]) | ((unsigned)f2bf(in[7]) << 16);
+  return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- host side
+void sl_set_error(const char* fmt, ...);
+#define SL_REQUIRE(cond, ...)            \
+  do {                                   \
+    if (!(cond)) {                       \
+      sl_set_error(__VA_ARGS__);         \
+      return SL_EINVAL;                  \
+    }                                    \
+  } while (0)
+#define SL_LAUNCH_CHECK(name)                                                \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      sl_set_error("%s: %s", name, hipGetErrorString(e__));                  \
+      return (int)e__;                                                       \
+    }                                                                        \
+  } while (0)
+
+__host__ __device__ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

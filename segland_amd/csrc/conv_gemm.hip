@@ -1,0 +1,317 @@
+// Implicit-GEMM convolution on MFMA for gfx950: forward (gather) and data-gradient (transposed gather).
+//
+//   out[m][n] = sum_{tap, c} src[pix(m, tap)][c] * wt[n][tap][c]
+//
+// rows m   = destination pixels (b, yd, xd), NHWC
+// cols n   = destination channels
+// K        = taps x source channels, one K-tile = 128 bytes of channels of one tap (64 bf16 / 32 f32)
+// Both element types share the LDS geometry: tiles of [rows][8 x 16-byte chunks], chunk index XOR-swizzled with
+// (row>>1)&7 so that the ds_read_b128 fragment reads (row = lane&31) are bank-conflict free.  A bf16 k-step is one
+// v_mfma_f32_32x32x16_bf16 per chunk pair; an f32 k-step is four v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+#include "common.h"
+
+namespace {
+
+struct ConvGemmParams {
+  const void* src1; const void* src2;   // source tensors (virtual channel concat), NHWC
+  int C1, C2;                           // channels in src1 / src2
+  const void* wt;                       // [N][taps][C1+C2]
+  void* out;                            // [M][N]
+  int B, Hs, Ws;                        // source spatial
+  int Hd, Wd;                           // destination spatial
+  int N, KH, KW, stride, pad, dil;
+  int mode;                             // 0: forward gather, 1: data-gradient gather
+  const float* bias; int relu;
+  const void* addend; const void* mask_src;
+  float* stat_partial;                  // [gridM][2][N] or null
+  int M;
+  int gridM, gridN;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+    // lanes 0-31 hold k = 4j..4j+3 of the chunk pair, lanes 32-63 the next four: any pairing of k is valid as long
+    // as A and B use the same one.
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
+  constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
+  constexpr int BKE = 8 * EPC;             // elements per K-tile
+  constexpr int AR = BM / 32, BR = BN / 32;  // chunks per thread
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lds_a = smem;                       // [2][BM][128]
+  unsigned char* lds_b = smem + 2 * BM * 128;        // [2][BN][128]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware block remap: blocks that share an A row-block run back to back on one XCD (private L2).
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / p.gridN, bn = bid % p.gridN;
+
+  const int kc = tid & 7;          // chunk column handled by this thread
+  const int r0 = tid >> 3;         // first row handled (then +32, +64, ...)
+
+  // per-row destination coordinates
+  int rb[AR], ry[AR], rx[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = bm * BM + r0 + 32 * i;
+    if (m < p.M) {
+      int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
+      int yd = rem / p.Wd, xd = rem - yd * p.Wd;
+      rb[i] = b;
+      if (p.mode == 0) { ry[i] = yd * p.stride - p.pad; rx[i] = xd * p.stride - p.pad; }
+      else             { ry[i] = yd + p.pad;            rx[i] = xd + p.pad; }
+    } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
+  }
+
+  const int CT = p.C1 + p.C2;
+  const int ctiles = CT / BKE;
+  const int taps = p.KH * p.KW;
+  const int nk = taps * ctiles;
+  const T* wrow[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) wrow[i] = (const T*)p.wt + (size_t)(bn * BN + r0 + 32 * i) * taps * CT + kc * EPC;
+
+  uint4 areg[AR], breg[BR];
+  int tap = 0, ct = 0;   // K-tile counters of the NEXT tile to load
+
+  auto load_global = [&]() {
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int c0 = ct * BKE;
+    const T* base; int pitch, coff;
+    if (c0 < p.C1) { base = (const T*)p.src1; pitch = p.C1; coff = c0; }
+    else           { base = (const T*)p.src2; pitch = p.C2; coff = c0 - p.C1; }
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      int ys, xs; bool ok = rb[i] >= 0;
+      if (p.mode == 0) { ys = ry[i] + ky * p.dil; xs = rx[i] + kx * p.dil; }
+      else {
+        int ty = ry[i] - ky * p.dil, tx = rx[i] - kx * p.dil;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (p.stride == 1) { ys = ty; xs = tx; }
+        else { ys = ty / p.stride; xs = tx / p.stride; ok = ok && (ys * p.stride == ty) && (xs * p.stride == tx); }
+      }
+      ok = ok && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *(const uint4*)(base + ((size_t)(rb[i] * p.Hs + ys) * p.Ws + xs) * pitch + coff + kc * EPC);
+      areg[i] = v;
+    }
+    const size_t koff = (size_t)tap * CT + c0;
+#pragma unroll
+    for (int i = 0; i < BR; ++i) breg[i] = *(const uint4*)(wrow[i] + koff);
+    if (++ct == ctiles) { ct = 0; ++tap; }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) *(uint4*)(lds_a + buf * BM * 128 + lds_off(r0 + 32 * i, kc)) = areg[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) *(uint4*)(lds_b + buf * BN * 128 + lds_off(r0 + 32 * i, kc)) = breg[i];
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_global();
+  store_lds(0);
+  __syncthreads();
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_global();
+    const unsigned char* la = lds_a + buf * BM * 128;
+    const unsigned char* lb = lds_b + buf * BN * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(la + lds_off(wm * (BM / WM) + i * 32 + frow, 2 * s + fhalf));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(lb + lds_off(wn * (BN / WN) + j * 32 + frow, 2 * s + fhalf));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  T* out = (T*)p.out;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn * BN + wn * (BN / WN) + j * 32 + frow;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        float v = acc[i][j][r];
+        csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
+        if (m < p.M) {
+          v += bias;
+          const size_t o = (size_t)m * p.N + n;
+          if (p.addend) v += to_f<T>(((const T*)p.addend)[o]);
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          if (p.mask_src) v = to_f<T>(((const T*)p.mask_src)[o]) > 0.f ? v : 0.f;
+          out[o] = from_f<T>(v);
+        }
+      }
+    }
+  }
+  if (p.stat_partial) {
+    float* red = (float*)smem;   // [WM][2][BN]; tiles are dead after the final barrier of the main loop
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (fhalf == 0) {
+        const int col = wn * (BN / WN) + j * 32 + frow;
+        red[(wm * 2 + 0) * BN + col] = s;
+        red[(wm * 2 + 1) * BN + col] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
+      p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
+    }
+  }
+}
+
+template <typename T, int BN>
+int launch_gemm(ConvGemmParams& p, hipStream_t st) {
+  constexpr int BM = 128;
+  p.gridM = cdiv(p.M, BM);
+  p.gridN = p.N / BN;
+  const size_t lds = 2 * (BM + BN) * 128;
+  dim3 grid(p.gridM * p.gridN);
+  if (BN == 128) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
+  else           hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_kernel");
+  return 0;
+}
+
+int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
+  const int bke = dtype == SL_BF16 ? 64 : 32;
+  SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "conv: bad dtype %d", dtype);
+  SL_REQUIRE(p.C1 > 0 && p.C1 % bke == 0 && p.C2 % bke == 0, "conv: source channels (%d,%d) must be multiples of %d", p.C1, p.C2, bke);
+  SL_REQUIRE(p.N > 0 && p.N % 64 == 0, "conv: output channels %d must be a multiple of 64", p.N);
+  SL_REQUIRE(p.M > 0, "conv: empty output");
+  const bool wide = (p.N % 128 == 0);
+  if (dtype == SL_BF16) return wide ? launch_gemm<bf16_t, 128>(p, st) : launch_gemm<bf16_t, 64>(p, st);
+  return wide ? launch_gemm<float, 128>(p, st) : launch_gemm<float, 64>(p, st);
+}
+
+int check_desc(const SlConvDesc* d) {
+  SL_REQUIRE(d != nullptr, "conv: null descriptor");
+  SL_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: bad sizes");
+  SL_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dil > 0 && d->pad >= 0, "conv: bad window");
+  const int ho = (d->H + 2 * d->pad - d->dil * (d->KH - 1) - 1) / d->stride + 1;
+  const int wo = (d->W + 2 * d->pad - d->dil * (d->KW - 1) - 1) / d->stride + 1;
+  SL_REQUIRE(ho == d->Ho && wo == d->Wo, "conv: Ho/Wo (%d,%d) inconsistent with input (expected %d,%d)", d->Ho, d->Wo, ho, wo);
+  SL_REQUIRE(d->C1 > 0 && d->C1 <= d->Cin, "conv: bad C1");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
+  if (!d) return SL_EINVAL;
+  return cdiv((long long)d->B * d->Ho * d->Wo, 128);
+}
+
+extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias,
+                             int relu, void* y, float* stat_partial, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(x && w && y, "conv fwd: null buffer");
+  SL_REQUIRE(d->C1 == d->Cin || x2, "conv fwd: x2 missing for a concat input");
+  SL_REQUIRE(!(stat_partial && (bias || relu)), "conv fwd: statistics are defined on the raw conv output");
+  ConvGemmParams p{};
+  p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.wt = w; p.out = y;
+  p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
+  p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
+  p.bias = bias; p.relu = relu; p.stat_partial = stat_partial;
+  p.M = d->B * d->Ho * d->Wo;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend,
+                                  const void* mask_src, void* dx, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && dx, "conv bwd_data: null buffer");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.addend = addend; p.mask_src = mask_src;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ weight prep
+namespace {
+template <typename T>
+__global__ void weight_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int KHW, T* wf, T* wb) {
+  // one thread per (o, i, t) element of the OIHW tensor
+  const long long n = (long long)Cout * Cin * KHW;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % KHW);
+    const long long oi = e / KHW;
+    const int i = (int)(oi % Cin), o = (int)(oi / Cin);
+    const T v = from_f<T>(w[e]);
+    if (wf) wf[((size_t)o * KHW + t) * Cin + i] = v;
+    if (wb) wb[((size_t)i * KHW + t) * Cout + o] = v;
+  }
+}
+}  // namespace
+
+extern "C" int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd,
+                              void* w_bwd, sl_stream_t stream) {
+  SL_REQUIRE(w_oihw && (w_fwd || w_bwd), "weight_prep: null buffer");
+  const long long n = (long long)Cout * Cin * KH * KW;
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (dtype == SL_BF16)
+    hipLaunchKernelGGL(weight_prep_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH * KW, (bf16_t*)w_fwd, (bf16_t*)w_bwd);
+  else if (dtype == SL_F32)
+    hipLaunchKernelGGL(weight_prep_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH * KW, (float*)w_fwd, (float*)w_bwd);
+  else SL_REQUIRE(false, "weight_prep: bad dtype");
+  SL_LAUNCH_CHECK("weight_prep_kernel");
+  return 0;
+}

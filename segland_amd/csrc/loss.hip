@@ -1,0 +1,303 @@
+// Fused bilinear upsample (align_corners=True) + cross-entropy (loss/criterion.py:51-52), the ft pseudo-label step
+// (networks/pspnet_pop.py:221-231), upsample+argmax (eval_base.py:168-169), IoU histogram (utils/pyt_utils.py:293-305)
+// and masked average pooling (networks/pspnet.py:7-15).  The H x W logits are never materialised.
+#include "common.h"
+
+namespace {
+
+constexpr int KMAXC = 16;   // max logit channels
+
+struct UpGeom { int B, K, h, w, H, W; float sy, sx; };
+
+__host__ inline float ac1_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+// ATen upsample_bilinear2d source index, align_corners = True
+__device__ __forceinline__ void src_index_ac1(int dst, int in, float scale, int& i0, int& i1, float& l1) {
+  const float src = scale * (float)dst;
+  i0 = (int)src;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+}
+
+// interpolated logits of pixel (Y,X) of image b into v[0..K)
+__device__ __forceinline__ void pixel_logits(const UpGeom& g, const float* __restrict__ lg, int b, int Y, int X, float* v) {
+  int y0, y1, x0, x1; float ly, lx;
+  src_index_ac1(Y, g.h, g.sy, y0, y1, ly);
+  src_index_ac1(X, g.w, g.sx, x0, x1, lx);
+  const float wy0 = 1.f - ly, wx0 = 1.f - lx;
+  const float* p = lg + (size_t)b * g.K * g.h * g.w;
+#pragma unroll
+  for (int k = 0; k < KMAXC; ++k) {
+    if (k < g.K) {
+      const float* q = p + (size_t)k * g.h * g.w;
+      v[k] = wy0 * (wx0 * q[y0 * g.w + x0] + lx * q[y0 * g.w + x1]) + ly * (wx0 * q[y1 * g.w + x0] + lx * q[y1 * g.w + x1]);
+    } else v[k] = -INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_ce_fwd_kernel(UpGeom g, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
+                                                              int ignore, float* __restrict__ part) {
+  __shared__ float red[2][4];
+  const long long total = (long long)g.B * g.H * g.W;
+  float loss = 0.f, cnt = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const long long t = tgt[i];
+    if (t == ignore || t < 0 || t >= g.K) continue;
+    const int X = (int)(i % g.W); const long long r = i / g.W;
+    const int Y = (int)(r % g.H), b = (int)(r / g.H);
+    float v[KMAXC];
+    pixel_logits(g, lg, b, Y, X, v);
+    float m = v[0], vt = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) { m = fmaxf(m, v[k]); if (k == (int)t) vt = v[k]; }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) if (k < g.K) s += expf(v[k] - m);
+    loss += logf(s) + m - vt;
+    cnt += 1.f;
+  }
+  loss = wave_sum(loss); cnt = wave_sum(cnt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = loss; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    part[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ void upsample_ce_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+  __shared__ double rs[256], rc[256];
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) { s += (double)part[2 * i]; c += (double)part[2 * i + 1]; }
+  rs[threadIdx.x] = s; rc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rc[threadIdx.x] += rc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = (float)(rs[0] / rc[0]); out[1] = (float)rc[0]; }
+}
+
+// one thread per low-resolution cell: gather over the pixels whose bilinear footprint touches it
+__global__ __launch_bounds__(64) void upsample_ce_bwd_kernel(UpGeom g, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
+                                                             const float* __restrict__ loss_cnt, const float* __restrict__ gscale,
+                                                             int ignore, float* __restrict__ dlg) {
+  const long long cells = (long long)g.B * g.h * g.w;
+  const long long ci = blockIdx.x * 64LL + threadIdx.x;
+  if (ci >= cells) return;
+  const int j = (int)(ci % g.w); const long long r = ci / g.w;
+  const int i = (int)(r % g.h), b = (int)(r / g.h);
+  float acc[KMAXC];
+#pragma unroll
+  for (int k = 0; k < KMAXC; ++k) acc[k] = 0.f;
+  // pixels Y with src in (i-1, i+1)
+  const int Ylo = g.sy > 0.f ? max(0, (int)floorf((float)(i - 1) / g.sy)) : 0;
+  const int Yhi = g.sy > 0.f ? min(g.H - 1, (int)ceilf((float)(i + 1) / g.sy)) : g.H - 1;
+  const int Xlo = g.sx > 0.f ? max(0, (int)floorf((float)(j - 1) / g.sx)) : 0;
+  const int Xhi = g.sx > 0.f ? min(g.W - 1, (int)ceilf((float)(j + 1) / g.sx)) : g.W - 1;
+  for (int Y = Ylo; Y <= Yhi; ++Y) {
+    int y0, y1; float ly;
+    src_index_ac1(Y, g.h, g.sy, y0, y1, ly);
+    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+    if (wy == 0.f) continue;
+    for (int X = Xlo; X <= Xhi; ++X) {
+      int x0, x1; float lx;
+      src_index_ac1(X, g.w, g.sx, x0, x1, lx);
+      const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
+      if (wx == 0.f) continue;
+      const long long t = tgt[((size_t)b * g.H + Y) * g.W + X];
+      if (t == ignore || t < 0 || t >= g.K) continue;
+      float v[KMAXC];
+      pixel_logits(g, lg, b, Y, X, v);
+      float m = v[0];
+#pragma unroll
+      for (int k = 0; k < KMAXC; ++k) m = fmaxf(m, v[k]);
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAXC; ++k) { v[k] = k < g.K ? expf(v[k] - m) : 0.f; s += v[k]; }
+      const float wgt = wy * wx, inv = 1.f / s;
+#pragma unroll
+      for (int k = 0; k < KMAXC; ++k) acc[k] += wgt * (v[k] * inv - (k == (int)t ? 1.f : 0.f));
+    }
+  }
+  const float f = gscale[0] / loss_cnt[1];
+#pragma unroll
+  for (int k = 0; k < KMAXC; ++k)
+    if (k < g.K) dlg[(((size_t)b * g.K + k) * g.h + i) * g.w + j] = acc[k] * f;
+}
+
+template <bool PSEUDO>
+__global__ void upsample_argmax_kernel(UpGeom g, const float* __restrict__ lg, uint8_t* __restrict__ labels, int64_t* __restrict__ mask,
+                                       int n_base) {
+  const long long total = (long long)g.B * g.H * g.W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    if (PSEUDO && mask[i] != 0) continue;
+    const int X = (int)(i % g.W); const long long r = i / g.W;
+    const int Y = (int)(r % g.H), b = (int)(r / g.H);
+    float v[KMAXC];
+    pixel_logits(g, lg, b, Y, X, v);
+    int best = 0; float bv = v[0];
+#pragma unroll
+    for (int k = 1; k < KMAXC; ++k) if (k < g.K && v[k] > bv) { bv = v[k]; best = k; }   // first maximum wins (torch.argmax)
+    if (PSEUDO) mask[i] = best > 0 ? best + n_base : 0;
+    else labels[i] = (uint8_t)best;
+  }
+}
+
+__global__ __launch_bounds__(256) void iou_hist_kernel(const uint8_t* __restrict__ pred, const int64_t* __restrict__ tgt, long long n, int K,
+                                                       int ignore, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[3 * 256];
+  for (int i = threadIdx.x; i < 3 * K; i += 256) h[i] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+    const long long t = tgt[i];
+    if (t == ignore) continue;                       // output[target == ignore] = ignore: contributes to no bin
+    const int p = pred[i];
+    if (p < K) atomicAdd(&h[K + p], 1u);
+    if (t >= 0 && t < K) { atomicAdd(&h[2 * K + (int)t], 1u); if (p == (int)t) atomicAdd(&h[p], 1u); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * K; i += 256) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+template <typename T>
+__global__ void masked_avg_pool_kernel(const T* __restrict__ feat, const float* __restrict__ mask, int B, int h, int w, int C, int H, int W,
+                                       float sy, float sx, float* __restrict__ proto) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float total = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float sf = 0.f, sm = 0.f;
+    for (int y = 0; y < h; ++y) {
+      int y0, y1; float ly;
+      src_index_ac1(y, H, sy, y0, y1, ly);
+      for (int x = 0; x < w; ++x) {
+        int x0, x1; float lx;
+        src_index_ac1(x, W, sx, x0, x1, lx);
+        const float* mb = mask + (size_t)b * H * W;
+        const float m = (1.f - ly) * ((1.f - lx) * mb[y0 * W + x0] + lx * mb[y0 * W + x1]) + ly * ((1.f - lx) * mb[y1 * W + x0] + lx * mb[y1 * W + x1]);
+        sf += to_f<T>(feat[((size_t)(b * h + y) * w + x) * C + c]) * m;
+        sm += m;
+      }
+    }
+    total += sf / (sm + 1e-5f);
+  }
+  proto[c] = total / (float)B;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int HW, int C) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % HW); const long long r = i / HW;     // i enumerates the NCHW destination
+    const int c = (int)(r % C), b = (int)(r / C);
+    dst[i] = to_f<T>(src[((size_t)b * HW + p) * C + c]);
+  }
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int HW, int C) {
+  const long long total = (long long)B * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long long r = i / C;       // i enumerates the NHWC destination
+    const int p = (int)(r % HW), b = (int)(r / HW);
+    dst[i] = from_f<T>(src[((size_t)b * C + c) * HW + p]);
+  }
+}
+
+inline UpGeom make_up(int B, int K, int h, int w, int H, int W) {
+  UpGeom g; g.B = B; g.K = K; g.h = h; g.w = w; g.H = H; g.W = W; g.sy = ac1_scale(h, H); g.sx = ac1_scale(w, W);
+  return g;
+}
+inline int ce_blocks(long long total) { long long b = (total + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+}  // namespace
+
+extern "C" int sl_upsample_ce_rows(int B, int H, int W) { return ce_blocks((long long)B * H * W); }
+
+extern "C" int sl_upsample_ce_fwd(const float* logits, const int64_t* target, int B, int K, int h, int w, int H, int W,
+                                  int ignore_index, float* partial, sl_stream_t stream) {
+  SL_REQUIRE(logits && target && partial && B > 0 && K >= 1 && K <= KMAXC && h > 0 && w > 0 && H > 0 && W > 0, "upsample_ce_fwd: bad args");
+  const UpGeom g = make_up(B, K, h, w, H, W);
+  hipLaunchKernelGGL(upsample_ce_fwd_kernel, dim3(ce_blocks((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, logits, target, ignore_index, partial);
+  SL_LAUNCH_CHECK("upsample_ce_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_upsample_ce_finalize(const float* partial, int nblk, float* loss_and_count, sl_stream_t stream) {
+  SL_REQUIRE(partial && loss_and_count && nblk > 0, "upsample_ce_finalize: bad args");
+  hipLaunchKernelGGL(upsample_ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, loss_and_count);
+  SL_LAUNCH_CHECK("upsample_ce_finalize_kernel");
+  return 0;
+}
+
+extern "C" int sl_upsample_ce_bwd(const float* logits, const int64_t* target, const float* loss_and_count, const float* gscale,
+                                  int B, int K, int h, int w, int H, int W, int ignore_index, float* dlogits,
+                                  sl_stream_t stream) {
+  SL_REQUIRE(logits && target && loss_and_count && gscale && dlogits && K >= 1 && K <= KMAXC, "upsample_ce_bwd: bad args");
+  const UpGeom g = make_up(B, K, h, w, H, W);
+  const long long cells = (long long)B * h * w;
+  hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g, logits, target, loss_and_count, gscale, ignore_index, dlogits);
+  SL_LAUNCH_CHECK("upsample_ce_bwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_pseudo_label(const float* logits, int K2, int h, int w, int64_t* mask, int B, int H, int W, int n_base,
+                               sl_stream_t stream) {
+  SL_REQUIRE(logits && mask && K2 >= 1 && K2 <= KMAXC && B > 0, "pseudo_label: bad args");
+  const UpGeom g = make_up(B, K2, h, w, H, W);
+  hipLaunchKernelGGL(upsample_argmax_kernel<true>, dim3(ce_blocks((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, logits, (uint8_t*)nullptr, mask, n_base);
+  SL_LAUNCH_CHECK("pseudo_label_kernel");
+  return 0;
+}
+
+extern "C" int sl_upsample_argmax(const float* logits, int B, int K, int h, int w, int H, int W, uint8_t* labels,
+                                  sl_stream_t stream) {
+  SL_REQUIRE(logits && labels && K >= 1 && K <= KMAXC && B > 0, "upsample_argmax: bad args");
+  const UpGeom g = make_up(B, K, h, w, H, W);
+  hipLaunchKernelGGL(upsample_argmax_kernel<false>, dim3(ce_blocks((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, logits, labels, (int64_t*)nullptr, 0);
+  SL_LAUNCH_CHECK("upsample_argmax_kernel");
+  return 0;
+}
+
+extern "C" int sl_iou_hist(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* hist,
+                           sl_stream_t stream) {
+  SL_REQUIRE(pred && target && hist && n > 0 && K >= 1 && K <= 256, "iou_hist: bad args");
+  hipLaunchKernelGGL(iou_hist_kernel, dim3(ce_blocks(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, K, ignore_index, (unsigned long long*)hist);
+  SL_LAUNCH_CHECK("iou_hist_kernel");
+  return 0;
+}
+
+extern "C" int sl_masked_avg_pool(int dtype, const void* feature, const float* mask, int B, int h, int w, int C, int H, int W,
+                                  float* proto, sl_stream_t stream) {
+  SL_REQUIRE(feature && mask && proto && B > 0 && C > 0, "masked_avg_pool: bad args");
+  const float sy = ac1_scale(H, h), sx = ac1_scale(W, w);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(masked_avg_pool_kernel<bf16_t>, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)feature, mask, B, h, w, C, H, W, sy, sx, proto);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(masked_avg_pool_kernel<float>, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)feature, mask, B, h, w, C, H, W, sy, sx, proto);
+  else SL_REQUIRE(false, "masked_avg_pool: bad dtype");
+  SL_LAUNCH_CHECK("masked_avg_pool_kernel");
+  return 0;
+}
+
+extern "C" int sl_nhwc_to_nchw_f32(int dtype, const void* src, float* dst, int B, int H, int W, int C, sl_stream_t stream) {
+  SL_REQUIRE(src && dst && B > 0, "nhwc_to_nchw: bad args");
+  const long long total = (long long)B * H * W * C;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, B, H * W, C);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, B, H * W, C);
+  else SL_REQUIRE(false, "nhwc_to_nchw: bad dtype");
+  SL_LAUNCH_CHECK("nhwc_to_nchw_kernel");
+  return 0;
+}
+
+extern "C" int sl_nchw_f32_to_nhwc(int dtype, const float* src, void* dst, int B, int H, int W, int C, sl_stream_t stream) {
+  SL_REQUIRE(src && dst && B > 0, "nchw_to_nhwc: bad args");
+  const long long total = (long long)B * H * W * C;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, B, H * W, C);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, B, H * W, C);
+  else SL_REQUIRE(false, "nchw_to_nhwc: bad dtype");
+  SL_LAUNCH_CHECK("nchw_to_nhwc_kernel");
+  return 0;
+}

@@ -1,0 +1,352 @@
+// POP head kernels (networks/pspnet_pop.py:95-121 orthogonal_decompose, :178-182 / :210-219 classifier on components)
+// in the collapsed form of SURVEY.md 0.7: the [B,K,C,N] component tensors are never built.
+//   proj[r][k] = S_k . q_r            bg_r = q_r - sum_k proj[r][k] S_k          (fp32, as the reference forces)
+//   pred[r][0] = MLP(bg_r)            pred[r][1+k] = a_k max(p,0) + b_k max(-p,0),  a_k = MLP(S_k), b_k = MLP(-S_k)
+// One wavefront per pixel row (C = 512 channels = 8 per lane), wave-shuffle reductions for the K projections.
+#include "common.h"
+
+namespace {
+
+constexpr int KMAXP = 16;  // max prototypes (base + novel)
+
+template <typename T, int NV>   // NV 16-byte vectors per lane
+__global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ S, int Kt,
+                                                                float* __restrict__ proj, T* __restrict__ bg, long long R, int C) {
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Sl = sm;                       // [Kt][C]
+  for (int e = threadIdx.x; e < Kt * C; e += 256) Sl[e] = S[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += gridDim.x * 4LL) {
+    float q[NV * V], o[NV * V];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * 64 + lane) * V), &q[j * V]);
+#pragma unroll
+    for (int e = 0; e < NV * V; ++e) o[e] = q[e];
+    for (int k = 0; k < Kt; ++k) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) d = fmaf(q[j * V + e], Sl[k * C + (j * 64 + lane) * V + e], d);
+      d = wave_sum(d);
+      if (lane == 0) proj[(size_t)r * Kt + k] = d;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[j * V + e] -= d * Sl[k * C + (j * 64 + lane) * V + e];
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) *(uint4*)(bg + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(&o[j * V]);
+  }
+}
+
+template <typename T>
+__global__ void pop_proto_rows_kernel(const float* __restrict__ S, int Kt, int C, T* __restrict__ dst) {
+  const int n = Kt * C;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    dst[e] = from_f<T>(S[e]);
+    dst[n + e] = from_f<T>(-S[e]);
+  }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, float* __restrict__ z,
+                                                         long long R, int C) {
+  constexpr int V = Vec16<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[NV * V];
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < V; ++e) wv[j * V + e] = w[(j * 64 + lane) * V + e];
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += gridDim.x * 4LL) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float t[V];
+      unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * 64 + lane) * V), t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) d = fmaf(t[e], wv[j * V + e], d);
+    }
+    d = wave_sum(d);
+    if (lane == 0) z[r] = d;
+  }
+}
+
+// dh = dz * w * (h > 0); partial[blk][c] = sum_r dz[r] * h[r][c]
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ dz,
+                                                         T* __restrict__ dh, float* __restrict__ part, long long R, int C,
+                                                         long long rows_per_blk) {
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wv[NV * V], acc[NV * V];
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < V; ++e) { wv[j * V + e] = w[(j * 64 + lane) * V + e]; acc[j * V + e] = 0.f; }
+  const long long r0 = blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
+  for (long long r = r0 + wave; r < r1; r += 4) {
+    const float g = dz[r];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      float t[V], o[V];
+      unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * 64 + lane) * V), t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { acc[j * V + e] = fmaf(g, t[e], acc[j * V + e]); o[e] = t[e] > 0.f ? g * wv[j * V + e] : 0.f; }
+      *(uint4*)(dh + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(o);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < V; ++e) sm[wave * C + (j * 64 + lane) * V + e] = acc[j * V + e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = sm[c] + sm[C + c] + sm[2 * C + c] + sm[3 * C + c];
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < nblk; ++r) s += (double)part[(size_t)r * C + c];
+  out[c] = (float)s;
+}
+
+__global__ void pop_combine_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ zbg, const float* __restrict__ a,
+                                       const float* __restrict__ b, int Kt, float* __restrict__ preds, int B, int N) {
+  const long long R = (long long)B * N;
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < R; r += (long long)gridDim.x * blockDim.x) {
+    const int bb = (int)(r / N), n = (int)(r % N);
+    float* o = preds + (size_t)bb * (1 + Kt) * N + n;
+    o[0] = zbg[r];
+    for (int k = 0; k < Kt; ++k) {
+      const float p = proj[(size_t)r * Kt + k];
+      o[(size_t)(1 + k) * N] = a[k] * fmaxf(p, 0.f) + b[k] * fmaxf(-p, 0.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pop_combine_bwd_kernel(const float* __restrict__ dpreds, const float* __restrict__ proj,
+                                                              const float* __restrict__ a, const float* __restrict__ b, int Kt,
+                                                              float* __restrict__ dzbg, float* __restrict__ dproj,
+                                                              float* __restrict__ dab, int B, int N, long long rows_per_blk) {
+  __shared__ float red[4][2 * KMAXP];
+  const long long R = (long long)B * N;
+  float da[KMAXP], db[KMAXP];
+#pragma unroll
+  for (int k = 0; k < KMAXP; ++k) { da[k] = 0.f; db[k] = 0.f; }
+  const long long r0 = blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
+  for (long long r = r0 + threadIdx.x; r < r1; r += 256) {
+    const int bb = (int)(r / N), n = (int)(r % N);
+    const float* g = dpreds + (size_t)bb * (1 + Kt) * N + n;
+    dzbg[r] = g[0];
+#pragma unroll
+    for (int k = 0; k < KMAXP; ++k) {
+      if (k < Kt) {
+        const float p = proj[(size_t)r * Kt + k], d = g[(size_t)(1 + k) * N];
+        dproj[(size_t)r * Kt + k] = p > 0.f ? d * a[k] : (p < 0.f ? -d * b[k] : 0.f);
+        da[k] += d * fmaxf(p, 0.f);
+        db[k] += d * fmaxf(-p, 0.f);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KMAXP; ++k) {
+    const float x = wave_sum(da[k]), y = wave_sum(db[k]);
+    if (lane == 0) { red[wave][k] = x; red[wave][KMAXP + k] = y; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * Kt) {
+    const int k = threadIdx.x % Kt, which = threadIdx.x / Kt;
+    const int s = which * KMAXP + k;
+    dab[(size_t)blockIdx.x * 2 * Kt + which * Kt + k] = red[0][s] + red[1][s] + red[2][s] + red[3][s];
+  }
+}
+
+// t_k = dproj[r][k] - dg_r . S_k ;  dq_r = dg_r + sum_k t_k S_k ;  dS_k += t_k q_r - proj[r][k] dg_r
+template <typename T, int NV, int KM>
+__global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ feats, const float* __restrict__ S,
+                                                                const float* __restrict__ proj, const float* __restrict__ dproj, int Kt,
+                                                                T* __restrict__ dq, float* __restrict__ dSpart, long long R, int C,
+                                                                long long rows_per_blk) {
+  constexpr int V = Vec16<T>::N, CL = NV * V;     // channels per lane
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* Sl = sm;                                 // [KM][C]; reused for the cross-wave reduction
+  for (int e = threadIdx.x; e < KM * C; e += 256) Sl[e] = e < Kt * C ? S[e] : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[KM][CL];
+#pragma unroll
+  for (int k = 0; k < KM; ++k)
+#pragma unroll
+    for (int e = 0; e < CL; ++e) acc[k][e] = 0.f;
+  const long long r0 = blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
+  for (long long r = r0 + wave; r < r1; r += 4) {
+    float g[CL], q[CL], o[CL];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      unpack16<T>(*(const uint4*)(dg + (size_t)r * C + (j * 64 + lane) * V), &g[j * V]);
+      unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * 64 + lane) * V), &q[j * V]);
+    }
+#pragma unroll
+    for (int e = 0; e < CL; ++e) o[e] = g[e];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      if (k < Kt) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+          for (int e = 0; e < V; ++e) d = fmaf(g[j * V + e], Sl[k * C + (j * 64 + lane) * V + e], d);
+        d = wave_sum(d);
+        const float t = dproj[(size_t)r * Kt + k] - d, p = proj[(size_t)r * Kt + k];
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            o[j * V + e] = fmaf(t, Sl[k * C + (j * 64 + lane) * V + e], o[j * V + e]);
+            acc[k][j * V + e] += t * q[j * V + e] - p * g[j * V + e];
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) *(uint4*)(dq + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(&o[j * V]);
+  }
+  // cross-wave reduction, one prototype at a time through LDS
+  __syncthreads();
+  float* red = sm;   // [4][C]
+#pragma unroll
+  for (int k = 0; k < KM; ++k) {
+    if (k < Kt) {     // Kt is block-uniform
+#pragma unroll
+      for (int e = 0; e < CL; ++e) red[wave * C + ((e / V) * 64 + lane) * V + (e % V)] = acc[k][e];
+      __syncthreads();
+      for (int c = threadIdx.x; c < C; c += 256)
+        dSpart[((size_t)blockIdx.x * Kt + k) * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
+      __syncthreads();
+    }
+  }
+}
+
+inline int row_blocks(long long R, int cap) { long long b = (R + 63) / 64; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+}  // namespace
+
+#define POP_DISPATCH(dtype, C, CALL_BF, CALL_F32)                                         \
+  do {                                                                                    \
+    if ((dtype) == SL_BF16 && (C) == 512) { CALL_BF; }                                    \
+    else if ((dtype) == SL_F32 && (C) == 512) { CALL_F32; }                               \
+    else SL_REQUIRE(false, "pop head: unsupported dtype/C (%d, %d); C must be 512", (int)(dtype), (int)(C)); \
+  } while (0)
+
+extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, float* proj, void* bg, long long R,
+                                    int C, sl_stream_t stream) {
+  SL_REQUIRE(feats && S && proj && bg && R > 0 && Kt >= 1 && Kt <= KMAXP, "pop_decompose_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = row_blocks(R * 16, 2048);
+  const size_t lds = (size_t)KMAXP * C * sizeof(float);
+  POP_DISPATCH(dtype, C,
+               hipLaunchKernelGGL((pop_decompose_fwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), lds, st, (const bf16_t*)feats, S, Kt, proj, (bf16_t*)bg, R, C),
+               hipLaunchKernelGGL((pop_decompose_fwd_kernel<float, 2>), dim3(blocks), dim3(256), lds, st, (const float*)feats, S, Kt, proj, (float*)bg, R, C));
+  SL_LAUNCH_CHECK("pop_decompose_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_pop_proto_rows(int dtype, const float* S, int Kt, int C, void* dst, sl_stream_t stream) {
+  SL_REQUIRE(S && dst && Kt >= 1 && C > 0, "pop_proto_rows: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SL_BF16) hipLaunchKernelGGL(pop_proto_rows_kernel<bf16_t>, dim3(cdiv(Kt * C, 256)), dim3(256), 0, st, S, Kt, C, (bf16_t*)dst);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(pop_proto_rows_kernel<float>, dim3(cdiv(Kt * C, 256)), dim3(256), 0, st, S, Kt, C, (float*)dst);
+  else SL_REQUIRE(false, "pop_proto_rows: bad dtype");
+  SL_LAUNCH_CHECK("pop_proto_rows_kernel");
+  return 0;
+}
+
+extern "C" int sl_rowdot_fwd(int dtype, const void* h, const float* w, float* z, long long R, int C, sl_stream_t stream) {
+  SL_REQUIRE(h && w && z && R > 0, "rowdot_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = row_blocks(R * 16, 2048);
+  POP_DISPATCH(dtype, C,
+               hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, w, z, R, C),
+               hipLaunchKernelGGL((rowdot_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, st, (const float*)h, w, z, R, C));
+  SL_LAUNCH_CHECK("rowdot_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_rowdot_bwd_rows(long long R, int C) { (void)C; return row_blocks(R, 512); }
+
+extern "C" int sl_rowdot_bwd(int dtype, const void* h, const float* w, const float* dz, void* dh, float* partial, long long R,
+                             int C, sl_stream_t stream) {
+  SL_REQUIRE(h && w && dz && dh && partial && R > 0, "rowdot_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = row_blocks(R, 512);
+  const long long rpb = (R + nblk - 1) / nblk;
+  const size_t lds = 4 * (size_t)C * sizeof(float);
+  POP_DISPATCH(dtype, C,
+               hipLaunchKernelGGL((rowdot_bwd_kernel<bf16_t, 1>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)h, w, dz, (bf16_t*)dh, partial, R, C, rpb),
+               hipLaunchKernelGGL((rowdot_bwd_kernel<float, 2>), dim3(nblk), dim3(256), lds, st, (const float*)h, w, dz, (float*)dh, partial, R, C, rpb));
+  SL_LAUNCH_CHECK("rowdot_bwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream) {
+  SL_REQUIRE(partial && out && nblk > 0 && C > 0, "colsum_finalize: bad args");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial, nblk, C, out);
+  SL_LAUNCH_CHECK("colsum_finalize_kernel");
+  return 0;
+}
+
+extern "C" int sl_pop_combine_fwd(const float* proj, const float* z_bg, const float* a, const float* b, int Kt, float* preds,
+                                  int B, int N, sl_stream_t stream) {
+  SL_REQUIRE(proj && z_bg && a && b && preds && Kt >= 1 && Kt <= KMAXP && B > 0 && N > 0, "pop_combine_fwd: bad args");
+  const long long R = (long long)B * N;
+  const int blocks = (int)((R + 255) / 256 < 4096 ? (R + 255) / 256 : 4096);
+  hipLaunchKernelGGL(pop_combine_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, proj, z_bg, a, b, Kt, preds, B, N);
+  SL_LAUNCH_CHECK("pop_combine_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_pop_combine_bwd_rows(int B, int N) { return row_blocks((long long)B * N / 4, 256); }
+
+extern "C" int sl_pop_combine_bwd(const float* dpreds, const float* proj, const float* a, const float* b, int Kt, float* dz_bg,
+                                  float* dproj, float* dab_partial, int B, int N, sl_stream_t stream) {
+  SL_REQUIRE(dpreds && proj && a && b && dz_bg && dproj && dab_partial && Kt >= 1 && Kt <= KMAXP, "pop_combine_bwd: bad args");
+  const long long R = (long long)B * N;
+  const int nblk = sl_pop_combine_bwd_rows(B, N);
+  const long long rpb = (R + nblk - 1) / nblk;
+  hipLaunchKernelGGL(pop_combine_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dpreds, proj, a, b, Kt, dz_bg, dproj, dab_partial, B, N, rpb);
+  SL_LAUNCH_CHECK("pop_combine_bwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_pop_decompose_bwd_rows(long long R) { return row_blocks(R, 512); }
+
+extern "C" int sl_pop_decompose_bwd(int dtype, const void* dg, const void* feats, const float* S, const float* proj,
+                                    const float* dproj, int Kt, void* dq, float* dS_partial, long long R, int C,
+                                    sl_stream_t stream) {
+  SL_REQUIRE(dg && feats && S && proj && dproj && dq && dS_partial && R > 0 && Kt >= 1 && Kt <= KMAXP, "pop_decompose_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = row_blocks(R, 512);
+  const long long rpb = (R + nblk - 1) / nblk;
+  if (Kt <= 8) {
+    const size_t lds = 8 * (size_t)C * sizeof(float);
+    POP_DISPATCH(dtype, C,
+                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<bf16_t, 1, 8>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)dg, (const bf16_t*)feats, S, proj, dproj, Kt, (bf16_t*)dq, dS_partial, R, C, rpb),
+                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<float, 2, 8>), dim3(nblk), dim3(256), lds, st, (const float*)dg, (const float*)feats, S, proj, dproj, Kt, (float*)dq, dS_partial, R, C, rpb));
+  } else {
+    const size_t lds = 16 * (size_t)C * sizeof(float);
+    POP_DISPATCH(dtype, C,
+                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<bf16_t, 1, 16>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)dg, (const bf16_t*)feats, S, proj, dproj, Kt, (bf16_t*)dq, dS_partial, R, C, rpb),
+                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<float, 2, 16>), dim3(nblk), dim3(256), lds, st, (const float*)dg, (const float*)feats, S, proj, dproj, Kt, (float*)dq, dS_partial, R, C, rpb));
+  }
+  SL_LAUNCH_CHECK("pop_decompose_bwd_kernel");
+  return 0;
+}

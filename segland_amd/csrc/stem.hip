@@ -1,0 +1,299 @@
+// ResNet stem for gfx950: conv 7x7 s2 p3 (3 -> 64) straight from the NCHW float image, fused BN+ReLU+maxpool 3x3 s2 p1,
+// and their backward (networks/backbones/resnet.py:86-90,124-125).  Cin = 3 makes this stage bandwidth/VALU bound,
+// so it is a direct LDS-tiled fp32 convolution (input patch + all 64x147 weights resident in LDS), not MFMA.
+#include "common.h"
+
+namespace {
+
+constexpr int TS = 16;                 // output tile edge
+constexpr int PS = (TS - 1) * 2 + 7;   // input patch edge = 37
+constexpr int NTAP = 147;              // 3*7*7
+
+__device__ __forceinline__ void load_patch(float* patch, const float* img, int b, int H, int W, int oy0, int ox0, int tid) {
+  // patch[c][PS][PS] of image rows 2*oy0-3 .., zero outside
+  for (int e = tid; e < 3 * PS * PS; e += 256) {
+    const int c = e / (PS * PS), r = (e / PS) % PS, q = e % PS;
+    const int iy = 2 * oy0 - 3 + r, ix = 2 * ox0 - 3 + q;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[((size_t)(b * 3 + c) * H + iy) * W + ix];
+    patch[e] = v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                            T* __restrict__ y, float* __restrict__ part, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                  // [147][64]
+  float* patch = sm + NTAP * 64;   // [3][37][37]
+  const int Ho = H / 2, Wo = W / 2;
+  const int tx = cdiv(Wo, TS), ty = cdiv(Ho, TS);
+  const int tid = threadIdx.x;
+  int blk = blockIdx.x;
+  const int bx = blk % tx; blk /= tx;
+  const int by = blk % ty; const int b = blk / ty;
+  for (int e = tid; e < 64 * NTAP; e += 256) { const int n = e / NTAP, t = e % NTAP; wl[t * 64 + n] = w[e]; }
+  load_patch(patch, img, b, H, W, by * TS, bx * TS, tid);
+  __syncthreads();
+
+  const int pg = tid & 63, cg = tid >> 6;     // wave = channel group of 16, lane = 4-pixel group
+  const int py = pg >> 2, px0 = (pg & 3) * 4;
+  float acc[4][16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+  for (int c = 0; c < 3; ++c)
+    for (int ky = 0; ky < 7; ++ky) {
+      const float* prow = patch + (c * PS + 2 * py + ky) * PS + 2 * px0;
+      const float* wrow = wl + ((c * 7 + ky) * 7) * 64 + cg * 16;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        float wv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) { const float4 t = *(const float4*)(wrow + kx * 64 + k); wv[k] = t.x; wv[k + 1] = t.y; wv[k + 2] = t.z; wv[k + 3] = t.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = prow[2 * j + kx];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[j][k] = fmaf(a, wv[k], acc[j][k]);
+        }
+      }
+    }
+  const int oy = by * TS + py;
+  float s1[16], s2[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ox = bx * TS + px0 + j;
+    if (oy < Ho && ox < Wo) {
+      T* o = y + ((size_t)(b * Ho + oy) * Wo + ox) * 64 + cg * 16;
+      constexpr int V = Vec16<T>::N;
+#pragma unroll
+      for (int k = 0; k < 16; k += V) *(uint4*)(o + k) = pack16<T>(&acc[j][k]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { s1[k] += acc[j][k]; s2[k] += acc[j][k] * acc[j][k]; }
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { s1[k] = wave_sum(s1[k]); s2[k] = wave_sum(s2[k]); }
+    if (pg == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        part[((size_t)blockIdx.x * 2 + 0) * 64 + cg * 16 + k] = s1[k];
+        part[((size_t)blockIdx.x * 2 + 1) * 64 + cg * 16 + k] = s2[k];
+      }
+    }
+  }
+}
+
+// pooled = maxpool3x3s2p1(relu(c0*scale+shift)); idx = first-max window position ky*3+kx (ATen scan order)
+template <typename T>
+__global__ void stem_bn_relu_pool_fwd_kernel(const T* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
+                                             T* __restrict__ pooled, uint8_t* __restrict__ idx, int B, int Hc, int Wc) {
+  constexpr int V = Vec16<T>::N, NV = 64 / V;
+  const int Hp = Hc / 2, Wp = Wc / 2;
+  const long long total = (long long)B * Hp * Wp * NV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % NV); long long r = i / NV;
+    const int px = (int)(r % Wp); r /= Wp;
+    const int py = (int)(r % Hp); const int b = (int)(r / Hp);
+    float best[V]; int bi[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { best[k] = -INFINITY; bi[k] = 0; }
+    float sc[V], sh[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { sc[k] = scale[v * V + k]; sh[k] = shift[v * V + k]; }
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = 2 * py - 1 + ky;
+      if ((unsigned)yy >= (unsigned)Hc) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int xx = 2 * px - 1 + kx;
+        if ((unsigned)xx >= (unsigned)Wc) continue;
+        float xv[V];
+        unpack16<T>(*(const uint4*)(c0 + ((size_t)(b * Hc + yy) * Wc + xx) * 64 + v * V), xv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          float a = xv[k] * sc[k] + sh[k];
+          a = a > 0.f ? a : 0.f;
+          if (a > best[k] || a != a) { best[k] = a; bi[k] = ky * 3 + kx; }
+        }
+      }
+    }
+    const size_t o = ((size_t)(b * Hp + py) * Wp + px) * 64 + v * V;
+    *(uint4*)(pooled + o) = pack16<T>(best);
+    if (idx) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) idx[o + k] = (uint8_t)bi[k];
+    }
+  }
+}
+
+// g0[b][y][x][c] = relu'(a0) * sum over windows whose first max sits at (y,x) of dpooled
+template <typename T>
+__global__ void stem_pool_relu_bwd_kernel(const T* __restrict__ dp, const uint8_t* __restrict__ idx, const T* __restrict__ c0,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ g0,
+                                          int B, int Hc, int Wc) {
+  constexpr int V = Vec16<T>::N, NV = 64 / V;
+  const int Hp = Hc / 2, Wp = Wc / 2;
+  const long long total = (long long)B * Hc * Wc * NV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % NV); long long r = i / NV;
+    const int x = (int)(r % Wc); r /= Wc;
+    const int y = (int)(r % Hc); const int b = (int)(r / Hc);
+    float g[V], xv[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = 0.f;
+    // windows py with 2py-1 <= y <= 2py+1
+    const int py_lo = y / 2, py_hi = (y + 1) / 2, px_lo = x / 2, px_hi = (x + 1) / 2;
+    for (int py = py_lo; py <= py_hi; ++py) {
+      if (py >= Hp) continue;
+      const int ky = y - (2 * py - 1);
+      for (int px = px_lo; px <= px_hi; ++px) {
+        if (px >= Wp) continue;
+        const int kx = x - (2 * px - 1);
+        const size_t o = ((size_t)(b * Hp + py) * Wp + px) * 64 + v * V;
+        float d[V];
+        unpack16<T>(*(const uint4*)(dp + o), d);
+        const int want = ky * 3 + kx;
+#pragma unroll
+        for (int k = 0; k < V; ++k) if (idx[o + k] == want) g[k] += d[k];
+      }
+    }
+    const size_t oc = ((size_t)(b * Hc + y) * Wc + x) * 64 + v * V;
+    unpack16<T>(*(const uint4*)(c0 + oc), xv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = (xv[k] * scale[v * V + k] + shift[v * V + k]) > 0.f ? g[k] : 0.f;
+    *(uint4*)(g0 + oc) = pack16<T>(g);
+  }
+}
+
+// dw partial per block: ws[blk][64][147] (OIHW order inside), block loops over `tiles_per_blk` 16x16 tiles
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dc0, float* __restrict__ ws,
+                                                         int B, int H, int W, int tiles_per_blk, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* dyl = sm;                    // [256 px][64]
+  float* patch = sm + 256 * 64;       // [3][37][37]
+  const int Ho = H / 2, Wo = W / 2;
+  const int tx = cdiv(Wo, TS), ty = cdiv(Ho, TS);
+  const int tid = threadIdx.x, n = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: (c,ky) combos g, g+4, ...
+  float acc[6][7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[i][k] = 0.f;
+  for (int t = 0; t < tiles_per_blk; ++t) {
+    int tile = blockIdx.x * tiles_per_blk + t;
+    if (tile >= ntiles) break;
+    const int bx = tile % tx; tile /= tx;
+    const int by = tile % ty; const int b = tile / ty;
+    __syncthreads();
+    load_patch(patch, img, b, H, W, by * TS, bx * TS, tid);
+    for (int e = tid; e < 256 * 64; e += 256) {
+      const int p = e >> 6, c = e & 63;
+      const int oy = by * TS + (p >> 4), ox = bx * TS + (p & 15);
+      float v = 0.f;
+      if (oy < Ho && ox < Wo) v = to_f<T>(dc0[((size_t)(b * Ho + oy) * Wo + ox) * 64 + c]);
+      dyl[e] = v;
+    }
+    __syncthreads();
+    for (int p = 0; p < 256; ++p) {
+      const float a = dyl[p * 64 + n];
+      const int py = p >> 4, px = p & 15;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int id = g + 4 * i;
+        if (id < 21) {
+          const int c = id / 7, ky = id - 7 * c;
+          const float* prow = patch + (c * PS + 2 * py + ky) * PS + 2 * px;
+#pragma unroll
+          for (int k = 0; k < 7; ++k) acc[i][k] = fmaf(a, prow[k], acc[i][k]);
+        }
+      }
+    }
+  }
+  float* o = ws + (size_t)blockIdx.x * 64 * NTAP + n * NTAP;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int id = g + 4 * i;
+    if (id < 21) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) o[id * 7 + k] = acc[i][k];
+    }
+  }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 64 * NTAP) return;
+  float s = 0.f;
+  for (int k = 0; k < nblk; ++k) s += ws[(size_t)k * 64 * NTAP + e];
+  dw[e] = s;
+}
+
+inline int stem_tiles(int B, int H, int W) { return B * cdiv(H / 2, TS) * cdiv(W / 2, TS); }
+inline int stem_wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+
+}  // namespace
+
+extern "C" int sl_stem_conv_stat_rows(int B, int H, int W) { return stem_tiles(B, H, W); }
+
+extern "C" int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w_oihw, void* y, float* stat_partial, int B,
+                                int H, int W, sl_stream_t stream) {
+  SL_REQUIRE(img_nchw && w_oihw && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_conv_fwd: bad args");
+  const size_t lds = (NTAP * 64 + 3 * PS * PS) * sizeof(float);
+  dim3 grid(stem_tiles(B, H, W));
+  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_conv_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (bf16_t*)y, stat_partial, B, H, W);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (float*)y, stat_partial, B, H, W);
+  else SL_REQUIRE(false, "stem_conv_fwd: bad dtype");
+  SL_LAUNCH_CHECK("stem_conv_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_stem_bn_relu_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* pooled,
+                                        uint8_t* argmax, int B, int Hc, int Wc, sl_stream_t stream) {
+  SL_REQUIRE(c0 && scale && shift && pooled && B > 0 && Hc % 2 == 0 && Wc % 2 == 0, "stem_bn_relu_pool_fwd: bad args");
+  const long long total = (long long)B * (Hc / 2) * (Wc / 2) * (dtype == SL_BF16 ? 8 : 16);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)c0, scale, shift, (bf16_t*)pooled, argmax, B, Hc, Wc);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_bn_relu_pool_fwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)c0, scale, shift, (float*)pooled, argmax, B, Hc, Wc);
+  else SL_REQUIRE(false, "stem_bn_relu_pool_fwd: bad dtype");
+  SL_LAUNCH_CHECK("stem_bn_relu_pool_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_stem_pool_relu_bwd(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale,
+                                     const float* shift, void* g0, int B, int Hc, int Wc, sl_stream_t stream) {
+  SL_REQUIRE(dpooled && argmax && c0 && scale && shift && g0 && B > 0 && Hc % 2 == 0 && Wc % 2 == 0, "stem_pool_relu_bwd: bad args");
+  const long long total = (long long)B * Hc * Wc * (dtype == SL_BF16 ? 8 : 16);
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_pool_relu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpooled, argmax, (const bf16_t*)c0, scale, shift, (bf16_t*)g0, B, Hc, Wc);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_pool_relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dpooled, argmax, (const float*)c0, scale, shift, (float*)g0, B, Hc, Wc);
+  else SL_REQUIRE(false, "stem_pool_relu_bwd: bad dtype");
+  SL_LAUNCH_CHECK("stem_pool_relu_bwd_kernel");
+  return 0;
+}
+
+extern "C" size_t sl_stem_conv_bwd_weight_workspace(int B, int H, int W) {
+  return (size_t)stem_wgrad_blocks(stem_tiles(B, H, W)) * 64 * NTAP * sizeof(float);
+}
+
+extern "C" int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const void* dc0, float* dw_oihw, void* workspace,
+                                       size_t workspace_bytes, int B, int H, int W, sl_stream_t stream) {
+  SL_REQUIRE(img_nchw && dc0 && dw_oihw && workspace && B > 0 && H % 2 == 0 && W % 2 == 0, "stem_conv_bwd_weight: bad args");
+  const int ntiles = stem_tiles(B, H, W), nblk = stem_wgrad_blocks(ntiles), tpb = cdiv(ntiles, nblk);
+  if (workspace_bytes < (size_t)nblk * 64 * NTAP * sizeof(float)) { sl_set_error("stem_conv_bwd_weight: workspace too small"); return SL_EWORKSPACE; }
+  const size_t lds = (256 * 64 + 3 * PS * PS) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), lds, st, img_nchw, (const float*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
+  else SL_REQUIRE(false, "stem_conv_bwd_weight: bad dtype");
+  SL_LAUNCH_CHECK("stem_wgrad_kernel");
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(64 * NTAP, 256)), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk);
+  SL_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
+  return 0;
+}

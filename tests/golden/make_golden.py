@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE itself (build container only).
+
+Imports /root/reference (read-only, never copied) with stub modules for the packages the
+image lacks, loads oracle/formula.py weights into both the reference model
+and oracle/pop_oracle.py, asserts the two agree, and stores the reference's outputs.
+Only data (inputs are regenerated from formulas; expected outputs are stored) lands here.
+
+    python tests/golden/make_golden.py [g1 g2 ...]
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+
+def import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    stub('cv2')
+    stub('timm'); stub('timm.models')
+    stub('timm.models.layers', DropPath=nn.Identity, to_2tuple=lambda x: (x, x),
+         trunc_normal_=nn.init.trunc_normal_)
+    stub('timm.models.registry', register_model=lambda f: f)
+    stub('torchvision'); stub('torchvision.models')
+    sys.path.insert(0, REF)
+    import networks.pspnet_pop as ref_pop          # noqa
+    import networks.pspnet as ref_psp              # noqa
+    from loss.criterion import OrthLoss            # noqa
+    import utils.pyt_utils as ref_utils            # noqa
+    from networks.backbones.resnet import Bottleneck  # noqa
+    return ref_pop, ref_psp, OrthLoss, ref_utils, Bottleneck
+
+
+ref_pop, ref_psp, RefOrthLoss, ref_utils, RefBottleneck = import_reference()
+from oracle import formula as fm            # noqa: E402
+from oracle import pop_oracle as po         # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, '%.1f KB' % (os.path.getsize(path) / 1024))
+
+
+def same(a, b, what, tol=0.0):
+    a, b = a.detach(), b.detach()
+    if tol == 0.0:
+        assert torch.equal(a, b), '%s: oracle != reference (max abs %g)' % (what, (a - b).abs().max())
+    else:
+        assert torch.allclose(a, b, rtol=tol, atol=tol), '%s: max abs %g' % (what, (a - b).abs().max())
+
+
+def build_pair(is_ft=False, n_novel=0, backbone='resnet50'):
+    crit_r, crit_o = RefOrthLoss(ignore_index=255), po.OrthLossOracle(ignore_index=255)
+    ref = ref_pop.GFSS_Model(n_base=7, criterion=crit_r, is_ft=is_ft, n_novel=n_novel, backbone=backbone,
+                             pretrained_model=None, dilated=True, os=8)
+    ora = po.PopOracle(n_base=7, criterion=crit_o, is_ft=is_ft, n_novel=n_novel, backbone=backbone)
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), 'state_dict keys differ'
+    assert [k for k, _ in ref.named_parameters()] == [k for k, _ in ora.named_parameters()]
+    sd = fm.formula_state_dict(ref)
+    ref.load_state_dict(sd, strict=True)
+    ora.load_state_dict(sd, strict=True)
+    return ref, ora
+
+
+# ------------------------------------------------------------------------------------------ G1
+def g1():
+    feats = fm.sym('g1/feats', (2, 512, 24), 1.0)
+    bb, bn = fm.sym('g1/bb', (1, 7, 512), 1.0), fm.sym('g1/bn', (1, 4, 512), 1.0)
+    ref, _ = build_pair()
+    fg, bg = ref.orthogonal_decompose(feats, bb)
+    fg_o, bg_o = po.orthogonal_decompose(feats, bb)
+    same(fg, fg_o, 'g1 fg'); same(bg, bg_o, 'g1 bg')
+    fgb2, fgn2, bg2 = ref.orthogonal_decompose(feats, bb, bn)
+    o = po.orthogonal_decompose(feats, bb, bn)
+    same(fgb2, o[0], 'g1 fgb2'); same(fgn2, o[1], 'g1 fgn2'); same(bg2, o[2], 'g1 bg2')
+    s1 = F.normalize(bb, p=2, dim=-1)
+    save('g1_decompose', proj=torch.matmul(s1, feats), fg_sub=fg[:, :, ::32], bg=bg,
+         fgn_sub=fgn2[:, :, ::32], bg2=bg2)
+
+
+# ------------------------------------------------------------------------------------------ G2
+def _head_only(model):
+    model.backbone.base_forward = lambda x: x
+    model.decoder = nn.Identity()
+    return model
+
+
+def g2():
+    ref, ora = build_pair()
+    _head_only(ref)
+    feats = fm.sym('g2/feats', (2, 512, 8, 8), 1.0).requires_grad_(True)
+    coef = fm.sym('g2/coef', (2, 8, 8, 8), 1.0)
+    ref.criterion = None
+    preds = ref(feats)
+    (preds * coef).sum().backward()
+    feats_o = feats.detach().clone().requires_grad_(True)
+    preds_o = po.head_base(ora, feats_o)
+    (preds_o * coef).sum().backward()
+    same(preds, preds_o, 'g2 preds')
+    same(feats.grad, feats_o.grad, 'g2 dfeats', 1e-6)
+    same(ref.base_emb.grad, ora.base_emb.grad, 'g2 demb', 1e-6)
+    save('g2_head', preds=preds, dfeats=feats.grad, d_base_emb=ref.base_emb.grad,
+         d_cls0=ref.classifier[0].weight.grad[::8, ::8, 0, 0], d_cls2=ref.classifier[2].weight.grad[::8, ::8, 0, 0],
+         d_cls4=ref.classifier[4].weight.grad[0, :, 0, 0])
+    # ft head (forward_all) on the same feats
+    ref, ora = build_pair(is_ft=True, n_novel=4)
+    _head_only(ref)
+    ref.eval(); ora.eval()
+    pa = ref(feats.detach())
+    pa_o, _ = po.head_all(ora, feats.detach())
+    same(pa, pa_o, 'g2 preds_all')
+    save('g2_head_all', preds=pa)
+
+
+# ------------------------------------------------------------------------------------------ G3
+def g3():
+    cr, co = RefOrthLoss(ignore_index=255), po.OrthLossOracle(ignore_index=255)
+    preds = fm.sym('g3/preds', (2, 8, 8, 8), 2.0).requires_grad_(True)
+    target = fm.formula_mask(2, 64, 64, 8, tag='g3/mask', block=8, ignore_rows=5)
+    e = F.normalize(fm.sym('g3/emb', (7, 512), 1.0), dim=-1)
+    sim = (e @ e.t()).requires_grad_(True)
+    d = cr(preds, target, proto_sim=sim)
+    d['total_loss'].backward()
+    po_preds = preds.detach().clone().requires_grad_(True)
+    d_o = co(po_preds, target, proto_sim=sim.detach())
+    d_o['total_loss'].backward()
+    for k in d:
+        same(d[k], d_o[k], 'g3 ' + k)
+    same(preds.grad, po_preds.grad, 'g3 dpreds')
+    rect = fm.sym('g3/rect', (4, 11), 1.0).requires_grad_(True)
+    orth_rect = cr.get_orth_loss(rect, is_ft=True)
+    orth_rect.backward()
+    same(orth_rect, co.get_orth_loss(rect.detach()), 'g3 rect')
+    # 12-class ft-shaped case with labels 0..11 and 255
+    preds12 = fm.sym('g3/preds12', (2, 12, 8, 8), 2.0).requires_grad_(True)
+    t12 = fm.formula_mask(2, 64, 64, 12, tag='g3/mask12', block=8, ignore_rows=3)
+    d12 = cr(preds12, t12, is_ft=True, proto_sim=rect.detach())
+    d12['total_loss'].backward()
+    save('g3_loss', total=d['total_loss'], seg=d['seg_loss'], orth=d['orth_loss'], dpreds=preds.grad, dsim=sim.grad,
+         orth_rect=orth_rect, d_rect=rect.grad, total12=d12['total_loss'], seg12=d12['seg_loss'], dpreds12=preds12.grad)
+
+
+# ------------------------------------------------------------------------------------------ G4
+def g4():
+    for tag, (feat, outf, hw) in {'a': (64, 64, 12), 'b': (128, 64, 16)}.items():
+        ref = ref_pop.PSPModule(feat, out_features=outf)
+        ora = po.make_ppm(feat, outf)
+        sd = {k: fm.formula_tensor('g4' + tag + '/' + k, v) for k, v in ref.state_dict().items()}
+        ref.load_state_dict(sd); ora.load_state_dict(sd)
+        x = fm.sym('g4%s/x' % tag, (2, feat, hw, hw), 1.0).relu_().requires_grad_(True)
+        coef = fm.sym('g4%s/coef' % tag, (2, outf, hw, hw), 1.0)
+        ref.train(); ora.train()
+        y = ref(x); (y * coef).sum().backward()
+        xo = x.detach().clone().requires_grad_(True)
+        yo = po.ppm_forward(ora, xo); (yo * coef).sum().backward()
+        same(y, yo, 'g4 y'); same(x.grad, xo.grad, 'g4 dx', 1e-6)
+        ref.eval()
+        ye = ref(x.detach())
+        save('g4_ppm_' + tag, y=y, dx=x.grad, y_eval=ye,
+             d_bott_w=ref.bottleneck[0].weight.grad[::4, ::16], d_stage3_w=ref.stages[3][1].weight.grad[:, :, 0, 0],
+             d_stage0_gamma=ref.stages[0][2].weight.grad, rm_stage3=ref.stages[3][2].running_mean,
+             rv_bott=ref.bottleneck[1].running_var)
+
+
+# ------------------------------------------------------------------------------------------ G5
+G5_CASES = {  # name: (inplanes, planes, stride, dilation, downsample)
+    's1_ds': (64, 64, 1, 1, True),
+    's1_id': (256, 64, 1, 1, False),
+    's2_ds': (256, 128, 2, 1, True),
+    'd2_ds': (512, 256, 1, 2, True),
+    'd4_id': (1024, 256, 1, 4, False),
+}
+
+
+def g5():
+    for name, (inp, pl, st, dil, ds) in G5_CASES.items():
+        dsm = None
+        if ds:
+            dsm = nn.Sequential(nn.Conv2d(inp, pl * 4, 1, stride=st, bias=False), nn.BatchNorm2d(pl * 4))
+        ref = RefBottleneck(inp, pl, stride=st, dilation=dil, downsample=dsm)
+        ora = po.make_bottleneck(inp, pl, st, dil, ds)
+        sd = {k: fm.formula_tensor('g5' + name + '/' + k, v) for k, v in ref.state_dict().items()}
+        ref.load_state_dict(sd); ora.load_state_dict(sd)
+        x = fm.sym('g5%s/x' % name, (2, inp, 16, 16), 1.0).relu_().requires_grad_(True)
+        ref.train(); ora.train()
+        y = ref(x)
+        coef = fm.sym('g5%s/coef' % name, tuple(y.shape), 1.0)
+        (y * coef).sum().backward()
+        xo = x.detach().clone().requires_grad_(True)
+        yo = po.bottleneck_forward(ora, xo); (yo * coef).sum().backward()
+        same(y, yo, 'g5 y ' + name); same(x.grad, xo.grad, 'g5 dx ' + name, 1e-6)
+        same(ref.bn2.running_var, ora.bn2.running_var, 'g5 rv')
+        ref.eval()
+        ye = ref(x.detach())
+        save('g5_bottleneck_' + name, y=y[:, ::4], dx=x.grad[:, ::4], y_eval=ye[:, ::4],
+             d_conv2_w=ref.conv2.weight.grad[::4, ::4], d_conv1_w=ref.conv1.weight.grad[::4, ::4, 0, 0],
+             d_conv3_w=ref.conv3.weight.grad[::8, ::4, 0, 0],
+             d_bn3_gamma=ref.bn3.weight.grad, d_bn1_beta=ref.bn1.bias.grad,
+             rm_bn2=ref.bn2.running_mean, rv_bn2=ref.bn2.running_var)
+
+
+# ------------------------------------------------------------------------------------------ G6
+def g6():
+    ref, ora = build_pair()
+    img = fm.formula_image(2, 512, 512, 'g6/img')
+    mask = fm.formula_mask(2, 512, 512, 8, 'g6/mask')
+    ref.train(); ora.train()
+    crit = ref.criterion
+    ref.criterion = None
+    logits = ref(img)                          # train-mode forward (batch-stat BN), updates running stats
+    ref.criterion = crit
+    sim_e = F.normalize(ref.base_emb.unsqueeze(0), p=2, dim=-1).squeeze(0)
+    loss = crit(logits, mask, proto_sim=sim_e @ sim_e.t())
+    loss['total_loss'].backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 1e30)
+    lo = ora(img, mask)
+    lo['total_loss'].backward()
+    gnorm_o = torch.nn.utils.clip_grad_norm_(ora.parameters(), 1e30)
+    for k in loss:
+        same(loss[k], lo[k], 'g6 ' + k)
+    same(gnorm, gnorm_o, 'g6 gnorm', 1e-6)
+    same(ref.backbone.conv1.weight.grad, ora.backbone.conv1.weight.grad, 'g6 dconv1', 1e-6)
+    up = F.interpolate(logits, size=(512, 512), mode='bilinear', align_corners=True)
+    amax = up.argmax(1).to(torch.uint8)
+    ref.eval()
+    logits_eval = ref(img)                     # eval-mode forward with the just-updated running stats
+    gn = {k: p.grad.norm() for k, p in ref.named_parameters()}
+    keys = sorted(gn)
+    save('g6_full_r50', logits=logits, argmax=amax, total=loss['total_loss'], seg=loss['seg_loss'], orth=loss['orth_loss'],
+         gnorm=gnorm, d_base_emb=ref.base_emb.grad, d_cls4=ref.classifier[4].weight.grad[0, :, 0, 0],
+         d_conv1=ref.backbone.conv1.weight.grad, d_dec_bias=ref.decoder.bottleneck[3].bias.grad,
+         rm_bn1=ref.backbone.bn1.running_mean, rv_bn1=ref.backbone.bn1.running_var,
+         rm_l4=ref.backbone.layer4[2].bn3.running_mean,
+         logits_eval=logits_eval, grad_norm_keys=np.array(keys), grad_norms=torch.stack([gn[k] for k in keys]))
+
+
+# ------------------------------------------------------------------------------------------ G7
+def g7():
+    ref, ora = build_pair(is_ft=True, n_novel=4)
+    ref.init_cls_n(); po.init_cls_n(ora)
+    # make classifier_n differ from classifier so channel routing mistakes show
+    with torch.no_grad():
+        for (k, p), (_, q) in zip(ref.classifier_n.named_parameters(), ora.classifier_n.named_parameters()):
+            p.add_(fm.sym('g7/cn/' + k, tuple(p.shape), 0.01)); q.copy_(p)
+    img = fm.formula_image(1, 512, 512, 'g7/img')
+    img_b = fm.formula_image(1, 512, 512, 'g7/img_b')
+    mask = fm.formula_mask(1, 512, 512, 4, 'g7/mask', ignore_rows=0, lo=8)     # novel ids 8..11
+    mask[mask == 8] = 255                                                     # some ignore (oem_ft.py:197 style)
+    mask_b = fm.formula_mask(1, 512, 512, 8, 'g7/mask_b', ignore_rows=0)       # base ids 0..7
+    mb_r, mb_o = mask_b.clone(), mask_b.clone()
+    ref.train_mode(); po.train_mode(ora)
+    d = ref(img, mask, img_b, mb_r)
+    d['total_loss'].backward()
+    do = ora(img, mask, img_b, mb_o)
+    do['total_loss'].backward()
+    for k in d:
+        same(d[k], do[k], 'g7 ' + k)
+    assert torch.equal(mb_r, mb_o), 'g7 pseudo labels differ'
+    same(ref.novel_emb.grad, ora.novel_emb.grad, 'g7 dnovel', 1e-6)
+    crit = ref.criterion
+    ref.criterion = None
+    preds = ref(img, mask, img_b, mask_b.clone())
+    ref.criterion = crit
+    ref.eval()
+    pall = ref(img)
+    save('g7_ft', preds=preds, mask_b_new=mb_r.to(torch.uint8), total=d['total_loss'], seg=d['seg_loss'], orth=d['orth_loss'],
+         d_novel_emb=ref.novel_emb.grad, d_clsn4=ref.classifier_n[4].weight.grad[0, :, 0, 0],
+         d_clsn0=ref.classifier_n[0].weight.grad[::8, ::8, 0, 0], preds_all=pall)
+
+
+# ------------------------------------------------------------------------------------------ G8
+def g8():
+    ref, ora = build_pair()
+    img = fm.formula_image(2, 512, 512, 'g6/img')
+    mask = fm.formula_mask(2, 512, 512, 8, 'g6/mask')
+    groups = ref_utils.get_parameters(ref, lr=1e-5)
+    groups_o, keys_o = po.param_groups(ora, lr=1e-5)
+    sizes = [(len(g['params']), sum(p.numel() for p in g['params'])) for g in groups]
+    sizes_o = [(len(g['params']), sum(p.numel() for p in g['params'])) for g in groups_o]
+    assert sizes == sizes_o, (sizes, sizes_o)
+    opt = torch.optim.AdamW(groups, lr=1e-5, weight_decay=1e-4)
+    ref.train()
+    losses, norms = [], []
+    for step in range(3):
+        # loop body of train_base.py:250-264 with GradScaler as identity (CPU): the scaler's step + the
+        # explicit optimizer.step() == two AdamW steps on the same grads
+        opt.zero_grad()
+        d = ref(img, mask)
+        d['total_loss'].backward()
+        norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), 5.0)
+        opt.step(); opt.step()
+        losses.append([float(d['total_loss']), float(d['seg_loss']), float(d['orth_loss'])]); norms.append(float(norm))
+        print('g8 step', step, losses[-1], norms[-1])
+    save('g8_traj', losses=np.array(losses, dtype=np.float64), norms=np.array(norms, dtype=np.float64),
+         group_sizes=np.array(sizes, dtype=np.int64), base_emb_after=ref.base_emb.detach(),
+         group_keys0=np.array(keys_o[0]), group_keys1=np.array(keys_o[1]), group_keys2=np.array(keys_o[2]))
+
+
+# ------------------------------------------------------------------------------------------ G9 / G10
+def g9():
+    feat = fm.sym('g9/feat', (2, 32, 8, 8), 1.0)
+    m = (fm.uniform01('g9/mask', 2 * 64 * 64).reshape(2, 1, 64, 64) > 0.5).float()
+    r = ref_psp.masked_average_pooling(feat, m)
+    same(r, po.masked_average_pooling(feat, m), 'g9')
+    save('g9_map', proto=r)
+
+
+def g10():
+    pred = (fm.uniform01('g10/pred', 2 * 64 * 64) * 8).floor().long().reshape(2, 64, 64)
+    tgt = (fm.uniform01('g10/tgt', 2 * 64 * 64) * 8).floor().long().reshape(2, 64, 64)
+    tgt[0, :5] = 255
+    # the reference's histc rejects int64 on CPU; run it on float copies -- same counts
+    i, u, t = ref_utils.intersectionAndUnionGPU(pred.clone().float(), tgt.clone().float(), 8, 255)
+    io, uo, to = po.intersection_and_union(pred.clone(), tgt.clone(), 8, 255)
+    same(i, io, 'g10 i'); same(u, uo, 'g10 u'); same(t, to, 'g10 t')
+    save('g10_iou', inter=i, union=u, target=t)
+
+
+ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        print('==', w)
+        ALL[w]()
