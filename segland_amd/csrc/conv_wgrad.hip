@@ -228,10 +228,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+int g_use_tr = -1;
 int use_tr() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v;
+  if (g_use_tr < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); g_use_tr = (e && e[0] == '0') ? 0 : 1; }
+  return g_use_tr;
 }
 
 struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; size_t ws_bytes; };
@@ -275,6 +275,9 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+// test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
+extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 
 extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 32) return 0;

@@ -1,0 +1,360 @@
+"""Block-level autograd Functions: each one runs a fused chain of libsegland_hip.so kernels forward and the
+hand-written backward chain, so PyTorch's autograd only links blocks together and accumulates parameter gradients
+(which is what lets DDP's bucketed RCCL all-reduce overlap with the backward of earlier blocks).
+
+nn.Conv2d / nn.BatchNorm2d modules are used purely as parameter holders (state_dict compatibility with the
+reference); their own forward is never called.
+"""
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from .ops import ConvSpec
+
+_wcache = {}            # id(param) -> (version, dtype, data_ptr, w_fwd, w_bwd)
+_nbt_pending = []       # num_batches_tracked buffers to bump once per forward
+
+
+def prepared(w, dtype):
+    """GEMM-layout copies of a conv weight in the compute dtype, refreshed when the parameter changes."""
+    key = id(w)
+    ent = _wcache.get(key)
+    if ent is None or ent[0] != w._version or ent[1] != dtype or ent[2] != w.data_ptr():
+        wf, wb = ops.weight_prep(w, dtype)
+        ent = (w._version, dtype, w.data_ptr(), wf, wb)
+        _wcache[key] = ent
+    return ent[3], ent[4]
+
+
+def flush_num_batches_tracked():
+    if _nbt_pending:
+        torch._foreach_add_(_nbt_pending, 1)
+        _nbt_pending.clear()
+
+
+def spec_of(conv):
+    return ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
+
+
+def _bn_coeffs(bn, part, count):
+    """(mean, invstd, scale, shift) for this call; train mode also updates the running statistics."""
+    if bn.training:
+        if count <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got %d' % count)   # as F.batch_norm
+        if bn.momentum is None:
+            raise RuntimeError('segland_amd: cumulative-average BatchNorm (momentum=None) is not supported')
+        out = ops.bn_finalize_train(part, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
+        _nbt_pending.append(bn.num_batches_tracked)
+        return out
+    return ops.bn_finalize_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+
+
+def conv_bn_fwd(x, conv, bn, relu, residual=None, x2=None, out=None):
+    wf, _ = prepared(conv.weight, x.dtype)
+    c, part = ops.conv2d_fwd(x, wf, spec_of(conv), x2=x2, want_stats=bn.training)
+    mean, invstd, scale, shift = _bn_coeffs(bn, part, c.numel() // c.shape[-1])
+    y = ops.bn_act(c, scale, shift, residual=residual, relu=relu, out=out)
+    return c, y, mean, invstd
+
+
+def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None):
+    """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres)."""
+    dc, dres, dgamma, dbeta = ops.bn_bwd(dy, y_mask, c, mean, invstd, bn.weight, train=bn.training, want_dres=want_dres)
+    spec = spec_of(conv)
+    dx = dw = None
+    if need_dx:
+        _, wb = prepared(conv.weight, c.dtype)
+        dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, C1=(x.shape[3] if x2 is not None else None), out=dx_out)
+    if need_dw:
+        dw = ops.conv2d_bwd_weight(x, dc, spec, x2=x2)
+    return dx, dw, dgamma, dbeta, dres
+
+
+# ------------------------------------------------------------------------------------------------ stem
+class StemFn(torch.autograd.Function):
+    """conv1 7x7 s2 -> bn1 -> relu -> maxpool 3x3 s2 (networks/backbones/resnet.py:124-125). img: NCHW float."""
+
+    @staticmethod
+    def forward(ctx, img, w, gamma, beta, net, dtype):
+        bn = net.bn1
+        c0, part = ops.stem_conv_fwd(img, w.detach(), dtype, bn.training)
+        mean, invstd, scale, shift = _bn_coeffs(bn, part, c0.numel() // 64)
+        pooled, idx = ops.stem_bn_relu_pool(c0, scale, shift, want_idx=True)
+        ctx.net = net
+        ctx.save_for_backward(img, c0, idx, mean, invstd, scale, shift)
+        return pooled
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dp):
+        img, c0, idx, mean, invstd, scale, shift = ctx.saved_tensors
+        bn = ctx.net.bn1
+        g0 = ops.stem_pool_relu_bwd(dp.contiguous(), idx, c0, scale, shift)
+        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training)
+        dw = ops.stem_conv_bwd_weight(img, dc0) if ctx.needs_input_grad[1] else None
+        return None, dw, dgamma, dbeta, None, None
+
+
+# ------------------------------------------------------------------------------------------------ bottleneck
+class BottleneckFn(torch.autograd.Function):
+    """networks/backbones/resnet.py:57-78 as one kernel chain; x and the result are NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        c1, a1, m1, i1 = conv_bn_fwd(x, blk.conv1, blk.bn1, relu=True)
+        c2, a2, m2, i2 = conv_bn_fwd(a1, blk.conv2, blk.bn2, relu=True)
+        if blk.downsample is not None:
+            cd, res, md, idd = conv_bn_fwd(x, blk.downsample[0], blk.downsample[1], relu=False)
+        else:
+            cd, res, md, idd = None, x, None, None
+        c3, out, m3, i3 = conv_bn_fwd(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res)
+        ctx.blk = blk
+        ctx.has_ds = blk.downsample is not None
+        saved = [x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3]
+        if ctx.has_ds:
+            saved += [cd, md, idd]
+        ctx.save_for_backward(*saved)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        blk = ctx.blk
+        sv = ctx.saved_tensors
+        x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3 = sv[:13]
+        dout = dout.contiguous()
+        need_w = ctx.needs_input_grad[2]            # params are all-or-nothing frozen in this model family
+        need_x = ctx.needs_input_grad[0]
+        # bn3 (+ residual add + last relu): dres = masked dout feeds the shortcut
+        da2, dw3, dg3, db3, dres = conv_bn_bwd(dout, out if blk.last_relu else None, c3, a2, blk.conv3, blk.bn3, m3, i3,
+                                               True, need_w, want_dres=blk.last_relu)
+        if not blk.last_relu:
+            dres = dout
+        da1, dw2, dg2, db2, _ = conv_bn_bwd(da2, a2, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w)
+        grads_ds = ()
+        if ctx.has_ds:
+            cd, md, idd = sv[13:16]
+            dxd, dwd, dgd, dbd, _ = conv_bn_bwd(dres, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w)
+            grads_ds = (dwd, dgd, dbd)
+            addend = dxd
+        else:
+            addend = dres
+        dx, dw1, dg1, db1, _ = conv_bn_bwd(da1, a1, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w, addend=addend if need_x else None)
+        return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
+
+
+def bottleneck_params(blk):
+    p = [blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+         blk.conv3.weight, blk.bn3.weight, blk.bn3.bias]
+    if blk.downsample is not None:
+        p += [blk.downsample[0].weight, blk.downsample[1].weight, blk.downsample[1].bias]
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ pyramid pooling
+class PPMFn(torch.autograd.Function):
+    """networks/pspnet_pop.py:31-35: 4 x (adaptive pool -> 1x1 -> BN -> ReLU -> bilinear up) (+) feats -> 3x3 -> BN -> ReLU -> 1x1+bias.
+    The 4096-channel concat is virtual: the 3x3 conv reads [priors | feats] from two tensors."""
+
+    @staticmethod
+    def forward(ctx, x4, dec, *params):
+        sizes = dec.sizes
+        B, H, W, Cf = x4.shape
+        Cs = dec.stages[0][1].out_channels
+        pooled = ops.ppm_pool_fwd(x4, sizes)
+        stage_act = torch.empty((pooled.shape[0], Cs), dtype=x4.dtype, device=x4.device)
+        cl, ml, il, off = [], [], [], 0
+        for s, st in zip(sizes, dec.stages):
+            n = B * s * s
+            xin = pooled[off:off + n].view(B, s, s, Cf)
+            c, _, m, i = conv_bn_fwd(xin, st[1], st[2], relu=True, out=stage_act[off:off + n].view(B, s, s, Cs))
+            cl.append(c); ml.append(m); il.append(i); off += n
+        priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes)
+        bt = dec.bottleneck
+        cb, ab, mb, ib = conv_bn_fwd(priors, bt[0], bt[1], relu=True, x2=x4)
+        wf, _ = prepared(bt[3].weight, x4.dtype)
+        feat, _ = ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())
+        ctx.dec = dec
+        ctx.save_for_backward(x4, pooled, stage_act, priors, cb, ab, mb, ib, *cl, *ml, *il)
+        return feat
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dfeat):
+        dec = ctx.dec
+        sizes, nl = dec.sizes, len(dec.sizes)
+        sv = ctx.saved_tensors
+        x4, pooled, stage_act, priors, cb, ab, mb, ib = sv[:8]
+        cl, ml, il = sv[8:8 + nl], sv[8 + nl:8 + 2 * nl], sv[8 + 2 * nl:8 + 3 * nl]
+        B, H, W, Cf = x4.shape
+        Cs = stage_act.shape[1]
+        bt = dec.bottleneck
+        dfeat = dfeat.contiguous()
+        need_w = ctx.needs_input_grad[2]
+        need_x = ctx.needs_input_grad[0]
+        spec_f = spec_of(bt[3])
+        _, wbf = prepared(bt[3].weight, x4.dtype)
+        dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
+        dwf = ops.conv2d_bwd_weight(ab, dfeat, spec_f) if need_w else None
+        dbias = ops.colsum_rows(dfeat) if need_w else None
+        dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
+        dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
+        dpooled = torch.empty_like(pooled)
+        gstage, off = [], 0
+        for k, (s, st) in enumerate(zip(sizes, dec.stages)):
+            n = B * s * s
+            xin = pooled[off:off + n].view(B, s, s, Cf)
+            dxs, dws, dgs, dbs, _ = conv_bn_bwd(dstage[off:off + n].view(B, s, s, Cs), stage_act[off:off + n].view(B, s, s, Cs), cl[k], xin,
+                                                st[1], st[2], ml[k], il[k], need_x, need_w, dx_out=dpooled[off:off + n].view(B, s, s, Cf))
+            gstage += [dws, dgs, dbs]; off += n
+        dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=len(sizes) * Cs) if need_x else None
+        return (dx4, None, *gstage, dwb, dgb, dbb, dwf, dbias)
+
+
+def ppm_params(dec):
+    p = []
+    for st in dec.stages:
+        p += [st[1].weight, st[2].weight, st[2].bias]
+    bt = dec.bottleneck
+    return p + [bt[0].weight, bt[1].weight, bt[1].bias, bt[3].weight, bt[3].bias]
+
+
+# ------------------------------------------------------------------------------------------------ POP head
+def _mlp_fwd(X, cls):
+    """classifier MLP (pspnet_pop.py:46-52) on rows X [R,512]: two MFMA 1x1 convs with fused ReLU, then a row dot."""
+    R, Cn = X.shape
+    x4 = X.view(1, 1, R, Cn)
+    w1f, _ = prepared(cls[0].weight, X.dtype)
+    w2f, _ = prepared(cls[2].weight, X.dtype)
+    h1, _ = ops.conv2d_fwd(x4, w1f, spec_of(cls[0]), relu=True)
+    h2, _ = ops.conv2d_fwd(h1, w2f, spec_of(cls[2]), relu=True)
+    w3 = cls[4].weight.detach().view(-1)
+    z = ops.rowdot_fwd(h2.view(R, Cn), w3)
+    return h1, h2, z
+
+
+def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x):
+    R, Cn = X.shape
+    w3 = cls[4].weight.detach().view(-1)
+    dh2, dw3 = ops.rowdot_bwd(h2.view(R, Cn), w3, dz)
+    dh2 = dh2.view(1, 1, R, Cn)
+    _, w2b = prepared(cls[2].weight, X.dtype)
+    dh1 = ops.conv2d_bwd_data(dh2, w2b, spec_of(cls[2]), (1, R), mask_src=h1)
+    dw2 = ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2])) if need_w else None
+    dX = None
+    if need_x:
+        _, w1b = prepared(cls[0].weight, X.dtype)
+        dX = ops.conv2d_bwd_data(dh1, w1b, spec_of(cls[0]), (1, R)).view(R, Cn)
+    dw1 = ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0])) if need_w else None
+    return dX, dw1, dw2, (dw3.view_as(cls[4].weight) if need_w else None)
+
+
+class PopHeadFn(torch.autograd.Function):
+    """orthogonal_decompose + classifier(s) in the collapsed form.
+    feat NHWC [B,h,w,512]; S_b / S_n: L2-normalised prototypes (float).  Returns preds [B, 1+Kb+Kn, h, w] float,
+    channel order [bg | base | novel] (pspnet_pop.py:159,219).
+    Base mode (cls_n is None): one MLP chain (classifier) over [bg rows ; +-S_b].
+    ft mode: classifier over [+-S_b] (base scalars), classifier_n over [bg rows ; +-S_n]."""
+
+    @staticmethod
+    def forward(ctx, feat, S_b, S_n, model, *params):
+        B, h, w, Cn = feat.shape
+        R, N = B * h * w, h * w
+        Kb = S_b.shape[0]
+        Kn = 0 if S_n is None else S_n.shape[0]
+        ft = S_n is not None
+        S = torch.cat([S_b, S_n], 0).contiguous() if ft else S_b.contiguous()
+        feats2d = feat.view(R, Cn)
+        S_main = S_n.contiguous() if ft else S            # prototypes whose +- rows ride the bg chain
+        Km = S_main.shape[0]
+        X = torch.empty((R + 2 * Km, Cn), dtype=feat.dtype, device=feat.device)
+        proj = ops.pop_decompose_into(feats2d, S, X[:R])
+        ops.pop_proto_rows(S_main, X[R:])
+        cls_main = model.classifier_n if ft else model.classifier
+        h1, h2, z = _mlp_fwd(X, cls_main)
+        if ft:
+            Xb = torch.empty((2 * Kb, Cn), dtype=feat.dtype, device=feat.device)
+            ops.pop_proto_rows(S_b.contiguous(), Xb)
+            h1b, h2b, zb = _mlp_fwd(Xb, model.classifier)
+            a = torch.cat([zb[:Kb], z[R:R + Kn]]).contiguous()
+            b = torch.cat([zb[Kb:], z[R + Kn:]]).contiguous()
+        else:
+            Xb = h1b = h2b = None
+            a, b = z[R:R + Kb].contiguous(), z[R + Kb:].contiguous()
+        z_bg = z[:R].contiguous()
+        preds = ops.pop_combine_fwd(proj, z_bg, a, b, B, N)
+        ctx.model, ctx.ft, ctx.dims = model, ft, (B, h, w, Cn, Kb, Kn)
+        ctx.save_for_backward(feat, S, X, proj, h1, h2, a, b, *([Xb, h1b, h2b] if ft else []))
+        return preds.view(B, 1 + Kb + Kn, h, w)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpreds):
+        model, ft = ctx.model, ctx.ft
+        B, h, w, Cn, Kb, Kn = ctx.dims
+        R, N = B * h * w, h * w
+        sv = ctx.saved_tensors
+        feat, S, X, proj, h1, h2, a, b = sv[:8]
+        ni = ctx.needs_input_grad
+        need_feat, need_sb, need_sn = ni[0], ni[1], ni[2]
+        dpreds = dpreds.contiguous().view(B, 1 + Kb + Kn, N)
+        dz_bg, dproj, da, db = ops.pop_combine_bwd(dpreds, proj, a, b, B, N)
+        cls_main = model.classifier_n if ft else model.classifier
+        npar = 3
+        need_w_main = ni[4 + (npar if ft else 0)]
+        if ft:
+            dz = torch.cat([dz_bg, da[Kb:], db[Kb:]]).contiguous()
+        else:
+            dz = torch.cat([dz_bg, da, db]).contiguous()
+        dX, dw1, dw2, dw3 = _mlp_bwd(X, h1, h2, cls_main, dz, need_w_main, need_feat or need_sb or need_sn)
+        gb = (None, None, None)
+        dS = None
+        dfeat = None
+        if need_feat or need_sb or need_sn:
+            dq, dS = ops.pop_decompose_bwd(dX[:R], feat.view(R, Cn), S, proj, dproj)
+            dfeat = dq.view(B, h, w, Cn) if need_feat else None
+            Km = Kn if ft else Kb
+            rows = dX[R:].float()
+            dS_rows = rows[:Km] - rows[Km:]
+            if ft:
+                dS = torch.cat([dS[:Kb], dS[Kb:] + dS_rows], 0)
+            else:
+                dS = dS + dS_rows
+        if ft:
+            Xb, h1b, h2b = sv[8:11]
+            need_w_b = ni[4]
+            if need_w_b or need_sb:
+                dzb = torch.cat([da[:Kb], db[:Kb]]).contiguous()
+                dXb, bw1, bw2, bw3 = _mlp_bwd(Xb, h1b, h2b, model.classifier, dzb, need_w_b, need_sb)
+                gb = (bw1, bw2, bw3)
+                if need_sb:
+                    rb = dXb.float()
+                    dS = torch.cat([dS[:Kb] + rb[:Kb] - rb[Kb:], dS[Kb:]], 0)
+            dSb = dS[:Kb].contiguous() if (need_sb and dS is not None) else None
+            dSn = dS[Kb:].contiguous() if (need_sn and dS is not None) else None
+            return (dfeat, dSb, dSn, None, *gb, dw1, dw2, dw3)
+        return (dfeat, dS if need_sb else None, None, None, dw1, dw2, dw3)
+
+
+def cls_params(cls):
+    return [cls[0].weight, cls[2].weight, cls[4].weight]
+
+
+# ------------------------------------------------------------------------------------------------ loss
+class UpsampleCEFn(torch.autograd.Function):
+    """F.interpolate(align_corners=True) + CrossEntropyLoss(ignore_index, mean) of loss/criterion.py:51-52, fused."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        logits = logits.contiguous()
+        out = ops.upsample_ce_fwd(logits, target, ignore_index)
+        ctx.ignore = ignore_index
+        ctx.save_for_backward(logits, target, out)
+        return out[0].clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        logits, target, out = ctx.saved_tensors
+        gs = g.detach().reshape(1).float().contiguous()
+        return ops.upsample_ce_bwd(logits, target, out, gs, ctx.ignore), None, None

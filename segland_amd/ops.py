@@ -1,0 +1,387 @@
+"""Tensor-level wrappers over the C ABI (include/segland_hip.h).
+
+PyTorch supplies device memory (caching allocator) and the current HIP stream only; every arithmetic op on the hot
+path is a kernel of libsegland_hip.so.  Activations are NHWC tensors ([B,H,W,C], contiguous) in the compute dtype
+(torch.bfloat16 or torch.float32); statistics, logits and weight gradients are float32.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import SL_BF16, SL_F32, SlConvDesc, SlPpmDesc, check
+
+_DT = {torch.float32: SL_F32, torch.bfloat16: SL_BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise RuntimeError('segland_amd: unsupported compute dtype %s (bfloat16 or float32)' % (t,))
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('segland_amd: tensor is not on the GPU; the HIP path has no CPU fallback')
+    if not t.is_contiguous():
+        raise RuntimeError('segland_amd: non-contiguous tensor passed to a kernel')
+    return C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(n, dev, zero=False):
+    return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
+
+
+# --------------------------------------------------------------------------------------------- convolution
+class ConvSpec:
+    __slots__ = ('cin', 'cout', 'k', 'stride', 'pad', 'dil')
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1):
+        self.cin, self.cout, self.k, self.stride, self.pad, self.dil = cin, cout, k, stride, pad, dil
+
+    def out_hw(self, H, W):
+        f = lambda n: (n + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
+        return f(H), f(W)
+
+
+_desc_cache = {}
+
+
+def conv_desc(dtype, B, H, W, spec, C1=None):
+    key = (dtype, B, H, W, spec.cin, spec.cout, spec.k, spec.stride, spec.pad, spec.dil, C1)
+    d = _desc_cache.get(key)
+    if d is None:
+        Ho, Wo = spec.out_hw(H, W)
+        d = SlConvDesc(_DT[dtype], B, H, W, spec.cin, spec.cout, spec.k, spec.k, spec.stride, spec.pad, spec.dil, Ho, Wo,
+                       spec.cin if C1 is None else C1)
+        _desc_cache[key] = d
+    return d
+
+
+def weight_prep(w, dtype, want_fwd=True, want_bwd=True):
+    """OIHW float master weight -> (w_fwd [O][kh][kw][I], w_bwd [I][kh][kw][O]) in the compute dtype."""
+    O, I, KH, KW = w.shape
+    wf = torch.empty((O, KH, KW, I), dtype=dtype, device=w.device) if want_fwd else None
+    wb = torch.empty((I, KH, KW, O), dtype=dtype, device=w.device) if want_bwd else None
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    check(_lib.lib().sl_weight_prep(_DT[dtype], _p(wd), O, I, KH, KW, _p(wf), _p(wb), _s()), 'weight_prep')
+    return wf, wb
+
+
+def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False):
+    B, H, W, C1 = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
+    y = torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    part = None
+    if want_stats:
+        part = _f32((_lib.lib().sl_conv2d_stat_rows(C.byref(d)), 2, spec.cout), x.device)
+    check(_lib.lib().sl_conv2d_fwd(C.byref(d), _p(x), _p(x2), _p(wf), _p(bias), int(relu), _p(y), _p(part), _s()), 'conv2d_fwd')
+    return y, part
+
+
+def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, out=None):
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, C1)
+    dx = out if out is not None else torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    assert dx.numel() == B * H * W * spec.cin and dx.dtype == dy.dtype
+    check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
+    return dx
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, dev):
+    """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream)."""
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _ws_cache[key] = w
+    return w
+
+
+def conv2d_bwd_weight(x, dy, spec, x2=None):
+    B, H, W, C1 = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
+    need = _lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d))
+    ws = workspace(need, x.device)
+    dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    check(_lib.lib().sl_conv2d_bwd_weight(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
+    return dw
+
+
+# --------------------------------------------------------------------------------------------- batch norm
+def bn_finalize_train(part, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+    Cn = part.shape[-1]
+    o = _f32((4, Cn), part.device)
+    check(_lib.lib().sl_bn_finalize_train(_p(part), part.shape[0], Cn, int(count), _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                                          momentum, eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _s()), 'bn_finalize_train')
+    return o[0], o[1], o[2], o[3]          # mean, invstd, scale, shift
+
+
+def bn_finalize_eval(gamma, beta, rmean, rvar, eps=1e-5):
+    Cn = rmean.shape[0]
+    o = _f32((4, Cn), rmean.device)
+    check(_lib.lib().sl_bn_finalize_eval(Cn, _p(gamma), _p(beta), _p(rmean), _p(rvar), eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _s()),
+          'bn_finalize_eval')
+    return o[0], o[1], o[2], o[3]
+
+
+def bn_act(x, scale, shift, residual=None, relu=True, out=None):
+    Cn = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    assert y.numel() == x.numel() and y.dtype == x.dtype
+    check(_lib.lib().sl_bn_act_fwd(dt(x), _p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), x.numel() // Cn, Cn, _s()), 'bn_act_fwd')
+    return y
+
+
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False):
+    """Returns (dx, dres, dgamma, dbeta).  y: post-activation output when a ReLU follows the BN (mask), else None."""
+    Cn = x.shape[-1]
+    rows = x.numel() // Cn
+    L = _lib.lib()
+    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
+    part = _f32((nblk, 2, Cn), x.device)
+    check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
+    o = _f32((5, Cn), x.device)
+    check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
+          'bn_bwd_finalize')
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_dres else None
+    check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
+    return dx, dres, o[0], o[1]
+
+
+def colsum_rows(t):
+    """Per-channel sum over all rows of an NHWC tensor (conv bias gradient) via the BN reduce kernel (S1 with no mask)."""
+    Cn = t.shape[-1]
+    rows = t.numel() // Cn
+    L = _lib.lib()
+    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
+    part = _f32((nblk, 2, Cn), t.device)
+    z = _f32((2, Cn), t.device, zero=True)
+    check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
+    return colsum(part)[0].contiguous()
+
+
+# --------------------------------------------------------------------------------------------- stem
+def stem_conv_fwd(img, w, dtype, want_stats):
+    B, _, H, W = img.shape
+    L = _lib.lib()
+    y = torch.empty((B, H // 2, W // 2, 64), dtype=dtype, device=img.device)
+    part = _f32((L.sl_stem_conv_stat_rows(B, H, W), 2, 64), img.device) if want_stats else None
+    check(L.sl_stem_conv_fwd(_DT[dtype], _p(img), _p(w), _p(y), _p(part), B, H, W, _s()), 'stem_conv_fwd')
+    return y, part
+
+
+def stem_bn_relu_pool(c0, scale, shift, want_idx):
+    B, Hc, Wc, _ = c0.shape
+    pooled = torch.empty((B, Hc // 2, Wc // 2, 64), dtype=c0.dtype, device=c0.device)
+    idx = torch.empty((B, Hc // 2, Wc // 2, 64), dtype=torch.uint8, device=c0.device) if want_idx else None
+    check(_lib.lib().sl_stem_bn_relu_pool_fwd(dt(c0), _p(c0), _p(scale), _p(shift), _p(pooled), _p(idx), B, Hc, Wc, _s()), 'stem_bn_relu_pool_fwd')
+    return pooled, idx
+
+
+def stem_pool_relu_bwd(dpooled, idx, c0, scale, shift):
+    B, Hc, Wc, _ = c0.shape
+    g0 = torch.empty_like(c0)
+    check(_lib.lib().sl_stem_pool_relu_bwd(dt(c0), _p(dpooled), _p(idx), _p(c0), _p(scale), _p(shift), _p(g0), B, Hc, Wc, _s()), 'stem_pool_relu_bwd')
+    return g0
+
+
+def stem_conv_bwd_weight(img, dc0):
+    B, _, H, W = img.shape
+    L = _lib.lib()
+    ws = workspace(L.sl_stem_conv_bwd_weight_workspace(B, H, W), img.device)
+    dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=img.device)
+    check(L.sl_stem_conv_bwd_weight(dt(dc0), _p(img), _p(dc0), _p(dw), _p(ws), ws.numel(), B, H, W, _s()), 'stem_conv_bwd_weight')
+    return dw
+
+
+# --------------------------------------------------------------------------------------------- pyramid pooling
+def ppm_desc(x, sizes):
+    B, H, W, Cn = x.shape
+    return SlPpmDesc(dt(x), B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+
+
+def ppm_rows(B, sizes):
+    return B * sum(s * s for s in sizes)
+
+
+def ppm_pool_fwd(x, sizes):
+    d = ppm_desc(x, sizes)
+    L = _lib.lib()
+    ws = workspace(L.sl_ppm_workspace(C.byref(d)), x.device)
+    pooled = torch.empty((ppm_rows(x.shape[0], sizes), x.shape[3]), dtype=x.dtype, device=x.device)
+    check(L.sl_ppm_pool_fwd(C.byref(d), _p(x), _p(pooled), _p(ws), ws.numel(), _s()), 'ppm_pool_fwd')
+    return pooled
+
+
+def ppm_pool_bwd(dpooled, x_shape, dtype, sizes, dcat=None, cat_off=0):
+    B, H, W, Cn = x_shape
+    d = SlPpmDesc(_DT[dtype], B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+    dx = torch.empty((B, H, W, Cn), dtype=dtype, device=dpooled.device)
+    pitch = dcat.shape[-1] if dcat is not None else 0
+    check(_lib.lib().sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _s()), 'ppm_pool_bwd')
+    return dx
+
+
+def ppm_upsample_fwd(stage, x_shape, sizes):
+    B, H, W, Cn = x_shape
+    Cs = stage.shape[1]
+    d = SlPpmDesc(dt(stage), B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+    priors = torch.empty((B, H, W, len(sizes) * Cs), dtype=stage.dtype, device=stage.device)
+    check(_lib.lib().sl_ppm_upsample_fwd(C.byref(d), Cs, _p(stage), _p(priors), _s()), 'ppm_upsample_fwd')
+    return priors
+
+
+def ppm_upsample_bwd(dcat, x_shape, sizes, Cs):
+    B, H, W, Cn = x_shape
+    L = _lib.lib()
+    d = SlPpmDesc(dt(dcat), B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+    ws = workspace(L.sl_ppm_workspace(C.byref(d)), dcat.device)
+    dstage = torch.empty((ppm_rows(B, sizes), Cs), dtype=dcat.dtype, device=dcat.device)
+    check(L.sl_ppm_upsample_bwd(C.byref(d), Cs, _p(dcat), dcat.shape[-1], _p(dstage), _p(ws), ws.numel(), _s()), 'ppm_upsample_bwd')
+    return dstage
+
+
+# --------------------------------------------------------------------------------------------- POP head
+def pop_decompose_into(feats2d, S, bg_out):
+    R, Cn = feats2d.shape
+    Kt = S.shape[0]
+    proj = _f32((R, Kt), feats2d.device)
+    check(_lib.lib().sl_pop_decompose_fwd(dt(feats2d), _p(feats2d), _p(S), Kt, _p(proj), _p(bg_out), R, Cn, _s()), 'pop_decompose_fwd')
+    return proj
+
+
+def pop_proto_rows(S, dst):
+    Kt, Cn = S.shape
+    check(_lib.lib().sl_pop_proto_rows(dt(dst), _p(S), Kt, Cn, _p(dst), _s()), 'pop_proto_rows')
+
+
+def rowdot_fwd(h, w):
+    R, Cn = h.shape
+    z = _f32((R,), h.device)
+    check(_lib.lib().sl_rowdot_fwd(dt(h), _p(h), _p(w), _p(z), R, Cn, _s()), 'rowdot_fwd')
+    return z
+
+
+def colsum(part):
+    nblk, Cn = part.shape[0], part[0].numel()
+    out = _f32(tuple(part.shape[1:]), part.device)
+    check(_lib.lib().sl_colsum_finalize(_p(part), nblk, Cn, _p(out), _s()), 'colsum_finalize')
+    return out
+
+
+def rowdot_bwd(h, w, dz):
+    R, Cn = h.shape
+    L = _lib.lib()
+    nblk = L.sl_rowdot_bwd_rows(R, Cn)
+    part = _f32((nblk, Cn), h.device)
+    dh = torch.empty_like(h)
+    check(L.sl_rowdot_bwd(dt(h), _p(h), _p(w), _p(dz), _p(dh), _p(part), R, Cn, _s()), 'rowdot_bwd')
+    return dh, colsum(part)
+
+
+def pop_combine_fwd(proj, z_bg, a, b, B, N):
+    Kt = proj.shape[1]
+    preds = _f32((B, 1 + Kt, N), proj.device)
+    check(_lib.lib().sl_pop_combine_fwd(_p(proj), _p(z_bg), _p(a), _p(b), Kt, _p(preds), B, N, _s()), 'pop_combine_fwd')
+    return preds
+
+
+def pop_combine_bwd(dpreds, proj, a, b, B, N):
+    Kt = proj.shape[1]
+    L = _lib.lib()
+    nblk = L.sl_pop_combine_bwd_rows(B, N)
+    dz = _f32((B * N,), proj.device)
+    dproj = torch.empty_like(proj)
+    part = _f32((nblk, 2 * Kt), proj.device)
+    check(L.sl_pop_combine_bwd(_p(dpreds), _p(proj), _p(a), _p(b), Kt, _p(dz), _p(dproj), _p(part), B, N, _s()), 'pop_combine_bwd')
+    dab = colsum(part)
+    return dz, dproj, dab[:Kt], dab[Kt:]
+
+
+def pop_decompose_bwd(dg, feats2d, S, proj, dproj):
+    R, Cn = feats2d.shape
+    Kt = S.shape[0]
+    L = _lib.lib()
+    nblk = L.sl_pop_decompose_bwd_rows(R)
+    part = _f32((nblk, Kt, Cn), feats2d.device)
+    dq = torch.empty_like(feats2d)
+    check(L.sl_pop_decompose_bwd(dt(feats2d), _p(dg), _p(feats2d), _p(S), _p(proj), _p(dproj), Kt, _p(dq), _p(part), R, Cn, _s()), 'pop_decompose_bwd')
+    return dq, colsum(part)
+
+
+# --------------------------------------------------------------------------------------------- loss & labels
+def upsample_ce_fwd(logits, target, ignore_index):
+    B, K, h, w = logits.shape
+    H, W = target.shape[1:]
+    L = _lib.lib()
+    nblk = L.sl_upsample_ce_rows(B, H, W)
+    part = _f32((nblk, 2), logits.device)
+    check(L.sl_upsample_ce_fwd(_p(logits), _p(target), B, K, h, w, H, W, ignore_index, _p(part), _s()), 'upsample_ce_fwd')
+    out = _f32((2,), logits.device)
+    check(L.sl_upsample_ce_finalize(_p(part), nblk, _p(out), _s()), 'upsample_ce_finalize')
+    return out
+
+
+def upsample_ce_bwd(logits, target, loss_cnt, gscale, ignore_index):
+    B, K, h, w = logits.shape
+    H, W = target.shape[1:]
+    dl = torch.empty_like(logits)
+    check(_lib.lib().sl_upsample_ce_bwd(_p(logits), _p(target), _p(loss_cnt), _p(gscale), B, K, h, w, H, W, ignore_index, _p(dl), _s()), 'upsample_ce_bwd')
+    return dl
+
+
+def pseudo_label_(logits, mask, n_base):
+    """In place on `mask` (int64 [B,H,W]); logits [B,K2,h,w] float."""
+    B, K2, h, w = logits.shape
+    check(_lib.lib().sl_pseudo_label(_p(logits), K2, h, w, _p(mask), B, mask.shape[1], mask.shape[2], n_base, _s()), 'pseudo_label')
+    return mask
+
+
+def upsample_argmax(logits, size):
+    B, K, h, w = logits.shape
+    out = torch.empty((B, size[0], size[1]), dtype=torch.uint8, device=logits.device)
+    check(_lib.lib().sl_upsample_argmax(_p(logits), B, K, h, w, size[0], size[1], _p(out), _s()), 'upsample_argmax')
+    return out
+
+
+def iou_hist(pred_u8, target, K, ignore_index):
+    hist = torch.zeros((3, K), dtype=torch.int64, device=target.device)
+    check(_lib.lib().sl_iou_hist(_p(pred_u8), _p(target), target.numel(), K, ignore_index, _p(hist), _s()), 'iou_hist')
+    return hist
+
+
+def masked_avg_pool(feature_nhwc, mask):
+    B, h, w, Cn = feature_nhwc.shape
+    H, W = mask.shape[-2:]
+    proto = _f32((Cn,), mask.device)
+    check(_lib.lib().sl_masked_avg_pool(dt(feature_nhwc), _p(feature_nhwc), _p(mask), B, h, w, Cn, H, W, _p(proto), _s()), 'masked_avg_pool')
+    return proto
+
+
+def nhwc_to_nchw_f32(x):
+    B, H, W, Cn = x.shape
+    out = _f32((B, Cn, H, W), x.device)
+    check(_lib.lib().sl_nhwc_to_nchw_f32(dt(x), _p(x), _p(out), B, H, W, Cn, _s()), 'nhwc_to_nchw_f32')
+    return out
+
+
+def nchw_f32_to_nhwc(x, dtype):
+    B, Cn, H, W = x.shape
+    out = torch.empty((B, H, W, Cn), dtype=dtype, device=x.device)
+    check(_lib.lib().sl_nchw_f32_to_nhwc(_DT[dtype], _p(x), _p(out), B, H, W, Cn, _s()), 'nchw_f32_to_nhwc')
+    return out

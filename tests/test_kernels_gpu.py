@@ -1,0 +1,288 @@
+"""Per-kernel parity of libsegland_hip.so (through the C ABI) against CPU fp32/fp64 references, the oracle and
+the golden vectors.  Tolerances: f32 kernels 1e-4 relative to the tensor scale (fp32 MFMA is an exact fma chain, only
+the summation order differs); bf16 kernels 2e-2 (inputs rounded to bf16, fp32 accumulate).  Integer outputs bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from oracle import formula as fm
+from oracle import pop_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+DEV = 'cuda'
+
+
+def tol(dtype):
+    return 1e-4 if dtype == torch.float32 else 2.5e-2
+
+
+def nhwc(x, dtype):          # NCHW float cpu -> NHWC dtype gpu
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+
+
+def nchw(x):                 # NHWC gpu -> NCHW float cpu
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(x, dtype):           # round a CPU float tensor through the compute dtype
+    return x.to(dtype).float()
+
+
+def assert_close(got, ref, dtype, what='', scale=None, factor=1.0):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    s = float(ref.abs().max()) if scale is None else scale
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype) * factor * max(s, 1e-6), '%s: max abs err %g vs scale %g (%s)' % (what, err, s, dtype)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dil
+    (2, 16, 16, 64, 64, 1, 1, 0, 1),
+    (2, 16, 16, 128, 256, 1, 1, 0, 1),
+    (1, 12, 12, 64, 128, 3, 1, 1, 1),       # 144 rows: ragged row block
+    (2, 16, 16, 128, 128, 3, 2, 1, 1),
+    (2, 16, 16, 256, 512, 1, 2, 0, 1),
+    (2, 16, 16, 64, 64, 3, 1, 2, 2),
+    (2, 16, 16, 128, 64, 3, 1, 4, 4),
+    (3, 1, 5, 512, 512, 1, 1, 0, 1),        # tiny M (PPM stage / head prototype rows)
+]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(hip, dtype, case):
+    from segland_amd import ops
+    B, H, W, Cin, Cout, k, st, pad, dil = case
+    tag = 'conv%s' % (case,)
+    x = rnd(fm.sym(tag + 'x', (B, Cin, H, W), 1.0), dtype)
+    w = rnd(fm.sym(tag + 'w', (Cout, Cin, k, k), (3.0 / (Cin * k * k)) ** 0.5), dtype)
+    x.requires_grad_(True); w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, st, pad, dil)
+    gy = rnd(fm.sym(tag + 'gy', tuple(y_ref.shape), 1.0), dtype)
+    y_ref.backward(gy)
+    spec = ops.ConvSpec(Cin, Cout, k, st, pad, dil)
+    wf, wb = ops.weight_prep(w.detach().to(DEV), dtype)
+    xg = nhwc(x.detach(), dtype)
+    y, part = ops.conv2d_fwd(xg, wf, spec, want_stats=True)
+    assert_close(nchw(y), y_ref, dtype, 'fwd')
+    # BN partial statistics = column sums / sums of squares of the fp32 result
+    s = part.sum(0).cpu()
+    assert_close(s[0], y_ref.detach().sum((0, 2, 3)), dtype, 'stat sum', scale=float(y_ref.abs().sum((0, 2, 3)).max()))
+    assert_close(s[1], (y_ref.detach() ** 2).sum((0, 2, 3)), dtype, 'stat sq')
+    gyg = nhwc(gy, dtype)
+    dx = ops.conv2d_bwd_data(gyg, wb, spec, (H, W))
+    assert_close(nchw(dx), x.grad, dtype, 'dgrad')
+    hip.sl_debug_wgrad_tr(1)
+    dw = ops.conv2d_bwd_weight(xg, gyg, spec)
+    assert_close(dw, w.grad, dtype, 'wgrad')
+    if dtype == torch.bfloat16:
+        hip.sl_debug_wgrad_tr(0)
+        dw0 = ops.conv2d_bwd_weight(xg, gyg, spec)
+        hip.sl_debug_wgrad_tr(1)
+        assert_close(dw0, w.grad, dtype, 'wgrad (scalar LDS path)')
+        assert torch.equal(dw0, dw), 'transpose-read and scalar fragment paths must agree bit for bit'
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv_concat_bias_relu_addend_mask(hip, dtype):
+    from segland_amd import ops
+    B, H, W, C1, C2, Cout = 2, 12, 12, 128, 64, 64
+    x1 = rnd(fm.sym('cc/x1', (B, C1, H, W), 1.0), dtype); x2 = rnd(fm.sym('cc/x2', (B, C2, H, W), 1.0), dtype)
+    w = rnd(fm.sym('cc/w', (Cout, C1 + C2, 3, 3), 0.05), dtype)
+    bias = fm.sym('cc/b', (Cout,), 0.5)
+    x = torch.cat([x1, x2], 1).requires_grad_(True); wr = w.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(x, wr, bias, 1, 1, 1))
+    spec = ops.ConvSpec(C1 + C2, Cout, 3, 1, 1, 1)
+    wf, wb = ops.weight_prep(w.to(DEV), dtype)
+    a, b2 = nhwc(x1, dtype), nhwc(x2, dtype)
+    y, _ = ops.conv2d_fwd(a, wf, spec, x2=b2, bias=bias.to(DEV), relu=True)
+    assert_close(nchw(y), y_ref, dtype, 'concat fwd')
+    gy = rnd(fm.sym('cc/gy', tuple(y_ref.shape), 1.0), dtype)
+    pre = F.conv2d(x, wr, None, 1, 1, 1)
+    pre.backward(gy)
+    gyg = nhwc(gy, dtype)
+    dw = ops.conv2d_bwd_weight(a, gyg, spec, x2=b2)
+    assert_close(dw, wr.grad, dtype, 'concat wgrad')
+    add = rnd(fm.sym('cc/add', (B, C1 + C2, H, W), 1.0), dtype); msk = rnd(fm.sym('cc/msk', (B, C1 + C2, H, W), 1.0), dtype)
+    dx = ops.conv2d_bwd_data(gyg, wb, spec, (H, W), addend=nhwc(add, dtype), mask_src=nhwc(msk, dtype))
+    assert_close(nchw(dx), (x.grad + add) * (msk > 0), dtype, 'dgrad + addend, masked')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('C_,rows', [(64, 2 * 16 * 16), (512, 2 * 3 * 3), (2048, 70)])
+def test_bn_train_eval_fwd_bwd(hip, dtype, C_, rows):
+    from segland_amd import ops
+    x = rnd(fm.sym('bn/x%d' % C_, (rows, C_), 2.0) + 0.3, dtype)
+    res = rnd(fm.sym('bn/r%d' % C_, (rows, C_), 1.0), dtype)
+    gamma = 0.8 + 0.4 * fm.uniform01('bn/g', C_).float(); beta = fm.sym('bn/b', (C_,), 0.2)
+    rm, rv = fm.sym('bn/rm', (C_,), 0.1), (0.9 + 0.2 * fm.uniform01('bn/rv', C_)).float()
+    gy = rnd(fm.sym('bn/gy%d' % C_, (rows, C_), 1.0), dtype)
+    for train in (True, False):
+        xr = x.clone().requires_grad_(True); g_ = gamma.clone().requires_grad_(True); b_ = beta.clone().requires_grad_(True)
+        rm_r, rv_r = rm.clone(), rv.clone()
+        pre = F.batch_norm(xr.t().reshape(1, C_, rows, 1).permute(2, 1, 0, 3), rm_r, rv_r, g_, b_, train, 0.1, 1e-5)
+        pre = pre.permute(2, 1, 0, 3).reshape(C_, rows).t()
+        y_ref = F.relu(pre + res)
+        y_ref.backward(gy)
+        xg = x.to(DEV).to(dtype); dev = lambda t: t.to(DEV)
+        rm_g, rv_g = dev(rm.clone()), dev(rv.clone())
+        if train:
+            # statistics as the conv epilogue would deliver them: per-block (sum, sumsq)
+            xf = xg.float()
+            part = torch.stack([xf.sum(0), (xf * xf).sum(0)]).unsqueeze(0).contiguous()
+            mean, invstd, scale, shift = ops.bn_finalize_train(part, rows, dev(gamma), dev(beta), rm_g, rv_g)
+            assert_close(rm_g, rm_r, torch.float32, 'running_mean'); assert_close(rv_g, rv_r, torch.float32, 'running_var')
+        else:
+            mean, invstd, scale, shift = ops.bn_finalize_eval(dev(gamma), dev(beta), rm_g, rv_g)
+        y = ops.bn_act(xg, scale, shift, residual=res.to(DEV).to(dtype), relu=True)
+        assert_close(y, y_ref, dtype, 'bn_act train=%s' % train)
+        dx, dres, dgamma, dbeta = ops.bn_bwd(gy.to(DEV).to(dtype), y, xg, mean, invstd, dev(gamma), train=train, want_dres=True)
+        assert_close(dx, xr.grad, dtype, 'bn dx train=%s' % train, factor=4)
+        assert_close(dres, gy * (y_ref > 0), dtype, 'bn dres')
+        assert_close(dgamma, g_.grad, dtype, 'dgamma', factor=4); assert_close(dbeta, b_.grad, dtype, 'dbeta', factor=4)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_stem(hip, dtype):
+    from segland_amd import ops
+    B, H, W = 2, 64, 48
+    img = fm.formula_image(B, H, W, 'stem/img')
+    w = fm.sym('stem/w', (64, 3, 7, 7), (6.0 / 147) ** 0.5).requires_grad_(True)
+    c_ref = F.conv2d(img, w, None, 2, 3)
+    c0, part = ops.stem_conv_fwd(img.to(DEV), w.detach().to(DEV), dtype, True)
+    assert_close(nchw(c0), c_ref, dtype, 'stem conv')
+    s = part.sum(0).cpu()
+    assert_close(s[0], c_ref.detach().sum((0, 2, 3)), torch.float32, 'stem stat sum', scale=float(c_ref.abs().sum((0, 2, 3)).max()))
+    assert_close(s[1], (c_ref.detach() ** 2).sum((0, 2, 3)), torch.float32, 'stem stat sq')
+    # BN(eval-style affine) + ReLU + maxpool and its backward, on the kernel's own (rounded) conv output
+    scale = (0.8 + 0.4 * fm.uniform01('stem/sc', 64)).float(); shift = fm.sym('stem/sh', (64,), 0.3)
+    cr = nchw(c0).requires_grad_(True)
+    a = F.relu(cr * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    p_ref = F.max_pool2d(a, 3, 2, 1)
+    gp = rnd(fm.sym('stem/gp', tuple(p_ref.shape), 1.0), dtype)
+    p_ref.backward(gp)
+    pooled, idx = ops.stem_bn_relu_pool(c0, scale.to(DEV), shift.to(DEV), True)
+    assert_close(nchw(pooled), p_ref, dtype, 'pool fwd')
+    g0 = ops.stem_pool_relu_bwd(nhwc(gp, dtype), idx, c0, scale.to(DEV), shift.to(DEV))
+    # d(bn out): undo the affine part of autograd's chain to compare the masked pool gradient itself
+    g_ref = cr.grad / scale.view(1, -1, 1, 1)
+    assert_close(nchw(g0), g_ref, dtype, 'pool+relu bwd')
+    gc = rnd(fm.sym('stem/gc', tuple(c_ref.shape), 1.0), dtype)
+    c_ref.backward(gc)
+    dw = ops.stem_conv_bwd_weight(img.to(DEV), nhwc(gc, dtype))
+    assert_close(dw, w.grad, dtype, 'stem wgrad')
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('hw', [12, 16, 64])
+def test_ppm_pool_and_upsample(hip, dtype, hw):
+    from segland_amd import ops
+    B, Cf, Cs, sizes = 2, 128, 64, (1, 2, 3, 6)
+    x = rnd(fm.sym('ppm/x%d' % hw, (B, Cf, hw, hw), 1.0), dtype).requires_grad_(True)
+    pools = [F.adaptive_avg_pool2d(x, (s, s)) for s in sizes]
+    xg = nhwc(x.detach(), dtype)
+    pooled = ops.ppm_pool_fwd(xg, sizes)
+    off = 0
+    for s, pr in zip(sizes, pools):
+        got = pooled[off:off + B * s * s].float().cpu().view(B, s, s, Cf).permute(0, 3, 1, 2)
+        assert_close(got, pr, dtype, 'pool level %d' % s); off += B * s * s
+    # backward of the pooling, fused with the direct (concat) gradient
+    gps = [rnd(fm.sym('ppm/gp%d_%d' % (hw, s), (B, Cf, s, s), 1.0), dtype) for s in sizes]
+    gdir = rnd(fm.sym('ppm/gd%d' % hw, (B, Cf, hw, hw), 1.0), dtype)
+    (sum((p * g).sum() for p, g in zip(pools, gps)) + (x * gdir).sum()).backward()
+    dpooled = torch.cat([g.permute(0, 2, 3, 1).reshape(-1, Cf) for g in gps]).contiguous().to(DEV).to(dtype)
+    dcat = torch.zeros((B, hw, hw, 64 + Cf), dtype=dtype, device=DEV)
+    dcat[..., 64:] = nhwc(gdir, dtype)
+    dx = ops.ppm_pool_bwd(dpooled, (B, hw, hw, Cf), dtype, sizes, dcat=dcat, cat_off=64)
+    assert_close(nchw(dx), x.grad, dtype, 'pool bwd', factor=2)
+    # upsample (align_corners=False) of stage maps and its backward
+    stages = [rnd(fm.sym('ppm/st%d_%d' % (hw, s), (B, Cs, s, s), 1.0), dtype).requires_grad_(True) for s in sizes]
+    ups = torch.cat([F.interpolate(t, size=(hw, hw), mode='bilinear', align_corners=False) for t in stages], 1)
+    stage_rows = torch.cat([t.detach().permute(0, 2, 3, 1).reshape(-1, Cs) for t in stages]).contiguous().to(DEV).to(dtype)
+    pri = ops.ppm_upsample_fwd(stage_rows, (B, hw, hw, Cf), sizes)
+    assert_close(nchw(pri), ups, dtype, 'upsample fwd')
+    gu = rnd(fm.sym('ppm/gu%d' % hw, tuple(ups.shape), 1.0), dtype)
+    ups.backward(gu)
+    dcat2 = torch.zeros((B, hw, hw, 4 * Cs + 64), dtype=dtype, device=DEV)
+    dcat2[..., :4 * Cs] = nhwc(gu, dtype)
+    dst = ops.ppm_upsample_bwd(dcat2, (B, hw, hw, Cf), sizes, Cs)
+    ref = torch.cat([t.grad.permute(0, 2, 3, 1).reshape(-1, Cs) for t in stages])
+    assert_close(dst, ref, dtype, 'upsample bwd', factor=4)
+
+
+def test_loss_golden_g3(hip):
+    from segland_amd import ops
+    g = golden('g3_loss')
+    for preds_tag, mask_tag, K, rows, tot, dp in [('g3/preds', 'g3/mask', 8, 5, 'seg', 'dpreds'), ('g3/preds12', 'g3/mask12', 12, 3, 'seg12', 'dpreds12')]:
+        preds = fm.sym(preds_tag, (2, K, 8, 8), 2.0)
+        target = fm.formula_mask(2, 64, 64, K, tag=mask_tag, block=8, ignore_rows=rows)
+        out = ops.upsample_ce_fwd(preds.to(DEV), target.to(DEV), 255)
+        np.testing.assert_allclose(out[0].item(), g[tot], rtol=2e-5)
+        assert out[1].item() == float((target != 255).sum())
+        dl = ops.upsample_ce_bwd(preds.to(DEV), target.to(DEV), out, torch.ones(1, device=DEV), 255)
+        np.testing.assert_allclose(dl.cpu().numpy(), g[dp], rtol=2e-4, atol=2e-7)
+
+
+def test_loss_vs_oracle_512(hip):
+    from segland_amd import ops
+    preds = fm.sym('l512/p', (2, 8, 64, 64), 3.0).requires_grad_(True)
+    target = fm.formula_mask(2, 512, 512, 8, tag='l512/m')
+    up = F.interpolate(preds, size=(512, 512), mode='bilinear', align_corners=True)
+    ref = F.cross_entropy(up, target, ignore_index=255)
+    (ref * 0.7).backward()
+    out = ops.upsample_ce_fwd(preds.detach().to(DEV), target.to(DEV), 255)
+    np.testing.assert_allclose(out[0].item(), ref.item(), rtol=2e-5)
+    dl = ops.upsample_ce_bwd(preds.detach().to(DEV), target.to(DEV), out, torch.full((1,), 0.7, device=DEV), 255)
+    np.testing.assert_allclose(dl.cpu().numpy(), preds.grad.numpy(), rtol=1e-3, atol=1e-8)
+    # all-ignored target: mean over zero valid pixels is NaN in the reference too
+    t2 = torch.full((1, 64, 64), 255, dtype=torch.int64)
+    out2 = ops.upsample_ce_fwd(preds.detach()[:1].contiguous().to(DEV), t2.to(DEV), 255)
+    assert np.isnan(out2[0].item()) and out2[1].item() == 0
+
+
+def test_pseudo_label_argmax_iou_bitexact(hip):
+    from segland_amd import ops
+    logits = fm.sym('pl/l', (2, 5, 64, 64), 2.0)
+    mask = fm.formula_mask(2, 512, 512, 8, tag='pl/m', ignore_rows=0)
+    ref = mask.clone()
+    for b in range(2):
+        po.pseudo_label(logits[b], ref[b], 7)
+    mg = mask.clone().to(DEV)
+    ops.pseudo_label_(logits.to(DEV), mg, 7)
+    up = F.interpolate(logits, size=(512, 512), mode='bilinear', align_corners=True)
+    top2 = up.topk(2, dim=1).values
+    tied = (top2[:, 0] - top2[:, 1]) < 1e-6
+    diff = (mg.cpu() != ref) & ~tied
+    assert int(diff.sum()) == 0
+    am = ops.upsample_argmax(logits.to(DEV), (512, 512)).cpu()
+    assert int(((am.long() != up.argmax(1)) & ~tied).sum()) == 0
+    g = golden('g10_iou')
+    pred = (fm.uniform01('g10/pred', 2 * 64 * 64) * 8).floor().long().reshape(2, 64, 64)
+    tgt = (fm.uniform01('g10/tgt', 2 * 64 * 64) * 8).floor().long().reshape(2, 64, 64)
+    tgt[0, :5] = 255
+    h = ops.iou_hist(pred.to(torch.uint8).to(DEV), tgt.to(DEV), 8, 255).cpu().numpy()
+    assert np.array_equal(h[0], g['inter'].astype(np.int64))
+    assert np.array_equal(h[1] + h[2] - h[0], g['union'].astype(np.int64))
+    assert np.array_equal(h[2], g['target'].astype(np.int64))
+
+
+def test_masked_average_pooling_g9(hip):
+    from segland_amd import ops
+    feat = fm.sym('g9/feat', (2, 32, 8, 8), 1.0)
+    m = (fm.uniform01('g9/mask', 2 * 64 * 64).reshape(2, 1, 64, 64) > 0.5).float()
+    proto = ops.masked_avg_pool(nhwc(feat, torch.float32), m.view(2, 64, 64).contiguous().to(DEV))
+    np.testing.assert_allclose(proto.cpu().numpy(), golden('g9_map')['proto'].reshape(-1), rtol=2e-5, atol=1e-6)
+
+
+def test_layout_roundtrip(hip):
+    from segland_amd import ops
+    x = fm.sym('lay/x', (2, 24, 5, 7), 1.0)
+    a = ops.nchw_f32_to_nhwc(x.to(DEV), torch.float32)
+    assert torch.equal(a.cpu(), x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw_f32(a).cpu(), x)
