@@ -123,7 +123,8 @@ int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const void* dc0, f
 /* ------------------------------------------------------------------------------------------------ pyramid pooling
  * pspnet_pop.py:26 AdaptiveAvgPool2d(1,2,3,6) (bins [floor(i*H/s), ceil((i+1)*H/s))) and :33 bilinear
  * (align_corners=False) upsampling of the four stage outputs.  Level l has s_l*s_l cells; the pooled / stage tensors
- * are stored level after level as rows [sum_l B*s_l^2][C], level-major then (b, i, j). */
+ * are stored level after level as rows [sum_l B*s_l^2][C], level-major then (b, i, j), and are ALWAYS float
+ * (pooled, dpooled, stage, dstage): train-mode BN over B*s^2 samples must not see bf16-rounded inputs. */
 typedef struct SlPpmDesc {
   int dtype;
   int B, H, W, C;        /* feature map x4 [B][H][W][C] */
@@ -131,15 +132,15 @@ typedef struct SlPpmDesc {
   int sizes[4];
 } SlPpmDesc;
 size_t sl_ppm_workspace(const SlPpmDesc* d);
-int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, void* pooled, void* workspace, size_t workspace_bytes,
+int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, float* pooled, void* workspace, size_t workspace_bytes,
                     sl_stream_t stream);
 /* dx[b,y,x,c] = dcat[b,y,x, cat_off + c] + sum over levels/bins covering (y,x) of dpooled/bin_area.
  * dcat has row pitch cat_pitch channels (the dgrad of the virtual concat). */
-int sl_ppm_pool_bwd(const SlPpmDesc* d, const void* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
+int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
                     sl_stream_t stream);
 /* priors[b,y,x, l*Cs + c] = bilinear(stage_l)[b,y,x,c]; stage rows as above with Cs channels */
-int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const void* stage, void* priors, sl_stream_t stream);
-int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, void* dstage, void* workspace,
+int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* priors, sl_stream_t stream);
+int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,
                         size_t workspace_bytes, sl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ POP head

@@ -1,3 +1,5 @@
+// The pooled maps and the stage tensors (B*(1+4+9+36) rows) are ALWAYS float: train-mode BatchNorm over 2..576 samples
+// is hypersensitive to rounding of its input, and these tensors are tiny.
 // Pyramid pooling side kernels (networks/pspnet_pop.py:26,33): AdaptiveAvgPool2d to (1,2,3,6) in ONE pass over the
 // feature map, and the bilinear (align_corners=False) upsampling of the four stage outputs, forward and backward.
 // All HBM-bound; the feature map is read exactly once in each direction.
@@ -72,8 +74,7 @@ __global__ void ppm_cells_kernel(PpmGeom g, const T* __restrict__ x, float* __re
 }
 
 // pooled[level rows][C] = (sum of the cells inside the bin) / bin area
-template <typename T>
-__global__ void ppm_bins_kernel(PpmGeom g, const float* __restrict__ cells, T* __restrict__ pooled) {
+__global__ void ppm_bins_kernel(PpmGeom g, const float* __restrict__ cells, float* __restrict__ pooled) {
   const long long total = (long long)g.rowoff[4] * g.C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % g.C); const int row = (int)(i / g.C);
@@ -92,12 +93,12 @@ __global__ void ppm_bins_kernel(PpmGeom g, const float* __restrict__ cells, T* _
         sum += cells[(((size_t)b * g.ncy + cy) * g.ncx + cx) * g.C + c];
       }
     }
-    pooled[i] = from_f<T>(sum / (float)((ye - ys) * (xe - xs)));
+    pooled[i] = sum / (float)((ye - ys) * (xe - xs));
   }
 }
 
 template <typename T>
-__global__ void ppm_pool_bwd_kernel(PpmGeom g, const T* __restrict__ dpooled, const T* __restrict__ dcat, int cat_pitch, int cat_off,
+__global__ void ppm_pool_bwd_kernel(PpmGeom g, const float* __restrict__ dpooled, const T* __restrict__ dcat, int cat_pitch, int cat_off,
                                     T* __restrict__ dx) {
   constexpr int V = Vec16<T>::N;
   const int nv = g.C / V;
@@ -121,8 +122,7 @@ __global__ void ppm_pool_bwd_kernel(PpmGeom g, const T* __restrict__ dpooled, co
         for (int j = max(0, j0 - 1); j <= min(s - 1, j0 + 1); ++j) {
           const int xs = d_bin_start(j, g.W, s), xe = d_bin_end(j, g.W, s);
           if (xx < xs || xx >= xe) continue;
-          float t[V];
-          unpack16<T>(*(const uint4*)(dpooled + ((size_t)g.rowoff[l] + (size_t)(b * s + ii) * s + j) * g.C + v * V), t);
+          const float* t = dpooled + ((size_t)g.rowoff[l] + (size_t)(b * s + ii) * s + j) * g.C + v * V;
           const float inv = 1.f / (float)((ye - ys) * (xe - xs));
 #pragma unroll
           for (int k = 0; k < V; ++k) acc[k] += t[k] * inv;
@@ -145,7 +145,7 @@ __device__ __forceinline__ void src_index_ac0(int dst, int in, int out, int& i0,
 }
 
 template <typename T>
-__global__ void ppm_upsample_fwd_kernel(PpmGeom g, int Cs, const T* __restrict__ stage, T* __restrict__ priors) {
+__global__ void ppm_upsample_fwd_kernel(PpmGeom g, int Cs, const float* __restrict__ stage, T* __restrict__ priors) {
   constexpr int V = Vec16<T>::N;
   const int nv = Cs / V, pitch = g.nlevels * Cs;
   const long long total = (long long)g.B * g.H * g.W * g.nlevels * nv;
@@ -158,12 +158,12 @@ __global__ void ppm_upsample_fwd_kernel(PpmGeom g, int Cs, const T* __restrict__
     int y0, y1, x0, x1; float ly, lx;
     src_index_ac0(y, s, g.H, y0, y1, ly);
     src_index_ac0(xx, s, g.W, x0, x1, lx);
-    const T* base = stage + ((size_t)g.rowoff[l] + (size_t)b * s * s) * Cs + v * V;
-    float v00[V], v01[V], v10[V], v11[V], o[V];
-    unpack16<T>(*(const uint4*)(base + (size_t)(y0 * s + x0) * Cs), v00);
-    unpack16<T>(*(const uint4*)(base + (size_t)(y0 * s + x1) * Cs), v01);
-    unpack16<T>(*(const uint4*)(base + (size_t)(y1 * s + x0) * Cs), v10);
-    unpack16<T>(*(const uint4*)(base + (size_t)(y1 * s + x1) * Cs), v11);
+    const float* base = stage + ((size_t)g.rowoff[l] + (size_t)b * s * s) * Cs + v * V;
+    const float* v00 = base + (size_t)(y0 * s + x0) * Cs;
+    const float* v01 = base + (size_t)(y0 * s + x1) * Cs;
+    const float* v10 = base + (size_t)(y1 * s + x0) * Cs;
+    const float* v11 = base + (size_t)(y1 * s + x1) * Cs;
+    float o[V];
     const float wy0 = 1.f - ly, wx0 = 1.f - lx;
 #pragma unroll
     for (int k = 0; k < V; ++k) o[k] = wy0 * (wx0 * v00[k] + lx * v01[k]) + ly * (wx0 * v10[k] + lx * v11[k]);
@@ -204,8 +204,7 @@ __global__ void ppm_upsample_bwd_x_kernel(PpmGeom g, int Cs, const T* __restrict
 }
 
 // stage B: dstage[row(l,b,i,j)][c] = sum_y wy(y, i) * tmp[b][y][lj][c]
-template <typename T>
-__global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __restrict__ tmp, T* __restrict__ dstage, int nlj) {
+__global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __restrict__ tmp, float* __restrict__ dstage, int nlj) {
   const long long total = (long long)g.rowoff[4] * Cs;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % Cs); const int row = (int)(i / Cs);
@@ -223,7 +222,7 @@ __global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __rest
       if (wgt == 0.f) continue;
       acc += wgt * tmp[(((size_t)b * g.H + y) * nlj + ljoff + j) * Cs + c];
     }
-    dstage[i] = from_f<T>(acc);
+    dstage[i] = acc;
   }
 }
 
@@ -240,7 +239,7 @@ extern "C" size_t sl_ppm_workspace(const SlPpmDesc* d) {
   return cells > tmp ? cells : tmp;
 }
 
-extern "C" int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, void* pooled, void* workspace, size_t workspace_bytes,
+extern "C" int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, float* pooled, void* workspace, size_t workspace_bytes,
                                sl_stream_t stream) {
   PpmGeom g;
   if (int e = make_geom(d, g)) return e;
@@ -251,16 +250,16 @@ extern "C" int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, void* pooled, 
   float* cells = (float*)workspace;
   if (d->dtype == SL_BF16) {
     hipLaunchKernelGGL(ppm_cells_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.ncy * g.ncx * g.C / 8)), dim3(256), 0, st, g, (const bf16_t*)x, cells);
-    hipLaunchKernelGGL(ppm_bins_kernel<bf16_t>, dim3(gs_blocks((long long)g.rowoff[4] * g.C)), dim3(256), 0, st, g, cells, (bf16_t*)pooled);
+    hipLaunchKernelGGL(ppm_bins_kernel, dim3(gs_blocks((long long)g.rowoff[4] * g.C)), dim3(256), 0, st, g, cells, (float*)pooled);
   } else if (d->dtype == SL_F32) {
     hipLaunchKernelGGL(ppm_cells_kernel<float>, dim3(gs_blocks((long long)g.B * g.ncy * g.ncx * g.C / 4)), dim3(256), 0, st, g, (const float*)x, cells);
-    hipLaunchKernelGGL(ppm_bins_kernel<float>, dim3(gs_blocks((long long)g.rowoff[4] * g.C)), dim3(256), 0, st, g, cells, (float*)pooled);
+    hipLaunchKernelGGL(ppm_bins_kernel, dim3(gs_blocks((long long)g.rowoff[4] * g.C)), dim3(256), 0, st, g, cells, (float*)pooled);
   } else SL_REQUIRE(false, "ppm_pool_fwd: bad dtype");
   SL_LAUNCH_CHECK("ppm_pool_fwd");
   return 0;
 }
 
-extern "C" int sl_ppm_pool_bwd(const SlPpmDesc* d, const void* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
+extern "C" int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
                                sl_stream_t stream) {
   PpmGeom g;
   if (int e = make_geom(d, g)) return e;
@@ -268,7 +267,7 @@ extern "C" int sl_ppm_pool_bwd(const SlPpmDesc* d, const void* dpooled, const vo
   SL_REQUIRE(!dcat || (cat_pitch >= cat_off + g.C && cat_pitch % 8 == 0 && cat_off % 8 == 0), "ppm_pool_bwd: bad concat geometry");
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == SL_BF16)
-    hipLaunchKernelGGL(ppm_pool_bwd_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.C / 8)), dim3(256), 0, st, g, (const bf16_t*)dpooled, (const bf16_t*)dcat, cat_pitch, cat_off, (bf16_t*)dx);
+    hipLaunchKernelGGL(ppm_pool_bwd_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.C / 8)), dim3(256), 0, st, g, (const float*)dpooled, (const bf16_t*)dcat, cat_pitch, cat_off, (bf16_t*)dx);
   else if (d->dtype == SL_F32)
     hipLaunchKernelGGL(ppm_pool_bwd_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.C / 4)), dim3(256), 0, st, g, (const float*)dpooled, (const float*)dcat, cat_pitch, cat_off, (float*)dx);
   else SL_REQUIRE(false, "ppm_pool_bwd: bad dtype");
@@ -276,13 +275,13 @@ extern "C" int sl_ppm_pool_bwd(const SlPpmDesc* d, const void* dpooled, const vo
   return 0;
 }
 
-extern "C" int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const void* stage, void* priors, sl_stream_t stream) {
+extern "C" int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* priors, sl_stream_t stream) {
   PpmGeom g;
   if (int e = make_geom(d, g)) return e;
   SL_REQUIRE(stage && priors && Cs > 0 && Cs % 8 == 0, "ppm_upsample_fwd: bad args");
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == SL_BF16)
-    hipLaunchKernelGGL(ppm_upsample_fwd_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.nlevels * Cs / 8)), dim3(256), 0, st, g, Cs, (const bf16_t*)stage, (bf16_t*)priors);
+    hipLaunchKernelGGL(ppm_upsample_fwd_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.nlevels * Cs / 8)), dim3(256), 0, st, g, Cs, (const float*)stage, (bf16_t*)priors);
   else if (d->dtype == SL_F32)
     hipLaunchKernelGGL(ppm_upsample_fwd_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.nlevels * Cs / 4)), dim3(256), 0, st, g, Cs, (const float*)stage, (float*)priors);
   else SL_REQUIRE(false, "ppm_upsample_fwd: bad dtype");
@@ -290,7 +289,7 @@ extern "C" int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const void* stage
   return 0;
 }
 
-extern "C" int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, void* dstage, void* workspace,
+extern "C" int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,
                                    size_t workspace_bytes, sl_stream_t stream) {
   PpmGeom g;
   if (int e = make_geom(d, g)) return e;
@@ -302,10 +301,10 @@ extern "C" int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat,
   float* tmp = (float*)workspace;
   if (d->dtype == SL_BF16) {
     hipLaunchKernelGGL(ppm_upsample_bwd_x_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * nlj * Cs / 8)), dim3(256), 0, st, g, Cs, (const bf16_t*)dcat, cat_pitch, tmp, nlj);
-    hipLaunchKernelGGL(ppm_upsample_bwd_y_kernel<bf16_t>, dim3(gs_blocks((long long)g.rowoff[4] * Cs)), dim3(256), 0, st, g, Cs, tmp, (bf16_t*)dstage, nlj);
+    hipLaunchKernelGGL(ppm_upsample_bwd_y_kernel, dim3(gs_blocks((long long)g.rowoff[4] * Cs)), dim3(256), 0, st, g, Cs, tmp, (float*)dstage, nlj);
   } else if (d->dtype == SL_F32) {
     hipLaunchKernelGGL(ppm_upsample_bwd_x_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * nlj * Cs / 4)), dim3(256), 0, st, g, Cs, (const float*)dcat, cat_pitch, tmp, nlj);
-    hipLaunchKernelGGL(ppm_upsample_bwd_y_kernel<float>, dim3(gs_blocks((long long)g.rowoff[4] * Cs)), dim3(256), 0, st, g, Cs, tmp, (float*)dstage, nlj);
+    hipLaunchKernelGGL(ppm_upsample_bwd_y_kernel, dim3(gs_blocks((long long)g.rowoff[4] * Cs)), dim3(256), 0, st, g, Cs, tmp, (float*)dstage, nlj);
   } else SL_REQUIRE(false, "ppm_upsample_bwd: bad dtype");
   SL_LAUNCH_CHECK("ppm_upsample_bwd");
   return 0;

@@ -11,18 +11,17 @@ from torch.autograd.function import once_differentiable
 from . import ops
 from .ops import ConvSpec
 
-_wcache = {}            # id(param) -> (version, dtype, data_ptr, w_fwd, w_bwd)
 _nbt_pending = []       # num_batches_tracked buffers to bump once per forward
 
 
 def prepared(w, dtype):
-    """GEMM-layout copies of a conv weight in the compute dtype, refreshed when the parameter changes."""
-    key = id(w)
-    ent = _wcache.get(key)
+    """GEMM-layout copies of a conv weight in the compute dtype, refreshed when the parameter changes.
+    The cache lives on the Parameter object itself (version counter + storage pointer + dtype as the key)."""
+    ent = getattr(w, '_sl_prep', None)
     if ent is None or ent[0] != w._version or ent[1] != dtype or ent[2] != w.data_ptr():
         wf, wb = ops.weight_prep(w, dtype)
         ent = (w._version, dtype, w.data_ptr(), wf, wb)
-        _wcache[key] = ent
+        w._sl_prep = ent
     return ent[3], ent[4]
 
 
@@ -162,14 +161,14 @@ class PPMFn(torch.autograd.Function):
         B, H, W, Cf = x4.shape
         Cs = dec.stages[0][1].out_channels
         pooled = ops.ppm_pool_fwd(x4, sizes)
-        stage_act = torch.empty((pooled.shape[0], Cs), dtype=x4.dtype, device=x4.device)
+        stage_act = torch.empty((pooled.shape[0], Cs), dtype=torch.float32, device=x4.device)   # stage path is fp32 (see ppm.hip)
         cl, ml, il, off = [], [], [], 0
         for s, st in zip(sizes, dec.stages):
             n = B * s * s
             xin = pooled[off:off + n].view(B, s, s, Cf)
             c, _, m, i = conv_bn_fwd(xin, st[1], st[2], relu=True, out=stage_act[off:off + n].view(B, s, s, Cs))
             cl.append(c); ml.append(m); il.append(i); off += n
-        priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes)
+        priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
         bt = dec.bottleneck
         cb, ab, mb, ib = conv_bn_fwd(priors, bt[0], bt[1], relu=True, x2=x4)
         wf, _ = prepared(bt[3].weight, x4.dtype)

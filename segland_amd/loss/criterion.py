@@ -1,0 +1,32 @@
+"""OrthLoss (loss/criterion.py:29-65 of the reference) with the bilinear upsample + cross-entropy fused in one HIP
+kernel pair (the H x W logits are never materialised).  Returns the same dict of scalar tensors."""
+import torch
+import torch.nn as nn
+
+from ..functional import UpsampleCEFn
+
+
+class OrthLoss(nn.Module):
+    def __init__(self, ignore_index=255, reduction='mean'):
+        super().__init__()
+        if reduction != 'mean':
+            raise ValueError('segland_amd OrthLoss implements reduction="mean" (what the reference uses)')
+        self.ignore_index = ignore_index
+        self.w = 10.0
+
+    def get_orth_loss(self, proto_sim, is_ft=False):
+        # mean |.| over the strict upper triangle, also of a rectangular [K1,K2] matrix (criterion.py:37-43)
+        sel = torch.triu(torch.ones_like(proto_sim), diagonal=1) == 1
+        return torch.abs(proto_sim[sel]).mean()
+
+    def seg_loss(self, preds, target):
+        return UpsampleCEFn.apply(preds.float(), target.contiguous(), self.ignore_index)
+
+    def forward(self, preds, target, is_ft=False, proto_sim=None, aux_preds=None):
+        seg_loss = self.seg_loss(preds, target)
+        orth_loss = self.get_orth_loss(proto_sim, is_ft=is_ft)
+        if aux_preds is not None:
+            aux_loss = self.seg_loss(aux_preds, target)
+            total = seg_loss + orth_loss * self.w + 0.4 * aux_loss
+            return {'total_loss': total, 'seg_loss': seg_loss, 'aux_loss': aux_loss, 'orth_loss': orth_loss}
+        return {'total_loss': seg_loss + orth_loss * self.w, 'seg_loss': seg_loss, 'orth_loss': orth_loss}

@@ -1,0 +1,1 @@
+from . import pspnet_pop  # noqa: F401  (drivers resolve `networks.<model>.GFSS_Model` like the reference does)

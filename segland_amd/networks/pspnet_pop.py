@@ -1,0 +1,130 @@
+"""PSPNet-POP on MI355X: drop-in for networks/pspnet_pop.py of LiZhuoHong/SegLand.
+
+Same constructor, same parameter names/shapes, same forward dispatch and return conventions, same side effects
+(forward_novel mutates mask_b in place; train-mode BN updates running stats; train_mode() leaves backbone+decoder in
+eval).  All arithmetic runs in libsegland_hip.so (segland_amd.functional); there is no PyTorch/CPU fallback.
+
+Extra (keyword-only) knob: compute_dtype = torch.bfloat16 (default, MFMA bf16 with fp32 accumulate) or torch.float32
+(exact-fp32 MFMA; the parity mode).  BatchNorm statistics are always per-GPU (nn.SyncBatchNorm modules passed as
+norm_layer are accepted as parameter holders; see DESIGN.md, multi-GPU).
+"""
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import ops
+from ..functional import PopHeadFn, PPMFn, cls_params, flush_num_batches_tracked, ppm_params
+from .backbones import get_backbone
+
+
+class PSPModule(nn.Module):
+    """networks/pspnet_pop.py:8-35.  forward(x4 NHWC) -> features NHWC [B,h,w,out_features]."""
+
+    def __init__(self, features, out_features=256, sizes=(1, 2, 3, 6), norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.sizes = tuple(sizes)
+        self.stages = nn.ModuleList([
+            nn.Sequential(nn.AdaptiveAvgPool2d(output_size=(s, s)), nn.Conv2d(features, out_features, kernel_size=1, bias=False),
+                          norm_layer(out_features), nn.ReLU(inplace=True)) for s in sizes])
+        self.bottleneck = nn.Sequential(
+            nn.Conv2d(features + len(sizes) * out_features, out_features, kernel_size=3, padding=1, dilation=1, bias=False),
+            norm_layer(out_features), nn.ReLU(inplace=True), nn.Conv2d(out_features, out_features, kernel_size=1))
+
+    def forward(self, feats):
+        return PPMFn.apply(feats, self, *ppm_params(self))
+
+
+def _classifier(d):
+    return nn.Sequential(nn.Conv2d(d, d, kernel_size=1, bias=False), nn.ReLU(inplace=True),
+                         nn.Conv2d(d, d, kernel_size=1, bias=False), nn.ReLU(inplace=True),
+                         nn.Conv2d(d, 1, kernel_size=1, bias=False))
+
+
+class GFSS_Model(nn.Module):
+    """Segmenter for Generalized Few-shot Semantic Segmentation (networks/pspnet_pop.py:37-243)."""
+
+    def __init__(self, n_base, criterion=None, norm_layer=nn.BatchNorm2d, use_base=True, is_ft=False, n_novel=0,
+                 compute_dtype=torch.bfloat16, **kwargs):
+        super().__init__()
+        d_model = 512
+        self.backbone = get_backbone(norm_layer=norm_layer, compute_dtype=compute_dtype, **kwargs)
+        self.decoder = PSPModule(2048, out_features=d_model, norm_layer=norm_layer)
+        self.classifier = _classifier(d_model)
+        if is_ft:
+            self.base_emb = nn.Parameter(torch.zeros(n_base, d_model), requires_grad=False)
+            self.novel_emb = nn.Parameter(torch.zeros(n_novel, d_model), requires_grad=True)
+            self.classifier_n = _classifier(d_model)
+            nn.init.orthogonal_(self.novel_emb)
+            self.ft_freeze()
+        else:
+            self.base_emb = nn.Parameter(torch.zeros(n_base, d_model), requires_grad=True)
+            nn.init.orthogonal_(self.base_emb)
+            self.novel_emb = None
+        self.n_novel, self.use_base, self.is_ft = n_novel, use_base, is_ft
+        self.criterion, self.n_base = criterion, n_base
+        self.compute_dtype = compute_dtype
+
+    # ---- helpers of the reference API
+    def init_cls_n(self):
+        for src, dst in zip(self.classifier.parameters(), self.classifier_n.parameters()):
+            dst.data.copy_(src.data)
+
+    def train_mode(self):
+        self.train()
+        self.backbone.eval()     # BN uses running statistics (pspnet_pop.py:82-84)
+        self.decoder.eval()
+
+    def ft_freeze(self):
+        for part in (self.backbone, self.decoder, self.classifier):
+            for p in part.parameters():
+                p.requires_grad = False
+
+    # ---- forward
+    def forward(self, img, mask=None, img_b=None, mask_b=None):
+        if self.is_ft:
+            if self.training:
+                return self.forward_novel(img, mask, img_b, mask_b)
+            return self.forward_all(img, mask)
+        return self.forward_base(img, mask)
+
+    def _features(self, img):
+        if not img.is_cuda:
+            raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
+        x4 = self.backbone.base_forward(img)
+        feat = self.decoder(x4)
+        flush_num_batches_tracked()
+        return feat
+
+    def _head(self, feat):
+        sb = F.normalize(self.base_emb.float(), p=2, dim=-1)
+        if self.is_ft:
+            sn = F.normalize(self.novel_emb.float(), p=2, dim=-1)
+            return PopHeadFn.apply(feat, sb, sn, self, *cls_params(self.classifier), *cls_params(self.classifier_n)), sb, sn
+        return PopHeadFn.apply(feat, sb, None, self, *cls_params(self.classifier)), sb, None
+
+    def forward_all(self, img, mask=None):
+        preds, _, _ = self._head(self._features(img))
+        return preds
+
+    def forward_base(self, img, mask=None):
+        preds, sb, _ = self._head(self._features(img))
+        if self.criterion is not None and mask is not None:
+            proto_sim = torch.matmul(sb, sb.t())                       # [Kb,Kb] (pspnet_pop.py:185-186)
+            return self.criterion(preds, mask, proto_sim=proto_sim)
+        return preds
+
+    def forward_novel(self, img, mask, img_b, mask_b):
+        img_full = torch.cat([img, img_b], dim=0)
+        preds, sb, sn = self._head(self._features(img_full))
+        B = img_full.shape[0]
+        kb = self.n_base
+        # pseudo-label the base tiles' background with the novel head (pspnet_pop.py:221-231); mutates mask_b in place
+        preds2_b = torch.cat([preds[B // 2:, 0:1], preds[B // 2:, 1 + kb:]], dim=1).detach().contiguous()
+        if not mask_b.is_contiguous():
+            raise RuntimeError('mask_b must be contiguous (it is updated in place)')
+        ops.pseudo_label_(preds2_b, mask_b, kb)
+        if self.criterion is not None and mask is not None:
+            mask_all = torch.cat([mask, mask_b], dim=0)
+            proto_sim = torch.matmul(sn, torch.cat([sn, sb], dim=0).t())   # [Kn, Kn+Kb] (pspnet_pop.py:236-239)
+            return self.criterion(preds, mask_all, is_ft=True, proto_sim=proto_sim)
+        return preds

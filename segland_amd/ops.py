@@ -223,7 +223,7 @@ def ppm_pool_fwd(x, sizes):
     d = ppm_desc(x, sizes)
     L = _lib.lib()
     ws = workspace(L.sl_ppm_workspace(C.byref(d)), x.device)
-    pooled = torch.empty((ppm_rows(x.shape[0], sizes), x.shape[3]), dtype=x.dtype, device=x.device)
+    pooled = torch.empty((ppm_rows(x.shape[0], sizes), x.shape[3]), dtype=torch.float32, device=x.device)
     check(L.sl_ppm_pool_fwd(C.byref(d), _p(x), _p(pooled), _p(ws), ws.numel(), _s()), 'ppm_pool_fwd')
     return pooled
 
@@ -231,17 +231,19 @@ def ppm_pool_fwd(x, sizes):
 def ppm_pool_bwd(dpooled, x_shape, dtype, sizes, dcat=None, cat_off=0):
     B, H, W, Cn = x_shape
     d = SlPpmDesc(_DT[dtype], B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+    assert dpooled.dtype == torch.float32
     dx = torch.empty((B, H, W, Cn), dtype=dtype, device=dpooled.device)
     pitch = dcat.shape[-1] if dcat is not None else 0
     check(_lib.lib().sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _s()), 'ppm_pool_bwd')
     return dx
 
 
-def ppm_upsample_fwd(stage, x_shape, sizes):
+def ppm_upsample_fwd(stage, x_shape, sizes, dtype):
     B, H, W, Cn = x_shape
     Cs = stage.shape[1]
-    d = SlPpmDesc(dt(stage), B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
-    priors = torch.empty((B, H, W, len(sizes) * Cs), dtype=stage.dtype, device=stage.device)
+    assert stage.dtype == torch.float32
+    d = SlPpmDesc(_DT[dtype], B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+    priors = torch.empty((B, H, W, len(sizes) * Cs), dtype=dtype, device=stage.device)
     check(_lib.lib().sl_ppm_upsample_fwd(C.byref(d), Cs, _p(stage), _p(priors), _s()), 'ppm_upsample_fwd')
     return priors
 
@@ -251,7 +253,7 @@ def ppm_upsample_bwd(dcat, x_shape, sizes, Cs):
     L = _lib.lib()
     d = SlPpmDesc(dt(dcat), B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
     ws = workspace(L.sl_ppm_workspace(C.byref(d)), dcat.device)
-    dstage = torch.empty((ppm_rows(B, sizes), Cs), dtype=dcat.dtype, device=dcat.device)
+    dstage = torch.empty((ppm_rows(B, sizes), Cs), dtype=torch.float32, device=dcat.device)
     check(L.sl_ppm_upsample_bwd(C.byref(d), Cs, _p(dcat), dcat.shape[-1], _p(dstage), _p(ws), ws.numel(), _s()), 'ppm_upsample_bwd')
     return dstage
 
