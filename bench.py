@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 tiles/sec, forward+backward (+clip +AdamW), PSPNet-POP on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is the loop body of the reference's train_base.py:250-264 over one synthetic batch that is already resident
+in HBM: zero_grad, forward (backbone + PPM + POP head + fused upsample/CE + orth loss), backward, clip_grad_norm_(5.0),
+AdamW step(s).  Workload at every N: BASELINE.json configs[1] per GPU -- PSPNet-POP ResNet-50, bf16, batch 16, 512x512,
+8 logit channels -- so scaling is weak and `value` is the whole-job tiles/s.
+
+The JSON line also carries
+  roofline     : the dominant kernel (picked by an instrumented warm-up pass), timed live with HIP events on the
+                 launch stream during the timed steps; achieved = algorithmic FLOPs of that launch / mean duration,
+                 peak = 2500 TFLOP/s (bf16 dense MFMA, MI355X_MICROARCH.md);
+  cpu_baseline : the CPU oracle (a port: oracle/pop_oracle.py) running the same loop body on config C1 (batch 2,
+                 fp32) on this host's cores -- rank 0, N = 1 only.  Reported, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_TILE = {'resnet50': 1170.7, 'resnet101': 1636.1}      # fwd+bwd, reference algorithm
+PEAK_BF16_TFLOPS = 2500.0
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--batch', type=int, default=16, help='tiles per GPU')
+    p.add_argument('--backbone', default='resnet50')
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--size', type=int, default=512)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-budget', type=float, default=40.0, help='seconds of CPU work allowed for the cpu_baseline sample')
+    p.add_argument('--single-step', action='store_true', help='one AdamW step per iteration (the reference does two, train_base.py:262-264)')
+    p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
+    return p.parse_args()
+
+
+def synthetic_batch(B, size, device, seed=0):
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    img = torch.randn(B, 3, size, size, generator=g)
+    mask = torch.randint(0, 8, (B, size, size), generator=g, dtype=torch.int64)
+    mask[0, :50] = 255
+    return img.to(device), mask.to(device)
+
+
+def make_optimizer(model, lr=1e-3, wd=1e-4):
+    from segland_amd.utils.pyt_utils import get_parameters
+    return torch.optim.AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd)
+
+
+def train_step(model, opt, img, mask, params, double_step):
+    opt.zero_grad(set_to_none=True)
+    loss = model(img, mask)
+    loss['total_loss'].backward()
+    torch.nn.utils.clip_grad_norm_(params, 5.0)
+    opt.step()
+    if double_step:
+        opt.step()
+    return loss
+
+
+def usable_cpus():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota (containers report all host CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(budget_s, backbone):
+    """CPU port (oracle) of the same loop body, on a BOUNDED sample: batch 2 at 256x256 first (1/4 of the pixels of
+    config C1); if that step takes < budget/8 the full C1 sample (batch 2, 512x512) is timed too and reported instead.
+    tiles/s is always in units of 512x512 tiles (a 256x256 tile counts 1/4)."""
+    from oracle import pop_oracle as po
+    torch.manual_seed(0)
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    m = po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), backbone=backbone).train()
+    groups, _ = po.param_groups(m, lr=1e-5)
+    opt = torch.optim.AdamW(groups, lr=1e-5, weight_decay=1e-4)
+
+    def timed(size, n):
+        img, mask = synthetic_batch(2, size, 'cpu')
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            po.train_step(m, opt, img, mask)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    t_small = timed(256, 2)[-1]                        # first call is the warm-up
+    size, t = 256, t_small
+    if t_small * 4 * 2 < budget_s:
+        size, t = 512, min(timed(512, 2))
+    cpu = ''
+    try:
+        cpu = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
+    except Exception:
+        pass
+    return {'value': 2.0 * (size * size) / (512.0 * 512.0) / t, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
+            'sample': 'oracle/pop_oracle.py train_step (train_base.py:250-264 body), %s fp32, batch 2 at %dx%d, %.2f s/step after warm-up, '
+                      '%d threads (cgroup/affinity limit) on %s' % (backbone, size, size, t, threads, cpu)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://')       # "nccl" is RCCL on ROCm
+
+    from segland_amd import ops
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+
+    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    torch.manual_seed(0)
+    model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, dilated=True, os=8,
+                       compute_dtype=dtype).to(dev).train()
+    opt = make_optimizer(model)
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
+                                                        gradient_as_bucket_view=True, bucket_cap_mb=64)
+    params = [p for p in model.parameters() if p.requires_grad]
+    img, mask = synthetic_batch(a.batch, a.size, dev, seed=rank)
+    double = not a.single_step
+
+    # ---- warm-up; the last warm-up step is instrumented to find the dominant kernel shape
+    for i in range(a.warmup):
+        if i == a.warmup - 1:
+            ops.PROFILER.start(all_shapes=True)
+        train_step(net, opt, img, mask, params, double)
+    if a.warmup == 0:
+        ops.PROFILER.start(all_shapes=True)
+        train_step(net, opt, img, mask, params, double)
+    torch.cuda.synchronize()
+    table = ops.PROFILER.stop()
+    dominant = max(table.values(), key=lambda e: e['ms_total']) if table else None
+
+    # ---- timed region
+    if dominant is not None:
+        ops.PROFILER.start(only=dominant['key'])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        train_step(net, opt, img, mask, params, double)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    live = ops.PROFILER.stop()
+    if world > 1:
+        t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_s = float(t.item())
+
+    if a.profile_table and rank == 0:
+        rows = sorted(table.values(), key=lambda e: -e['ms_total'])
+        with open(a.profile_table, 'w') as f:
+            f.write('# one instrumented step, %s %s batch %d: per conv launch shape (HIP events on the launch stream)\n' % (a.backbone, a.dtype, a.batch))
+            f.write('%-10s %-46s %6s %10s %10s %9s\n' % ('kind', 'shape', 'calls', 'ms_total', 'GFLOP', 'TFLOP/s'))
+            for e in rows:
+                f.write('%-10s %-46s %6d %10.3f %10.1f %9.1f\n' % (e['kind'], e['shape'], e['calls'], e['ms_total'], e['gflop'], e['gflop'] / max(e['ms_total'], 1e-9)))
+            f.write('# total conv-kernel time %.2f ms, total conv GFLOP %.1f\n' % (sum(e['ms_total'] for e in rows), sum(e['gflop'] for e in rows)))
+
+    if rank == 0:
+        tiles = a.batch * world * a.steps
+        value = tiles / dt_s
+        peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
+        out = {
+            'metric': '512x512 tiles/sec fwd+bwd PSPNet-POP', 'value': round(value, 3), 'unit': 'tiles/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt_s / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': 'PSPNet-POP %s %s, batch %d/GPU, %dx%d, 8 logit channels, train_base.py loop body '
+                                   '(fwd+loss+bwd+clip+AdamW x%d), %d x MI355X' % (a.backbone, a.dtype, a.batch, a.size, a.size, 2 if double else 1, world),
+                       'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
+            'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
+        }
+        if live:
+            e = list(live.values())[0]
+            ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
+            out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                               'traffic': None, 'kernel': '%s %s' % (e['kind'], e['shape']), 'launches': e['calls'],
+                               'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
+                               'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2)}
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

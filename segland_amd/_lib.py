@@ -7,6 +7,8 @@ import os
 import re
 import subprocess
 
+import torch  # noqa: F401  -- must be imported BEFORE libsegland_hip.so so both share torch's HIP runtime (libamdhip64)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libsegland_hip.so')

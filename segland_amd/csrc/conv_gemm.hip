@@ -8,6 +8,7 @@
 // Both element types share the LDS geometry: tiles of [rows][8 x 16-byte chunks], chunk index XOR-swizzled with
 // (row>>1)&7 so that the ds_read_b128 fragment reads (row = lane&31) are bank-conflict free.  A bf16 k-step is one
 // v_mfma_f32_32x32x16_bf16 per chunk pair; an f32 k-step is four v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -46,6 +47,62 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                              int lane, int tid, unsigned char* smem) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  // ---------------------------------------------------------------- epilogue
+  // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  T* out = (T*)p.out;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = bn * BN + wn * (BN / WN) + j * 32 + frow;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        float v = acc[i][j][r];
+        csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
+        if (m < p.M) {
+          v += bias;
+          const size_t o = (size_t)m * p.N + n;
+          if (p.addend) v += to_f<T>(((const T*)p.addend)[o]);
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          if (p.mask_src) v = to_f<T>(((const T*)p.mask_src)[o]) > 0.f ? v : 0.f;
+          out[o] = from_f<T>(v);
+        }
+      }
+    }
+  }
+  if (p.stat_partial) {
+    float* red = (float*)smem;   // [WM][2][BN]; tiles are dead after the final barrier of the main loop
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (fhalf == 0) {
+        const int col = wn * (BN / WN) + j * 32 + frow;
+        red[(wm * 2 + 0) * BN + col] = s;
+        red[(wm * 2 + 1) * BN + col] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
+      p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
+    }
+  }
+}
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
@@ -164,55 +221,140 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- epilogue
-  // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float csum[TN], csq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
-  T* out = (T*)p.out;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn * BN + wn * (BN / WN) + j * 32 + frow;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        float v = acc[i][j][r];
-        csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
-        if (m < p.M) {
-          v += bias;
-          const size_t o = (size_t)m * p.N + n;
-          if (p.addend) v += to_f<T>(((const T*)p.addend)[o]);
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          if (p.mask_src) v = to_f<T>(((const T*)p.mask_src)[o]) > 0.f ? v : 0.f;
-          out[o] = from_f<T>(v);
-        }
-      }
-    }
+  conv_epilogue<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2: operands go HBM -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging, no ds_write pass).
+// The LDS destination of one wave-instruction is lane-linear (base + lane*16 = 8 rows x 128 B), so the bank swizzle is
+// applied to the SOURCE chunk index: LDS position p of row r receives global chunk p ^ ((r>>1)&7) -- still inside the
+// same 128-byte line of that row, so coalescing is untouched.  Lanes whose tap falls into the padding (or rows >= M)
+// read a zero page instead.
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)g, (lds_void_t*)l, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(ConvGemmParams p) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int BKE = 8 * EPC;
+  constexpr int AR = BM / 32, BR = BN / 32;     // 8-row groups per wave
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lds_a = smem;
+  unsigned char* lds_b = smem + 2 * BM * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  if (p.stat_partial) {
-    float* red = (float*)smem;   // [WM][2][BN]; tiles are dead after the final barrier of the main loop
+  const int bm = bid / p.gridN, bn = bid % p.gridN;
+
+  const int lrow = lane >> 3, lpos = lane & 7;
+  // rows handled by this lane: A: (wave*AR + j)*8 + lrow, B: (wave*BR + j)*8 + lrow
+  int rb[AR], ry[AR], rx[AR], rsw[AR];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
-      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
-      if (fhalf == 0) {
-        const int col = wn * (BN / WN) + j * 32 + frow;
-        red[(wm * 2 + 0) * BN + col] = s;
-        red[(wm * 2 + 1) * BN + col] = q;
+  for (int j = 0; j < AR; ++j) {
+    const int row = (wave * AR + j) * 8 + lrow;
+    rsw[j] = (lpos ^ ((row >> 1) & 7)) * EPC;      // source chunk (element offset) feeding this LDS position
+    const int m = bm * BM + row;
+    if (m < p.M) {
+      const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
+      const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
+      rb[j] = b;
+      if (p.mode == 0) { ry[j] = yd * p.stride - p.pad; rx[j] = xd * p.stride - p.pad; }
+      else             { ry[j] = yd + p.pad;            rx[j] = xd + p.pad; }
+    } else { rb[j] = -1; ry[j] = 0; rx[j] = 0; }
+  }
+  const int CT = p.C1 + p.C2;
+  const int ctiles = CT / BKE;
+  const int taps = p.KH * p.KW;
+  const int nk = taps * ctiles;
+  const T* wrow[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int row = (wave * BR + j) * 8 + lrow;
+    wrow[j] = (const T*)p.wt + (size_t)(bn * BN + row) * taps * CT + (lpos ^ ((row >> 1) & 7)) * EPC;
+  }
+
+  int tap = 0, ct = 0;
+  auto issue = [&](int buf) {
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int c0 = ct * BKE;
+    const T* base; int pitch, coff;
+    if (c0 < p.C1) { base = (const T*)p.src1; pitch = p.C1; coff = c0; }
+    else           { base = (const T*)p.src2; pitch = p.C2; coff = c0 - p.C1; }
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      int ys, xs; bool ok = rb[j] >= 0;
+      if (p.mode == 0) { ys = ry[j] + ky * p.dil; xs = rx[j] + kx * p.dil; }
+      else {
+        const int ty = ry[j] - ky * p.dil, tx = rx[j] - kx * p.dil;
+        ok = ok && ty >= 0 && tx >= 0;
+        if (p.stride == 1) { ys = ty; xs = tx; }
+        else { ys = ty / p.stride; xs = tx / p.stride; ok = ok && (ys * p.stride == ty) && (xs * p.stride == tx); }
       }
+      ok = ok && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
+      const void* src = ok ? (const void*)(base + ((size_t)(rb[j] * p.Hs + ys) * p.Ws + xs) * pitch + coff + rsw[j])
+                           : (const void*)(g_zero_page + lpos * 16);
+      glds16(src, lds_a + buf * BM * 128 + (wave * AR + j) * 1024);
+    }
+    const size_t koff = (size_t)tap * CT + c0;
+#pragma unroll
+    for (int j = 0; j < BR; ++j) glds16(wrow[j] + koff, lds_b + buf * BN * 128 + (wave * BR + j) * 1024);
+    if (++ct == ctiles) { ct = 0; ++tap; }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue(0);
+  __syncthreads();      // the barrier's release waits for the LDS-DMA (vmcnt) of every wave
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue(buf ^ 1);
+    const unsigned char* la = lds_a + buf * BM * 128;
+    const unsigned char* lb = lds_b + buf * BN * 128;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(la + lds_off(wm * (BM / WM) + i * 32 + frow, 2 * s + fhalf));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(lb + lds_off(wn * (BN / WN) + j * 32 + frow, 2 * s + fhalf));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
     }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid % BN;
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
-      p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
-    }
   }
+
+  conv_epilogue<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+int g_conv_variant = -1;   // 1: register-staged loads, 2: global_load_lds (default); SEGLAND_CONV_VARIANT / sl_debug_conv_variant
+static int conv_variant() {
+  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] == '1') ? 1 : 2; }
+  return g_conv_variant;
 }
 
 template <typename T, int BN>
@@ -222,8 +364,13 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   p.gridN = p.N / BN;
   const size_t lds = 2 * (BM + BN) * 128;
   dim3 grid(p.gridM * p.gridN);
-  if (BN == 128) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
-  else           hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  if (conv_variant() == 1) {
+    if (BN == 128) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
+    else           hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  } else {
+    if (BN == 128) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
+    else           hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  }
   SL_LAUNCH_CHECK("conv_gemm_kernel");
   return 0;
 }
@@ -251,6 +398,9 @@ int check_desc(const SlConvDesc* d) {
 }
 
 }  // namespace
+
+// test hook (not part of the public ABI)
+extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
 
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;

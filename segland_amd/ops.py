@@ -39,6 +39,54 @@ def _f32(n, dev, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
 
 
+# --------------------------------------------------------------------------------------------- live kernel timing
+class _Profiler:
+    """HIP-event timing of the conv launches on the launch stream (bench.py: roofline of the dominant kernel).
+    Off by default; when on, either every conv launch shape is timed (one instrumented step) or a single shape."""
+
+    def __init__(self):
+        self.on, self.only, self.rec = False, None, {}
+
+    def start(self, all_shapes=False, only=None):
+        self.on, self.only, self.rec = True, (None if all_shapes else only), {}
+
+    def begin(self, kind, d):
+        if not self.on:
+            return None
+        key = (kind, d.dtype, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
+        if self.only is not None and key != self.only:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return key, e0, e1, d
+
+    def end(self, tok):
+        if tok is None:
+            return
+        key, e0, e1, d = tok
+        e1.record()
+        ent = self.rec.get(key)
+        if ent is None:
+            gflop = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW / 1e9
+            ent = self.rec[key] = {'key': key, 'kind': key[0], 'events': [], 'gflop_per_call': gflop,
+                                   'shape': 'B%d %dx%d %d->%d k%d s%d d%d %s' % (d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil, 'bf16' if d.dtype == SL_BF16 else 'f32')}
+        ent['events'].append((e0, e1))
+
+    def stop(self):
+        self.on = False
+        torch.cuda.synchronize()
+        out = {}
+        for key, ent in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b in ent['events'])
+            n = len(ent['events'])
+            out[key] = {'key': key, 'kind': ent['kind'], 'shape': ent['shape'], 'calls': n, 'ms_total': ms, 'gflop': ent['gflop_per_call'] * n}
+        self.rec = {}
+        return out
+
+
+PROFILER = _Profiler()
+
+
 # --------------------------------------------------------------------------------------------- convolution
 class ConvSpec:
     __slots__ = ('cin', 'cout', 'k', 'stride', 'pad', 'dil')
@@ -84,7 +132,9 @@ def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False):
     part = None
     if want_stats:
         part = _f32((_lib.lib().sl_conv2d_stat_rows(C.byref(d)), 2, spec.cout), x.device)
+    tok = PROFILER.begin('conv_fwd', d)
     check(_lib.lib().sl_conv2d_fwd(C.byref(d), _p(x), _p(x2), _p(wf), _p(bias), int(relu), _p(y), _p(part), _s()), 'conv2d_fwd')
+    PROFILER.end(tok)
     return y, part
 
 
@@ -94,7 +144,9 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
     d = conv_desc(dy.dtype, B, H, W, spec, C1)
     dx = out if out is not None else torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
     assert dx.numel() == B * H * W * spec.cin and dx.dtype == dy.dtype
+    tok = PROFILER.begin('conv_dgrad', d)
     check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
+    PROFILER.end(tok)
     return dx
 
 
@@ -117,7 +169,9 @@ def conv2d_bwd_weight(x, dy, spec, x2=None):
     need = _lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d))
     ws = workspace(need, x.device)
     dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    tok = PROFILER.begin('conv_wgrad', d)
     check(_lib.lib().sl_conv2d_bwd_weight(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
+    PROFILER.end(tok)
     return dw
 
 
