@@ -1,0 +1,124 @@
+"""Shared pieces of the two training entry points (train_base.py / ft_pop.py of the reference): the command-line
+surface, LR schedule, validation loop and checkpoint writer.  The flag names, defaults and meanings are the reference's
+(train_base.py:47-111, ft_pop.py:47-115) so scripts/*.sh work with only the module path edited."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from .utils import pyt_utils as my_utils
+
+
+def str2bool(v):
+    if v.lower() in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if v.lower() in ('no', 'false', 'f', 'n', '0'):
+        return False
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+# (flag, kwargs) -- common to both drivers
+_COMMON = [
+    ('--dataset', dict(type=str, default='cityscapes', help='Dataset for training')),
+    ('--batch-size', dict(type=int, default=8, help='Number of images sent to the network in one step.')),
+    ('--data-dir', dict(type=str, default='/data/pascal-context', help='Path to the dataset directory.')),
+    ('--train-list', dict(type=str, default='./dataset/list/context/train.txt', help='File listing the training images.')),
+    ('--base-size', dict(type=str, default='1024,1024', help='Base size of images for resize.')),
+    ('--input-size', dict(type=str, default='512,512', help='Comma-separated height,width of the training crops.')),
+    ('--learning-rate', dict(type=float, default=1e-2, help='Base learning rate (polynomial decay).')),
+    ('--momentum', dict(type=float, default=0.9, help='Momentum component of the optimiser.')),
+    ('--power', dict(type=float, default=0.9, help='Decay parameter of the learning rate.')),
+    ('--weight-decay', dict(type=float, default=0.0005, help='Regularisation parameter for L2-loss.')),
+    ('--start-epoch', dict(type=int, default=0, help='Which epoch to start.')),
+    ('--num-epoch', dict(type=int, default=100, help='Number of training epochs.')),
+    ('--restore-from', dict(type=str, default='/home/model/resnet_backbone/resnet101-imagenet.pth', help='Where to restore model parameters from.')),
+    ('--snapshot-dir', dict(type=str, default='/home/output', help='Where to save snapshots of the model.')),
+    ('--model', dict(type=str, default='None', help='choose model.')),
+    ('--num-workers', dict(type=int, default=4, help='choose the number of workers.')),
+    ('--backbone', dict(type=str, default='resnet50', help='backbone model: resnet101, resnet50 (default)')),
+    ('--os', dict(type=int, default=8, help='output stride')),
+    ('--print-frequency', dict(type=int, default=100, help='Number of training steps between log lines.')),
+    ('--save-pred-every', dict(type=int, default=5, help='Save summaries and checkpoint every often.')),
+    ('--shot', dict(type=int, default=1, help='number of support pairs')),
+    ('--val-list', dict(type=str, default='./dataset/list/context/val.txt', help='File listing the validation images.')),
+    ('--test-batch-size', dict(type=int, default=1, help='Number of images sent to the network in one validation step.')),
+    ('--filter-novel', dict(action='store_true', default=False, help='filter images containing novel classes during training.')),
+    ('--freeze-backbone', dict(action='store_true', default=False, help='freeze the backbone during training.')),
+    ('--fp16', dict(action='store_true', default=False, help='mixed precision: bf16 MFMA with fp32 accumulate on MI355X '
+                                                                '(the reference uses fp16 autocast + GradScaler); default is exact-fp32 MFMA.')),
+]
+_BASE_ONLY = [
+    ('--random-seed', dict(type=int, default=321, help='Random seed to have reproducible results.')),
+    ('--fold', dict(type=int, default=0, choices=[-1, 0, 1, 2, 3], help='validation fold')),
+    ('--fix-bn', dict(action='store_true', default=False, help='whether to fix batchnorm during training.')),
+    ('--finetune', dict(action='store_true', default=False, help='whether to finetune the decoder.')),
+    ('--single-step', dict(action='store_true', default=False, help='ONE AdamW step per iteration; default mirrors the reference, '
+                                                                      'whose scaler.step + optimizer.step is two (train_base.py:262-264).')),
+]
+_FT_ONLY = [
+    ('--random-seed', dict(type=str, default='123,234', help='Comma-separated seeds; one fine-tune run per seed.')),
+    ('--fold', dict(type=int, default=0, choices=[0, 1, 2, 3], help='validation fold')),
+    ('--fix-bn', dict(action='store_true', default=True, help='whether to fix batchnorm during training.')),
+    ('--update-base', dict(action='store_true', default=False, help='whether to update base class with novel class.')),
+    ('--update-epoch', dict(type=int, default=1, help='epoch interval for base-list update / validation.')),
+    ('--fix-lr', dict(action='store_true', default=False, help='whether to fix learning rate during training.')),
+]
+
+
+def build_parser(ft=False):
+    p = argparse.ArgumentParser(description='Few-shot Segmentation Framework (MI355X build)')
+    for flag, kw in _COMMON + (_FT_ONLY if ft else _BASE_ONLY):
+        p.add_argument(flag, **kw)
+    return p
+
+
+def lr_poly(base_lr, it, max_iter, power):
+    return base_lr * ((1 - float(it) / max_iter) ** power)
+
+
+def adjust_learning_rate_poly(optimizer, learning_rate, i_iter, max_iter, power, split=0, scale_lr=10.0):
+    """Groups with index <= split get lr, the others lr*scale (train_base.py:116-128, ft_pop.py:119-131)."""
+    lr = lr_poly(learning_rate, i_iter, max_iter, power)
+    for index, group in enumerate(optimizer.param_groups):
+        group['lr'] = lr if index <= split else lr * scale_lr
+    return lr
+
+
+def compute_dtype(args):
+    return torch.bfloat16 if args.fp16 else torch.float32
+
+
+def validate(model, dataloader, num_classes, ignore_label, device):
+    """train_base.py:316-340 / ft_pop.py:312-336: logits -> upsample(align_corners=True) -> argmax -> IoU histogram,
+    with the upsample+argmax fused in one HIP kernel (no H x W logits) and the histogram in another."""
+    from . import ops
+    model.eval()
+    inter = torch.zeros(num_classes, device=device)
+    union = torch.zeros(num_classes, device=device)
+    for img, mask, _ in dataloader:
+        img, mask = img.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+        with torch.no_grad():
+            logits = model(img)
+            pred = ops.upsample_argmax(logits.float().contiguous(), mask.shape[1:])
+        i, u, _ = my_utils.intersectionAndUnionGPU(pred, mask, num_classes, ignore_label)
+        inter += i
+        union += u
+    return inter, union
+
+
+def save_checkpoint(model, path):
+    """Legacy (non-zipfile) serialisation and `module.`-prefixed keys, exactly the reference's on-disk format."""
+    torch.save(model.state_dict(), path, _use_new_zipfile_serialization=False)
+
+
+def miou(inter, union):
+    return np.nanmean((inter / union).cpu().numpy())
+
+
+def resolve(dataset_pkg, name):
+    mod = getattr(dataset_pkg, name, None)
+    if mod is None:
+        raise RuntimeError("dataset '%s' is not built in this round (available: synthetic); the OpenEarthMap reader "
+                           "(rasterio/cv2) is row f-2 of SURVEY.md section 8" % name)
+    return mod

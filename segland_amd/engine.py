@@ -1,0 +1,112 @@
+"""Process-group runtime of the drivers (counterpart of the reference's engine.py:23-141).
+
+One process per GPU.  On MI355X the backend string "nccl" resolves to RCCL and the gradient all-reduce travels over
+xGMI; on a CPU-only host (unit tests) the same code runs over gloo.  Differences from the reference, on purpose:
+  * one process per GPU also on a single GPU (no nn.DataParallel); a pass-through wrapper keeps the `module.` key prefix
+    of the reference's checkpoints and the `model.module.<attr>` access pattern of its drivers;
+  * DDP is built with find_unused_parameters=False (every parameter of the POP path receives a gradient; the reference's
+    True forces a graph walk per iteration), gradient_as_bucket_view=True and broadcast_buffers=False (BatchNorm
+    statistics are per GPU -- see DESIGN.md "Multi-GPU");
+  * loss scalars are reduced as ONE 3-float all-reduce, and only when they are printed (the reference does three
+    blocking all-reduce + .item() round trips per iteration, train_base.py:266-267).
+"""
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL on this driver stack
+
+
+class ModuleWrapper(nn.Module):
+    """Single-process stand-in for nn.DataParallel: same `.module` attribute and `module.`-prefixed state_dict."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class Engine(object):
+    def __init__(self, custom_parser=None, argv=None):
+        self.parser = custom_parser if custom_parser is not None else argparse.ArgumentParser()
+        self.inject_default_parser()
+        self.args = self.parser.parse_args(argv)
+        self.continue_state_object = self.args.continue_fpath
+        self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
+        self.distributed = self.world_size > 1
+        self.local_rank = int(os.environ.get('LOCAL_RANK', self.args.local_rank))
+        self.use_cuda = torch.cuda.is_available()
+        if self.use_cuda:
+            torch.cuda.set_device(self.local_rank)
+        self.device = torch.device('cuda', self.local_rank) if self.use_cuda else torch.device('cpu')
+        if self.distributed and not dist.is_initialized():
+            dist.init_process_group(backend='nccl' if self.use_cuda else 'gloo', init_method='env://')
+        self.rank = dist.get_rank() if self.distributed else 0
+        self.devices = list(range(self.world_size))
+
+    def inject_default_parser(self):
+        p = self.parser
+        p.add_argument('-d', '--devices', default='', help='set data parallel training')
+        p.add_argument('-c', '--continue', type=str, metavar='FILE', dest='continue_fpath', help='continue from one certain checkpoint')
+        p.add_argument('--local_rank', default=0, type=int, help='process rank on node')
+
+    @property
+    def is_main(self):
+        return self.rank == 0
+
+    def data_parallel(self, model):
+        model = model.to(self.device)
+        if not self.distributed:
+            return ModuleWrapper(model)
+        kw = dict(find_unused_parameters=False, gradient_as_bucket_view=True, broadcast_buffers=False, bucket_cap_mb=64)
+        if self.use_cuda:
+            return nn.parallel.DistributedDataParallel(model, device_ids=[self.local_rank], output_device=self.local_rank, **kw)
+        return nn.parallel.DistributedDataParallel(model, **kw)
+
+    def _loader(self, dataset, batch_size, num_workers, train):
+        sampler = None
+        if self.distributed:
+            sampler = torch.utils.data.distributed.DistributedSampler(dataset)
+            batch_size = max(1, batch_size // self.world_size)          # engine.py:86 of the reference
+            num_workers = num_workers // self.world_size if train else num_workers
+        loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, drop_last=train,
+                                             shuffle=(train and sampler is None), pin_memory=self.use_cuda, sampler=sampler)
+        return loader, sampler
+
+    def get_train_loader(self, train_dataset):
+        return self._loader(train_dataset, self.args.batch_size, self.args.num_workers, True)
+
+    def get_test_loader(self, test_dataset):
+        return self._loader(test_dataset, self.args.test_batch_size, self.args.num_workers, False)
+
+    def all_reduce_tensor(self, tensor, norm=True):
+        if not self.distributed:
+            return tensor
+        with torch.no_grad():
+            t = tensor.detach().clone()
+            dist.all_reduce(t, dist.ReduceOp.SUM)
+            if norm:
+                t.div_(self.world_size)
+        return t
+
+    def reduce_loss_dict(self, loss_dict):
+        """{name: python float}, averaged over ranks, with ONE collective and ONE device->host copy."""
+        keys = list(loss_dict.keys())
+        vec = torch.stack([loss_dict[k].detach().float().reshape(()) for k in keys])
+        vec = self.all_reduce_tensor(vec, norm=True)
+        return dict(zip(keys, vec.tolist()))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, type, value, tb):
+        if self.use_cuda:
+            torch.cuda.empty_cache()
+        if self.distributed and dist.is_initialized():
+            dist.destroy_process_group()
+        return False

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Base-class training entry point (counterpart of the reference's train_base.py) on the MI355X HIP path.
+
+    python -m segland_amd.train_base --model pspnet_pop --backbone resnet50 --dataset synthetic --batch-size 16 --fp16 ...
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m segland_amd.train_base ...
+"""
+import os
+import os.path as osp
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import dataset as dataset_pkg
+from . import networks
+from .drivers import adjust_learning_rate_poly, build_parser, compute_dtype, miou, resolve, save_checkpoint, validate
+from .engine import Engine
+from .loss import get_loss
+from .utils import pyt_utils as my_utils
+
+
+def train_iteration(model, optimizer, loss_scaler, img, mask, double_step=True):
+    """Loop body of train_base.py:250-264."""
+    optimizer.zero_grad()
+    loss_dict = model(img, mask)
+    grad_norm = loss_scaler(loss_dict['total_loss'], optimizer, clip_grad=5.0, parameters=model.parameters())
+    if double_step:
+        optimizer.step()          # the reference's second step on the same gradients
+    return loss_dict, grad_norm
+
+
+def main(argv=None):
+    parser = build_parser(ft=False)
+    with Engine(custom_parser=parser, argv=argv) as engine:
+        args = engine.args
+        logger = my_utils.prep_experiment(args) if engine.is_main else None
+        if args.random_seed > 0:
+            my_utils.set_seed(args.random_seed)
+        args.input_size = tuple(map(int, args.input_size.split(',')))
+        args.base_size = tuple(map(int, args.base_size.split(',')))
+        ds = resolve(dataset_pkg, args.dataset)
+        trainset = ds.GFSSegTrain(args.data_dir, args.train_list, args.fold, args.shot, crop_size=args.input_size,
+                                  base_size=args.base_size, mode='train', filter=args.filter_novel)
+        train_loader, train_sampler = engine.get_train_loader(trainset)
+        args.ignore_label, args.num_classes = trainset.ignore_label, trainset.num_classes
+        args.base_classes = len(trainset.base_classes)
+        testset = ds.GFSSegVal(args.data_dir, args.val_list, args.fold, base_size=args.base_size, resize_label=False, use_novel=False)
+        test_loader, test_sampler = engine.get_test_loader(testset)
+        if engine.distributed:
+            test_sampler.set_epoch(0)
+
+        criterion = get_loss(args)
+        norm = nn.SyncBatchNorm if engine.distributed else nn.BatchNorm2d       # parameter holders; statistics are per GPU
+        assert args.os in (8, 16, 32)
+        model_cls = getattr(networks, args.model).GFSS_Model                    # `networks.<model>.GFSS_Model`
+        seg_model = model_cls(n_base=args.base_classes, criterion=criterion, backbone=args.backbone, norm_layer=norm,
+                              pretrained_model=(args.restore_from if args.start_epoch == 0 and osp.exists(str(args.restore_from)) else None),
+                              dilated=(args.os != 32), os=args.os, compute_dtype=compute_dtype(args))
+        if args.freeze_backbone:
+            my_utils.load_model(seg_model, args.restore_from, backbone_only=args.finetune, is_restore=not args.finetune)
+        params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
+        optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
+        model = engine.data_parallel(seg_model)
+        loss_scaler = my_utils.NativeScalerWithGradNormCount()
+        if engine.is_main:
+            os.makedirs(args.snapshot_dir, exist_ok=True)
+
+        it, best, best_epoch = args.start_epoch * len(train_loader), 0.0, 0
+        for epoch in range(args.start_epoch, args.num_epoch):
+            if args.random_seed > 0:
+                my_utils.set_seed(args.random_seed + epoch)
+            if engine.distributed:
+                train_sampler.set_epoch(epoch)
+            if args.freeze_backbone:
+                model.module.train_mode()
+            else:
+                model.train()
+            lr = adjust_learning_rate_poly(optimizer, args.learning_rate, epoch, args.num_epoch, args.power,
+                                           split=-1 if args.freeze_backbone else 0)      # per EPOCH (train_base.py:248)
+            for i, (img, mask, _) in enumerate(train_loader):
+                it += 1
+                img, mask = img.to(engine.device, non_blocking=True), mask.to(engine.device, non_blocking=True)
+                loss_dict, grad_norm = train_iteration(model, optimizer, loss_scaler, img, mask, double_step=not args.single_step)
+                if i % args.print_frequency == 0:
+                    vals = engine.reduce_loss_dict(loss_dict)
+                    if engine.is_main:
+                        logger.info('Epoch{}/Iters{} Iter{}/{}: lr={:.2e} grad_norm={:.4f}'.format(epoch + 1, it, i + 1, len(train_loader), lr, float(grad_norm))
+                                    + ''.join(' %s=%.4f' % kv for kv in vals.items()))
+            e1 = epoch + 1
+            if engine.is_main and (e1 % 10 == 0 or e1 >= args.num_epoch):
+                save_checkpoint(model, osp.join(args.snapshot_dir, 'epoch_%d.pth' % e1))
+            if e1 > 35 and (e1 % 10 == 0 or epoch == args.num_epoch - 1):
+                inter, union = validate(model, test_loader, args.base_classes + 1, args.ignore_label, engine.device)
+                inter, union = engine.all_reduce_tensor(inter, norm=False), engine.all_reduce_tensor(union, norm=False)
+                m = miou(inter, union)
+                if engine.is_main:
+                    if m >= best:
+                        save_checkpoint(model, osp.join(args.snapshot_dir, 'best.pth'))
+                        best, best_epoch = m, e1
+                    logger.info('>>>>>>> Evaluation Results: meanIU: {:.2%}, best_IU: {:.2%}, best_epoch: {} <<<<<<<'.format(m, best, best_epoch))
+
+
+if __name__ == '__main__':
+    main()

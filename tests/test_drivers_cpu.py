@@ -1,0 +1,151 @@
+"""CPU tests of the host-side harness: command-line surface, LR schedule, parameter groups, checkpoint key format,
+and the N > 1 data-parallel path over gloo (world_size 2) with the CPU oracle standing in for the HIP model
+(the collectives, sharding and reductions of engine.py are device-agnostic)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden
+from oracle import formula as fm
+from oracle import pop_oracle as po
+
+REF_BASE_FLAGS = ['--dataset', '--batch-size', '--data-dir', '--train-list', '--base-size', '--input-size', '--learning-rate', '--momentum',
+                  '--power', '--weight-decay', '--start-epoch', '--num-epoch', '--random-seed', '--restore-from', '--snapshot-dir', '--model',
+                  '--num-workers', '--backbone', '--os', '--print-frequency', '--save-pred-every', '--fold', '--shot', '--val-list',
+                  '--test-batch-size', '--fix-bn', '--filter-novel', '--freeze-backbone', '--fp16', '--finetune']       # train_base.py:47-111
+REF_FT_FLAGS = [f for f in REF_BASE_FLAGS if f != '--finetune'] + ['--update-base', '--update-epoch', '--fix-lr']       # ft_pop.py:47-115
+
+
+def flags_of(parser):
+    return {s for a in parser._actions for s in a.option_strings}
+
+
+def test_cli_surface_matches_reference():
+    from segland_amd.drivers import build_parser
+    base, ft = build_parser(False), build_parser(True)
+    assert set(REF_BASE_FLAGS) <= flags_of(base)
+    assert set(REF_FT_FLAGS) <= flags_of(ft)
+    a = base.parse_args([])
+    assert (a.batch_size, a.learning_rate, a.weight_decay, a.power, a.num_epoch, a.random_seed, a.os, a.backbone) == (8, 1e-2, 0.0005, 0.9, 100, 321, 8, 'resnet50')
+    f = ft.parse_args([])
+    assert f.random_seed == '123,234' and f.fix_bn is True and f.update_epoch == 1
+    # Engine-injected flags (engine.py:58-67 of the reference)
+    from segland_amd.engine import Engine
+    e = Engine(custom_parser=build_parser(False), argv=['--model', 'pspnet_pop', '--local_rank', '0'])
+    assert {'-d', '--devices', '-c', '--continue', '--local_rank'} <= flags_of(e.parser) and not e.distributed
+
+
+def test_lr_schedule_and_param_groups():
+    from segland_amd.drivers import adjust_learning_rate_poly, lr_poly
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    from segland_amd.utils.pyt_utils import get_parameters
+    assert lr_poly(1e-2, 0, 100, 0.9) == 1e-2
+    np.testing.assert_allclose(lr_poly(1e-2, 50, 100, 0.9), 1e-2 * 0.5 ** 0.9)
+    m = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=None, dilated=True, os=8)
+    groups = get_parameters(m, lr=1e-3)
+    sizes = [(len(g['params']), sum(p.numel() for p in g['params'])) for g in groups]
+    assert sizes == [(159, 23508032), (6, 3072), (15, 23861760)]                     # SURVEY 8 a-12, == golden g8
+    assert np.array_equal(np.array(sizes), golden('g8_traj')['group_sizes'])
+    assert groups[1]['weight_decay'] == 0.0 and groups[1]['lr'] == 1e-2 and groups[0]['lr'] == 1e-3
+    opt = torch.optim.AdamW(groups, lr=1e-3)
+    lr = adjust_learning_rate_poly(opt, 1e-3, 10, 100, 0.9, split=0)
+    assert opt.param_groups[0]['lr'] == lr and opt.param_groups[2]['lr'] == lr * 10
+    # ft model: only novel_emb + classifier_n are trainable (SURVEY 3.2 [probe])
+    mf = GFSS_Model(n_base=7, is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, dilated=True, os=8)
+    assert sorted(k for k, p in mf.named_parameters() if p.requires_grad) == ['classifier_n.0.weight', 'classifier_n.2.weight', 'classifier_n.4.weight', 'novel_emb']
+
+
+def test_checkpoint_format_roundtrip(tmp_path):
+    from segland_amd.drivers import save_checkpoint
+    from segland_amd.engine import ModuleWrapper
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    from segland_amd.utils.pyt_utils import load_model
+    m = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=None, dilated=True, os=8)
+    fm.load_formula_weights(m)
+    path = str(tmp_path / 'epoch_1.pth')
+    save_checkpoint(ModuleWrapper(m), path)
+    sd = torch.load(path, map_location='cpu')
+    assert all(k.startswith('module.') for k in sd) and 'module.decoder.bottleneck.3.bias' in sd       # the reference's key format
+    # ... which loads back both into our model and into the oracle (== reference layout) with is_restore=True
+    m2 = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=None, dilated=True, os=8)
+    load_model(m2, path, is_restore=True)
+    assert torch.equal(m2.backbone.layer3[4].conv2.weight, m.backbone.layer3[4].conv2.weight)
+    o = po.PopOracle(7)
+    o.load_state_dict({k[7:]: v for k, v in sd.items()}, strict=True)
+
+
+def test_gpu_only_model_fails_loudly_on_cpu():
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    m = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=None, dilated=True, os=8)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(2, 3, 64, 64))
+
+
+# ------------------------------------------------------------------------------------------------ world_size 2 over gloo
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _small_oracle():
+    """A 2-block 'backbone' oracle: same code path as the full model (stem, bottlenecks, PPM, POP head, OrthLoss), sized for CPU."""
+    torch.manual_seed(0)
+    bb = po._Holder()
+    bb.conv1 = po._conv(3, 64, 7, stride=2, pad=3); bb.bn1 = torch.nn.BatchNorm2d(64)
+    bb.layer1 = torch.nn.Sequential(po.make_bottleneck(64, 16, 1, 1, True)); bb.layer2 = torch.nn.Sequential(po.make_bottleneck(64, 16, 2, 1, True))
+    bb.layer3 = torch.nn.Sequential(); bb.layer4 = torch.nn.Sequential()
+    m = po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), _custom_backbone=bb, feat_channels=64)
+    fm.load_formula_weights(m)
+    return m
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from segland_amd.drivers import build_parser
+    from segland_amd.engine import Engine
+    with Engine(custom_parser=build_parser(False), argv=['--model', 'pspnet_pop', '--batch-size', '4']) as engine:
+        assert engine.distributed and engine.world_size == world and dist.get_backend() == 'gloo'
+        m = _small_oracle()
+        po.train_mode(m)                          # BN in eval: DP over a split batch == one process over the full batch
+        model = engine.data_parallel(m)
+        img = fm.formula_image(4, 64, 64, 'ddp/img'); mask = fm.formula_mask(4, 64, 64, 8, 'ddp/mask', block=16, ignore_rows=0)
+        sl = slice(rank * 2, rank * 2 + 2)        # the sampler's shard: per-rank batch = global / world (engine.py:84-86)
+        d = model(img[sl], mask[sl])
+        d['total_loss'].backward()
+        vals = engine.reduce_loss_dict(d)
+        inter = engine.all_reduce_tensor(torch.tensor([1.0 + rank, 2.0]), norm=False)
+        grads = {k: p.grad.clone() for k, p in model.module.named_parameters() if p.grad is not None}
+        if rank == 0:
+            q.put((vals, inter.tolist(), {k: v.numpy() for k, v in list(grads.items())[:6]}, float(torch.stack([g.norm() for g in grads.values()]).norm())))
+
+
+def test_ddp_over_gloo_matches_single_process():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    vals, inter, grads, gnorm = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process on the full batch.  DDP averages gradients over ranks; the mean-over-valid-pixels CE of the full
+    # batch equals the mean of the two shard losses here because both shards have the same number of valid pixels.
+    m = _small_oracle(); po.train_mode(m)
+    img = fm.formula_image(4, 64, 64, 'ddp/img'); mask = fm.formula_mask(4, 64, 64, 8, 'ddp/mask', block=16, ignore_rows=0)
+    d = m(img, mask); d['total_loss'].backward()
+    np.testing.assert_allclose(vals['total_loss'], float(d['total_loss']), rtol=1e-5)
+    np.testing.assert_allclose(vals['seg_loss'], float(d['seg_loss']), rtol=1e-5)
+    assert inter == [3.0, 4.0]
+    ref = dict(m.named_parameters())
+    for k, g in grads.items():
+        np.testing.assert_allclose(g, ref[k].grad.numpy(), rtol=2e-4, atol=1e-7, err_msg=k)
+    ref_norm = float(torch.stack([p.grad.norm() for p in m.parameters() if p.grad is not None]).norm())
+    np.testing.assert_allclose(gnorm, ref_norm, rtol=1e-4)
