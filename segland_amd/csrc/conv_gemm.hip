@@ -94,8 +94,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t 
       }
     }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid % BN;
+    for (int e = tid; e < 2 * BN; e += 64 * WM * WN) {
+      const int which = e / BN, col = e % BN;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
@@ -225,6 +225,122 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Epilogue of the glds kernels.  The MFMAs are issued with the operand roles swapped (A = weight rows, B = pixel rows),
+// so a lane holds, for ONE pixel (col = lane&31), four consecutive output channels per register quad
+// (n = 8*(r>>2) + 4*(lane>>5) + (r&3)).  The tile is staged through LDS ([pixel][channel], 16-byte padded rows) with
+// 8/16-byte writes and then streamed out with 16-byte coalesced global stores; bias, ReLU, the residual addend and the
+// ReLU mask are applied on those vectors (16-byte coalesced loads), and the per-channel BN statistics (sum, sum of
+// squares of the stored values) are accumulated in the same pass.
+template <typename T, int BM, int BN, int WM, int WN>
+struct EpiGeom {
+  static constexpr int PITCH = BN * (int)sizeof(T) + 16;
+  static constexpr int TILE_BYTES = BM * PITCH;
+  static constexpr int NPASS = TILE_BYTES > 150 * 1024 ? 2 : 1;
+  static constexpr int MAIN_BYTES = 2 * (BM + BN) * 128;
+  static constexpr int LDS_BYTES = (TILE_BYTES / NPASS) > MAIN_BYTES ? (TILE_BYTES / NPASS) : MAIN_BYTES;
+  static_assert(WM % NPASS == 0, "passes split whole wave rows");
+};
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                                  int lane, int tid, unsigned char* smem) {
+  using G = EpiGeom<T, BM, BN, WM, WN>;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CPR = BN / EPC;              // 16-byte chunks per tile row
+  constexpr int RS = NT / CPR;               // rows covered per sweep of the block
+  constexpr int ROWS = BM / G::NPASS;
+  static_assert(NT % CPR == 0 && CPR <= 64, "store-phase mapping");
+  const int fhalf = lane >> 5;
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int ncol = bn * BN + cc * EPC;
+  float bias[EPC], ssum[EPC], ssq[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { bias[e] = p.bias ? p.bias[ncol + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
+  T* out = (T*)p.out;
+#pragma unroll
+  for (int pass = 0; pass < G::NPASS; ++pass) {
+    if (wm / (WM / G::NPASS) == pass) {
+      const int lrow = (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned char* dst = smem + (lrow + i * 32) * G::PITCH + (wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf) * (int)sizeof(T);
+            if constexpr (sizeof(T) == 2) {
+              uint2 v;
+              v.x = (unsigned)f2bf(acc[i][j][4 * q + 0]) | ((unsigned)f2bf(acc[i][j][4 * q + 1]) << 16);
+              v.y = (unsigned)f2bf(acc[i][j][4 * q + 2]) | ((unsigned)f2bf(acc[i][j][4 * q + 3]) << 16);
+              *(uint2*)dst = v;
+            } else {
+              *(float4*)dst = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+          }
+    }
+    __syncthreads();
+    for (int row = r0; row < ROWS; row += RS) {
+      const int m = bm * BM + pass * ROWS + row;
+      if (m >= p.M) break;
+      float v[EPC];
+      unpack16<T>(*(const uint4*)(smem + row * G::PITCH + cc * 16), v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+      const size_t o = (size_t)m * p.N + ncol;
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] += bias[e];
+      }
+      if (p.addend) {
+        float a[EPC];
+        unpack16<T>(*(const uint4*)((const T*)p.addend + o), a);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] += a[e];
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      if (p.mask_src) {
+        float k[EPC];
+        unpack16<T>(*(const uint4*)((const T*)p.mask_src + o), k);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
+      }
+      *(uint4*)(out + o) = pack16<T>(v);
+    }
+    __syncthreads();
+  }
+  if (p.stat_partial) {
+    // lanes l and l + CPR*k of a wave own the same chunk column
+#pragma unroll
+    for (int off = CPR; off < 64; off <<= 1) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { ssum[e] += __shfl_xor(ssum[e], off, 64); ssq[e] += __shfl_xor(ssq[e], off, 64); }
+    }
+    float* red = (float*)smem;                       // [NW][2][BN]
+    const int wave = tid >> 6;
+    if (lane < CPR) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        red[(wave * 2 + 0) * BN + cc * EPC + e] = ssum[e];
+        red[(wave * 2 + 1) * BN + cc * EPC + e] = ssq[e];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * BN; e += NT) {
+      const int which = e / BN, col = e % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM * WN; ++w) t += red[(w * 2 + which) * BN + col];
+      p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v2: operands go HBM -> LDS directly (global_load_lds, 16 B per lane, no VGPR staging, no ds_write pass).
 // The LDS destination of one wave-instruction is lane-linear (base + lane*16 = 8 rows x 128 B), so the bank swizzle is
 // applied to the SOURCE chunk index: LDS position p of row r receives global chunk p ^ ((r>>1)&7) -- still inside the
@@ -240,12 +356,13 @@ __device__ __forceinline__ void glds16(const void* g, unsigned char* l) {
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_glds_kernel(ConvGemmParams p) {
   constexpr int EPC = 16 / sizeof(T);
   constexpr int BKE = 8 * EPC;
-  constexpr int AR = BM / 32, BR = BN / 32;     // 8-row groups per wave
+  constexpr int NW = WM * WN;                   // waves per block (4 or 8)
+  constexpr int AR = BM / 8 / NW, BR = BN / 8 / NW;     // 8-row (1 KiB) groups loaded per wave
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert(AR >= 1 && BR >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* lds_a = smem;
   unsigned char* lds_b = smem + 2 * BM * 128;
@@ -343,36 +460,59 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(ConvGemmParams p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < TN; ++j) Mma<T>::run(bf[j], af[i], acc[i][j]);     // swapped roles: D[n][m]
     }
     __syncthreads();
   }
 
-  conv_epilogue<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  conv_epilogue_lds<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
-int g_conv_variant = -1;   // 1: register-staged loads, 2: global_load_lds (default); SEGLAND_CONV_VARIANT / sl_debug_conv_variant
+int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3 (default): glds, 256-row 8-wave tiles where M allows
 static int conv_variant() {
-  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] == '1') ? 1 : 2; }
+  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3; }
   return g_conv_variant;
 }
 
-template <typename T, int BN>
-int launch_gemm(ConvGemmParams& p, hipStream_t st) {
-  constexpr int BM = 128;
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_glds(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, BM);
   p.gridN = p.N / BN;
-  const size_t lds = 2 * (BM + BN) * 128;
-  dim3 grid(p.gridM * p.gridN);
-  if (conv_variant() == 1) {
-    if (BN == 128) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
-    else           hipLaunchKernelGGL((conv_gemm_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
-  } else {
-    if (BN == 128) hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM, 128, 2, 2>), grid, dim3(256), lds, st, p);
-    else           hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM, 64, 2, 2>), grid, dim3(256), lds, st, p);
+  const size_t lds = EpiGeom<T, BM, BN, WM, WN>::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<T, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
   }
-  SL_LAUNCH_CHECK("conv_gemm_kernel");
+  hipLaunchKernelGGL((conv_gemm_glds_kernel<T, BM, BN, WM, WN>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_glds_kernel");
   return 0;
+}
+
+// rows per block of the kernel that will run for an M-row problem (also the granularity of the BN partial statistics)
+static int block_rows(long long M) { return (conv_variant() >= 3 && M >= 256 * 96) ? 256 : 128; }
+
+template <typename T>
+int launch_gemm(ConvGemmParams& p, hipStream_t st) {
+  const int v = conv_variant();
+  const bool n128 = (p.N % 128 == 0), n256 = (p.N % 256 == 0);
+  if (v == 1) {
+    p.gridM = cdiv(p.M, 128); p.gridN = p.N / (n128 ? 128 : 64);
+    const size_t lds = 2 * (128 + (n128 ? 128 : 64)) * 128;
+    if (n128) hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), dim3(p.gridM * p.gridN), dim3(256), lds, st, p);
+    else      hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), dim3(p.gridM * p.gridN), dim3(256), lds, st, p);
+    SL_LAUNCH_CHECK("conv_gemm_kernel");
+    return 0;
+  }
+  // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
+  const bool big = block_rows(p.M) == 256;
+  if (big) {
+    if (n256) return launch_glds<T, 256, 256, 2, 4>(p, st);
+    if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
+    return launch_glds<T, 256, 64, 8, 1>(p, st);
+  }
+  if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
+  return launch_glds<T, 128, 64, 2, 2>(p, st);
 }
 
 int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
@@ -381,9 +521,8 @@ int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
   SL_REQUIRE(p.C1 > 0 && p.C1 % bke == 0 && p.C2 % bke == 0, "conv: source channels (%d,%d) must be multiples of %d", p.C1, p.C2, bke);
   SL_REQUIRE(p.N > 0 && p.N % 64 == 0, "conv: output channels %d must be a multiple of 64", p.N);
   SL_REQUIRE(p.M > 0, "conv: empty output");
-  const bool wide = (p.N % 128 == 0);
-  if (dtype == SL_BF16) return wide ? launch_gemm<bf16_t, 128>(p, st) : launch_gemm<bf16_t, 64>(p, st);
-  return wide ? launch_gemm<float, 128>(p, st) : launch_gemm<float, 64>(p, st);
+  if (dtype == SL_BF16) return launch_gemm<bf16_t>(p, st);
+  return launch_gemm<float>(p, st);
 }
 
 int check_desc(const SlConvDesc* d) {
@@ -404,7 +543,8 @@ extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
 
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
-  return cdiv((long long)d->B * d->Ho * d->Wo, 128);
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  return cdiv(M, block_rows(M));
 }
 
 extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias,

@@ -51,6 +51,12 @@ CONV_CASES = [
     (2, 16, 16, 64, 64, 3, 1, 2, 2),
     (2, 16, 16, 128, 64, 3, 1, 4, 4),
     (3, 1, 5, 512, 512, 1, 1, 0, 1),        # tiny M (PPM stage / head prototype rows)
+    # M >= 24576 rows: the 256-row / 8-wave tile variants (N % 256, N % 128, N = 64), incl. a ragged last row block
+    (8, 64, 64, 64, 256, 1, 1, 0, 1),
+    (6, 64, 64, 128, 128, 3, 1, 1, 1),
+    (8, 64, 64, 256, 64, 1, 1, 0, 1),
+    (7, 60, 64, 64, 512, 3, 1, 2, 2),
+    (2, 128, 128, 128, 128, 3, 2, 1, 1),
 ]
 
 
