@@ -8,6 +8,7 @@
 //   - f32 : by plain ds_read_b32 (v_mfma_f32_32x32x2_f32 takes one k per lane), conflict-free.
 // Split over m with per-split fp32 slabs in the caller's workspace and a fixed-order reduce that also converts
 // [Cout][tap][Cin] -> OIHW, so results are bit-stable run to run.
+#include <math.h>
 #include <stdlib.h>
 #include "common.h"
 
@@ -215,16 +216,215 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 }
 
-// dw_oihw[n][c][t] = sum_s ws[s][n][t][c]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits) {
-  const long long total = (long long)Cout * taps * Cin;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % Cin);
-    const long long nt = e / Cin;
-    const int t = (int)(nt % taps), n = (int)(nt / taps);
+// ---------------------------------------------------------------------------------------------------------------
+// v2: up to 256 x 256 output tiles (8 waves) and HBM -> LDS by global_load_lds.  A stage holds KM = 32 pixel rows of dy
+// ([m][BNN]) and of x ([m][BCC]) unpadded; the 16-byte chunk c of stage row r is stored at position c ^ ((r&3)<<2)
+// (source-side swizzle, the LDS image of each 1 KiB wave-instruction stays lane-linear).  For the bf16 transpose reads a
+// 32-lane service group touches 4 rows x 2 column groups x 32 B = eight distinct 32-byte segments of one 256-byte bank
+// window: conflict-free.  The f32 ds_read_b32 pattern (32 consecutive columns of one row) is conflict-free under any
+// per-row chunk permutation.
+__device__ __attribute__((aligned(256))) unsigned char g_wzero_page[256];
+
+typedef __attribute__((address_space(3))) void wlds_void_t;
+typedef const __attribute__((address_space(1))) void wgbl_void_t;
+__device__ __forceinline__ void wglds16(const void* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((wgbl_void_t*)g, (wlds_void_t*)l, 16, 0, 0);
+}
+
+template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR>
+__global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradParams p) {
+  constexpr int ES = sizeof(T), EPC = 16 / ES, NW = WNN * WCC;
+  constexpr int RB_A = BNN * ES, RB_B = BCC * ES;                  // stage row bytes
+  constexpr int RPI_A = 1024 / RB_A, RPI_B = 1024 / RB_B;          // rows per 1 KiB wave-instruction
+  constexpr int IA = KM / RPI_A / NW, IB = KM / RPI_B / NW;        // instructions per wave per stage
+  constexpr int TM = BNN / WNN / 32, TN = BCC / WCC / 32;
+  static_assert(RB_A >= 256 && RB_B >= 256 && RB_A <= 1024 && RB_B <= 1024, "row bytes 256..1024");
+  static_assert(IA >= 1 && IB >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lds_a = smem;                         // [2][KM][RB_A]
+  unsigned char* lds_b = smem + 2 * KM * RB_A;         // [2][KM][RB_B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WCC, wn = wave % WCC;
+
+  int bid = blockIdx.x;
+  const int bc = bid % p.gridC; bid /= p.gridC;
+  const int bn = bid % p.gridN; bid /= p.gridN;
+  const int tap = bid % p.taps; const int split = bid / p.taps;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+
+  const int CT = p.C1 + p.C2;
+  const int c0 = bc * BCC;
+  const T* xbase; int xpitch, xoff;
+  if (c0 < p.C1) { xbase = (const T*)p.src1; xpitch = p.C1; xoff = c0; }
+  else           { xbase = (const T*)p.src2; xpitch = p.C2; xoff = c0 - p.C1; }
+  const T* dyb = (const T*)p.dy + bn * BNN;
+  const bool ident = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
+
+  const int m_begin = split * p.rows_per_split;
+  const int m_end = min(p.M, m_begin + p.rows_per_split);
+  const int nit = (m_end - m_begin + KM - 1) / KM;
+
+  // per-lane constants of the loader
+  const int a_rin = (lane * 16) / RB_A, a_pos = ((lane * 16) % RB_A) / 16;
+  const int b_rin = (lane * 16) / RB_B, b_pos = ((lane * 16) % RB_B) / 16;
+
+  auto issue = [&](int it, int buf) {
+    const int m0 = m_begin + it * KM;
+#pragma unroll
+    for (int j = 0; j < IA; ++j) {
+      const int ins = wave * IA + j, r = ins * RPI_A + a_rin, m = m0 + r;
+      const void* src = (m < m_end) ? (const void*)(dyb + (size_t)m * p.Cout + (a_pos ^ ((r & 3) << 2)) * EPC)
+                                    : (const void*)(g_wzero_page + (lane & 7) * 16);
+      wglds16(src, lds_a + (buf * KM + ins * RPI_A) * RB_A);
+    }
+#pragma unroll
+    for (int j = 0; j < IB; ++j) {
+      const int ins = wave * IB + j, r = ins * RPI_B + b_rin, m = m0 + r;
+      const void* src = (const void*)(g_wzero_page + (lane & 7) * 16);
+      if (m < m_end) {
+        const int ce = xoff + (b_pos ^ ((r & 3) << 2)) * EPC;
+        if (ident) src = (const void*)(xbase + (size_t)m * xpitch + ce);
+        else {
+          const int hw = p.Ho * p.Wo;
+          const int b = m / hw, rem = m - b * hw, yo = rem / p.Wo, xo = rem - yo * p.Wo;
+          const int ys = yo * p.stride - p.pad + ky * p.dil, xs = xo * p.stride - p.pad + kx * p.dil;
+          if ((unsigned)ys < (unsigned)p.H && (unsigned)xs < (unsigned)p.W)
+            src = (const void*)(xbase + ((size_t)(b * p.H + ys) * p.W + xs) * xpitch + ce);
+        }
+      }
+      wglds16(src, lds_b + (buf * KM + ins * RPI_B) * RB_B);
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nit > 0) issue(0, 0);
+  __syncthreads();
+
+  const int frow = lane & 31, fhalf = lane >> 5;
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < nit) issue(it + 1, buf ^ 1);
+    const unsigned char* la = lds_a + buf * KM * RB_A;
+    const unsigned char* lb = lds_b + buf * KM * RB_B;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int ks = 0; ks < KM / 2; ++ks) {
+        float af[TM], bf[TN];
+        const int row = 2 * ks + fhalf, sw = (row & 3) << 2;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { const int n = wm * (BNN / WNN) + i * 32 + frow; af[i] = *(const float*)(la + row * RB_A + (((n >> 2) ^ sw) << 4) + (n & 3) * 4); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { const int c = wn * (BCC / WCC) + j * 32 + frow; bf[j] = *(const float*)(lb + row * RB_B + (((c >> 2) ^ sw) << 4) + (c & 3) * 4); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KM / 16; ++ks) {
+        uint4 af[TM], bf[TN];
+        if constexpr (USE_TR) {
+          const int g = lane >> 4, l = lane & 15;
+          const int r = 16 * ks + 8 * (g >> 1) + (l >> 2);          // (r & 3) == l >> 2; the second read is 4 rows below
+          const int sw = (l >> 2) << 2;
+          const int cofs = 16 * (g & 1) + 4 * (l & 3);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int e = wm * (BNN / WNN) + i * 32 + cofs;
+            const unsigned char* a0 = la + r * RB_A + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+            const uint2 lo = lds_tr16_b64(a0), hi = lds_tr16_b64(a0 + 4 * RB_A);
+            af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int e = wn * (BCC / WCC) + j * 32 + cofs;
+            const unsigned char* b0 = lb + r * RB_B + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+            const uint2 lo = lds_tr16_b64(b0), hi = lds_tr16_b64(b0 + 4 * RB_B);
+            bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
+        } else {
+          const int rb = 16 * ks + 8 * fhalf;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int n = wm * (BNN / WNN) + i * 32 + frow;
+            unsigned e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(la + (rb + k) * RB_A + (((n >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (n & 7) * 2);
+            af[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int c = wn * (BCC / WCC) + j * 32 + frow;
+            unsigned e[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(lb + (rb + k) * RB_B + (((c >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (c & 7) * 2);
+            bf[j] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* ws = p.ws + (size_t)split * p.Cout * p.taps * CT;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int c = c0 + wn * (BCC / WCC) + j * 32 + frow;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = bn * BNN + wm * (BNN / WNN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+        ws[((size_t)n * p.taps + tap) * CT + c] = acc[i][j][r];
+      }
+    }
+}
+
+// dw_oihw[n][c][t] = sum_s ws[s][n][t][c].  One block per (n, 64-channel chunk): the taps x 64 slab values are read as
+// 256-byte rows (coalesced), transposed through LDS and written as ONE contiguous run of 64*taps floats.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits) {
+  __shared__ float tile[64 * 49];      // [c][t], taps <= 49
+  const int cchunks = Cin / 64;
+  const int n = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * 64;
+  const size_t slab = (size_t)Cout * taps * Cin;
+  for (int e = threadIdx.x; e < taps * 64; e += 256) {
+    const int t = e / 64, c = e % 64;
+    const size_t off = ((size_t)n * taps + t) * Cin + c0 + c;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + e];
-    dw[((size_t)n * Cin + c) * taps + t] = s;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * slab + off];
+    tile[c * taps + t] = s;
+  }
+  __syncthreads();
+  float* o = dw + ((size_t)n * Cin + c0) * taps;
+  for (int e = threadIdx.x; e < taps * 64; e += 256) o[e] = tile[e];
+}
+
+// taps == 1: the slab layout already equals OIHW
+__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += ws[(size_t)k * total + e]; s1 += ws[(size_t)(k + 1) * total + e];
+      s2 += ws[(size_t)(k + 2) * total + e]; s3 += ws[(size_t)(k + 3) * total + e];
+    }
+    for (; k < splits; ++k) s0 += ws[(size_t)k * total + e];
+    dw[e] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -234,32 +434,73 @@ int use_tr() {
   return g_use_tr;
 }
 
-struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; size_t ws_bytes; };
+int g_wgrad_variant = -1;   // 1: register-staged 128x128 tiles, 2 (default): glds tiles up to 256x256; SEGLAND_WGRAD_VARIANT
+int wgrad_variant() {
+  if (g_wgrad_variant < 0) { const char* e = getenv("SEGLAND_WGRAD_VARIANT"); g_wgrad_variant = (e && e[0] == '1') ? 1 : 2; }
+  return g_wgrad_variant;
+}
+
+struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; bool glds; size_t ws_bytes; };
 
 WgradPlan plan(const SlConvDesc* d) {
   WgradPlan pl;
   const int c2 = d->Cin - d->C1;
-  pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
-  pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;
+  const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
+  pl.glds = wgrad_variant() >= 2 && all128;
+  if (pl.glds) {
+    pl.bnn = d->Cout % 256 == 0 ? 256 : 128;
+    pl.bcc = (d->C1 % 256 == 0 && c2 % 256 == 0) ? 256 : 128;
+  } else {
+    pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
+    pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;
+  }
   pl.gridN = d->Cout / pl.bnn; pl.gridC = d->Cin / pl.bcc; pl.taps = d->KH * d->KW;
   const long long tiles = (long long)pl.gridN * pl.gridC * pl.taps;
   const long long M = (long long)d->B * d->Ho * d->Wo;
-  long long splits = (1536 + tiles - 1) / tiles;
-  const long long max_by_rows = (M + 4 * KM - 1) / (4 * KM);          // at least 128 rows per split
-  if (splits > max_by_rows) splits = max_by_rows;
-  const size_t slab = (size_t)d->Cout * pl.taps * d->Cin * sizeof(float);
-  while (splits > 1 && slab * splits > ((size_t)192 << 20)) --splits;
-  if (splits < 1) splits = 1;
+  const double slab = (double)d->Cout * pl.taps * d->Cin * sizeof(float);
+  // split-K factor: balance the block count over the 256 CUs (time ~ number of block waves) against the slab
+  // traffic (written once, read once by the reduce), at >= 128 reduction rows per split and <= 1 GiB of slabs.
+  const double flops = 2.0 * M * d->Cout * (double)d->Cin * pl.taps;
+  const double cu_rate = 2.5e12, hbm = 3.0e12;      // ~640 TFLOP/s chip-wide when every CU is busy
+  const long long max_s = (M + 127) / 128;
+  int best = 1; double best_t = 1e30;
+  for (int sp = 1; sp <= 512 && sp <= max_s; ++sp) {
+    if (slab * sp > 1024.0 * 1024.0 * 1024.0 && sp > 1) break;
+    const double blocks = (double)tiles * sp;
+    const double waves = ceil(blocks / 256.0);
+    const double t = flops / blocks / cu_rate * waves + 2.0 * slab * sp / hbm + 3e-6 * waves;
+    if (t < best_t) { best_t = t; best = sp; }
+  }
+  long long splits = best;
   long long rps = (M + splits - 1) / splits;
   rps = (rps + KM - 1) / KM * KM;
   splits = (M + rps - 1) / rps;
-  pl.splits = (int)splits; pl.rows_per_split = (int)rps; pl.ws_bytes = slab * splits;
+  pl.splits = (int)splits; pl.rows_per_split = (int)rps; pl.ws_bytes = (size_t)(slab * splits);
   return pl;
+}
+
+template <typename T, int BNN, int BCC, int WNN, int WCC, bool TR>
+int launch_wgrad_glds(dim3 grid, WgradParams& p, hipStream_t st) {
+  const size_t lds = 2 * KM * (BNN + BCC) * sizeof(T);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>), grid, dim3(64 * WNN * WCC), lds, st, p);
+  SL_LAUNCH_CHECK("conv_wgrad_glds_kernel");
+  return 0;
 }
 
 template <typename T, bool TR>
 int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
   dim3 grid(pl.gridN * pl.gridC * pl.taps * pl.splits);
+  if (pl.glds) {
+    if (pl.bnn == 256 && pl.bcc == 256) return launch_wgrad_glds<T, 256, 256, 2, 4, TR>(grid, p, st);
+    if (pl.bnn == 256) return launch_wgrad_glds<T, 256, 128, 4, 2, TR>(grid, p, st);
+    if (pl.bcc == 256) return launch_wgrad_glds<T, 128, 256, 2, 4, TR>(grid, p, st);
+    return launch_wgrad_glds<T, 128, 128, 2, 2, TR>(grid, p, st);
+  }
 #define WG_LAUNCH(BNN, BCC)                                                                                   \
   do {                                                                                                        \
     const size_t lds = 2 * KM * ((BNN + BCC) * sizeof(T) + 2 * WPad<T>::v);                                   \
@@ -276,6 +517,7 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" void sl_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
 // test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 
@@ -307,9 +549,13 @@ extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const vo
   else if (use_tr()) e = launch_wgrad<bf16_t, true>(pl, p, st);
   else e = launch_wgrad<bf16_t, false>(pl, p, st);
   if (e) return e;
-  const long long total = (long long)d->Cout * pl.taps * d->Cin;
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits);
+  SL_REQUIRE(pl.taps <= 49, "conv bwd_weight: kernel window larger than 7x7");
+  if (pl.taps == 1) {
+    const long long total = (long long)d->Cout * d->Cin;
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits);
+  }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
   return 0;
 }

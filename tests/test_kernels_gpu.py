@@ -96,9 +96,10 @@ def test_conv_fwd_dgrad_wgrad(hip, dtype, case):
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
-def test_conv_concat_bias_relu_addend_mask(hip, dtype):
+@pytest.mark.parametrize('C1,C2,Cout', [(128, 64, 64), (256, 256, 256)])
+def test_conv_concat_bias_relu_addend_mask(hip, dtype, C1, C2, Cout):
     from segland_amd import ops
-    B, H, W, C1, C2, Cout = 2, 12, 12, 128, 64, 64
+    B, H, W = 2, 12, 12
     x1 = rnd(fm.sym('cc/x1', (B, C1, H, W), 1.0), dtype); x2 = rnd(fm.sym('cc/x2', (B, C2, H, W), 1.0), dtype)
     w = rnd(fm.sym('cc/w', (Cout, C1 + C2, 3, 3), 0.05), dtype)
     bias = fm.sym('cc/b', (Cout,), 0.5)
