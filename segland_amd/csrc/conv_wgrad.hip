@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 // 32-lane service group touches 4 rows x 2 column groups x 32 B = eight distinct 32-byte segments of one 256-byte bank
 // window: conflict-free.  The f32 ds_read_b32 pattern (32 consecutive columns of one row) is conflict-free under any
 // per-row chunk permutation.
+template <typename T> struct WgKM { static constexpr int v = sizeof(T) == 2 ? 64 : 32; };
 __device__ __attribute__((aligned(256))) unsigned char g_wzero_page[256];
 
 typedef __attribute__((address_space(3))) void wlds_void_t;
@@ -234,6 +235,7 @@ __device__ __forceinline__ void wglds16(const void* g, unsigned char* l) {
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR>
 __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradParams p) {
   constexpr int ES = sizeof(T), EPC = 16 / ES, NW = WNN * WCC;
+  constexpr int KM = WgKM<T>::v;                                   // reduction rows per LDS stage (shadows the v1 constant)
   constexpr int RB_A = BNN * ES, RB_B = BCC * ES;                  // stage row bytes
   constexpr int RPI_A = 1024 / RB_A, RPI_B = 1024 / RB_B;          // rows per 1 KiB wave-instruction
   constexpr int IA = KM / RPI_A / NW, IB = KM / RPI_B / NW;        // instructions per wave per stage
@@ -473,7 +475,7 @@ WgradPlan plan(const SlConvDesc* d) {
   }
   long long splits = best;
   long long rps = (M + splits - 1) / splits;
-  rps = (rps + KM - 1) / KM * KM;
+  rps = (rps + 63) / 64 * 64;
   splits = (M + rps - 1) / rps;
   pl.splits = (int)splits; pl.rows_per_split = (int)rps; pl.ws_bytes = (size_t)(slab * splits);
   return pl;
@@ -481,7 +483,7 @@ WgradPlan plan(const SlConvDesc* d) {
 
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool TR>
 int launch_wgrad_glds(dim3 grid, WgradParams& p, hipStream_t st) {
-  const size_t lds = 2 * KM * (BNN + BCC) * sizeof(T);
+  const size_t lds = 2 * WgKM<T>::v * (BNN + BCC) * sizeof(T);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
