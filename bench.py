@@ -131,7 +131,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    use_ddp = world > 1 or os.environ.get('SEGLAND_FORCE_DDP') == '1'       # the env knob exercises DDP/RCCL on one GPU
+    if use_ddp:
         dist.init_process_group('nccl', init_method='env://')       # "nccl" is RCCL on ROCm
 
     from segland_amd import ops
@@ -144,7 +145,7 @@ def main():
                        compute_dtype=dtype).to(dev).train()
     opt = make_optimizer(model)
     net = model
-    if world > 1:
+    if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
     params = [p for p in model.parameters() if p.requires_grad]
@@ -166,18 +167,18 @@ def main():
     # ---- timed region
     if dominant is not None:
         ops.PROFILER.start(only=dominant['key'])
-    if world > 1:
+    if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         train_step(net, opt, img, mask, params, double)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_ddp:
         dist.barrier()
     dt_s = time.perf_counter() - t0
     live = ops.PROFILER.stop()
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_s = float(t.item())
@@ -214,7 +215,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

@@ -405,13 +405,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_glds_kernel(ConvGemmPa
     wrow[j] = (const T*)p.wt + (size_t)(bn * BN + row) * taps * CT + (lpos ^ ((row >> 1) & 7)) * EPC;
   }
 
-  int tap = 0, ct = 0;
-  auto issue = [&](int buf) {
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const int c0 = ct * BKE;
-    const T* base; int pitch, coff;
-    if (c0 < p.C1) { base = (const T*)p.src1; pitch = p.C1; coff = c0; }
-    else           { base = (const T*)p.src2; pitch = p.C2; coff = c0 - p.C1; }
+  // Source pixel index of every row for the CURRENT tap (-1: padding / out of range / row >= M).  Recomputed only when
+  // the tap changes (once per Cin/64 K-tiles); issuing a K-tile is then one 64-bit mad + select per row.
+  int apix[AR];
+  auto set_tap = [&](int tap_) {
+    const int ky = tap_ / p.KW, kx = tap_ - ky * p.KW;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
       int ys, xs; bool ok = rb[j] >= 0;
@@ -423,8 +421,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_glds_kernel(ConvGemmPa
         else { ys = ty / p.stride; xs = tx / p.stride; ok = ok && (ys * p.stride == ty) && (xs * p.stride == tx); }
       }
       ok = ok && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
-      const void* src = ok ? (const void*)(base + ((size_t)(rb[j] * p.Hs + ys) * p.Ws + xs) * pitch + coff + rsw[j])
-                           : (const void*)(g_zero_page + lpos * 16);
+      apix[j] = ok ? (rb[j] * p.Hs + ys) * p.Ws + xs : -1;
+    }
+  };
+  int tap = 0, ct = 0;
+  const unsigned char* zsrc = g_zero_page + lpos * 16;
+  auto issue = [&](int buf) {
+    if (ct == 0) set_tap(tap);
+    const int c0 = ct * BKE;
+    const unsigned char* base; unsigned pitchb;
+    if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
+    else           { base = (const unsigned char*)p.src2 + (size_t)(c0 - p.C1) * sizeof(T); pitchb = p.C2 * (unsigned)sizeof(T); }
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      const unsigned char* src = base + (size_t)((unsigned)apix[j]) * pitchb + rsw[j] * (int)sizeof(T);
+      src = apix[j] >= 0 ? src : zsrc;
       glds16(src, lds_a + buf * BM * 128 + (wave * AR + j) * 1024);
     }
     const size_t koff = (size_t)tap * CT + c0;
@@ -490,7 +501,12 @@ int launch_glds(ConvGemmParams& p, hipStream_t st) {
 }
 
 // rows per block of the kernel that will run for an M-row problem (also the granularity of the BN partial statistics)
-static int block_rows(long long M) { return (conv_variant() >= 3 && M >= 256 * 96) ? 256 : 128; }
+static int small_k() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SEGLAND_CONV_SMALLK"); v = e ? atoi(e) : 0; }
+  return v;
+}
+static int block_rows(long long M, int ktot) { return (conv_variant() >= 3 && M >= 256 * 96 && ktot > small_k()) ? 256 : 128; }
 
 template <typename T>
 int launch_gemm(ConvGemmParams& p, hipStream_t st) {
@@ -505,7 +521,7 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
     return 0;
   }
   // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
-  const bool big = block_rows(p.M) == 256;
+  const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
   if (big) {
     if (n256) return launch_glds<T, 256, 256, 2, 4>(p, st);
     if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
@@ -544,7 +560,7 @@ extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;
-  return cdiv(M, block_rows(M));
+  return cdiv(M, block_rows(M, d->KH * d->KW * d->Cin));
 }
 
 extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias,
