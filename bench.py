@@ -60,7 +60,7 @@ def synthetic_batch(B, size, device, seed=0):
 
 def make_optimizer(model, lr=1e-3, wd=1e-4):
     from segland_amd.utils.pyt_utils import get_parameters
-    return torch.optim.AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd)
+    return torch.optim.AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd, fused=True)
 
 
 def train_step(model, opt, img, mask, params, double_step):

@@ -116,6 +116,10 @@ int sl_stem_bn_relu_pool_fwd(int dtype, const void* c0, const float* scale, cons
 /* g0 = maxpool_bwd(dpooled) masked by relu'(bn(c0)) */
 int sl_stem_pool_relu_bwd(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale,
                           const float* shift, void* g0, int B, int Hc, int Wc, sl_stream_t stream);
+/* im2col of the 7x7 s2 p3 receptive fields: col [B*H/2*W/2][192] dtype, column t = c*49 + ky*7 + kx (t >= 147: zero).
+ * The stem weight gradient is then sl_conv2d_bwd_weight on (col as a 192-channel 1x1 input, dc0) -- an MFMA reduction. */
+int sl_stem_im2col(int dtype, const float* img_nchw, void* col, int B, int H, int W, sl_stream_t stream);
+/* direct (non-MFMA) variant of the same gradient, kept as a cross-check */
 size_t sl_stem_conv_bwd_weight_workspace(int B, int H, int W);
 int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const void* dc0, float* dw_oihw, void* workspace,
                             size_t workspace_bytes, int B, int H, int W, sl_stream_t stream);

@@ -80,52 +80,60 @@ __global__ void upsample_ce_finalize_kernel(const float* __restrict__ part, int 
   if (threadIdx.x == 0) { out[0] = (float)(rs[0] / rc[0]); out[1] = (float)rc[0]; }
 }
 
-// one thread per low-resolution cell: gather over the pixels whose bilinear footprint touches it
-__global__ __launch_bounds__(64) void upsample_ce_bwd_kernel(UpGeom g, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
-                                                             const float* __restrict__ loss_cnt, const float* __restrict__ gscale,
-                                                             int ignore, float* __restrict__ dlg) {
+// four lanes per low-resolution cell (each takes every 4th footprint row), gather over the pixels whose bilinear
+// footprint touches the cell, then a 4-lane shuffle reduction: deterministic, no atomics.
+__global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(UpGeom g, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
+                                                              const float* __restrict__ loss_cnt, const float* __restrict__ gscale,
+                                                              int ignore, float* __restrict__ dlg) {
   const long long cells = (long long)g.B * g.h * g.w;
-  const long long ci = blockIdx.x * 64LL + threadIdx.x;
-  if (ci >= cells) return;
-  const int j = (int)(ci % g.w); const long long r = ci / g.w;
+  const long long ci = (blockIdx.x * 256LL + threadIdx.x) >> 2;
+  const int sub = threadIdx.x & 3;
+  const bool live = ci < cells;
+  const long long cc = live ? ci : 0;
+  const int j = (int)(cc % g.w); const long long r = cc / g.w;
   const int i = (int)(r % g.h), b = (int)(r / g.h);
   float acc[KMAXC];
 #pragma unroll
   for (int k = 0; k < KMAXC; ++k) acc[k] = 0.f;
-  // pixels Y with src in (i-1, i+1)
   const int Ylo = g.sy > 0.f ? max(0, (int)floorf((float)(i - 1) / g.sy)) : 0;
   const int Yhi = g.sy > 0.f ? min(g.H - 1, (int)ceilf((float)(i + 1) / g.sy)) : g.H - 1;
   const int Xlo = g.sx > 0.f ? max(0, (int)floorf((float)(j - 1) / g.sx)) : 0;
   const int Xhi = g.sx > 0.f ? min(g.W - 1, (int)ceilf((float)(j + 1) / g.sx)) : g.W - 1;
-  for (int Y = Ylo; Y <= Yhi; ++Y) {
-    int y0, y1; float ly;
-    src_index_ac1(Y, g.h, g.sy, y0, y1, ly);
-    const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
-    if (wy == 0.f) continue;
-    for (int X = Xlo; X <= Xhi; ++X) {
-      int x0, x1; float lx;
-      src_index_ac1(X, g.w, g.sx, x0, x1, lx);
-      const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
-      if (wx == 0.f) continue;
-      const long long t = tgt[((size_t)b * g.H + Y) * g.W + X];
-      if (t == ignore || t < 0 || t >= g.K) continue;
-      float v[KMAXC];
-      pixel_logits(g, lg, b, Y, X, v);
-      float m = v[0];
+  if (live) {
+    for (int Y = Ylo + sub; Y <= Yhi; Y += 4) {
+      int y0, y1; float ly;
+      src_index_ac1(Y, g.h, g.sy, y0, y1, ly);
+      const float wy = (y0 == i ? 1.f - ly : 0.f) + (y1 == i ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = Xlo; X <= Xhi; ++X) {
+        int x0, x1; float lx;
+        src_index_ac1(X, g.w, g.sx, x0, x1, lx);
+        const float wx = (x0 == j ? 1.f - lx : 0.f) + (x1 == j ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const long long t = tgt[((size_t)b * g.H + Y) * g.W + X];
+        if (t == ignore || t < 0 || t >= g.K) continue;
+        float v[KMAXC];
+        pixel_logits(g, lg, b, Y, X, v);
+        float m = v[0];
 #pragma unroll
-      for (int k = 0; k < KMAXC; ++k) m = fmaxf(m, v[k]);
-      float s = 0.f;
+        for (int k = 0; k < KMAXC; ++k) m = fmaxf(m, v[k]);
+        float s = 0.f;
 #pragma unroll
-      for (int k = 0; k < KMAXC; ++k) { v[k] = k < g.K ? expf(v[k] - m) : 0.f; s += v[k]; }
-      const float wgt = wy * wx, inv = 1.f / s;
+        for (int k = 0; k < KMAXC; ++k) { v[k] = k < g.K ? expf(v[k] - m) : 0.f; s += v[k]; }
+        const float wgt = wy * wx, inv = 1.f / s;
 #pragma unroll
-      for (int k = 0; k < KMAXC; ++k) acc[k] += wgt * (v[k] * inv - (k == (int)t ? 1.f : 0.f));
+        for (int k = 0; k < KMAXC; ++k) acc[k] += wgt * (v[k] * inv - (k == (int)t ? 1.f : 0.f));
+      }
     }
   }
   const float f = gscale[0] / loss_cnt[1];
 #pragma unroll
-  for (int k = 0; k < KMAXC; ++k)
-    if (k < g.K) dlg[(((size_t)b * g.K + k) * g.h + i) * g.w + j] = acc[k] * f;
+  for (int k = 0; k < KMAXC; ++k) {
+    float a = acc[k];
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (live && sub == 0 && k < g.K) dlg[(((size_t)b * g.K + k) * g.h + i) * g.w + j] = a * f;
+  }
 }
 
 template <bool PSEUDO>
@@ -238,7 +246,7 @@ extern "C" int sl_upsample_ce_bwd(const float* logits, const int64_t* target, co
   SL_REQUIRE(logits && target && loss_and_count && gscale && dlogits && K >= 1 && K <= KMAXC, "upsample_ce_bwd: bad args");
   const UpGeom g = make_up(B, K, h, w, H, W);
   const long long cells = (long long)B * h * w;
-  hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3((unsigned)((cells + 63) / 64)), dim3(64), 0, (hipStream_t)stream, g, logits, target, loss_and_count, gscale, ignore_index, dlogits);
+  hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3((unsigned)((cells * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, logits, target, loss_and_count, gscale, ignore_index, dlogits);
   SL_LAUNCH_CHECK("upsample_ce_bwd_kernel");
   return 0;
 }

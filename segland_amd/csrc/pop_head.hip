@@ -109,12 +109,28 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ h
   for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = sm[c] + sm[C + c] + sm[2 * C + c] + sm[3 * C + c];
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] = sum_blk part[blk][c]: 64 columns x 16 row-lanes per block, fixed-order LDS tree (bit-stable)
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s = 0.0;
-  for (int r = 0; r < nblk; ++r) s += (double)part[(size_t)r * C + c];
-  out[c] = (float)s;
+  if (c < C) {
+    int r = rl;
+    for (; r + 3 * 16 < nblk; r += 4 * 16) {
+      const float v0 = part[(size_t)r * C + c], v1 = part[(size_t)(r + 16) * C + c], v2 = part[(size_t)(r + 32) * C + c], v3 = part[(size_t)(r + 48) * C + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; r < nblk; r += 16) s += (double)part[(size_t)r * C + c];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][cl];
+    out[c] = (float)t;
+  }
 }
 
 __global__ void pop_combine_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ zbg, const float* __restrict__ a,
@@ -299,7 +315,7 @@ extern "C" int sl_rowdot_bwd(int dtype, const void* h, const float* w, const flo
 
 extern "C" int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream) {
   SL_REQUIRE(partial && out && nblk > 0 && C > 0, "colsum_finalize: bad args");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, partial, nblk, C, out);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, out);
   SL_LAUNCH_CHECK("colsum_finalize_kernel");
   return 0;
 }

@@ -235,6 +235,33 @@ __global__ void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __
   dw[e] = s;
 }
 
+// im2col of the stem's receptive fields: col[m][t], t = c*49 + ky*7 + kx (OIHW tap order), padded to 192 columns with
+// zeros, so that the 7x7 weight gradient becomes a plain [64 x M] x [M x 192] MFMA reduction (conv_wgrad kernel).
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int H, int W) {
+  constexpr int V = Vec16<T>::N, NV = 192 / V;
+  const int Ho = H / 2, Wo = W / 2;
+  const long long total = (long long)B * Ho * Wo * NV;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % NV); long long r = i / NV;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); const int b = (int)(r / Ho);
+    float o[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const int t = v * V + k;
+      float val = 0.f;
+      if (t < NTAP) {
+        const int c = t / 49, rem = t - c * 49, ky = rem / 7, kx = rem - ky * 7;
+        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = img[((size_t)(b * 3 + c) * H + iy) * W + ix];
+      }
+      o[k] = val;
+    }
+    *(uint4*)(col + (size_t)i * V) = pack16<T>(o);
+  }
+}
+
 inline int stem_tiles(int B, int H, int W) { return B * cdiv(H / 2, TS) * cdiv(W / 2, TS); }
 inline int stem_wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
 
@@ -295,5 +322,16 @@ extern "C" int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const v
   SL_LAUNCH_CHECK("stem_wgrad_kernel");
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(64 * NTAP, 256)), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk);
   SL_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
+  return 0;
+}
+
+extern "C" int sl_stem_im2col(int dtype, const float* img_nchw, void* col, int B, int H, int W, sl_stream_t stream) {
+  SL_REQUIRE(img_nchw && col && B > 0 && H % 2 == 0 && W % 2 == 0, "stem_im2col: bad args");
+  const long long total = (long long)B * (H / 2) * (W / 2) * (dtype == SL_BF16 ? 24 : 48);
+  const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img_nchw, (bf16_t*)col, B, H, W);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, img_nchw, (float*)col, B, H, W);
+  else SL_REQUIRE(false, "stem_im2col: bad dtype");
+  SL_LAUNCH_CHECK("stem_im2col_kernel");
   return 0;
 }

@@ -59,7 +59,7 @@ def main(argv=None):
         if args.freeze_backbone:
             my_utils.load_model(seg_model, args.restore_from, backbone_only=args.finetune, is_restore=not args.finetune)
         params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
-        optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
+        optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, fused=engine.use_cuda)
         model = engine.data_parallel(seg_model)
         loss_scaler = my_utils.NativeScalerWithGradNormCount()
         if engine.is_main:

@@ -183,7 +183,9 @@ def test_stem(hip, dtype):
     gc = rnd(fm.sym('stem/gc', tuple(c_ref.shape), 1.0), dtype)
     c_ref.backward(gc)
     dw = ops.stem_conv_bwd_weight(img.to(DEV), nhwc(gc, dtype))
-    assert_close(dw, w.grad, dtype, 'stem wgrad')
+    assert_close(dw, w.grad, dtype, 'stem wgrad (im2col + MFMA)')
+    dw2 = ops.stem_conv_bwd_weight_direct(img.to(DEV), nhwc(gc, dtype))
+    assert_close(dw2, w.grad, dtype, 'stem wgrad (direct)')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
