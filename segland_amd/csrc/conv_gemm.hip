@@ -492,9 +492,211 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_glds_kernel(ConvGemmPa
   conv_epilogue_lds<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v4 "ring": NST LDS stages; the loads of stage i+NST-1 are issued while stage i is computed, and a wave only waits
+// (counted s_waitcnt vmcnt(N), raw s_barrier -- never vmcnt(0) inside the loop) for the stage it is about to read, so
+// the LDS-DMA of NST-2 stages stays in flight across every barrier.  A stage row holds RBYTES (64 or 128) bytes of K.
+template <int RBYTES> __device__ __forceinline__ int ring_off(int row, int chunk);
+template <> __device__ __forceinline__ int ring_off<128>(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+template <> __device__ __forceinline__ int ring_off<64>(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+template <int RBYTES> __device__ __forceinline__ int ring_swz(int row);
+template <> __device__ __forceinline__ int ring_swz<128>(int row) { return (row >> 1) & 7; }
+template <> __device__ __forceinline__ int ring_swz<64>(int row) { return (row >> 2) & 3; }
+
+// LDS-DMA issued from inline asm: hipcc does not count it, so it inserts no vmcnt(0) in front of the ds_reads; ordering
+// is ours (counted wait + barrier before the stage is read).  M0 carries the wave-uniform LDS byte address.
+__device__ __forceinline__ void glds16_asm(const void* g, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const unsigned char* p) {
+  return (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)p);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
+struct RingGeom {
+  static constexpr int STAGE = (BM + BN) * RBYTES;
+  static constexpr int RING_BYTES = NST * STAGE;
+  static constexpr int EPI = EpiGeom<T, BM, BN, WM, WN>::TILE_BYTES / EpiGeom<T, BM, BN, WM, WN>::NPASS;
+  static constexpr int LDS_BYTES = RING_BYTES > EPI ? RING_BYTES : EPI;
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmParams p) {
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int CPRW = RBYTES / 16;             // 16-byte chunks per stage row
+  constexpr int BKE = CPRW * EPC;               // K elements per stage
+  constexpr int RPI = 1024 / RBYTES;            // rows per 1 KiB wave-instruction
+  constexpr int NW = WM * WN;
+  constexpr int AR = BM / RPI / NW, BR = BN / RPI / NW;
+  constexpr int L = AR + BR;                    // LDS-DMA instructions per wave per stage
+  constexpr int KS = CPRW / 2;                  // MFMA k-steps per stage
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  using RG = RingGeom<T, BM, BN, WM, WN, RBYTES, NST>;
+  static_assert(AR >= 1 && BR >= 1, "ring shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / p.gridN, bn = bid % p.gridN;
+  const int lrow = lane / CPRW, lpos = lane % CPRW;
+  const int taps = p.KH * p.KW;
+  const int CT = p.C1 + p.C2;
+  const int ctiles = CT / BKE;
+  const int nk = taps * ctiles;
+  const bool affine = (p.mode == 0) || (p.stride == 1);
+  const int sgn = p.mode == 0 ? 1 : -1;
+
+  int rb[AR], ry[AR], rx[AR], rbase[AR], rsw[AR]; unsigned vmask[AR];
+#pragma unroll
+  for (int j = 0; j < AR; ++j) {
+    const int row = (wave * AR + j) * RPI + lrow;
+    rsw[j] = (lpos ^ ring_swz<RBYTES>(row)) * 16;             // byte offset of the source chunk inside the K slice
+    const int m = bm * BM + row;
+    rb[j] = -1; ry[j] = 0; rx[j] = 0;
+    if (m < p.M) {
+      const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
+      const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
+      rb[j] = b;
+      if (p.mode == 0) { ry[j] = yd * p.stride - p.pad; rx[j] = xd * p.stride - p.pad; }
+      else             { ry[j] = yd + p.pad;            rx[j] = xd + p.pad; }
+    }
+    rbase[j] = rb[j] >= 0 ? (rb[j] * p.Hs + ry[j]) * p.Ws + rx[j] : 0;
+    unsigned mk = 0;
+    if (rb[j] >= 0 && affine)
+      for (int t = 0; t < taps; ++t) {
+        const int ky = t / p.KW, kx = t - ky * p.KW;
+        const int ys = ry[j] + sgn * ky * p.dil, xs = rx[j] + sgn * kx * p.dil;
+        if ((unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws) mk |= 1u << t;
+      }
+    vmask[j] = mk;
+  }
+  auto slow_pix = [&](int j, int tap_) -> int {
+    const int ky = tap_ / p.KW, kx = tap_ - ky * p.KW;
+    const int ty = ry[j] - ky * p.dil, tx = rx[j] - kx * p.dil;
+    if (rb[j] < 0 || ty < 0 || tx < 0) return -1;
+    const int ys = ty / p.stride, xs = tx / p.stride;
+    if (ys * p.stride != ty || xs * p.stride != tx || ys >= p.Hs || xs >= p.Ws) return -1;
+    return (rb[j] * p.Hs + ys) * p.Ws + xs;
+  };
+  const unsigned char* wrow[BR];
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int row = (wave * BR + j) * RPI + lrow;
+    wrow[j] = (const unsigned char*)p.wt + ((size_t)(bn * BN + row) * taps * CT) * sizeof(T) + (lpos ^ ring_swz<RBYTES>(row)) * 16;
+  }
+  int tap = 0, ct = 0;
+  const unsigned char* zsrc = g_zero_page + lpos * 16;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  auto issue = [&](int slot) {
+    const unsigned la = lds_base + slot * RG::STAGE;
+    const unsigned lb = la + BM * RBYTES;
+    const int c0 = ct * BKE;
+    const unsigned char* base; unsigned pitchb;
+    if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
+    else           { base = (const unsigned char*)p.src2 + (size_t)(c0 - p.C1) * sizeof(T); pitchb = p.C2 * (unsigned)sizeof(T); }
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int delta = sgn * (ky * p.dil * p.Ws + kx * p.dil);
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+      int pix; bool ok;
+      if (affine) { pix = rbase[j] + delta; ok = (vmask[j] >> tap) & 1u; }
+      else { pix = slow_pix(j, tap); ok = pix >= 0; }
+      const unsigned char* src = base + (size_t)((unsigned)pix) * pitchb + rsw[j];
+      glds16_asm(ok ? src : zsrc, la + (wave * AR + j) * 1024);
+    }
+    const size_t koff = ((size_t)tap * CT + c0) * sizeof(T);
+#pragma unroll
+    for (int j = 0; j < BR; ++j) glds16_asm(wrow[j] + koff, lb + (wave * BR + j) * 1024);
+    if (++tap == taps) { tap = 0; ++ct; }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Pipeline invariant at the top of iteration i: stages i and i+1 are complete and visible to every wave, and the
+  // fragments of (stage i, k-step 0) are already in registers.  Inside the iteration the fragment loads of the NEXT
+  // k-step (the last one reaches into stage i+1) are issued before the MFMAs of the current one, so LDS latency hides
+  // behind the matrix pipe; the LDS-DMA of stages i+2 / i+3 stays in flight across the barrier.
+  static_assert(NST == 4 && (KS % 2) == 0, "ring schedule assumes 4 stages and an even number of k-steps");
+  const int frow = lane & 31, fhalf = lane >> 5;
+  auto ldfrag = [&](uint4* af, uint4* bf, int slot_, int s2) {
+    const unsigned char* la = smem + slot_ * RG::STAGE;
+    const unsigned char* lb = la + BM * RBYTES;
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii) af[ii] = *(const uint4*)(la + ring_off<RBYTES>(wm * (BM / WM) + ii * 32 + frow, 2 * s2 + fhalf));
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) bf[jj] = *(const uint4*)(lb + ring_off<RBYTES>(wn * (BN / WN) + jj * 32 + frow, 2 * s2 + fhalf));
+  };
+  auto mma = [&](const uint4* af, const uint4* bf) {
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) Mma<T>::run(bf[jj], af[ii], acc[ii][jj]);
+  };
+  uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
+
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+    if (st < nk) issue(st);
+  if (nk >= 3) wait_vmcnt<L>(); else wait_vmcnt<0>();     // stages 0 and 1 landed (stage 2 may still fly)
+  __builtin_amdgcn_s_barrier();
+  ldfrag(afA, bfA, 0, 0);
+
+  int slot = 0;
+  for (int i = 0; i < nk; ++i) {
+    if (i + 3 < nk) { int ns = slot + 3; if (ns >= NST) ns -= NST; issue(ns); }
+    int nslot = slot + 1; if (nslot == NST) nslot = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; s2 += 2) {
+      ldfrag(afB, bfB, slot, s2 + 1);
+      mma(afA, bfA);
+      if (s2 + 2 < KS) ldfrag(afA, bfA, slot, s2 + 2);
+      else             ldfrag(afA, bfA, nslot, 0);          // first k-step of the next stage (complete by the invariant)
+      mma(afB, bfB);
+    }
+    // make stage i+2 complete before anyone starts iteration i+1; stage i+3 (just issued) may stay in flight
+    if (i + 3 < nk) wait_vmcnt<L>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    slot = nslot;
+  }
+  __syncthreads();
+  conv_epilogue_lds<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
+int launch_ring(ConvGemmParams& p, hipStream_t st) {
+  using RG = RingGeom<T, BM, BN, WM, WN, RBYTES, NST>;
+  p.gridM = cdiv(p.M, BM);
+  p.gridN = p.N / BN;
+  const size_t lds = RG::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_ring_kernel");
+  return 0;
+}
+
 int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3 (default): glds, 256-row 8-wave tiles where M allows
 static int conv_variant() {
-  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3; }
+  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; }
   return g_conv_variant;
 }
 
@@ -535,6 +737,12 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   }
   // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
   const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
+  if (big && v >= 4) {
+    // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
+    if (n256) return launch_ring<T, 256, 256, 2, 4, 64, 4>(p, st);
+    if (n128) return launch_ring<T, 256, 128, 4, 2, 64, 4>(p, st);
+    return launch_glds<T, 256, 64, 8, 1>(p, st);        // N = 64 layers: too few weight rows for a 64-byte-row ring
+  }
   if (big) {
     if (n256) return launch_glds<T, 256, 256, 2, 4>(p, st);
     if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
