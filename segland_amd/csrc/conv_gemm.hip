@@ -748,6 +748,7 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
     if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
     return launch_glds<T, 256, 64, 8, 1>(p, st);
   }
+  if (v >= 4 && n128 && p.M >= 128 * 512) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
   if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
   return launch_glds<T, 128, 64, 2, 2>(p, st);
 }

@@ -228,23 +228,30 @@ __device__ __attribute__((aligned(256))) unsigned char g_wzero_page[256];
 
 typedef __attribute__((address_space(3))) void wlds_void_t;
 typedef const __attribute__((address_space(1))) void wgbl_void_t;
-__device__ __forceinline__ void wglds16(const void* g, unsigned char* l) {
-  __builtin_amdgcn_global_load_lds((wgbl_void_t*)g, (wlds_void_t*)l, 16, 0, 0);
+__device__ __forceinline__ void wglds16_asm(const void* g, unsigned lds_addr) {      // see conv_gemm.hip: glds16_asm
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
+__device__ __forceinline__ unsigned wlds_addr_of(const unsigned char* p) {
+  return (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)p);
+}
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR>
 __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradParams p) {
   constexpr int ES = sizeof(T), EPC = 16 / ES, NW = WNN * WCC;
-  constexpr int KM = WgKM<T>::v;                                   // reduction rows per LDS stage (shadows the v1 constant)
+  constexpr int KM = 32, NST = 4;                                  // rows per stage, stages in the LDS ring
   constexpr int RB_A = BNN * ES, RB_B = BCC * ES;                  // stage row bytes
   constexpr int RPI_A = 1024 / RB_A, RPI_B = 1024 / RB_B;          // rows per 1 KiB wave-instruction
-  constexpr int IA = KM / RPI_A / NW, IB = KM / RPI_B / NW;        // instructions per wave per stage
+  constexpr int IA = KM / RPI_A / NW, IB = KM / RPI_B / NW;        // LDS-DMA instructions per wave per stage
+  constexpr int L = IA + IB;
   constexpr int TM = BNN / WNN / 32, TN = BCC / WCC / 32;
+  constexpr int STAGE = KM * (RB_A + RB_B);
+  constexpr int KS = sizeof(T) == 2 ? KM / 16 : KM / 2;            // MFMA k-steps per stage (even)
   static_assert(RB_A >= 256 && RB_B >= 256 && RB_A <= 1024 && RB_B <= 1024, "row bytes 256..1024");
-  static_assert(IA >= 1 && IB >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
+  static_assert(IA >= 1 && IB >= 1 && TM >= 1 && TN >= 1 && KS % 2 == 0, "tile/wave shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* lds_a = smem;                         // [2][KM][RB_A]
-  unsigned char* lds_b = smem + 2 * KM * RB_A;         // [2][KM][RB_B]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -268,35 +275,48 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   const int m_end = min(p.M, m_begin + p.rows_per_split);
   const int nit = (m_end - m_begin + KM - 1) / KM;
 
-  // per-lane constants of the loader
   const int a_rin = (lane * 16) / RB_A, a_pos = ((lane * 16) % RB_A) / 16;
   const int b_rin = (lane * 16) / RB_B, b_pos = ((lane * 16) % RB_B) / 16;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(wlds_addr_of(smem));
+  const unsigned char* zsrc = g_wzero_page + (lane & 7) * 16;
 
-  auto issue = [&](int it, int buf) {
+  // Output-pixel coordinates of this lane's x rows for the NEXT stage to be issued, advanced incrementally (stages are
+  // issued in order, KM rows apart): no integer divisions inside the loop.
+  int qb[IB], qy[IB], qx[IB];
+#pragma unroll
+  for (int j = 0; j < IB; ++j) {
+    const int m = m_begin + (wave * IB + j) * RPI_B + b_rin;
+    const int hw = p.Ho * p.Wo;
+    qb[j] = m / hw; const int rem = m - qb[j] * hw; qy[j] = rem / p.Wo; qx[j] = rem - qy[j] * p.Wo;
+  }
+  auto issue = [&](int it, int slot) {
     const int m0 = m_begin + it * KM;
+    const unsigned la = lds_base + slot * STAGE, lb = la + KM * RB_A;
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
       const int ins = wave * IA + j, r = ins * RPI_A + a_rin, m = m0 + r;
-      const void* src = (m < m_end) ? (const void*)(dyb + (size_t)m * p.Cout + (a_pos ^ ((r & 3) << 2)) * EPC)
-                                    : (const void*)(g_wzero_page + (lane & 7) * 16);
-      wglds16(src, lds_a + (buf * KM + ins * RPI_A) * RB_A);
+      const void* src = (m < m_end) ? (const void*)(dyb + (size_t)m * p.Cout + (a_pos ^ ((r & 3) << 2)) * EPC) : (const void*)zsrc;
+      wglds16_asm(src, la + ins * 1024);
     }
 #pragma unroll
     for (int j = 0; j < IB; ++j) {
       const int ins = wave * IB + j, r = ins * RPI_B + b_rin, m = m0 + r;
-      const void* src = (const void*)(g_wzero_page + (lane & 7) * 16);
+      const void* src = (const void*)zsrc;
       if (m < m_end) {
         const int ce = xoff + (b_pos ^ ((r & 3) << 2)) * EPC;
         if (ident) src = (const void*)(xbase + (size_t)m * xpitch + ce);
         else {
-          const int hw = p.Ho * p.Wo;
-          const int b = m / hw, rem = m - b * hw, yo = rem / p.Wo, xo = rem - yo * p.Wo;
-          const int ys = yo * p.stride - p.pad + ky * p.dil, xs = xo * p.stride - p.pad + kx * p.dil;
+          const int ys = qy[j] * p.stride - p.pad + ky * p.dil, xs = qx[j] * p.stride - p.pad + kx * p.dil;
           if ((unsigned)ys < (unsigned)p.H && (unsigned)xs < (unsigned)p.W)
-            src = (const void*)(xbase + ((size_t)(b * p.H + ys) * p.W + xs) * xpitch + ce);
+            src = (const void*)(xbase + ((size_t)(qb[j] * p.H + ys) * p.W + xs) * xpitch + ce);
         }
       }
-      wglds16(src, lds_b + (buf * KM + ins * RPI_B) * RB_B);
+      wglds16_asm(src, lb + ins * 1024);
+      if (!ident) {                       // advance KM rows
+        qx[j] += KM;
+        while (qx[j] >= p.Wo) { qx[j] -= p.Wo; ++qy[j]; }
+        while (qy[j] >= p.Ho) { qy[j] -= p.Ho; ++qb[j]; }
+      }
     }
   };
 
@@ -308,79 +328,90 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nit > 0) issue(0, 0);
-  __syncthreads();
-
   const int frow = lane & 31, fhalf = lane >> 5;
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < nit) issue(it + 1, buf ^ 1);
-    const unsigned char* la = lds_a + buf * KM * RB_A;
-    const unsigned char* lb = lds_b + buf * KM * RB_B;
+  // fragment loaders: bf16 -> one uint4 (8 k) per 32-column tile via two transpose reads; f32 -> one float (1 k)
+  auto ldfrag = [&](uint4* af, uint4* bf, int slot, int ks) {
+    const unsigned char* la = smem + slot * STAGE;
+    const unsigned char* lb = la + KM * RB_A;
     if constexpr (sizeof(T) == 4) {
+      const int row = 2 * ks + fhalf, sw = (row & 3) << 2;
 #pragma unroll
-      for (int ks = 0; ks < KM / 2; ++ks) {
-        float af[TM], bf[TN];
-        const int row = 2 * ks + fhalf, sw = (row & 3) << 2;
+      for (int i = 0; i < TM; ++i) { const int n = wm * (BNN / WNN) + i * 32 + frow; af[i].x = *(const unsigned*)(la + row * RB_A + (((n >> 2) ^ sw) << 4) + (n & 3) * 4); }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { const int n = wm * (BNN / WNN) + i * 32 + frow; af[i] = *(const float*)(la + row * RB_A + (((n >> 2) ^ sw) << 4) + (n & 3) * 4); }
+      for (int j = 0; j < TN; ++j) { const int c = wn * (BCC / WCC) + j * 32 + frow; bf[j].x = *(const unsigned*)(lb + row * RB_B + (((c >> 2) ^ sw) << 4) + (c & 3) * 4); }
+    } else if constexpr (USE_TR) {
+      const int g = lane >> 4, l = lane & 15;
+      const int r = 16 * ks + 8 * (g >> 1) + (l >> 2);
+      const int sw = (l >> 2) << 2;
+      const int cofs = 16 * (g & 1) + 4 * (l & 3);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) { const int c = wn * (BCC / WCC) + j * 32 + frow; bf[j] = *(const float*)(lb + row * RB_B + (((c >> 2) ^ sw) << 4) + (c & 3) * 4); }
+      for (int i = 0; i < TM; ++i) {
+        const int e = wm * (BNN / WNN) + i * 32 + cofs;
+        const unsigned char* a0 = la + r * RB_A + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+        const uint2 lo = lds_tr16_b64(a0), hi = lds_tr16_b64(a0 + 4 * RB_A);
+        af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) {
+        const int e = wn * (BCC / WCC) + j * 32 + cofs;
+        const unsigned char* b0 = lb + r * RB_B + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+        const uint2 lo = lds_tr16_b64(b0), hi = lds_tr16_b64(b0 + 4 * RB_B);
+        bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
       }
     } else {
+      const int rb = 16 * ks + 8 * fhalf;
 #pragma unroll
-      for (int ks = 0; ks < KM / 16; ++ks) {
-        uint4 af[TM], bf[TN];
-        if constexpr (USE_TR) {
-          const int g = lane >> 4, l = lane & 15;
-          const int r = 16 * ks + 8 * (g >> 1) + (l >> 2);          // (r & 3) == l >> 2; the second read is 4 rows below
-          const int sw = (l >> 2) << 2;
-          const int cofs = 16 * (g & 1) + 4 * (l & 3);
+      for (int i = 0; i < TM; ++i) {
+        const int n = wm * (BNN / WNN) + i * 32 + frow;
+        unsigned e[8];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int e = wm * (BNN / WNN) + i * 32 + cofs;
-            const unsigned char* a0 = la + r * RB_A + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
-            const uint2 lo = lds_tr16_b64(a0), hi = lds_tr16_b64(a0 + 4 * RB_A);
-            af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
+        for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(la + (rb + k) * RB_A + (((n >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (n & 7) * 2);
+        af[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+      }
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int e = wn * (BCC / WCC) + j * 32 + cofs;
-            const unsigned char* b0 = lb + r * RB_B + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
-            const uint2 lo = lds_tr16_b64(b0), hi = lds_tr16_b64(b0 + 4 * RB_B);
-            bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          }
-        } else {
-          const int rb = 16 * ks + 8 * fhalf;
+      for (int j = 0; j < TN; ++j) {
+        const int c = wn * (BCC / WCC) + j * 32 + frow;
+        unsigned e[8];
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            const int n = wm * (BNN / WNN) + i * 32 + frow;
-            unsigned e[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(la + (rb + k) * RB_A + (((n >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (n & 7) * 2);
-            af[i] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-          }
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int c = wn * (BCC / WCC) + j * 32 + frow;
-            unsigned e[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(lb + (rb + k) * RB_B + (((c >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (c & 7) * 2);
-            bf[j] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[i][j], 0, 0, 0);
+        for (int k = 0; k < 8; ++k) e[k] = *(const unsigned short*)(lb + (rb + k) * RB_B + (((c >> 3) ^ (((rb + k) & 3) << 2)) << 4) + (c & 7) * 2);
+        bf[j] = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
       }
     }
-    __syncthreads();
+  };
+  auto mma = [&](const uint4* af, const uint4* bf) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if constexpr (sizeof(T) == 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[i].x), __uint_as_float(bf[j].x), acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[i][j], 0, 0, 0);
+      }
+  };
+
+  // same pipeline as conv_gemm_ring_kernel: stages i, i+1 complete at the top of iteration i, fragments of the next
+  // k-step (reaching into stage i+1) are loaded before the MFMAs of the current one, LDS-DMA of i+2 / i+3 in flight.
+  uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+    if (st < nit) issue(st, st);
+  if (nit >= 3) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  ldfrag(afA, bfA, 0, 0);
+  int slot = 0;
+  for (int it = 0; it < nit; ++it) {
+    if (it + 3 < nit) { int ns = slot + 3; if (ns >= NST) ns -= NST; issue(it + 3, ns); }
+    int nslot = slot + 1; if (nslot == NST) nslot = 0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks += 2) {
+      ldfrag(afB, bfB, slot, ks + 1);
+      mma(afA, bfA);
+      if (ks + 2 < KS) ldfrag(afA, bfA, slot, ks + 2);
+      else             ldfrag(afA, bfA, nslot, 0);
+      mma(afB, bfB);
+    }
+    if (it + 3 < nit) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    slot = nslot;
   }
 
   float* ws = p.ws + (size_t)split * p.Cout * p.taps * CT;
@@ -450,8 +481,9 @@ WgradPlan plan(const SlConvDesc* d) {
   const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
   pl.glds = wgrad_variant() >= 2 && all128;
   if (pl.glds) {
-    pl.bnn = d->Cout % 256 == 0 ? 256 : 128;
-    pl.bcc = (d->C1 % 256 == 0 && c2 % 256 == 0) ? 256 : 128;
+    const bool wide = d->dtype == SL_BF16;          // f32 stages are twice as large: 128-wide tiles keep the ring in 128 KiB
+    pl.bnn = (wide && d->Cout % 256 == 0) ? 256 : 128;
+    pl.bcc = (wide && d->C1 % 256 == 0 && c2 % 256 == 0) ? 256 : 128;
   } else {
     pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
     pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;
@@ -483,7 +515,7 @@ WgradPlan plan(const SlConvDesc* d) {
 
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool TR>
 int launch_wgrad_glds(dim3 grid, WgradParams& p, hipStream_t st) {
-  const size_t lds = 2 * WgKM<T>::v * (BNN + BCC) * sizeof(T);
+  const size_t lds = 4 * 32 * (BNN + BCC) * sizeof(T);        // 4-stage ring of 32-row stages
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
