@@ -60,6 +60,11 @@ int sl_conv2d_stat_rows(const SlConvDesc* d);
 int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias, int relu,
                   void* y, float* stat_partial, sl_stream_t stream);
 
+/* Inference / frozen-BN form: y = act(conv(x|x2, w) * scale[c] + shift[c] (+ residual)) in ONE kernel -- eval-mode
+ * BatchNorm (running statistics), the shortcut add and the ReLU of resnet.py:60-76 folded into the conv epilogue. */
+int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
+                         const float* shift, const void* residual, int relu, void* y, sl_stream_t stream);
+
 /* dx = conv_transpose(dy, w) (+addend) (masked by mask_src > 0).  wt: [Cin][KH][KW][Cout] dtype (sl_weight_prep).
  * dx: [B][H][W][Cin] (all Cin channels, also for a virtual concat).  addend / mask_src: NULL or [B][H][W][Cin]. */
 int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const void* mask_src,

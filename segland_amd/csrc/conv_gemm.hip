@@ -22,6 +22,7 @@ struct ConvGemmParams {
   int Hd, Wd;                           // destination spatial
   int N, KH, KW, stride, pad, dil;
   int mode;                             // 0: forward gather, 1: data-gradient gather
+  const float* scale;                   // per-output-channel multiplier applied before bias (folded eval-mode BN) or null
   const float* bias; int relu;
   const void* addend; const void* mask_src;
   float* stat_partial;                  // [gridM][2][N] or null
@@ -63,6 +64,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t 
   for (int j = 0; j < TN; ++j) {
     const int n = bn * BN + wn * (BN / WN) + j * 32 + frow;
     const float bias = p.bias ? p.bias[n] : 0.f;
+    const float scl = p.scale ? p.scale[n] : 1.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -71,7 +73,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t 
         float v = acc[i][j][r];
         csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
         if (m < p.M) {
-          v += bias;
+          v = v * scl + bias;
           const size_t o = (size_t)m * p.N + n;
           if (p.addend) v += to_f<T>(((const T*)p.addend)[o]);
           if (p.relu) v = v > 0.f ? v : 0.f;
@@ -255,9 +257,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
   const int fhalf = lane >> 5;
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
-  float bias[EPC], ssum[EPC], ssq[EPC];
+  float bias[EPC], scl[EPC], ssum[EPC], ssq[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { bias[e] = p.bias ? p.bias[ncol + e] : 0.f; ssum[e] = 0.f; ssq[e] = 0.f; }
+  for (int e = 0; e < EPC; ++e) { bias[e] = p.bias ? p.bias[ncol + e] : 0.f; scl[e] = p.scale ? p.scale[ncol + e] : 1.f; ssum[e] = 0.f; ssq[e] = 0.f; }
   T* out = (T*)p.out;
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
@@ -289,9 +291,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
       const size_t o = (size_t)m * p.N + ncol;
-      if (p.bias) {
+      if (p.bias || p.scale) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] += bias[e];
+        for (int e = 0; e < EPC; ++e) v[e] = v[e] * scl[e] + bias[e];
       }
       if (p.addend) {
         float a[EPC];
@@ -796,6 +798,20 @@ extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2,
   p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
   p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
   p.bias = bias; p.relu = relu; p.stat_partial = stat_partial;
+  p.M = d->B * d->Ho * d->Wo;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+extern "C" int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
+                                    const float* shift, const void* residual, int relu, void* y, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(x && w && y && scale && shift, "conv affine fwd: null buffer");
+  SL_REQUIRE(d->C1 == d->Cin || x2, "conv affine fwd: x2 missing for a concat input");
+  ConvGemmParams p{};
+  p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.wt = w; p.out = y;
+  p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
+  p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
+  p.scale = scale; p.bias = shift; p.relu = relu; p.addend = residual;
   p.M = d->B * d->Ho * d->Wo;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

@@ -56,6 +56,18 @@ def conv_bn_fwd(x, conv, bn, relu, residual=None, x2=None, out=None):
     return c, y, mean, invstd
 
 
+def conv_bn_infer(x, conv, bn, relu, residual=None, x2=None, out=None):
+    """Frozen-statistics conv+BN(+residual)(+ReLU) as ONE kernel (no conv-output round trip, nothing saved)."""
+    wf, _ = prepared(conv.weight, x.dtype)
+    _, _, scale, shift = ops.bn_finalize_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    return ops.conv2d_affine_fwd(x, wf, spec_of(conv), scale, shift, x2=x2, residual=residual, relu=relu, out=out)
+
+
+def _frozen(ctx, *bns):
+    """True when nothing in this block needs a gradient and every BN runs on its running statistics."""
+    return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
+
+
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None):
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres)."""
     dc, dres, dgamma, dbeta = ops.bn_bwd(dy, y_mask, c, mean, invstd, bn.weight, train=bn.training, want_dres=want_dres)
@@ -100,6 +112,12 @@ class BottleneckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, blk, *params):
+        bns = [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else [])
+        if _frozen(ctx, *bns):
+            a1 = conv_bn_infer(x, blk.conv1, blk.bn1, relu=True)
+            a2 = conv_bn_infer(a1, blk.conv2, blk.bn2, relu=True)
+            res = x if blk.downsample is None else conv_bn_infer(x, blk.downsample[0], blk.downsample[1], relu=False)
+            return conv_bn_infer(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res)
         c1, a1, m1, i1 = conv_bn_fwd(x, blk.conv1, blk.bn1, relu=True)
         c2, a2, m2, i2 = conv_bn_fwd(a1, blk.conv2, blk.bn2, relu=True)
         if blk.downsample is not None:
@@ -162,6 +180,17 @@ class PPMFn(torch.autograd.Function):
         Cs = dec.stages[0][1].out_channels
         pooled = ops.ppm_pool_fwd(x4, sizes)
         stage_act = torch.empty((pooled.shape[0], Cs), dtype=torch.float32, device=x4.device)   # stage path is fp32 (see ppm.hip)
+        if _frozen(ctx, dec.bottleneck[1], *[st[2] for st in dec.stages]):
+            off = 0
+            for s, st in zip(sizes, dec.stages):
+                n = B * s * s
+                conv_bn_infer(pooled[off:off + n].view(B, s, s, Cf), st[1], st[2], relu=True, out=stage_act[off:off + n].view(B, s, s, Cs))
+                off += n
+            priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
+            bt = dec.bottleneck
+            ab = conv_bn_infer(priors, bt[0], bt[1], relu=True, x2=x4)
+            wf, _ = prepared(bt[3].weight, x4.dtype)
+            return ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())[0]
         cl, ml, il, off = [], [], [], 0
         for s, st in zip(sizes, dec.stages):
             n = B * s * s

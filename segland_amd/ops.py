@@ -138,6 +138,17 @@ def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False):
     return y, part
 
 
+def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=True, out=None):
+    """y = act(conv(x|x2) * scale + shift (+ residual)): eval-mode BN folded into the conv epilogue."""
+    B, H, W, C1 = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
+    y = out if out is not None else torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    tok = PROFILER.begin('conv_fwd', d)
+    check(_lib.lib().sl_conv2d_affine_fwd(C.byref(d), _p(x), _p(x2), _p(wf), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _s()), 'conv2d_affine_fwd')
+    PROFILER.end(tok)
+    return y
+
+
 def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, out=None):
     B = dy.shape[0]
     H, W = in_hw

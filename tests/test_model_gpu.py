@@ -52,6 +52,20 @@ def check_grad(got, ref, tol, what):
         assert out <= 5e-4, '%s: %.4f%% outliers' % (what, 100 * out)
 
 
+def check_tight(got, ref, what):
+    """Same-machine comparison against the CPU oracle: tight where it can be (median error <= 2e-4 of scale: a flipped ReLU mask moves the
+    batch-statistic sums of the BN backward, i.e. every element, by ~1/rows), bounded where it cannot (one flipped mask element is
+    worth ~5e-3 relative L2 on these shapes; allow a few)."""
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = np.asarray(ref)
+    err = np.abs(got - ref)
+    scale = max(np.abs(ref).max(), 1e-20)
+    assert np.median(err) <= 2e-4 * scale, '%s: median error %.3g of scale' % (what, np.median(err) / scale)
+    l2 = float(np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-20))
+    assert l2 <= 2e-2, '%s: relative L2 error %.3g' % (what, l2)
+    assert (err > 1e-4 * scale).mean() <= 0.05, '%s: %.2f%% of the elements are off' % (what, 100 * (err > 1e-4 * scale).mean())
+
+
 TOLS = {torch.float32: 1e-3, torch.bfloat16: 6e-2}
 GTOLS = {torch.float32: 1e-2, torch.bfloat16: 0.15}   # vs cross-machine goldens; tight same-box checks below
 
@@ -96,9 +110,9 @@ def test_g5_bottleneck(hip, name, dtype):
         yo = po.bottleneck_forward(ora, xo)
         (yo * coef).sum().backward()
         check(nchw(y), yo.detach().numpy(), 1e-5, 'y vs same-box oracle')
-        check_grad(nchw(xg.grad), xo.grad.numpy(), 1e-3, 'dx vs same-box oracle')
-        check_grad(blk.conv2.weight.grad, ora.conv2.weight.grad.numpy(), 1e-3, 'd_conv2_w vs same-box oracle')
-        check_grad(blk.bn1.weight.grad, ora.bn1.weight.grad.numpy(), 1e-3, 'd_bn1_gamma vs same-box oracle')
+        check_tight(nchw(xg.grad), xo.grad.numpy(), 'dx vs same-box oracle')
+        check_tight(blk.conv2.weight.grad, ora.conv2.weight.grad.numpy(), 'd_conv2_w vs same-box oracle')
+        check_tight(blk.bn1.weight.grad, ora.bn1.weight.grad.numpy(), 'd_bn1_gamma vs same-box oracle')
     blk.eval()
     with torch.no_grad():
         check(nchw(blk(xg.detach()))[:, ::4], g['y_eval'], tol, 'y_eval')
