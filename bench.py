@@ -155,18 +155,19 @@ def main():
     # ---- warm-up; the last warm-up step is instrumented to find the dominant kernel shape
     for i in range(a.warmup):
         if i == a.warmup - 1:
-            ops.PROFILER.start(all_shapes=True)
+            ops.PROFILER.start()
         train_step(net, opt, img, mask, params, double)
     if a.warmup == 0:
-        ops.PROFILER.start(all_shapes=True)
+        ops.PROFILER.start()
         train_step(net, opt, img, mask, params, double)
     torch.cuda.synchronize()
     table = ops.PROFILER.stop()
-    dominant = max(table.values(), key=lambda e: e['ms_total']) if table else None
+    single = {k: v for k, v in table.items() if 'wgrad' not in k}     # families that are exactly one kernel per launch
+    dominant = max(single.values(), key=lambda e: e['ms_total']) if single else None
 
-    # ---- timed region
+    # ---- timed region (only the dominant kernel's launches carry event pairs)
     if dominant is not None:
-        ops.PROFILER.start(only=dominant['key'])
+        ops.PROFILER.start(only=dominant['family'])
     if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
@@ -184,13 +185,13 @@ def main():
         dt_s = float(t.item())
 
     if a.profile_table and rank == 0:
-        rows = sorted(table.values(), key=lambda e: -e['ms_total'])
         with open(a.profile_table, 'w') as f:
-            f.write('# one instrumented step, %s %s batch %d: per conv launch shape (HIP events on the launch stream)\n' % (a.backbone, a.dtype, a.batch))
-            f.write('%-10s %-46s %6s %10s %10s %9s\n' % ('kind', 'shape', 'calls', 'ms_total', 'GFLOP', 'TFLOP/s'))
-            for e in rows:
-                f.write('%-10s %-46s %6d %10.3f %10.1f %9.1f\n' % (e['kind'], e['shape'], e['calls'], e['ms_total'], e['gflop'], e['gflop'] / max(e['ms_total'], 1e-9)))
-            f.write('# total conv-kernel time %.2f ms, total conv GFLOP %.1f\n' % (sum(e['ms_total'] for e in rows), sum(e['gflop'] for e in rows)))
+            f.write('# one instrumented step, %s %s batch %d: conv launches by kernel and shape (HIP events on the launch stream)\n' % (a.backbone, a.dtype, a.batch))
+            for fam in sorted(table.values(), key=lambda e: -e['ms_total']):
+                f.write('== %-58s calls %4d  %8.3f ms  %9.1f GFLOP  %7.1f TFLOP/s\n' % (fam['family'], fam['calls'], fam['ms_total'], fam['gflop'], fam['gflop'] / max(fam['ms_total'], 1e-9)))
+                for shape, (n, ms, gf) in sorted(fam['shapes'].items(), key=lambda kv: -kv[1][1]):
+                    f.write('   %-50s %4d %9.3f ms %9.1f GFLOP %8.1f TFLOP/s\n' % (shape, n, ms, gf, gf / max(ms, 1e-9)))
+            f.write('# total conv time %.2f ms, total conv GFLOP %.1f\n' % (sum(e['ms_total'] for e in table.values()), sum(e['gflop'] for e in table.values())))
 
     if rank == 0:
         tiles = a.batch * world * a.steps
@@ -208,10 +209,20 @@ def main():
         if live:
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')      # PMC pass (tools/collect_traffic.py), bytes per launch
+            if os.path.exists(tpath):
+                try:
+                    t = json.load(open(tpath))
+                    if t.get('kernel') == e['family']:
+                        traffic = t.get('hbm_bytes_per_launch')
+                except Exception:
+                    pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                               'traffic': None, 'kernel': '%s %s' % (e['kind'], e['shape']), 'launches': e['calls'],
+                               'traffic': traffic, 'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
-                               'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2)}
+                               'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
+                               'note': 'all launches of this kernel in the timed steps (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone)
         print(json.dumps(out), flush=True)

@@ -51,6 +51,10 @@ typedef struct SlConvDesc {
   int C1;                /* channels read from x; the remaining Cin-C1 come from x2 (C1 == Cin: x2 unused) */
 } SlConvDesc;
 
+/* which tile kernel a shape is dispatched to (1000000*variant + 1000*BM + BN; variant 4 = 4-stage LDS ring, 2 = two-stage);
+ * mode 0 = forward, 1 = data gradient.  Lets a profiler attribute launches to kernel names. */
+int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
+
 /* number of row-blocks of the forward kernel == rows of the BN partial-statistics buffer */
 int sl_conv2d_stat_rows(const SlConvDesc* d);
 

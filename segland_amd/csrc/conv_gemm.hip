@@ -781,6 +781,23 @@ int check_desc(const SlConvDesc* d) {
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
 
+// Which kernel a shape runs on: 1000000*variant + 1000*BM + BN  (variant 4 = ring, 2 = two-stage glds, 1 = register staged).
+// mode 0: forward, 1: data gradient.  Used by bench.py to attribute HIP-event timings to rocprof kernel names.
+extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
+  if (!d) return SL_EINVAL;
+  const long long M = mode == 0 ? (long long)d->B * d->Ho * d->Wo : (long long)d->B * d->H * d->W;
+  const int N = mode == 0 ? d->Cout : d->Cin;
+  const int ktot = d->KH * d->KW * (mode == 0 ? d->Cin : d->Cout);
+  const int v = conv_variant();
+  const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
+  if (v == 1) return 1000000 + 128000 + (n128 ? 128 : 64);
+  const bool big = block_rows(M, ktot) == 256;
+  if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
+  if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));
+  if (v >= 4 && n128 && M >= 128 * 512) return 4128128;
+  return 2000000 + 128000 + (n128 ? 128 : 64);
+}
+
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;

@@ -42,44 +42,54 @@ def _f32(n, dev, zero=False):
 # --------------------------------------------------------------------------------------------- live kernel timing
 class _Profiler:
     """HIP-event timing of the conv launches on the launch stream (bench.py: roofline of the dominant kernel).
-    Off by default; when on, either every conv launch shape is timed (one instrumented step) or a single shape."""
+    Off by default.  Launches are attributed to the kernel they are dispatched to (`family`, the name rocprofv3 shows);
+    `only` restricts timing to one family so the timed region carries just those event pairs."""
+
+    FAMILY = {4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
         self.on, self.only, self.rec = False, None, {}
 
-    def start(self, all_shapes=False, only=None):
-        self.on, self.only, self.rec = True, (None if all_shapes else only), {}
+    def start(self, only=None):
+        self.on, self.only, self.rec = True, only, {}
+
+    def family(self, kind, d):
+        if kind == 'conv_wgrad':
+            return 'conv_wgrad (kernel + slab reduce)'
+        cfg = _lib.lib().sl_conv2d_tile_config(C.byref(d), 0 if kind == 'conv_fwd' else 1)
+        return '%s<%s, %d, %d>' % (self.FAMILY.get(cfg // 1000000, '?'), 'bf16' if d.dtype == SL_BF16 else 'f32', (cfg // 1000) % 1000, cfg % 1000)
 
     def begin(self, kind, d):
         if not self.on:
             return None
-        key = (kind, d.dtype, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
-        if self.only is not None and key != self.only:
+        fam = self.family(kind, d)
+        if self.only is not None and fam != self.only:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        return key, e0, e1, d
+        return fam, kind, e0, e1, d
 
     def end(self, tok):
         if tok is None:
             return
-        key, e0, e1, d = tok
+        fam, kind, e0, e1, d = tok
         e1.record()
-        ent = self.rec.get(key)
-        if ent is None:
-            gflop = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW / 1e9
-            ent = self.rec[key] = {'key': key, 'kind': key[0], 'events': [], 'gflop_per_call': gflop,
-                                   'shape': 'B%d %dx%d %d->%d k%d s%d d%d %s' % (d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil, 'bf16' if d.dtype == SL_BF16 else 'f32')}
-        ent['events'].append((e0, e1))
+        gflop = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW / 1e9
+        shape = '%s B%d %dx%d %d->%d k%d s%d d%d' % (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
+        self.rec.setdefault(fam, []).append((e0, e1, gflop, shape))
 
     def stop(self):
+        """{family: {calls, ms_total, gflop, shapes: {shape: [calls, ms, gflop]}}}"""
         self.on = False
         torch.cuda.synchronize()
         out = {}
-        for key, ent in self.rec.items():
-            ms = sum(a.elapsed_time(b) for a, b in ent['events'])
-            n = len(ent['events'])
-            out[key] = {'key': key, 'kind': ent['kind'], 'shape': ent['shape'], 'calls': n, 'ms_total': ms, 'gflop': ent['gflop_per_call'] * n}
+        for fam, evs in self.rec.items():
+            ent = out[fam] = {'family': fam, 'calls': 0, 'ms_total': 0.0, 'gflop': 0.0, 'shapes': {}}
+            for e0, e1, gflop, shape in evs:
+                ms = e0.elapsed_time(e1)
+                ent['calls'] += 1; ent['ms_total'] += ms; ent['gflop'] += gflop
+                sh = ent['shapes'].setdefault(shape, [0, 0.0, 0.0])
+                sh[0] += 1; sh[1] += ms; sh[2] += gflop
         self.rec = {}
         return out
 
