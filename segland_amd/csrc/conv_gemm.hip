@@ -283,35 +283,60 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
           }
     }
     __syncthreads();
-    for (int row = r0; row < ROWS; row += RS) {
-      const int m = bm * BM + pass * ROWS + row;
-      if (m >= p.M) break;
-      float v[EPC];
-      unpack16<T>(*(const uint4*)(smem + row * G::PITCH + cc * 16), v);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
-      const size_t o = (size_t)m * p.N + ncol;
-      if (p.bias || p.scale) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = v[e] * scl[e] + bias[e];
-      }
+    // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
+    // flight together instead of one load -> use -> store latency chain per row
+    constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+    static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
+    const int mrow0 = bm * BM + pass * ROWS + r0;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += CH) {
+      uint4 addv[CH], mskv[CH];
       if (p.addend) {
-        float a[EPC];
-        unpack16<T>(*(const uint4*)((const T*)p.addend + o), a);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] += a[e];
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        for (int u = 0; u < CH; ++u) {
+          const int m = mrow0 + (it0 + u) * RS;
+          if (m < p.M) addv[u] = *(const uint4*)((const T*)p.addend + (size_t)m * p.N + ncol);
+        }
       }
       if (p.mask_src) {
-        float k[EPC];
-        unpack16<T>(*(const uint4*)((const T*)p.mask_src + o), k);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
+        for (int u = 0; u < CH; ++u) {
+          const int m = mrow0 + (it0 + u) * RS;
+          if (m < p.M) mskv[u] = *(const uint4*)((const T*)p.mask_src + (size_t)m * p.N + ncol);
+        }
       }
-      *(uint4*)(out + o) = pack16<T>(v);
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int row = r0 + (it0 + u) * RS;
+        const int m = mrow0 + (it0 + u) * RS;
+        if (m < p.M) {
+          float v[EPC];
+          unpack16<T>(*(const uint4*)(smem + row * G::PITCH + cc * 16), v);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+          if (p.bias || p.scale) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = v[e] * scl[e] + bias[e];
+          }
+          if (p.addend) {
+            float a[EPC];
+            unpack16<T>(addv[u], a);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += a[e];
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          if (p.mask_src) {
+            float k[EPC];
+            unpack16<T>(mskv[u], k);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
+          }
+          *(uint4*)(out + (size_t)m * p.N + ncol) = pack16<T>(v);
+        }
+      }
     }
     __syncthreads();
   }
