@@ -13,10 +13,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
-  return (bf16_t)(u >> 16);
+  // hardware conversion (v_cvt_pk_bf16_f32 on gfx950): round to nearest even, NaN preserved
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -44,11 +42,13 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
   return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
-  uint4 r;
-  r.x = (unsigned)f2bf(in[0]) | ((unsigned)f2bf(in[1]) << 16);
-  r.y = (unsigned)f2bf(in[2]) | ((unsigned)f2bf(in[3]) << 16);
-  r.z = (unsigned)f2bf(in[4]) | ((unsigned)f2bf(in[5]) << 16);
-  r.w = (unsigned)f2bf(in[6]) | ((unsigned)f2bf(in[7]) << 16);
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  uint4 r;     // one v_cvt_pk_bf16_f32 per pair
+  r.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){in[0], in[1]}, bf16x2_t));
+  r.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){in[2], in[3]}, bf16x2_t));
+  r.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){in[4], in[5]}, bf16x2_t));
+  r.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){in[6], in[7]}, bf16x2_t));
   return r;
 }
 

@@ -233,6 +233,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
 // 8/16-byte writes and then streamed out with 16-byte coalesced global stores; bias, ReLU, the residual addend and the
 // ReLU mask are applied on those vectors (16-byte coalesced loads), and the per-channel BN statistics (sum, sum of
 // squares of the stored values) are accumulated in the same pass.
+// streamed-out tile store: non-temporal 16-byte stores (the tile is next touched by another kernel, after > L2 of traffic)
+template <typename T>
+__device__ __forceinline__ void st16(T* dst, const uint4& v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)dst);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 struct EpiGeom {
   static constexpr int PITCH = BN * (int)sizeof(T) + 16;
@@ -273,9 +280,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
           for (int q = 0; q < 4; ++q) {
             unsigned char* dst = smem + (lrow + i * 32) * G::PITCH + (wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf) * (int)sizeof(T);
             if constexpr (sizeof(T) == 2) {
+              typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+              typedef __attribute__((ext_vector_type(2))) float f32x2_t;
               uint2 v;
-              v.x = (unsigned)f2bf(acc[i][j][4 * q + 0]) | ((unsigned)f2bf(acc[i][j][4 * q + 1]) << 16);
-              v.y = (unsigned)f2bf(acc[i][j][4 * q + 2]) | ((unsigned)f2bf(acc[i][j][4 * q + 3]) << 16);
+              v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]}, bf16x2_t));
+              v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}, bf16x2_t));
               *(uint2*)dst = v;
             } else {
               *(float4*)dst = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
@@ -285,6 +294,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
     __syncthreads();
     // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
     // flight together instead of one load -> use -> store latency chain per row
+    const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src);
     constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
     static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
     const int mrow0 = bm * BM + pass * ROWS + r0;
@@ -311,9 +321,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
         const int m = mrow0 + (it0 + u) * RS;
         if (m < p.M) {
           float v[EPC];
-          unpack16<T>(*(const uint4*)(smem + row * G::PITCH + cc * 16), v);
+          const uint4 raw = *(const uint4*)(smem + row * G::PITCH + cc * 16);
+          unpack16<T>(raw, v);
 #pragma unroll
           for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+          if (plain) { st16(out + (size_t)m * p.N + ncol, raw); continue; }      // nothing to apply: stream the staged chunk
           if (p.bias || p.scale) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] = v[e] * scl[e] + bias[e];
@@ -334,7 +346,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
           }
-          *(uint4*)(out + (size_t)m * p.N + ncol) = pack16<T>(v);
+          st16(out + (size_t)m * p.N + ncol, pack16<T>(v));
         }
       }
     }
