@@ -69,10 +69,12 @@ int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void
 int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
                          const float* shift, const void* residual, int relu, void* y, sl_stream_t stream);
 
-/* dx = conv_transpose(dy, w) (+addend) (masked by mask_src > 0).  wt: [Cin][KH][KW][Cout] dtype (sl_weight_prep).
- * dx: [B][H][W][Cin] (all Cin channels, also for a virtual concat).  addend / mask_src: NULL or [B][H][W][Cin]. */
-int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const void* mask_src,
-                       void* dx, sl_stream_t stream);
+/* dx = conv_transpose(dy, w) (+addend [* relu bit of addend_mask]) (masked by mask_src > 0).
+ * wt: [Cin][KH][KW][Cout] dtype (sl_weight_prep).  dx: [B][H][W][Cin] (all Cin channels, also for a virtual concat).
+ * addend / mask_src: NULL or [B][H][W][Cin]; addend_mask: NULL or the relu_mask bytes (sl_bn_act_fwd) of that tensor --
+ * the shortcut gradient `dout * relu'(out)` of a bottleneck is applied here instead of being materialised. */
+int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
+                       const void* mask_src, void* dx, sl_stream_t stream);
 
 /* dw (float, OIHW [Cout][Cin][KH][KW]) = sum over pixels of dy (x) x.  Deterministic split-K through `workspace`. */
 size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);
@@ -95,22 +97,24 @@ int sl_bn_finalize_train(const float* stat_partial, int stat_rows, int C, long l
 int sl_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
                         sl_stream_t stream);
-/* y = x*scale[c] + shift[c] (+ residual) (relu)   -- BN affine + `out += residual` + ReLU of resnet.py:60-76 */
+/* y = x*scale[c] + shift[c] (+ residual) (relu)   -- BN affine + `out += residual` + ReLU of resnet.py:60-76.
+ * relu_mask (nullable): one byte per 16-byte vector of y, bit k = (y_k > 0): the backward reads this instead of y. */
 int sl_bn_act_fwd(int dtype, const void* x, const float* scale, const float* shift, const void* residual, int relu,
-                  void* y, long long rows, int C, sl_stream_t stream);
-/* Backward, step 1: partial[blk][0][c] = sum g, partial[blk][1][c] = sum g*xhat with g = dy * (y > 0 if y) and
+                  void* y, uint8_t* relu_mask, long long rows, int C, sl_stream_t stream);
+/* Backward, step 1: partial[blk][0][c] = sum g, partial[blk][1][c] = sum g*xhat with g = dy * relu'(y) (mask from
+ * relu_mask if given, else from y > 0 if y is given, else none) and
  * xhat = (x - mean)*invstd.  Returns the number of partial rows through *nblk (buffer: float[nblk][2][C]). */
 int sl_bn_bwd_reduce_rows(long long rows, int C);
-int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
-                     float* partial, long long rows, int C, sl_stream_t stream);
+int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x, const float* mean,
+                     const float* invstd, float* partial, long long rows, int C, sl_stream_t stream);
 /* step 2: dgamma = S2, dbeta = S1 and the per-channel coefficients of dx = cA*g + cB*(x-mean) + cC.
  * train != 0: batch-statistics backward; train == 0: frozen statistics (dx = scale*g). */
 int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, const float* gamma, const float* mean,
                        const float* invstd, int train, float* dgamma, float* dbeta, float* cA, float* cB, float* cC,
                        sl_stream_t stream);
 /* step 3: dx = cA*g + cB*(x-mean) + cC; if dres != NULL also dres = g (the residual-branch gradient). */
-int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* cA, const float* cB,
-                    const float* cC, const float* mean, void* dx, void* dres, long long rows, int C,
+int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x, const float* cA,
+                    const float* cB, const float* cC, const float* mean, void* dx, void* dres, long long rows, int C,
                     sl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ stem

@@ -78,7 +78,7 @@ __global__ void bn_finalize_eval_kernel(int C, const float* gamma, const float* 
 // coefficients live in registers; the loop is then a pure 16-byte stream (4 independent loads in flight per operand).
 template <typename T, bool FIXEDC>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  const T* __restrict__ res, int relu, T* __restrict__ y, unsigned nvec, unsigned nvc) {
+                                  const T* __restrict__ res, int relu, T* __restrict__ y, uint8_t* __restrict__ mask_out, unsigned nvec, unsigned nvc) {
   constexpr int V = Vec16<T>::N;
   const unsigned stride = gridDim.x * 256u;
   float sc[V], sh[V];
@@ -106,14 +106,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
       float a[V], r[V], o[V];
       unpack16<T>(xv[u], a);
       if (res) unpack16<T>(rv[u], r);
+      unsigned bits = 0;
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         float v = a[k] * sc[k] + sh[k];
         if (res) v += r[k];
         if (relu) v = v > 0.f ? v : 0.f;
+        bits |= (v > 0.f ? 1u : 0u) << k;
         o[k] = v;
       }
       ((uint4*)y)[i] = pack16<T>(o);
+      if (mask_out) mask_out[i] = (uint8_t)bits;       // 1 byte per 16-byte vector: bit k = (y_k > 0)
     }
   }
 }
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 // ------------------------------------------------------------------------------------------------ backward reduce
 // partial[blk][0][c] = sum g, partial[blk][1][c] = sum g * (x - mean) * invstd over the block's rows
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ part, long long rows, int C, long long rows_per_blk) {
   constexpr int V = Vec16<T>::N;
@@ -142,7 +145,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         float g[V], xv[V], yv[V];
         unpack16<T>(((const uint4*)dy)[o], g);
         unpack16<T>(((const uint4*)x)[o], xv);
-        if (y) {
+        if (mask) {
+          const unsigned b = mask[o];
+#pragma unroll
+          for (int k = 0; k < V; ++k) g[k] = (b >> k) & 1u ? g[k] : 0.f;
+        } else if (y) {
           unpack16<T>(((const uint4*)y)[o], yv);
 #pragma unroll
           for (int k = 0; k < V; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_bwd_finalize_kernel(const 
 }
 
 template <typename T, bool FIXEDC>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                     const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
                                     const float* __restrict__ mean, T* __restrict__ dx, T* __restrict__ dres, unsigned nvec, unsigned nvc) {
   constexpr int V = Vec16<T>::N;
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const unsigned i = i0 + u * stride;
-      if (i < nvec) { gv[u] = ((const uint4*)dy)[i]; xv[u] = ((const uint4*)x)[i]; if (y) yv[u] = ((const uint4*)y)[i]; }
+      if (i < nvec) { gv[u] = ((const uint4*)dy)[i]; xv[u] = ((const uint4*)x)[i]; if (y && !mask) yv[u] = ((const uint4*)y)[i]; }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -219,7 +226,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       float g[V], xx[V], yy[V], o[V];
       unpack16<T>(gv[u], g);
       unpack16<T>(xv[u], xx);
-      if (y) {
+      if (mask) {
+        const unsigned b = mask[i];
+#pragma unroll
+        for (int k = 0; k < V; ++k) g[k] = (b >> k) & 1u ? g[k] : 0.f;
+      } else if (y) {
         unpack16<T>(yv[u], yy);
 #pragma unroll
         for (int k = 0; k < V; ++k) g[k] = yy[k] > 0.f ? g[k] : 0.f;
@@ -259,40 +270,40 @@ extern "C" int sl_bn_finalize_eval(int C, const float* gamma, const float* beta,
 }
 
 template <typename T>
-static int launch_bn_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, void* y, long long rows, int C, hipStream_t st) {
+static int launch_bn_act(const void* x, const float* scale, const float* shift, const void* residual, int relu, void* y, uint8_t* mask_out, long long rows, int C, hipStream_t st) {
   constexpr int V = Vec16<T>::N;
   const long long nvec = rows * C / V;
   SL_REQUIRE(nvec < (1ll << 31), "bn_act_fwd: tensor too large");
   const unsigned nvc = C / V;
   const bool fixed = nvc <= 256 && 256 % nvc == 0;
   const int blocks = ew_blocks((nvec + 3) / 4);
-  if (fixed) hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, scale, shift, (const T*)residual, relu, (T*)y, (unsigned)nvec, nvc);
-  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, scale, shift, (const T*)residual, relu, (T*)y, (unsigned)nvec, nvc);
+  if (fixed) hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)x, scale, shift, (const T*)residual, relu, (T*)y, mask_out, (unsigned)nvec, nvc);
+  else hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)x, scale, shift, (const T*)residual, relu, (T*)y, mask_out, (unsigned)nvec, nvc);
   SL_LAUNCH_CHECK("bn_act_fwd_kernel");
   return 0;
 }
 
 extern "C" int sl_bn_act_fwd(int dtype, const void* x, const float* scale, const float* shift, const void* residual,
-                             int relu, void* y, long long rows, int C, sl_stream_t stream) {
+                             int relu, void* y, uint8_t* relu_mask, long long rows, int C, sl_stream_t stream) {
   SL_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0, "bn_act_fwd: bad args");
-  if (dtype == SL_BF16) return launch_bn_act<bf16_t>(x, scale, shift, residual, relu, y, rows, C, (hipStream_t)stream);
-  if (dtype == SL_F32) return launch_bn_act<float>(x, scale, shift, residual, relu, y, rows, C, (hipStream_t)stream);
+  if (dtype == SL_BF16) return launch_bn_act<bf16_t>(x, scale, shift, residual, relu, y, relu_mask, rows, C, (hipStream_t)stream);
+  if (dtype == SL_F32) return launch_bn_act<float>(x, scale, shift, residual, relu, y, relu_mask, rows, C, (hipStream_t)stream);
   SL_REQUIRE(false, "bn_act_fwd: bad dtype");
   return 0;
 }
 
 extern "C" int sl_bn_bwd_reduce_rows(long long rows, int C) { (void)C; return reduce_blocks(rows); }
 
-extern "C" int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* mean,
+extern "C" int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x, const float* mean,
                                 const float* invstd, float* partial, long long rows, int C, sl_stream_t stream) {
   SL_REQUIRE(dy && x && mean && invstd && partial && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad args");
   const int nblk = reduce_blocks(rows);
   const long long rpb = (rows + nblk - 1) / nblk;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SL_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, mean, invstd, partial, rows, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, relu_mask, (const bf16_t*)x, mean, invstd, partial, rows, C, rpb);
   else if (dtype == SL_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)y, (const float*)x, mean, invstd, partial, rows, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)y, relu_mask, (const float*)x, mean, invstd, partial, rows, C, rpb);
   else SL_REQUIRE(false, "bn_bwd_reduce: bad dtype");
   SL_LAUNCH_CHECK("bn_bwd_reduce_kernel");
   return 0;
@@ -309,7 +320,7 @@ extern "C" int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long lo
 }
 
 template <typename T>
-static int launch_bn_apply(const void* dy, const void* y, const void* x, const float* cA, const float* cB, const float* cC, const float* mean,
+static int launch_bn_apply(const void* dy, const void* y, const uint8_t* mask, const void* x, const float* cA, const float* cB, const float* cC, const float* mean,
                            void* dx, void* dres, long long rows, int C, hipStream_t st) {
   constexpr int V = Vec16<T>::N;
   const long long nvec = rows * C / V;
@@ -317,18 +328,18 @@ static int launch_bn_apply(const void* dy, const void* y, const void* x, const f
   const unsigned nvc = C / V;
   const bool fixed = nvc <= 256 && 256 % nvc == 0;
   const int blocks = ew_blocks((nvec + 1) / 2);
-  if (fixed) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, cA, cB, cC, mean, (T*)dx, (T*)dres, (unsigned)nvec, nvc);
-  else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)y, (const T*)x, cA, cB, cC, mean, (T*)dx, (T*)dres, (unsigned)nvec, nvc);
+  if (fixed) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)y, mask, (const T*)x, cA, cB, cC, mean, (T*)dx, (T*)dres, (unsigned)nvec, nvc);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)y, mask, (const T*)x, cA, cB, cC, mean, (T*)dx, (T*)dres, (unsigned)nvec, nvc);
   SL_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;
 }
 
-extern "C" int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* cA, const float* cB,
+extern "C" int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x, const float* cA, const float* cB,
                                const float* cC, const float* mean, void* dx, void* dres, long long rows, int C,
                                sl_stream_t stream) {
   SL_REQUIRE(dy && x && cA && cB && cC && mean && dx && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply: bad args");
-  if (dtype == SL_BF16) return launch_bn_apply<bf16_t>(dy, y, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
-  if (dtype == SL_F32) return launch_bn_apply<float>(dy, y, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
+  if (dtype == SL_BF16) return launch_bn_apply<bf16_t>(dy, y, relu_mask, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
+  if (dtype == SL_F32) return launch_bn_apply<float>(dy, y, relu_mask, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
   SL_REQUIRE(false, "bn_bwd_apply: bad dtype");
   return 0;
 }

@@ -25,6 +25,7 @@ struct ConvGemmParams {
   const float* scale;                   // per-output-channel multiplier applied before bias (folded eval-mode BN) or null
   const float* bias; int relu;
   const void* addend; const void* mask_src;
+  const unsigned char* addend_mask;     // relu bits (1 byte per 16-byte vector) gating the addend, or null
   float* stat_partial;                  // [gridM][2][N] or null
   int M;
   int gridM, gridN;
@@ -75,7 +76,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t 
         if (m < p.M) {
           v = v * scl + bias;
           const size_t o = (size_t)m * p.N + n;
-          if (p.addend) v += to_f<T>(((const T*)p.addend)[o]);
+          if (p.addend) {
+            float av = to_f<T>(((const T*)p.addend)[o]);
+            if (p.addend_mask) av = (p.addend_mask[o / (16 / sizeof(T))] >> (o % (16 / sizeof(T)))) & 1u ? av : 0.f;
+            v += av;
+          }
           if (p.relu) v = v > 0.f ? v : 0.f;
           if (p.mask_src) v = to_f<T>(((const T*)p.mask_src)[o]) > 0.f ? v : 0.f;
           out[o] = from_f<T>(v);
@@ -333,6 +338,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
           if (p.addend) {
             float a[EPC];
             unpack16<T>(addv[u], a);
+            if (p.addend_mask) {
+              const unsigned bits = p.addend_mask[((size_t)m * p.N + ncol) / EPC];
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) a[e] = (bits >> e) & 1u ? a[e] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] += a[e];
           }
@@ -870,7 +880,7 @@ extern "C" int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const vo
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }
 
-extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend,
+extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
                                   const void* mask_src, void* dx, sl_stream_t stream) {
   if (int e = check_desc(d)) return e;
   SL_REQUIRE(dy && wt && dx, "conv bwd_data: null buffer");
@@ -878,7 +888,7 @@ extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const voi
   p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
-  p.addend = addend; p.mask_src = mask_src;
+  p.addend = addend; p.mask_src = mask_src; p.addend_mask = addend ? addend_mask : nullptr;
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

@@ -48,10 +48,13 @@ def _bn_coeffs(bn, part, count):
     return ops.bn_finalize_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
-def conv_bn_fwd(x, conv, bn, relu, residual=None, x2=None, out=None):
+def conv_bn_fwd(x, conv, bn, relu, residual=None, x2=None, out=None, want_mask=False):
     wf, _ = prepared(conv.weight, x.dtype)
     c, part = ops.conv2d_fwd(x, wf, spec_of(conv), x2=x2, want_stats=bn.training)
     mean, invstd, scale, shift = _bn_coeffs(bn, part, c.numel() // c.shape[-1])
+    if want_mask:
+        y, mask = ops.bn_act(c, scale, shift, residual=residual, relu=relu, out=out, want_mask=True)
+        return c, y, mean, invstd, mask
     y = ops.bn_act(c, scale, shift, residual=residual, relu=relu, out=out)
     return c, y, mean, invstd
 
@@ -68,14 +71,19 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
-def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None):
-    """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres)."""
-    dc, dres, dgamma, dbeta = ops.bn_bwd(dy, y_mask, c, mean, invstd, bn.weight, train=bn.training, want_dres=want_dres)
+def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
+                bits=None, addend_bits=None):
+    """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres).
+    ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
+    `addend_bits` gate) is accumulated into dx by the dgrad epilogue."""
+    dc, dres, dgamma, dbeta = ops.bn_bwd(dy, None if bits is not None else y_mask, c, mean, invstd, bn.weight, train=bn.training,
+                                         want_dres=want_dres, mask=bits)
     spec = spec_of(conv)
     dx = dw = None
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
-        dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, C1=(x.shape[3] if x2 is not None else None), out=dx_out)
+        dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
+                                 C1=(x.shape[3] if x2 is not None else None), out=dx_out)
     if need_dw:
         dw = ops.conv2d_bwd_weight(x, dc, spec, x2=x2)
     return dx, dw, dgamma, dbeta, dres
@@ -118,18 +126,20 @@ class BottleneckFn(torch.autograd.Function):
             a2 = conv_bn_infer(a1, blk.conv2, blk.bn2, relu=True)
             res = x if blk.downsample is None else conv_bn_infer(x, blk.downsample[0], blk.downsample[1], relu=False)
             return conv_bn_infer(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res)
-        c1, a1, m1, i1 = conv_bn_fwd(x, blk.conv1, blk.bn1, relu=True)
-        c2, a2, m2, i2 = conv_bn_fwd(a1, blk.conv2, blk.bn2, relu=True)
+        c1, a1, m1, i1, k1 = conv_bn_fwd(x, blk.conv1, blk.bn1, relu=True, want_mask=True)
+        c2, a2, m2, i2, k2 = conv_bn_fwd(a1, blk.conv2, blk.bn2, relu=True, want_mask=True)
         if blk.downsample is not None:
             cd, res, md, idd = conv_bn_fwd(x, blk.downsample[0], blk.downsample[1], relu=False)
         else:
             cd, res, md, idd = None, x, None, None
-        c3, out, m3, i3 = conv_bn_fwd(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res)
+        c3, out, m3, i3, k3 = conv_bn_fwd(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res, want_mask=True)
         ctx.blk = blk
         ctx.has_ds = blk.downsample is not None
-        saved = [x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3]
+        saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3]
         if ctx.has_ds:
             saved += [cd, md, idd]
+        if k3 is not None:
+            saved.append(k3)
         ctx.save_for_backward(*saved)
         return out
 
@@ -138,25 +148,23 @@ class BottleneckFn(torch.autograd.Function):
     def backward(ctx, dout):
         blk = ctx.blk
         sv = ctx.saved_tensors
-        x, c1, a1, m1, i1, c2, a2, m2, i2, c3, out, m3, i3 = sv[:13]
+        x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3 = sv[:14]
+        k3 = sv[-1] if blk.last_relu else None        # ReLU bits of the block output (gates BOTH the bn3 and the shortcut gradient)
         dout = dout.contiguous()
         need_w = ctx.needs_input_grad[2]            # params are all-or-nothing frozen in this model family
         need_x = ctx.needs_input_grad[0]
-        # bn3 (+ residual add + last relu): dres = masked dout feeds the shortcut
-        da2, dw3, dg3, db3, dres = conv_bn_bwd(dout, out if blk.last_relu else None, c3, a2, blk.conv3, blk.bn3, m3, i3,
-                                               True, need_w, want_dres=blk.last_relu)
-        if not blk.last_relu:
-            dres = dout
-        da1, dw2, dg2, db2, _ = conv_bn_bwd(da2, a2, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w)
+        da2, dw3, dg3, db3, _ = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3)
+        da1, dw2, dg2, db2, _ = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=k2)
         grads_ds = ()
         if ctx.has_ds:
-            cd, md, idd = sv[13:16]
-            dxd, dwd, dgd, dbd, _ = conv_bn_bwd(dres, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w)
+            cd, md, idd = sv[14:17]
+            dxd, dwd, dgd, dbd, _ = conv_bn_bwd(dout, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w, bits=k3)
             grads_ds = (dwd, dgd, dbd)
-            addend = dxd
+            addend, abits = dxd, None
         else:
-            addend = dres
-        dx, dw1, dg1, db1, _ = conv_bn_bwd(da1, a1, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w, addend=addend if need_x else None)
+            addend, abits = dout, k3                # identity shortcut: dout * relu'(out), gated inside the dgrad epilogue
+        dx, dw1, dg1, db1, _ = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
+                                           addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=k1)
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
 
 

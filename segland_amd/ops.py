@@ -159,14 +159,14 @@ def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=Tr
     return y
 
 
-def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, out=None):
+def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, out=None, addend_mask=None):
     B = dy.shape[0]
     H, W = in_hw
     d = conv_desc(dy.dtype, B, H, W, spec, C1)
     dx = out if out is not None else torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
     assert dx.numel() == B * H * W * spec.cin and dx.dtype == dy.dtype
     tok = PROFILER.begin('conv_dgrad', d)
-    check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
+    check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(addend_mask), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
     PROFILER.end(tok)
     return dx
 
@@ -213,28 +213,30 @@ def bn_finalize_eval(gamma, beta, rmean, rvar, eps=1e-5):
     return o[0], o[1], o[2], o[3]
 
 
-def bn_act(x, scale, shift, residual=None, relu=True, out=None):
+def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False):
+    """y = act(x*scale + shift (+residual)).  want_mask: also return the ReLU bit mask (1 byte per 16-byte vector of y)."""
     Cn = x.shape[-1]
     y = out if out is not None else torch.empty_like(x)
     assert y.numel() == x.numel() and y.dtype == x.dtype
-    check(_lib.lib().sl_bn_act_fwd(dt(x), _p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), x.numel() // Cn, Cn, _s()), 'bn_act_fwd')
-    return y
+    mask = torch.empty(x.numel() * x.element_size() // 16, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    check(_lib.lib().sl_bn_act_fwd(dt(x), _p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _p(mask), x.numel() // Cn, Cn, _s()), 'bn_act_fwd')
+    return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False):
-    """Returns (dx, dres, dgamma, dbeta).  y: post-activation output when a ReLU follows the BN (mask), else None."""
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None):
+    """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given."""
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     L = _lib.lib()
     nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
     part = _f32((nblk, 2, Cn), x.device)
-    check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
+    check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
     o = _f32((5, Cn), x.device)
     check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_dres else None
-    check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
+    check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
     return dx, dres, o[0], o[1]
 
 
@@ -246,7 +248,7 @@ def colsum_rows(t):
     nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
     part = _f32((nblk, 2, Cn), t.device)
     z = _f32((2, Cn), t.device, zero=True)
-    check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
+    check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
     return colsum(part)[0].contiguous()
 
 

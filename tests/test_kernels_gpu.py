@@ -119,6 +119,12 @@ def test_conv_concat_bias_relu_addend_mask(hip, dtype, C1, C2, Cout):
     add = rnd(fm.sym('cc/add', (B, C1 + C2, H, W), 1.0), dtype); msk = rnd(fm.sym('cc/msk', (B, C1 + C2, H, W), 1.0), dtype)
     dx = ops.conv2d_bwd_data(gyg, wb, spec, (H, W), addend=nhwc(add, dtype), mask_src=nhwc(msk, dtype))
     assert_close(nchw(dx), (x.grad + add) * (msk > 0), dtype, 'dgrad + addend, masked')
+    # addend gated by the ReLU bits of another tensor (the bottleneck shortcut gradient dout * relu'(out))
+    gate = rnd(fm.sym('cc/gate', (B, C1 + C2, H, W), 1.0), dtype)
+    one = torch.ones(C1 + C2, device=DEV)
+    _, bits = ops.bn_act(nhwc(gate, dtype), one, torch.zeros_like(one), relu=True, want_mask=True)
+    dx = ops.conv2d_bwd_data(gyg, wb, spec, (H, W), addend=nhwc(add, dtype), addend_mask=bits)
+    assert_close(nchw(dx), x.grad + add * (gate > 0), dtype, 'dgrad + bit-gated addend')
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -153,6 +159,11 @@ def test_bn_train_eval_fwd_bwd(hip, dtype, C_, rows):
         assert_close(dx, xr.grad, dtype, 'bn dx train=%s' % train, factor=4)
         assert_close(dres, gy * (y_ref > 0), dtype, 'bn dres')
         assert_close(dgamma, g_.grad, dtype, 'dgamma', factor=4); assert_close(dbeta, b_.grad, dtype, 'dbeta', factor=4)
+        # the 1-bit ReLU mask emitted by the forward gates the backward exactly like the activation itself
+        y2, bits = ops.bn_act(xg, scale, shift, residual=res.to(DEV).to(dtype), relu=True, want_mask=True)
+        assert torch.equal(y2, y) and bits.dtype == torch.uint8 and bits.numel() == y.numel() * y.element_size() // 16
+        dx2, _, dg2, db2 = ops.bn_bwd(gy.to(DEV).to(dtype), None, xg, mean, invstd, dev(gamma), train=train, mask=bits)
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
