@@ -85,6 +85,11 @@ int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, con
 int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,
                    sl_stream_t stream);
 
+/* The same for n weights in ONE launch.  table_dev: device array of n 48-byte records
+ *   { const float* src; void* w_fwd; void* w_bwd; int O, I, KHW, dtype; long long start; }
+ * with `start` the running sum of O*I*KHW (ascending); total_elems the grand total. */
+int sl_weight_prep_batched(const void* table_dev, int n, long long total_elems, sl_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ batch norm
  * nn.BatchNorm2d call sites: resnet.py:45,48,50,88,111; pspnet_pop.py:20,28 (eps 1e-5, momentum 0.1). */
 

@@ -910,6 +910,37 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Cout, int Ci
 }
 }  // namespace
 
+namespace {
+struct PrepEntry { const float* src; void* wf; void* wb; int O, I, KHW, dtype; long long start; };
+
+// all conv weights of a model in ONE launch: entry table in device memory, elements concatenated in `start` order
+__global__ void weight_prep_batched_kernel(const PrepEntry* __restrict__ tab, int n, long long total) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= e) lo = mid; else hi = mid - 1; }
+    const PrepEntry t = tab[lo];
+    const long long l = e - t.start;
+    const int k = (int)(l % t.KHW);
+    const long long oi = l / t.KHW;
+    const int i = (int)(oi % t.I), o = (int)(oi / t.I);
+    const float v = t.src[l];
+    const size_t fo = ((size_t)o * t.KHW + k) * t.I + i, bo = ((size_t)i * t.KHW + k) * t.O + o;
+    if (t.dtype == SL_BF16) { if (t.wf) ((bf16_t*)t.wf)[fo] = f2bf(v); if (t.wb) ((bf16_t*)t.wb)[bo] = f2bf(v); }
+    else                    { if (t.wf) ((float*)t.wf)[fo] = v;        if (t.wb) ((float*)t.wb)[bo] = v; }
+  }
+}
+}  // namespace
+
+// table: device array of n entries {src, w_fwd, w_bwd (void*), O, I, KH*KW, dtype (int), start (int64)} = 48 bytes each
+extern "C" int sl_weight_prep_batched(const void* table_dev, int n, long long total_elems, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && n > 0 && total_elems > 0, "weight_prep_batched: bad args");
+  static_assert(sizeof(PrepEntry) == 48, "table layout is part of the ABI");
+  const int blocks = (int)((total_elems + 255) / 256 < 16384 ? (total_elems + 255) / 256 : 16384);
+  hipLaunchKernelGGL(weight_prep_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const PrepEntry*)table_dev, n, total_elems);
+  SL_LAUNCH_CHECK("weight_prep_batched_kernel");
+  return 0;
+}
+
 extern "C" int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd,
                               void* w_bwd, sl_stream_t stream) {
   SL_REQUIRE(w_oihw && (w_fwd || w_bwd), "weight_prep: null buffer");

@@ -25,6 +25,53 @@ def prepared(w, dtype):
     return ent[3], ent[4]
 
 
+class _PrepPlan:
+    """All conv weights of a model -> GEMM layouts in one kernel launch per optimizer step (instead of one per conv)."""
+
+    def __init__(self):
+        self.key, self.table, self.total, self.items = None, None, 0, []
+
+    def refresh(self, convs, dtypes):
+        import struct
+        ws = [c.weight for c in convs]
+        stale = [w for w, d in zip(ws, dtypes) if (getattr(w, '_sl_prep', None) is None or w._sl_prep[0] != w._version
+                                                    or w._sl_prep[1] != d or w._sl_prep[2] != w.data_ptr())]
+        if not stale:
+            return
+        key = tuple((w.data_ptr(), d) for w, d in zip(ws, dtypes))
+        if key != self.key:                                   # (re)build buffers + the device table
+            rec, start, self.items = b'', 0, []
+            for w, d in zip(ws, dtypes):
+                O, I, KH, KW = w.shape
+                wf = torch.empty((O, KH, KW, I), dtype=d, device=w.device)
+                wb = torch.empty((I, KH, KW, O), dtype=d, device=w.device)
+                rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(), wb.data_ptr(), O, I, KH * KW, ops.dt(d), start)
+                start += w.numel()
+                self.items.append((w, d, wf, wb))
+            self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(ws[0].device)
+            self.total, self.key = start, key
+        ops.weight_prep_batched(self.table, len(self.items), self.total)
+        for w, d, wf, wb in self.items:
+            w._sl_prep = (w._version, d, w.data_ptr(), wf, wb)
+
+
+def refresh_weights(model):
+    """Called once per forward by GFSS_Model: re-derives the GEMM-layout copies of every conv weight whose version changed."""
+    plan = model.__dict__.get('_sl_prep_plan')
+    if plan is None:
+        plan = model.__dict__['_sl_prep_plan'] = _PrepPlan()
+        convs, dtypes = [], []
+        stage_convs = {id(st[1]) for st in model.decoder.stages}
+        for m in list(model.backbone.modules()) + list(model.decoder.modules()) + list(model.classifier.modules()) + \
+                (list(model.classifier_n.modules()) if getattr(model, 'classifier_n', None) is not None else []):
+            if isinstance(m, torch.nn.Conv2d) and m.kernel_size[0] in (1, 3) and m.out_channels % 64 == 0:
+                convs.append(m)
+                dtypes.append(torch.float32 if id(m) in stage_convs else model.compute_dtype)     # PPM stage path is fp32
+        plan.convs, plan.dtypes = convs, dtypes
+    if all(w.weight.is_cuda and w.weight.dtype == torch.float32 and w.weight.is_contiguous() for w in plan.convs):
+        plan.refresh(plan.convs, plan.dtypes)
+
+
 def flush_num_batches_tracked():
     if _nbt_pending:
         torch._foreach_add_(_nbt_pending, 1)

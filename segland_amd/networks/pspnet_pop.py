@@ -13,7 +13,7 @@ import torch.nn as nn
 from torch.nn import functional as F
 
 from .. import ops
-from ..functional import PopHeadFn, PPMFn, cls_params, flush_num_batches_tracked, ppm_params
+from ..functional import PopHeadFn, PPMFn, cls_params, flush_num_batches_tracked, ppm_params, refresh_weights
 from .backbones import get_backbone
 
 
@@ -90,6 +90,7 @@ class GFSS_Model(nn.Module):
     def _features(self, img):
         if not img.is_cuda:
             raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
+        refresh_weights(self)
         x4 = self.backbone.base_forward(img)
         feat = self.decoder(x4)
         flush_num_batches_tracked()

@@ -135,6 +135,10 @@ def weight_prep(w, dtype, want_fwd=True, want_bwd=True):
     return wf, wb
 
 
+def weight_prep_batched(table, n, total):
+    check(_lib.lib().sl_weight_prep_batched(_p(table), n, int(total), _s()), 'weight_prep_batched')
+
+
 def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False):
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
