@@ -258,6 +258,12 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   const int wm = wave / WCC, wn = wave % WCC;
 
   int bid = blockIdx.x;
+  if (p.gridC * p.gridN * p.taps <= 64) {   // XCD-aware remap: consecutive logical blocks (same dy tile, neighbouring c tiles / taps) share
+    // one XCD's L2.  Measured: +10% on the 512->512 / 256->256 3x3 layers, -15% on the 4096-channel PPM conv (16 c-tiles
+    // per dy tile thrash one L2), hence the gate on the tile count.
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
   const int bc = bid % p.gridC; bid /= p.gridC;
   const int bn = bid % p.gridN; bid /= p.gridN;
   const int tap = bid % p.taps; const int split = bid / p.taps;
