@@ -64,6 +64,11 @@ int sl_conv2d_stat_rows(const SlConvDesc* d);
 int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias, int relu,
                   void* y, float* stat_partial, sl_stream_t stream);
 
+/* sl_conv2d_fwd with an extra [B][Ho][Wo][Cout] tensor (dtype) added to the accumulators BEFORE the statistics / bias:
+ * the contribution of input channels that are handled outside this launch (factorised PPM priors, see sl_ppm_fact_*). */
+int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend,
+                     const float* bias, int relu, void* y, float* stat_partial, sl_stream_t stream);
+
 /* Inference / frozen-BN form: y = act(conv(x|x2, w) * scale[c] + shift[c] (+ residual)) in ONE kernel -- eval-mode
  * BatchNorm (running statistics), the shortcut add and the ReLU of resnet.py:60-76 folded into the conv epilogue. */
 int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
@@ -81,9 +86,17 @@ size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);
 int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
                          void* workspace, size_t workspace_bytes, sl_stream_t stream);
 
+/* the same, writing into a WIDER gradient tensor dw [Cout][dw_cin_total][KH][KW] at input-channel offset dw_ci_off */
+int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                            int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
+
 /* OIHW float master weight -> w_fwd [Cout][KH][KW][Cin] and/or w_bwd [Cin][KH][KW][Cout] in dtype (either may be NULL) */
 int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,
                    sl_stream_t stream);
+
+/* GEMM layouts of the input-channel slice [ci_off, ci_off+ci_cnt) of an OIHW weight with CinTot input channels */
+int sl_weight_prep_slice(int dtype, const float* w_oihw, int Cout, int CinTot, int ci_off, int ci_cnt, int KH, int KW,
+                         void* w_fwd, void* w_bwd, sl_stream_t stream);
 
 /* The same for n weights in ONE launch.  table_dev: device array of n 48-byte records
  *   { const float* src; void* w_fwd; void* w_bwd; int O, I, KHW, dtype; long long start; }
@@ -164,6 +177,21 @@ int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, 
 int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* priors, sl_stream_t stream);
 int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,
                         size_t workspace_bytes, sl_stream_t stream);
+
+/* Factorised prior half of the PPM bottleneck 3x3 conv (pspnet_pop.py:19 applied to the concat of :33-34).  The 3x3 conv of a
+ * bilinearly upsampled s x s map is  sum_tap sum_cells u_tap(pixel; cell) * Q[cell][(tap, n)]  with  Q = (1x1 conv of the stage
+ * map with the tap's weight slice): exact by linearity, and it removes half of that conv's FLOPs (77 GFLOP/tile forward).
+ *   sl_ppm_wq_prep     : W_oihw [N][Ctot][3][3] -> per level l  wq_f [9N][Cs] / wq_b [Cs][9N]  (float; channels l*Cs..)
+ *   sl_ppm_fact_gather : gout[b,y,x,n] (dtype) = sum over levels/taps/cells of u * q   (q: float [rows][9N], rows as above)
+ *   sl_ppm_fact_scatter: gq[rows][9N] (float) = transpose of the gather applied to dcb [B][H][W][N] (dtype)
+ *   sl_ppm_dwq_scatter : dwq [l][(tap,n)][c] -> dw_oihw[n][l*Cs + c][tap] */
+int sl_ppm_wq_prep(const float* w_oihw, int N, int Ctot, int Cs, int nlevels, float* wq_f, float* wq_b, sl_stream_t stream);
+int sl_ppm_dwq_scatter(const float* dwq, int N, int Ctot, int Cs, int nlevels, float* dw_oihw, sl_stream_t stream);
+size_t sl_ppm_fact_workspace(const SlPpmDesc* d, int N);
+int sl_ppm_fact_gather(const SlPpmDesc* d, int N, const float* q, void* gout, void* workspace, size_t workspace_bytes,
+                       sl_stream_t stream);
+int sl_ppm_fact_scatter(const SlPpmDesc* d, int N, const void* dcb, float* gq, void* workspace, size_t workspace_bytes,
+                        sl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ POP head
  * pspnet_pop.py:95-121 orthogonal_decompose + :178-182 / :210-219 classifier on the components, evaluated in the

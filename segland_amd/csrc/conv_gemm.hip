@@ -25,6 +25,7 @@ struct ConvGemmParams {
   const float* scale;                   // per-output-channel multiplier applied before bias (folded eval-mode BN) or null
   const float* bias; int relu;
   const void* addend; const void* mask_src;
+  const void* pre_addend;               // [M][N] added to the accumulators BEFORE statistics / bias (factorised PPM priors) or null
   const unsigned char* addend_mask;     // relu bits (1 byte per 16-byte vector) gating the addend, or null
   float* stat_partial;                  // [gridM][2][N] or null
   int M;
@@ -72,6 +73,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t 
       for (int r = 0; r < 16; ++r) {
         const int m = bm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
         float v = acc[i][j][r];
+        if (p.pre_addend && m < p.M) v += to_f<T>(((const T*)p.pre_addend)[(size_t)m * p.N + n]);
         csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
         if (m < p.M) {
           v = v * scl + bias;
@@ -299,13 +301,20 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
     __syncthreads();
     // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
     // flight together instead of one load -> use -> store latency chain per row
-    const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src);
+    const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src || p.pre_addend);
     constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
     static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
     const int mrow0 = bm * BM + pass * ROWS + r0;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += CH) {
-      uint4 addv[CH], mskv[CH];
+      uint4 addv[CH], mskv[CH], prev[CH];
+      if (p.pre_addend) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const int m = mrow0 + (it0 + u) * RS;
+          if (m < p.M) prev[u] = *(const uint4*)((const T*)p.pre_addend + (size_t)m * p.N + ncol);
+        }
+      }
       if (p.addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -328,6 +337,12 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
           float v[EPC];
           const uint4 raw = *(const uint4*)(smem + row * G::PITCH + cc * 16);
           unpack16<T>(raw, v);
+          if (p.pre_addend) {
+            float a[EPC];
+            unpack16<T>(prev[u], a);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] += a[e];
+          }
 #pragma unroll
           for (int e = 0; e < EPC; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
           if (plain) { st16(out + (size_t)m * p.N + ncol, raw); continue; }      // nothing to apply: stream the staged chunk
@@ -851,8 +866,16 @@ extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   return cdiv(M, block_rows(M, d->KH * d->KW * d->Cin));
 }
 
+extern "C" int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend,
+                                const float* bias, int relu, void* y, float* stat_partial, sl_stream_t stream);
+
 extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* bias,
                              int relu, void* y, float* stat_partial, sl_stream_t stream) {
+  return sl_conv2d_fwd_ex(d, x, x2, w, nullptr, bias, relu, y, stat_partial, stream);
+}
+
+extern "C" int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend,
+                                const float* bias, int relu, void* y, float* stat_partial, sl_stream_t stream) {
   if (int e = check_desc(d)) return e;
   SL_REQUIRE(x && w && y, "conv fwd: null buffer");
   SL_REQUIRE(d->C1 == d->Cin || x2, "conv fwd: x2 missing for a concat input");
@@ -861,7 +884,7 @@ extern "C" int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2,
   p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.wt = w; p.out = y;
   p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
   p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
-  p.bias = bias; p.relu = relu; p.stat_partial = stat_partial;
+  p.bias = bias; p.relu = relu; p.stat_partial = stat_partial; p.pre_addend = pre_addend;
   p.M = d->B * d->Ho * d->Wo;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }
@@ -938,6 +961,34 @@ extern "C" int sl_weight_prep_batched(const void* table_dev, int n, long long to
   const int blocks = (int)((total_elems + 255) / 256 < 16384 ? (total_elems + 255) / 256 : 16384);
   hipLaunchKernelGGL(weight_prep_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const PrepEntry*)table_dev, n, total_elems);
   SL_LAUNCH_CHECK("weight_prep_batched_kernel");
+  return 0;
+}
+
+namespace {
+template <typename T>
+__global__ void weight_prep_slice_kernel(const float* __restrict__ w, int Cout, int CinTot, int ci_off, int ci_cnt, int KHW, T* wf, T* wb) {
+  const long long n = (long long)Cout * ci_cnt * KHW;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % KHW);
+    const long long oi = e / KHW;
+    const int i = (int)(oi % ci_cnt), o = (int)(oi / ci_cnt);
+    const T v = from_f<T>(w[((size_t)o * CinTot + ci_off + i) * KHW + t]);
+    if (wf) wf[((size_t)o * KHW + t) * ci_cnt + i] = v;
+    if (wb) wb[((size_t)i * KHW + t) * Cout + o] = v;
+  }
+}
+}  // namespace
+
+// GEMM layouts of the input-channel slice [ci_off, ci_off + ci_cnt) of an OIHW weight with CinTot input channels
+extern "C" int sl_weight_prep_slice(int dtype, const float* w_oihw, int Cout, int CinTot, int ci_off, int ci_cnt, int KH, int KW,
+                                    void* w_fwd, void* w_bwd, sl_stream_t stream) {
+  SL_REQUIRE(w_oihw && (w_fwd || w_bwd) && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= CinTot, "weight_prep_slice: bad args");
+  const long long n = (long long)Cout * ci_cnt * KH * KW;
+  const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  if (dtype == SL_BF16) hipLaunchKernelGGL(weight_prep_slice_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, CinTot, ci_off, ci_cnt, KH * KW, (bf16_t*)w_fwd, (bf16_t*)w_bwd);
+  else if (dtype == SL_F32) hipLaunchKernelGGL(weight_prep_slice_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, CinTot, ci_off, ci_cnt, KH * KW, (float*)w_fwd, (float*)w_bwd);
+  else SL_REQUIRE(false, "weight_prep_slice: bad dtype");
+  SL_LAUNCH_CHECK("weight_prep_slice_kernel");
   return 0;
 }
 

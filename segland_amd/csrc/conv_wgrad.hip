@@ -436,7 +436,8 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 
 // dw_oihw[n][c][t] = sum_s ws[s][n][t][c].  One block per (n, 64-channel chunk): the taps x 64 slab values are read as
 // 256-byte rows (coalesced), transposed through LDS and written as ONE contiguous run of 64*taps floats.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits,
+                                                           int dw_cin_total, int dw_ci_off) {
   __shared__ float tile[64 * 49];      // [c][t], taps <= 49
   const int cchunks = Cin / 64;
   const int n = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * 64;
@@ -449,12 +450,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     tile[c * taps + t] = s;
   }
   __syncthreads();
-  float* o = dw + ((size_t)n * Cin + c0) * taps;
+  float* o = dw + ((size_t)n * dw_cin_total + dw_ci_off + c0) * taps;
   for (int e = threadIdx.x; e < taps * 64; e += 256) o[e] = tile[e];
 }
 
 // taps == 1: the slab layout already equals OIHW
-__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits) {
+__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits, int Cin, int dw_cin_total, int dw_ci_off) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
@@ -463,7 +464,7 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __
       s2 += ws[(size_t)(k + 2) * total + e]; s3 += ws[(size_t)(k + 3) * total + e];
     }
     for (; k < splits; ++k) s0 += ws[(size_t)k * total + e];
-    dw[e] = (s0 + s1) + (s2 + s3);
+    dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -566,9 +567,19 @@ extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   return plan(d).ws_bytes;
 }
 
+extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                                       int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
+
 extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
                                     void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  return sl_conv2d_bwd_weight_ex(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream);
+}
+
+// dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
+extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                                       int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
+  SL_REQUIRE(dw_ci_off >= 0 && dw_ci_off + d->Cin <= dw_cin_total, "conv bwd_weight: bad dw channel window");
   const int bke = d->dtype == SL_BF16 ? 64 : 32;
   const int c2 = d->Cin - d->C1;
   SL_REQUIRE(d->dtype == SL_BF16 || d->dtype == SL_F32, "conv bwd_weight: bad dtype");
@@ -592,9 +603,9 @@ extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const vo
   SL_REQUIRE(pl.taps <= 49, "conv bwd_weight: kernel window larger than 7x7");
   if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off);
   } else {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
   }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
   return 0;

@@ -226,6 +226,159 @@ __global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Factorised prior half of the PPM bottleneck conv (networks/pspnet_pop.py:19,33-34).  For level l with stage map
+// P_l [B,s,s,Cs]:   conv3x3(upsample(P_l))[y,x,n] = sum_tap sum_(i,j) u_tap(y,x; i,j) * Q_l[i,j,(tap,n)],
+// Q_l[i,j,(tap,n)] = sum_c W[n][l*Cs+c][tap] * P_l[i,j,c]  (a 1x1 conv on the s x s grid, done by the MFMA kernel), and
+// u_tap = [pixel shifted by the tap is inside the map] * (bilinear weight of the shifted pixel on cell (i,j)), which is
+// separable in y and x.  Exact by linearity; removes 77 of the 154.6 GFLOP/tile of this conv (and of its dgrad / wgrad).
+
+// weight re-layout: W_oihw [N][Ctot][3][3] -> per level  wq_f [9N][Cs] (1x1 forward layout) and wq_b [Cs][9N] (dgrad layout)
+__global__ void ppm_wq_prep_kernel(const float* __restrict__ w, int N, int Ctot, int Cs, int nl, float* __restrict__ wq_f, float* __restrict__ wq_b) {
+  const long long total = (long long)nl * 9 * N * Cs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Cs); long long r = e / Cs;
+    const int n = (int)(r % N); r /= N;
+    const int tap = (int)(r % 9); const int l = (int)(r / 9);
+    const float v = w[((size_t)n * Ctot + l * Cs + c) * 9 + tap];
+    wq_f[((size_t)l * 9 * N + tap * N + n) * Cs + c] = v;
+    wq_b[((size_t)l * Cs + c) * 9 * N + tap * N + n] = v;
+  }
+}
+
+// dwq [l][(tap,n)][c] -> dw_oihw[n][l*Cs + c][tap]
+__global__ void ppm_dwq_scatter_kernel(const float* __restrict__ dwq, int N, int Ctot, int Cs, int nl, float* __restrict__ dw) {
+  const long long total = (long long)nl * 9 * N * Cs;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Cs); long long r = e / Cs;
+    const int n = (int)(r % N); r /= N;
+    const int tap = (int)(r % 9); const int l = (int)(r / 9);
+    dw[((size_t)n * Ctot + l * Cs + c) * 9 + tap] = dwq[e];
+  }
+}
+
+// bilinear weight of destination index d (shifted by the tap, may fall outside) on source cell `cell`
+__device__ __forceinline__ float tap_weight(int d, int s, int size, int cell) {
+  if ((unsigned)d >= (unsigned)size) return 0.f;
+  int i0, i1; float l1;
+  src_index_ac0(d, s, size, i0, i1, l1);
+  return (i0 == cell ? 1.f - l1 : 0.f) + (i1 == cell ? l1 : 0.f);
+}
+
+// stage 1 of the gather: t[b][y][kx][lj][n] = sum_ky sum_i wy_ky(y,i) * q_l[b][i][j][(ky*3+kx)*N + n]
+__global__ void ppm_fact_gather1_kernel(PpmGeom g, int N, const float* __restrict__ q, float* __restrict__ t, int nlj) {
+  const int nv = N / 4;
+  const long long total = (long long)g.B * g.H * 3 * nlj * nv;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(e % nv); long long r = e / nv;
+    int lj = (int)(r % nlj); r /= nlj;
+    const int kx = (int)(r % 3); r /= 3;
+    const int y = (int)(r % g.H); const int b = (int)(r / g.H);
+    int l = 0;
+    while (lj >= g.sizes[l]) { lj -= g.sizes[l]; ++l; }
+    const int s = g.sizes[l], j = lj;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int ky = 0; ky < 3; ++ky) {
+      const int d = y + ky - 1;
+      if ((unsigned)d >= (unsigned)g.H) continue;
+      int i0, i1; float l1;
+      src_index_ac0(d, s, g.H, i0, i1, l1);
+      const float* base = q + ((size_t)g.rowoff[l] + (size_t)b * s * s) * 9 * N + (ky * 3 + kx) * N + v * 4;
+      const float4 a = *(const float4*)(base + (size_t)(i0 * s + j) * 9 * N);
+      const float4 c = *(const float4*)(base + (size_t)(i1 * s + j) * 9 * N);
+      const float w0 = 1.f - l1;
+      acc.x += w0 * a.x + l1 * c.x; acc.y += w0 * a.y + l1 * c.y; acc.z += w0 * a.z + l1 * c.z; acc.w += w0 * a.w + l1 * c.w;
+    }
+    *(float4*)(t + (size_t)e * 4) = acc;
+  }
+}
+
+// stage 2: gout[b][y][x][n] = sum_l sum_kx sum_j wx_kx(x,j) * t[b][y][kx][ljoff_l + j][n]   (written in the compute dtype)
+template <typename T>
+__global__ void ppm_fact_gather2_kernel(PpmGeom g, int N, const float* __restrict__ t, T* __restrict__ gout, int nlj) {
+  constexpr int V = Vec16<T>::N;
+  const int nv = N / V;
+  const long long total = (long long)g.B * g.H * g.W * nv;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(e % nv); long long r = e / nv;
+    const int x = (int)(r % g.W); r /= g.W;
+    const int y = (int)(r % g.H); const int b = (int)(r / g.H);
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    int ljoff = 0;
+    for (int l = 0; l < g.nlevels; ++l) {
+      const int s = g.sizes[l];
+      for (int kx = 0; kx < 3; ++kx) {
+        const int d = x + kx - 1;
+        if ((unsigned)d >= (unsigned)g.W) continue;
+        int j0, j1; float l1;
+        src_index_ac0(d, s, g.W, j0, j1, l1);
+        const float* base = t + ((((size_t)b * g.H + y) * 3 + kx) * nlj + ljoff) * N + v * V;
+        const float w0 = 1.f - l1;
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += w0 * base[(size_t)j0 * N + k] + l1 * base[(size_t)j1 * N + k];
+      }
+      ljoff += s;
+    }
+    *(uint4*)(gout + (size_t)e * V) = pack16<T>(acc);
+  }
+}
+
+// transpose of the gather, stage A: sa[b][y][kx][lj][n] = sum_x wx_kx(x,j) * dcb[b][y][x][n]
+template <typename T>
+__global__ void ppm_fact_scatterA_kernel(PpmGeom g, int N, const T* __restrict__ dcb, float* __restrict__ sa, int nlj) {
+  constexpr int V = Vec16<T>::N;
+  const int nv = N / V;
+  const long long total = (long long)g.B * g.H * 3 * nlj * nv;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(e % nv); long long r = e / nv;
+    int lj = (int)(r % nlj); r /= nlj;
+    const int kx = (int)(r % 3); r /= 3;
+    const int y = (int)(r % g.H); const int b = (int)(r / g.H);
+    int l = 0;
+    while (lj >= g.sizes[l]) { lj -= g.sizes[l]; ++l; }
+    const int s = g.sizes[l], j = lj;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int x = 0; x < g.W; ++x) {
+      const float wgt = tap_weight(x + kx - 1, s, g.W, j);
+      if (wgt == 0.f) continue;
+      float d[V];
+      unpack16<T>(*(const uint4*)(dcb + (((size_t)b * g.H + y) * g.W + x) * N + v * V), d);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += wgt * d[k];
+    }
+    float* o = sa + (size_t)e * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = acc[k];
+  }
+}
+
+// stage B: gq[row_l(b,i,j)][(ky*3+kx)*N + n] = sum_y wy_ky(y,i) * sa[b][y][kx][lj][n]
+__global__ void ppm_fact_scatterB_kernel(PpmGeom g, int N, const float* __restrict__ sa, float* __restrict__ gq, int nlj) {
+  const long long total = (long long)g.rowoff[4] * 9 * N;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(e % N); long long r = e / N;
+    const int tap = (int)(r % 9); const int row = (int)(r / 9);
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    int l = 0, ljoff = 0;
+    while (l + 1 < g.nlevels && row >= g.rowoff[l + 1]) { ljoff += g.sizes[l]; ++l; }
+    const int s = g.sizes[l];
+    int rr = row - g.rowoff[l];
+    const int j = rr % s; rr /= s;
+    const int i = rr % s; const int b = rr / s;
+    float acc = 0.f;
+    for (int y = 0; y < g.H; ++y) {
+      const float wgt = tap_weight(y + ky - 1, s, g.H, i);
+      if (wgt == 0.f) continue;
+      acc += wgt * sa[((((size_t)b * g.H + y) * 3 + kx) * nlj + ljoff + j) * N + n];
+    }
+    gq[e] = acc;
+  }
+}
+
 inline int gs_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 inline int sum_sizes(const PpmGeom& g) { int n = 0; for (int l = 0; l < g.nlevels; ++l) n += g.sizes[l]; return n; }
 
@@ -307,5 +460,60 @@ extern "C" int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat,
     hipLaunchKernelGGL(ppm_upsample_bwd_y_kernel, dim3(gs_blocks((long long)g.rowoff[4] * Cs)), dim3(256), 0, st, g, Cs, tmp, (float*)dstage, nlj);
   } else SL_REQUIRE(false, "ppm_upsample_bwd: bad dtype");
   SL_LAUNCH_CHECK("ppm_upsample_bwd");
+  return 0;
+}
+
+// ---- factorised prior path (see the comment block above ppm_wq_prep_kernel)
+extern "C" int sl_ppm_wq_prep(const float* w_oihw, int N, int Ctot, int Cs, int nlevels, float* wq_f, float* wq_b, sl_stream_t stream) {
+  SL_REQUIRE(w_oihw && wq_f && wq_b && N > 0 && Cs > 0 && nlevels >= 1 && nlevels * Cs <= Ctot, "ppm_wq_prep: bad args");
+  hipLaunchKernelGGL(ppm_wq_prep_kernel, dim3(gs_blocks((long long)nlevels * 9 * N * Cs)), dim3(256), 0, (hipStream_t)stream, w_oihw, N, Ctot, Cs, nlevels, wq_f, wq_b);
+  SL_LAUNCH_CHECK("ppm_wq_prep_kernel");
+  return 0;
+}
+
+extern "C" int sl_ppm_dwq_scatter(const float* dwq, int N, int Ctot, int Cs, int nlevels, float* dw_oihw, sl_stream_t stream) {
+  SL_REQUIRE(dwq && dw_oihw && N > 0 && Cs > 0 && nlevels >= 1 && nlevels * Cs <= Ctot, "ppm_dwq_scatter: bad args");
+  hipLaunchKernelGGL(ppm_dwq_scatter_kernel, dim3(gs_blocks((long long)nlevels * 9 * N * Cs)), dim3(256), 0, (hipStream_t)stream, dwq, N, Ctot, Cs, nlevels, dw_oihw);
+  SL_LAUNCH_CHECK("ppm_dwq_scatter_kernel");
+  return 0;
+}
+
+extern "C" size_t sl_ppm_fact_workspace(const SlPpmDesc* d, int N) {
+  PpmGeom g;
+  if (make_geom(d, g)) return 0;
+  return (size_t)g.B * g.H * 3 * sum_sizes(g) * N * sizeof(float);
+}
+
+extern "C" int sl_ppm_fact_gather(const SlPpmDesc* d, int N, const float* q, void* gout, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  PpmGeom g;
+  if (int e = make_geom(d, g)) return e;
+  SL_REQUIRE(q && gout && workspace && N > 0 && N % 8 == 0, "ppm_fact_gather: bad args");
+  const int nlj = sum_sizes(g);
+  const size_t need = (size_t)g.B * g.H * 3 * nlj * N * sizeof(float);
+  if (workspace_bytes < need) { sl_set_error("ppm_fact_gather: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  float* t = (float*)workspace;
+  hipLaunchKernelGGL(ppm_fact_gather1_kernel, dim3(gs_blocks((long long)g.B * g.H * 3 * nlj * N / 4)), dim3(256), 0, st, g, N, q, t, nlj);
+  if (d->dtype == SL_BF16) hipLaunchKernelGGL(ppm_fact_gather2_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * N / 8)), dim3(256), 0, st, g, N, t, (bf16_t*)gout, nlj);
+  else if (d->dtype == SL_F32) hipLaunchKernelGGL(ppm_fact_gather2_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * g.W * N / 4)), dim3(256), 0, st, g, N, t, (float*)gout, nlj);
+  else SL_REQUIRE(false, "ppm_fact_gather: bad dtype");
+  SL_LAUNCH_CHECK("ppm_fact_gather");
+  return 0;
+}
+
+extern "C" int sl_ppm_fact_scatter(const SlPpmDesc* d, int N, const void* dcb, float* gq, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  PpmGeom g;
+  if (int e = make_geom(d, g)) return e;
+  SL_REQUIRE(dcb && gq && workspace && N > 0 && N % 8 == 0, "ppm_fact_scatter: bad args");
+  const int nlj = sum_sizes(g);
+  const size_t need = (size_t)g.B * g.H * 3 * nlj * N * sizeof(float);
+  if (workspace_bytes < need) { sl_set_error("ppm_fact_scatter: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  float* sa = (float*)workspace;
+  if (d->dtype == SL_BF16) hipLaunchKernelGGL(ppm_fact_scatterA_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * 3 * nlj * N / 8)), dim3(256), 0, st, g, N, (const bf16_t*)dcb, sa, nlj);
+  else if (d->dtype == SL_F32) hipLaunchKernelGGL(ppm_fact_scatterA_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * 3 * nlj * N / 4)), dim3(256), 0, st, g, N, (const float*)dcb, sa, nlj);
+  else SL_REQUIRE(false, "ppm_fact_scatter: bad dtype");
+  hipLaunchKernelGGL(ppm_fact_scatterB_kernel, dim3(gs_blocks((long long)g.rowoff[4] * 9 * N)), dim3(256), 0, st, g, N, sa, gq, nlj);
+  SL_LAUNCH_CHECK("ppm_fact_scatter");
   return 0;
 }

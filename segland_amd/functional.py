@@ -252,9 +252,27 @@ class PPMFn(torch.autograd.Function):
             xin = pooled[off:off + n].view(B, s, s, Cf)
             c, _, m, i = conv_bn_fwd(xin, st[1], st[2], relu=True, out=stage_act[off:off + n].view(B, s, s, Cs))
             cl.append(c); ml.append(m); il.append(i); off += n
-        priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
         bt = dec.bottleneck
-        cb, ab, mb, ib = conv_bn_fwd(priors, bt[0], bt[1], relu=True, x2=x4)
+        ctx.fact = _PPM_FACTORISED
+        if ctx.fact:
+            # prior half of the 3x3 conv contracted on the s x s grids (exact; see ppm.hip), x4 half on the MFMA kernel
+            N = bt[0].out_channels
+            wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, len(sizes), x4.dtype)
+            q = torch.empty((pooled.shape[0], 9 * N), dtype=torch.float32, device=x4.device)
+            qspec, off = ConvSpec(Cs, 9 * N, 1), 0
+            for k, s in enumerate(sizes):
+                n = B * s * s
+                ops.conv2d_fwd(stage_act[off:off + n].view(B, s, s, Cs), wq_f[k], qspec, out=q[off:off + n].view(B, s, s, 9 * N))
+                off += n
+            gpri = ops.ppm_fact_gather(q, x4.shape, sizes, N, x4.dtype)
+            spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
+            cb, part = ops.conv2d_fwd(x4, wf4, spec4, pre_addend=gpri, want_stats=bt[1].training)
+            mb, ib, scale, shift = _bn_coeffs(bt[1], part, cb.numel() // N)
+            ab = ops.bn_act(cb, scale, shift, relu=True)
+            priors = cb.new_empty(0)
+        else:
+            priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
+            cb, ab, mb, ib = conv_bn_fwd(priors, bt[0], bt[1], relu=True, x2=x4)
         wf, _ = prepared(bt[3].weight, x4.dtype)
         feat, _ = ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())
         ctx.dec = dec
@@ -280,8 +298,34 @@ class PPMFn(torch.autograd.Function):
         dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
         dwf = ops.conv2d_bwd_weight(ab, dfeat, spec_f) if need_w else None
         dbias = ops.colsum_rows(dfeat) if need_w else None
-        dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
-        dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
+        if ctx.fact:
+            N = bt[0].out_channels
+            wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, nl, x4.dtype)
+            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training)
+            spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
+            dcat = ops.conv2d_bwd_data(dcb, wb4, spec4, (H, W))                     # gradient of the x4 half only: [B,H,W,Cf]
+            cat_off = 0
+            dwb = None
+            gq = ops.ppm_fact_scatter(dcb, x4.shape, sizes)
+            dstage = torch.empty_like(stage_act)
+            qspec, off = ConvSpec(Cs, 9 * N, 1), 0
+            if need_w:
+                dwb = torch.empty_like(bt[0].weight, dtype=torch.float32)
+                ops.conv2d_bwd_weight(x4, dcb, spec4, out=dwb, out_ci_off=nl * Cs)
+                dwq = torch.empty((nl, 9 * N, Cs), dtype=torch.float32, device=x4.device)
+            for k, s in enumerate(sizes):
+                n = B * s * s
+                gk = gq[off:off + n].view(B, s, s, 9 * N)
+                ops.conv2d_bwd_data(gk, wq_b[k], qspec, (s, s), out=dstage[off:off + n].view(B, s, s, Cs))
+                if need_w:
+                    ops.conv2d_bwd_weight(stage_act[off:off + n].view(B, s, s, Cs), gk, qspec, out=dwq[k].view(9 * N, Cs, 1, 1))
+                off += n
+            if need_w:
+                ops.ppm_dwq_scatter(dwq, dwb, Cs, nl)
+        else:
+            dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
+            dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
+            cat_off = len(sizes) * Cs
         dpooled = torch.empty_like(pooled)
         gstage, off = [], 0
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
@@ -290,8 +334,30 @@ class PPMFn(torch.autograd.Function):
             dxs, dws, dgs, dbs, _ = conv_bn_bwd(dstage[off:off + n].view(B, s, s, Cs), stage_act[off:off + n].view(B, s, s, Cs), cl[k], xin,
                                                 st[1], st[2], ml[k], il[k], need_x, need_w, dx_out=dpooled[off:off + n].view(B, s, s, Cf))
             gstage += [dws, dgs, dbs]; off += n
-        dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=len(sizes) * Cs) if need_x else None
+        dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None
         return (dx4, None, *gstage, dwb, dgb, dbb, dwf, dbias)
+
+
+import os as _os
+_PPM_FACTORISED = _os.environ.get('SEGLAND_PPM_DIRECT') != '1'
+
+
+def set_ppm_factorised(flag):
+    """Test hook: choose between the factorised prior path (default) and the direct virtual-concat 3x3 conv."""
+    global _PPM_FACTORISED
+    _PPM_FACTORISED = bool(flag)
+
+
+def _ppm_weights(w, Cs, nl, dtype):
+    """Per-level 1x1 weights of the factorised prior path (float) + GEMM layouts of the x4 channel slice, cached on the Parameter."""
+    ent = getattr(w, '_sl_ppm', None)
+    if ent is None or ent[0] != w._version or ent[1] != dtype or ent[2] != w.data_ptr():
+        wq_f, wq_b = ops.ppm_wq_prep(w, Cs, nl)
+        wf4, wb4 = ops.weight_prep_slice(w, dtype, nl * Cs, w.shape[1] - nl * Cs)
+        N = w.shape[0]
+        ent = (w._version, dtype, w.data_ptr(), [wq_f[k].view(9 * N, 1, 1, Cs) for k in range(nl)], [wq_b[k].view(Cs, 1, 1, 9 * N) for k in range(nl)], wf4, wb4)
+        w._sl_ppm = ent
+    return ent[3], ent[4], ent[5], ent[6]
 
 
 def ppm_params(dec):

@@ -139,15 +139,16 @@ def weight_prep_batched(table, n, total):
     check(_lib.lib().sl_weight_prep_batched(_p(table), n, int(total), _s()), 'weight_prep_batched')
 
 
-def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False):
+def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False, pre_addend=None, out=None):
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
-    y = torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    y = out if out is not None else torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    assert y.numel() == B * d.Ho * d.Wo * spec.cout and y.dtype == x.dtype
     part = None
     if want_stats:
         part = _f32((_lib.lib().sl_conv2d_stat_rows(C.byref(d)), 2, spec.cout), x.device)
     tok = PROFILER.begin('conv_fwd', d)
-    check(_lib.lib().sl_conv2d_fwd(C.byref(d), _p(x), _p(x2), _p(wf), _p(bias), int(relu), _p(y), _p(part), _s()), 'conv2d_fwd')
+    check(_lib.lib().sl_conv2d_fwd_ex(C.byref(d), _p(x), _p(x2), _p(wf), _p(pre_addend), _p(bias), int(relu), _p(y), _p(part), _s()), 'conv2d_fwd')
     PROFILER.end(tok)
     return y, part
 
@@ -188,14 +189,16 @@ def workspace(nbytes, dev):
     return w
 
 
-def conv2d_bwd_weight(x, dy, spec, x2=None):
+def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0):
+    """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     need = _lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d))
     ws = workspace(need, x.device)
-    dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    tot = dw.shape[1]
     tok = PROFILER.begin('conv_wgrad', d)
-    check(_lib.lib().sl_conv2d_bwd_weight(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
+    check(_lib.lib().sl_conv2d_bwd_weight_ex(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
     PROFILER.end(tok)
     return dw
 
@@ -347,6 +350,52 @@ def ppm_upsample_bwd(dcat, x_shape, sizes, Cs):
     dstage = torch.empty((ppm_rows(B, sizes), Cs), dtype=torch.float32, device=dcat.device)
     check(L.sl_ppm_upsample_bwd(C.byref(d), Cs, _p(dcat), dcat.shape[-1], _p(dstage), _p(ws), ws.numel(), _s()), 'ppm_upsample_bwd')
     return dstage
+
+
+def weight_prep_slice(w, dtype, ci_off, ci_cnt):
+    O, I, KH, KW = w.shape
+    wf = torch.empty((O, KH, KW, ci_cnt), dtype=dtype, device=w.device)
+    wb = torch.empty((ci_cnt, KH, KW, O), dtype=dtype, device=w.device)
+    check(_lib.lib().sl_weight_prep_slice(_DT[dtype], _p(w.detach()), O, I, ci_off, ci_cnt, KH, KW, _p(wf), _p(wb), _s()), 'weight_prep_slice')
+    return wf, wb
+
+
+def ppm_wq_prep(w, Cs, nl):
+    N, Ctot = w.shape[0], w.shape[1]
+    wq_f = _f32((nl, 9 * N, Cs), w.device)
+    wq_b = _f32((nl, Cs, 9 * N), w.device)
+    check(_lib.lib().sl_ppm_wq_prep(_p(w.detach()), N, Ctot, Cs, nl, _p(wq_f), _p(wq_b), _s()), 'ppm_wq_prep')
+    return wq_f, wq_b
+
+
+def ppm_dwq_scatter(dwq, dw_full, Cs, nl):
+    N, Ctot = dw_full.shape[0], dw_full.shape[1]
+    check(_lib.lib().sl_ppm_dwq_scatter(_p(dwq), N, Ctot, Cs, nl, _p(dw_full), _s()), 'ppm_dwq_scatter')
+
+
+def _ppm_d(dtype, x_shape, sizes):
+    B, H, W, Cn = x_shape
+    return SlPpmDesc(_DT[dtype], B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+
+
+def ppm_fact_gather(q, x_shape, sizes, N, dtype):
+    d = _ppm_d(dtype, x_shape, sizes)
+    L = _lib.lib()
+    ws = workspace(L.sl_ppm_fact_workspace(C.byref(d), N), q.device)
+    B, H, W, _ = x_shape
+    g = torch.empty((B, H, W, N), dtype=dtype, device=q.device)
+    check(L.sl_ppm_fact_gather(C.byref(d), N, _p(q), _p(g), _p(ws), ws.numel(), _s()), 'ppm_fact_gather')
+    return g
+
+
+def ppm_fact_scatter(dcb, x_shape, sizes):
+    N = dcb.shape[-1]
+    d = _ppm_d(dcb.dtype, x_shape, sizes)
+    L = _lib.lib()
+    ws = workspace(L.sl_ppm_fact_workspace(C.byref(d), N), dcb.device)
+    gq = _f32((ppm_rows(x_shape[0], sizes), 9 * N), dcb.device)
+    check(L.sl_ppm_fact_scatter(C.byref(d), N, _p(dcb), _p(gq), _p(ws), ws.numel(), _s()), 'ppm_fact_scatter')
+    return gq
 
 
 # --------------------------------------------------------------------------------------------- POP head

@@ -120,9 +120,19 @@ def test_g5_bottleneck(hip, name, dtype):
         check(nchw(blk(xg.detach()))[:, ::4], g['y_eval'], tol, 'y_eval')
 
 
+@pytest.fixture
+def ppm_path(request):
+    """Both evaluation orders of the PPM bottleneck conv: factorised prior half (default) and the direct virtual-concat conv."""
+    from segland_amd import functional as sf
+    sf.set_ppm_factorised(request.param == 'factorised')
+    yield request.param
+    sf.set_ppm_factorised(True)
+
+
+@pytest.mark.parametrize('ppm_path', ['factorised', 'direct'], indirect=True)
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('tag,feat,outf,hw', [('a', 64, 64, 12), ('b', 128, 64, 16)])
-def test_g4_ppm(hip, tag, feat, outf, hw, dtype):
+def test_g4_ppm(hip, tag, feat, outf, hw, dtype, ppm_path):
     from segland_amd.networks.pspnet_pop import PSPModule
     g = golden('g4_ppm_' + tag)
     dec = PSPModule(feat, out_features=outf)
