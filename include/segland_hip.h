@@ -178,6 +178,15 @@ int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* pr
 int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,
                         size_t workspace_bytes, sl_stream_t stream);
 
+/* Grouped skinny 1x1 convolution over the pyramid rows (the four stage convs pspnet_pop.py:12-16 in one launch, and the per-level
+ * GEMMs of the factorised prior path):  y[r][n] = sum_k x[r][k] * w[l(r)][n][k]  with x [rows][K], w [nlevels][N][K], y [rows][N], all
+ * float, rows ordered as in sl_ppm_pool_fwd; d->C is ignored.  K % 32 == 0, N % 64 == 0.  stat_partial (optional):
+ * float [sl_ppm_rows_gemm_stat_rows][2][N], per level ceil(B*s*s/128) consecutive groups of (sum y, sum y^2) for the BN statistics. */
+int sl_ppm_rows_gemm_stat_rows(const SlPpmDesc* d);
+size_t sl_ppm_rows_gemm_workspace(const SlPpmDesc* d, int K, int N);
+int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x, const float* w, float* y, float* stat_partial,
+                     void* workspace, size_t workspace_bytes, sl_stream_t stream);
+
 /* Factorised prior half of the PPM bottleneck 3x3 conv (pspnet_pop.py:19 applied to the concat of :33-34).  The 3x3 conv of a
  * bilinearly upsampled s x s map is  sum_tap sum_cells u_tap(pixel; cell) * Q[cell][(tap, n)]  with  Q = (1x1 conv of the stage
  * map with the tap's weight slice): exact by linearity, and it removes half of that conv's FLOPs (77 GFLOP/tile forward).

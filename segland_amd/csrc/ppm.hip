@@ -478,6 +478,145 @@ extern "C" int sl_ppm_dwq_scatter(const float* dwq, int N, int Ctot, int Cs, int
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped skinny GEMM over the pyramid rows:  y[r][n] = sum_k x[r][k] * w[l(r)][n][k]   (exact fp32, v_mfma_f32_32x32x2_f32)
+// The four levels of the pyramid have 16..576 rows (B = 16) against K, N of 512..4608: one launch covers all levels, 64x64
+// output tiles, and K is split across blockIdx.z (slabs summed in a fixed order by the finish kernel -> deterministic).
+// The MFMA operand roles are swapped (A = weight rows, B = x rows) so that a lane ends up with 4 consecutive n of one row.
+struct RowsGemm {
+  const float* x; const float* w; float* out;
+  int K, N, nl, kslice;
+  int row_off[5], tile_off[5];
+  long long slab_stride;
+};
+
+constexpr int RG_KT = 32, RG_LD = 36;
+
+__global__ __launch_bounds__(256) void ppm_rows_gemm_kernel(RowsGemm p) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][64][RG_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][64][RG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int l = 0;
+  while (l + 1 < p.nl && (int)blockIdx.y >= p.tile_off[l + 1]) ++l;
+  const int m0 = p.row_off[l] + ((int)blockIdx.y - p.tile_off[l]) * 64, mend = p.row_off[l + 1];
+  const int n0 = blockIdx.x * 64;
+  const int kbeg = blockIdx.z * p.kslice, kend = min(p.K, kbeg + p.kslice);
+  const float* wl = p.w + (size_t)l * p.N * p.K;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;             // this thread loads rows lr, lr+32; floats lc..lc+3 of the k tile
+  float4 rx[2], rw[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + lr + 32 * h;
+      rx[h] = m < mend ? *reinterpret_cast<const float4*>(p.x + (size_t)m * p.K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rw[h] = *reinterpret_cast<const float4*>(wl + (size_t)(n0 + lr + 32 * h) * p.K + k0 + lc);
+    }
+  };
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int wn = (wave & 1) * 32, wm = (wave >> 1) * 32, li = lane & 31, lh = (lane >> 5) * 4;
+  gload(kbeg);
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += RG_KT, buf ^= 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(&Xs[buf][lr + 32 * h][lc]) = rx[h];
+      *reinterpret_cast<float4*>(&Ws[buf][lr + 32 * h][lc]) = rw[h];
+    }
+    __syncthreads();                                   // one barrier per k tile: the other buffer was last read a full iteration ago
+    if (k0 + RG_KT < kend) gload(k0 + RG_KT);
+#pragma unroll
+    for (int kk = 0; kk < RG_KT; kk += 8) {
+      const float4 a = *reinterpret_cast<const float4*>(&Ws[buf][wn + li][kk + lh]);
+      const float4 b = *reinterpret_cast<const float4*>(&Xs[buf][wm + li][kk + lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  const int m = m0 + wm + li;
+  if (m < mend) {
+    float* o = p.out + (size_t)blockIdx.z * p.slab_stride + (size_t)m * p.N + n0 + wn + lh;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(o + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+  }
+}
+
+// y = sum of the K slabs (fixed order) and/or the per-(level, 128-row group) column sums  part[g][0][n] = sum y, part[g][1][n] = sum y^2.
+__global__ __launch_bounds__(256) void ppm_rows_finish_kernel(const float* slabs, int ks, long long slab_stride, float* y, int N, RowsGemm g,
+                                                              float* part) {
+  __shared__ float red[2][4][64];
+  int l = 0;                                            // tile_off here = prefix of 128-row groups per level
+  while (l + 1 < g.nl && (int)blockIdx.y >= g.tile_off[l + 1]) ++l;
+  const int m0 = g.row_off[l] + ((int)blockIdx.y - g.tile_off[l]) * 128, mend = min(g.row_off[l + 1], m0 + 128);
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+  float s = 0.f, s2 = 0.f;
+  for (int m = m0 + rq; m < mend; m += 4) {
+    float v = slabs[(size_t)m * N + n];
+    for (int k = 1; k < ks; ++k) v += slabs[(size_t)k * slab_stride + (size_t)m * N + n];
+    if (ks > 1 || y != slabs) y[(size_t)m * N + n] = v;
+    s += v; s2 += v * v;
+  }
+  if (!part) return;
+  red[0][rq][threadIdx.x & 63] = s; red[1][rq][threadIdx.x & 63] = s2;
+  __syncthreads();
+  if (rq == 0) {
+    const int c = threadIdx.x;
+    part[((size_t)blockIdx.y * 2 + 0) * N + n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+    part[((size_t)blockIdx.y * 2 + 1) * N + n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  }
+}
+
+static int rows_gemm_plan(const SlPpmDesc* d, int K, int N, RowsGemm& mm, RowsGemm& fin, int& ks, int& mtiles, int& groups) {
+  SL_REQUIRE(d && d->nlevels >= 1 && d->nlevels <= 4 && d->B > 0, "ppm_rows_gemm: bad descriptor");
+  SL_REQUIRE(K > 0 && N > 0 && K % 32 == 0 && N % 64 == 0, "ppm_rows_gemm: K % 32 == 0 and N % 64 == 0 required");
+  mm.K = fin.K = K; mm.N = fin.N = N; mm.nl = fin.nl = d->nlevels;
+  mm.row_off[0] = fin.row_off[0] = mm.tile_off[0] = fin.tile_off[0] = 0;
+  for (int l = 0; l < d->nlevels; ++l) {
+    const int rows = d->B * d->sizes[l] * d->sizes[l];
+    mm.row_off[l + 1] = fin.row_off[l + 1] = mm.row_off[l] + rows;
+    mm.tile_off[l + 1] = mm.tile_off[l] + cdiv(rows, 64);
+    fin.tile_off[l + 1] = fin.tile_off[l] + cdiv(rows, 128);
+  }
+  mtiles = mm.tile_off[d->nlevels]; groups = fin.tile_off[d->nlevels];
+  const int tiles = mtiles * (N / 64);
+  ks = std::max(1, std::min(cdiv(1024, tiles), K / 128));
+  mm.kslice = cdiv(cdiv(K, ks), 32) * 32;
+  ks = cdiv(K, mm.kslice);
+  mm.slab_stride = fin.slab_stride = (long long)mm.row_off[d->nlevels] * N;
+  return 0;
+}
+
+extern "C" int sl_ppm_rows_gemm_stat_rows(const SlPpmDesc* d) {
+  if (!d || d->nlevels < 1 || d->nlevels > 4) return 0;
+  int g = 0;
+  for (int l = 0; l < d->nlevels; ++l) g += cdiv(d->B * d->sizes[l] * d->sizes[l], 128);
+  return g;
+}
+
+extern "C" size_t sl_ppm_rows_gemm_workspace(const SlPpmDesc* d, int K, int N) {
+  RowsGemm mm{}, fin{}; int ks, mt, gr;
+  if (rows_gemm_plan(d, K, N, mm, fin, ks, mt, gr)) return 0;
+  return ks > 1 ? (size_t)ks * mm.slab_stride * sizeof(float) : 0;
+}
+
+extern "C" int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x, const float* w, float* y, float* stat_partial,
+                                void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  RowsGemm mm{}, fin{}; int ks, mtiles, groups;
+  if (int e = rows_gemm_plan(d, K, N, mm, fin, ks, mtiles, groups)) return e;
+  SL_REQUIRE(x && w && y, "ppm_rows_gemm: null buffer");
+  SL_REQUIRE(ks == 1 || (workspace && workspace_bytes >= (size_t)ks * mm.slab_stride * sizeof(float)), "ppm_rows_gemm: workspace too small");
+  mm.x = x; mm.w = w; mm.out = ks > 1 ? (float*)workspace : y;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ppm_rows_gemm_kernel, dim3(N / 64, mtiles, ks), dim3(256), 0, st, mm);
+  if (ks > 1 || stat_partial)
+    hipLaunchKernelGGL(ppm_rows_finish_kernel, dim3(N / 64, groups), dim3(256), 0, st, (const float*)mm.out, ks, mm.slab_stride, y, N, fin, stat_partial);
+  return (int)hipGetLastError();
+}
+
 extern "C" size_t sl_ppm_fact_workspace(const SlPpmDesc* d, int N) {
   PpmGeom g;
   if (make_geom(d, g)) return 0;

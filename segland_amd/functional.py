@@ -246,11 +246,15 @@ class PPMFn(torch.autograd.Function):
             ab = conv_bn_infer(priors, bt[0], bt[1], relu=True, x2=x4)
             wf, _ = prepared(bt[3].weight, x4.dtype)
             return ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())[0]
-        cl, ml, il, off = [], [], [], 0
-        for s, st in zip(sizes, dec.stages):
+        # the four stage convs as ONE grouped skinny GEMM over the pyramid rows (16..576 rows per level)
+        wst_f, _ = _stage_weights(dec)
+        call, part = ops.ppm_rows_gemm(pooled, wst_f, B, sizes, want_stats=any(st[2].training for st in dec.stages))
+        cl, ml, il, off, grp = [], [], [], 0, ops.ppm_stat_groups(B, sizes)
+        for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
-            xin = pooled[off:off + n].view(B, s, s, Cf)
-            c, _, m, i = conv_bn_fwd(xin, st[1], st[2], relu=True, out=stage_act[off:off + n].view(B, s, s, Cs))
+            c = call[off:off + n]
+            m, i, scale, shift = _bn_coeffs(st[2], part[grp[k]:grp[k + 1]] if st[2].training else None, n)
+            ops.bn_act(c, scale, shift, relu=True, out=stage_act[off:off + n])
             cl.append(c); ml.append(m); il.append(i); off += n
         bt = dec.bottleneck
         ctx.fact = _PPM_FACTORISED
@@ -258,12 +262,7 @@ class PPMFn(torch.autograd.Function):
             # prior half of the 3x3 conv contracted on the s x s grids (exact; see ppm.hip), x4 half on the MFMA kernel
             N = bt[0].out_channels
             wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, len(sizes), x4.dtype)
-            q = torch.empty((pooled.shape[0], 9 * N), dtype=torch.float32, device=x4.device)
-            qspec, off = ConvSpec(Cs, 9 * N, 1), 0
-            for k, s in enumerate(sizes):
-                n = B * s * s
-                ops.conv2d_fwd(stage_act[off:off + n].view(B, s, s, Cs), wq_f[k], qspec, out=q[off:off + n].view(B, s, s, 9 * N))
-                off += n
+            q, _ = ops.ppm_rows_gemm(stage_act, wq_f, B, sizes)
             gpri = ops.ppm_fact_gather(q, x4.shape, sizes, N, x4.dtype)
             spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
             cb, part = ops.conv2d_fwd(x4, wf4, spec4, pre_addend=gpri, want_stats=bt[1].training)
@@ -307,33 +306,32 @@ class PPMFn(torch.autograd.Function):
             cat_off = 0
             dwb = None
             gq = ops.ppm_fact_scatter(dcb, x4.shape, sizes)
-            dstage = torch.empty_like(stage_act)
-            qspec, off = ConvSpec(Cs, 9 * N, 1), 0
+            dstage, _ = ops.ppm_rows_gemm(gq, wq_b, B, sizes)
             if need_w:
                 dwb = torch.empty_like(bt[0].weight, dtype=torch.float32)
                 ops.conv2d_bwd_weight(x4, dcb, spec4, out=dwb, out_ci_off=nl * Cs)
                 dwq = torch.empty((nl, 9 * N, Cs), dtype=torch.float32, device=x4.device)
-            for k, s in enumerate(sizes):
-                n = B * s * s
-                gk = gq[off:off + n].view(B, s, s, 9 * N)
-                ops.conv2d_bwd_data(gk, wq_b[k], qspec, (s, s), out=dstage[off:off + n].view(B, s, s, Cs))
-                if need_w:
-                    ops.conv2d_bwd_weight(stage_act[off:off + n].view(B, s, s, Cs), gk, qspec, out=dwq[k].view(9 * N, Cs, 1, 1))
-                off += n
+                qspec, off = ConvSpec(Cs, 9 * N, 1), 0
+                for k, s in enumerate(sizes):
+                    n = B * s * s
+                    ops.conv2d_bwd_weight(stage_act[off:off + n].view(B, s, s, Cs), gq[off:off + n].view(B, s, s, 9 * N), qspec,
+                                          out=dwq[k].view(9 * N, Cs, 1, 1))
+                    off += n
             if need_w:
                 ops.ppm_dwq_scatter(dwq, dwb, Cs, nl)
         else:
             dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
             dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
             cat_off = len(sizes) * Cs
-        dpooled = torch.empty_like(pooled)
+        dc_all = torch.empty_like(stage_act)
         gstage, off = [], 0
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
-            xin = pooled[off:off + n].view(B, s, s, Cf)
-            dxs, dws, dgs, dbs, _ = conv_bn_bwd(dstage[off:off + n].view(B, s, s, Cs), stage_act[off:off + n].view(B, s, s, Cs), cl[k], xin,
-                                                st[1], st[2], ml[k], il[k], need_x, need_w, dx_out=dpooled[off:off + n].view(B, s, s, Cf))
+            _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
+                                        out=dc_all[off:off + n])
+            dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1])) if need_w else None
             gstage += [dws, dgs, dbs]; off += n
+        dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None
         dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None
         return (dx4, None, *gstage, dwb, dgb, dbb, dwf, dbias)
 
@@ -348,6 +346,18 @@ def set_ppm_factorised(flag):
     _PPM_FACTORISED = bool(flag)
 
 
+def _stage_weights(dec):
+    """Stage 1x1 weights stacked for the grouped GEMM: ([nl][Cs][Cf] forward, [nl][Cf][Cs] data gradient), float, cached per version."""
+    ws = [st[1].weight for st in dec.stages]
+    key = tuple((w._version, w.data_ptr()) for w in ws)
+    ent = getattr(dec, '_sl_stage_w', None)
+    if ent is None or ent[0] != key:
+        f = torch.stack([w.detach().view(w.shape[0], w.shape[1]) for w in ws]).float().contiguous()
+        ent = (key, f, f.transpose(1, 2).contiguous())
+        dec._sl_stage_w = ent
+    return ent[1], ent[2]
+
+
 def _ppm_weights(w, Cs, nl, dtype):
     """Per-level 1x1 weights of the factorised prior path (float) + GEMM layouts of the x4 channel slice, cached on the Parameter."""
     ent = getattr(w, '_sl_ppm', None)
@@ -355,7 +365,7 @@ def _ppm_weights(w, Cs, nl, dtype):
         wq_f, wq_b = ops.ppm_wq_prep(w, Cs, nl)
         wf4, wb4 = ops.weight_prep_slice(w, dtype, nl * Cs, w.shape[1] - nl * Cs)
         N = w.shape[0]
-        ent = (w._version, dtype, w.data_ptr(), [wq_f[k].view(9 * N, 1, 1, Cs) for k in range(nl)], [wq_b[k].view(Cs, 1, 1, 9 * N) for k in range(nl)], wf4, wb4)
+        ent = (w._version, dtype, w.data_ptr(), wq_f, wq_b, wf4, wb4)
         w._sl_ppm = ent
     return ent[3], ent[4], ent[5], ent[6]
 

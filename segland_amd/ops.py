@@ -230,7 +230,7 @@ def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False)
     return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None):
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None):
     """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given."""
     Cn = x.shape[-1]
     rows = x.numel() // Cn
@@ -241,7 +241,8 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     o = _f32((5, Cn), x.device)
     check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
-    dx = torch.empty_like(x)
+    dx = out if out is not None else torch.empty_like(x)
+    assert dx.numel() == x.numel() and dx.dtype == x.dtype
     dres = torch.empty_like(x) if want_dres else None
     check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
     return dx, dres, o[0], o[1]
@@ -376,6 +377,29 @@ def ppm_dwq_scatter(dwq, dw_full, Cs, nl):
 def _ppm_d(dtype, x_shape, sizes):
     B, H, W, Cn = x_shape
     return SlPpmDesc(_DT[dtype], B, H, W, Cn, len(sizes), (C.c_int * 4)(*(list(sizes) + [0] * (4 - len(sizes)))))
+
+
+def ppm_rows_gemm(x, w, B, sizes, want_stats=False):
+    """y[r] = w[level(r)] @ x[r] over the pyramid rows; x [rows][K] float, w [nl][N][K] float.  Returns (y, stat partials or None)."""
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    rows, K = x.shape
+    nl, N, K2 = w.shape
+    assert K2 == K and nl == len(sizes) and rows == ppm_rows(B, sizes)
+    d = SlPpmDesc(SL_F32, B, 1, 1, 8, nl, (C.c_int * 4)(*(list(sizes) + [0] * (4 - nl))))
+    L = _lib.lib()
+    ws = workspace(L.sl_ppm_rows_gemm_workspace(C.byref(d), K, N), x.device)
+    y = _f32((rows, N), x.device)
+    part = _f32((L.sl_ppm_rows_gemm_stat_rows(C.byref(d)), 2, N), x.device) if want_stats else None
+    check(L.sl_ppm_rows_gemm(C.byref(d), K, N, _p(x), _p(w), _p(y), _p(part), _p(ws), ws.numel(), _s()), 'ppm_rows_gemm')
+    return y, part
+
+
+def ppm_stat_groups(B, sizes):
+    """Prefix of the 128-row statistic groups per level in ppm_rows_gemm's partials."""
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + (B * s * s + 127) // 128)
+    return off
 
 
 def ppm_fact_gather(q, x_shape, sizes, N, dtype):

@@ -237,6 +237,30 @@ def test_ppm_pool_and_upsample(hip, dtype, hw):
     assert_close(dst, ref, dtype, 'upsample bwd', factor=4)
 
 
+@pytest.mark.parametrize('B,K,N', [(2, 64, 64), (3, 96, 576), (16, 2048, 512), (16, 512, 4608), (16, 4608, 512)])
+def test_ppm_rows_gemm(hip, B, K, N):
+    """Grouped skinny GEMM over the pyramid rows (stage convs pspnet_pop.py:12-16 + the factorised prior GEMMs): exact fp32 MFMA vs a
+    float64 matmul, with and without split-K, plus the BN statistic partials."""
+    from segland_amd import ops
+    sizes = (1, 2, 3, 6)
+    rows = ops.ppm_rows(B, sizes)
+    x = fm.sym('rg/x%d_%d' % (K, N), (rows, K), 1.0)
+    w = fm.sym('rg/w%d_%d' % (K, N), (len(sizes), N, K), 1.0)
+    y, part = ops.ppm_rows_gemm(x.to(DEV), w.to(DEV), B, sizes, want_stats=True)
+    y2, none = ops.ppm_rows_gemm(x.to(DEV), w.to(DEV), B, sizes)
+    assert none is None and torch.equal(y, y2)
+    off, grp = 0, ops.ppm_stat_groups(B, sizes)
+    for k, s in enumerate(sizes):
+        n = B * s * s
+        ref = x[off:off + n].double() @ w[k].double().t()
+        got = y[off:off + n].cpu().double()
+        assert float((got - ref).abs().max() / ref.abs().max()) < 2e-6, 'level %d' % s
+        ps = part[grp[k]:grp[k + 1]].cpu().double().sum(0)
+        assert float((ps[0] - ref.sum(0)).abs().max() / ref.abs().sum(0).max()) < 1e-5
+        assert float((ps[1] - (ref * ref).sum(0)).abs().max() / (ref * ref).sum(0).max()) < 1e-5
+        off += n
+
+
 def test_loss_golden_g3(hip):
     from segland_amd import ops
     g = golden('g3_loss')
