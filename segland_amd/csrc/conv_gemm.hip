@@ -257,9 +257,181 @@ struct EpiGeom {
   static_assert(WM % NPASS == 0, "passes split whole wave rows");
 };
 
+// accumulators of the wave rows belonging to `pass` -> LDS staging tile (rounded to T), in the row-major layout the store phase reads
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int pass, int wm, int wn, int lane, unsigned char* smem) {
+  using G = EpiGeom<T, BM, BN, WM, WN>;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  const int fhalf = lane >> 5;
+  if (wm / (WM / G::NPASS) != pass) return;
+  const int lrow = (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned char* dst = smem + (lrow + i * 32) * G::PITCH + (wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf) * (int)sizeof(T);
+        if constexpr (sizeof(T) == 2) {
+          typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+          typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+          uint2 v;
+          v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]}, bf16x2_t));
+          v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}, bf16x2_t));
+          *(uint2*)dst = v;
+        } else {
+          *(float4*)dst = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        }
+      }
+}
+
+// Branch-free store phase for the two shapes of epilogue that carry almost all of the traffic, on tiles that lie completely
+// inside M:  MODE 1 = store the staged tile as is (+ BN statistic partials when requested),  MODE 2 = add the (optionally
+// bit-gated) addend and store.  No per-row predicates, one pointer increment per row, operand loads batched CH rows deep.
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                                   int lane, int tid, unsigned char* smem) {
+  using G = EpiGeom<T, BM, BN, WM, WN>;
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CPR = BN / EPC;
+  constexpr int RS = NT / CPR;
+  constexpr int ROWS = BM / G::NPASS;
+  constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int ncol = bn * BN + cc * EPC;
+  const size_t rstep = (size_t)RS * p.N * sizeof(T);
+  f2_t ssum[EPC / 2], ssq[EPC / 2];
+#pragma unroll
+  for (int e = 0; e < EPC / 2; ++e) { ssum[e] = (f2_t){0.f, 0.f}; ssq[e] = (f2_t){0.f, 0.f}; }
+  auto unpack2 = [](const uint4& raw, f2_t* v) {
+    if constexpr (sizeof(T) == 2) {
+      const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (f2_t){__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+    } else {
+      v[0] = (f2_t){__uint_as_float(raw.x), __uint_as_float(raw.y)}; v[1] = (f2_t){__uint_as_float(raw.z), __uint_as_float(raw.w)};
+    }
+  };
+#pragma unroll
+  for (int pass = 0; pass < G::NPASS; ++pass) {
+    epi_stage_acc<T, BM, BN, WM, WN>(acc, pass, wm, wn, lane, smem);
+    __syncthreads();
+    const size_t goff = ((size_t)(bm * BM + pass * ROWS + r0) * p.N + ncol) * sizeof(T);
+    unsigned char* o = (unsigned char*)p.out + goff;
+    const unsigned char* l = smem + r0 * G::PITCH + cc * 16;
+    if constexpr (MODE == 1) {
+      if (p.stat_partial) {
+#pragma unroll 4
+        for (int it = 0; it < NIT; ++it) {
+          const uint4 raw = *(const uint4*)(l + it * (RS * G::PITCH));
+          st16(o, raw); o += rstep;
+          f2_t v[EPC / 2];
+          unpack2(raw, v);
+#pragma unroll
+          for (int e = 0; e < EPC / 2; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * v[e]; }
+        }
+      } else {
+#pragma unroll 8
+        for (int it = 0; it < NIT; ++it) { st16(o, *(const uint4*)(l + it * (RS * G::PITCH))); o += rstep; }
+      }
+    } else {
+      const unsigned char* ad = (const unsigned char*)p.addend + goff;
+      const unsigned char* ab = p.addend_mask ? p.addend_mask + goff / 16 : nullptr;
+      const size_t bstep = rstep / 16;
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += CH) {
+        uint4 addv[CH]; unsigned bits[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) addv[u] = *(const uint4*)(ad + (size_t)(it0 + u) * rstep);
+        if (ab) {
+#pragma unroll
+          for (int u = 0; u < CH; ++u) bits[u] = ab[(size_t)(it0 + u) * bstep];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          const uint4 raw = *(const uint4*)(l + (it0 + u) * (RS * G::PITCH));
+          uint4 a = addv[u];
+          if (ab) {
+            const unsigned b = bits[u];
+            if constexpr (sizeof(T) == 2) {
+              // bit e gates element e: build a 16-bit-lane mask per packed pair from sign-extended single bits
+              a.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
+              a.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
+              a.z &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
+              a.w &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
+            } else {
+              a.x &= (unsigned)__builtin_amdgcn_sbfe(b, 0, 1); a.y &= (unsigned)__builtin_amdgcn_sbfe(b, 1, 1);
+              a.z &= (unsigned)__builtin_amdgcn_sbfe(b, 2, 1); a.w &= (unsigned)__builtin_amdgcn_sbfe(b, 3, 1);
+            }
+          }
+          f2_t v[EPC / 2], w[EPC / 2];
+          unpack2(raw, v); unpack2(a, w);
+#pragma unroll
+          for (int e = 0; e < EPC / 2; ++e) v[e] += w[e];
+          uint4 r;
+          if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v[0], bf16x2_t)); r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v[1], bf16x2_t));
+            r.z = __builtin_bit_cast(unsigned, __builtin_convertvector(v[2], bf16x2_t)); r.w = __builtin_bit_cast(unsigned, __builtin_convertvector(v[3], bf16x2_t));
+          } else {
+            r = make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
+          }
+          st16(o, r); o += rstep;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (MODE == 1) {
+    if (p.stat_partial) {
+      float fs[EPC], fq[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC / 2; ++e) { fs[2 * e] = ssum[e].x; fs[2 * e + 1] = ssum[e].y; fq[2 * e] = ssq[e].x; fq[2 * e + 1] = ssq[e].y; }
+#pragma unroll
+      for (int off = CPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { fs[e] += __shfl_xor(fs[e], off, 64); fq[e] += __shfl_xor(fq[e], off, 64); }
+      }
+      float* red = (float*)smem;                       // [NW][2][BN]
+      const int wave = tid >> 6;
+      if (lane < CPR) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          red[(wave * 2 + 0) * BN + cc * EPC + e] = fs[e];
+          red[(wave * 2 + 1) * BN + cc * EPC + e] = fq[e];
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < 2 * BN; e += NT) {
+        const int which = e / BN, col = e % BN;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM * WN; ++w) t += red[(w * 2 + which) * BN + col];
+        p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                                      int lane, int tid, unsigned char* smem);
+
 template <typename T, int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
+  const bool full = (bm + 1) * BM <= p.M;
+  const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend;
+  if (full && !shaped && !p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 1>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  else if (full && !shaped && !p.stat_partial) conv_epilogue_fast<T, BM, BN, WM, WN, 2>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  else conv_epilogue_generic<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                                      int lane, int tid, unsigned char* smem) {
   using G = EpiGeom<T, BM, BN, WM, WN>;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int EPC = 16 / sizeof(T);
@@ -315,11 +487,19 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
           if (m < p.M) prev[u] = *(const uint4*)((const T*)p.pre_addend + (size_t)m * p.N + ncol);
         }
       }
+      unsigned abit[CH];
       if (p.addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
           const int m = mrow0 + (it0 + u) * RS;
           if (m < p.M) addv[u] = *(const uint4*)((const T*)p.addend + (size_t)m * p.N + ncol);
+        }
+        if (p.addend_mask) {                    // the gate bytes ride in the same batch (one exposed latency, not one per row)
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int m = mrow0 + (it0 + u) * RS;
+            if (m < p.M) abit[u] = p.addend_mask[((size_t)m * p.N + ncol) / EPC];
+          }
         }
       }
       if (p.mask_src) {
@@ -354,7 +534,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x1
             float a[EPC];
             unpack16<T>(addv[u], a);
             if (p.addend_mask) {
-              const unsigned bits = p.addend_mask[((size_t)m * p.N + ncol) / EPC];
+              const unsigned bits = abit[u];
 #pragma unroll
               for (int e = 0; e < EPC; ++e) a[e] = (bits >> e) & 1u ? a[e] : 0.f;
             }
@@ -696,7 +876,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
   // fragments of (stage i, k-step 0) are already in registers.  Inside the iteration the fragment loads of the NEXT
   // k-step (the last one reaches into stage i+1) are issued before the MFMAs of the current one, so LDS latency hides
   // behind the matrix pipe; the LDS-DMA of stages i+2 / i+3 stays in flight across the barrier.
-  static_assert(NST == 4 && (KS % 2) == 0, "ring schedule assumes 4 stages and an even number of k-steps");
+  static_assert(NST >= 3 && NST <= 6 && (KS % 2) == 0, "ring schedule: 3..6 stages and an even number of k-steps");
+  constexpr int D = NST - 1;                    // stages issued ahead of the one being consumed
+  // wait until at most `fl` of the most recently issued stages are still in flight (fl is block-uniform)
+  auto wait_stages = [&](int fl) {
+    if constexpr (D >= 5) { if (fl >= 3) { wait_vmcnt<3 * L>(); return; } }
+    if constexpr (D >= 4) { if (fl == 2) { wait_vmcnt<2 * L>(); return; } }
+    if (fl >= 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
+  };
   const int frow = lane & 31, fhalf = lane >> 5;
   auto ldfrag = [&](uint4* af, uint4* bf, int slot_, int s2) {
     const unsigned char* la = smem + slot_ * RG::STAGE;
@@ -715,15 +902,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
   uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
 
 #pragma unroll
-  for (int st = 0; st < 3; ++st)
+  for (int st = 0; st < D; ++st)
     if (st < nk) issue(st);
-  if (nk >= 3) wait_vmcnt<L>(); else wait_vmcnt<0>();     // stages 0 and 1 landed (stage 2 may still fly)
+  wait_stages(min(nk, D) - 2);                            // stages 0 and 1 landed (later ones may still fly)
   __builtin_amdgcn_s_barrier();
   ldfrag(afA, bfA, 0, 0);
 
   int slot = 0;
   for (int i = 0; i < nk; ++i) {
-    if (i + 3 < nk) { int ns = slot + 3; if (ns >= NST) ns -= NST; issue(ns); }
+    if (i + D < nk) { int ns = slot + D; if (ns >= NST) ns -= NST; issue(ns); }
     int nslot = slot + 1; if (nslot == NST) nslot = 0;
 #pragma unroll
     for (int s2 = 0; s2 < KS; s2 += 2) {
@@ -733,8 +920,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
       else             ldfrag(afA, bfA, nslot, 0);          // first k-step of the next stage (complete by the invariant)
       mma(afB, bfB);
     }
-    // make stage i+2 complete before anyone starts iteration i+1; stage i+3 (just issued) may stay in flight
-    if (i + 3 < nk) wait_vmcnt<L>(); else wait_vmcnt<0>();
+    // make stage i+2 complete before anyone starts iteration i+1; stages i+3 .. i+D (already issued) may stay in flight
+    wait_stages(min(i + D, nk - 1) - (i + 2));
     __builtin_amdgcn_s_barrier();
     slot = nslot;
   }

@@ -5,6 +5,8 @@ hand-written backward chain, so PyTorch's autograd only links blocks together an
 nn.Conv2d / nn.BatchNorm2d modules are used purely as parameter holders (state_dict compatibility with the
 reference); their own forward is never called.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -127,13 +129,47 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
                                          want_dres=want_dres, mask=bits)
     spec = spec_of(conv)
     dx = dw = None
+    if need_dw:
+        dw = wgrad_async(x, dc, spec, x2=x2)      # side stream: overlaps the data gradient and the next BN backward
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
         dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
                                  C1=(x.shape[3] if x2 is not None else None), out=dx_out)
-    if need_dw:
-        dw = ops.conv2d_bwd_weight(x, dc, spec, x2=x2)
     return dx, dw, dgamma, dbeta, dres
+
+
+# Weight gradients have no consumer until the optimizer: they run on a second HIP stream so that their MFMA-bound
+# kernels fill the matrix pipes while the main stream is in HBM-bound phases (BN backward, conv epilogues).
+_SIDE = {}
+_WGRAD_STREAM = os.environ.get('SEGLAND_WGRAD_STREAM', '1') != '0'
+
+
+def wgrad_async(x, dy, spec, x2=None, out=None, out_ci_off=0):
+    if not _WGRAD_STREAM or (ops.PROFILER.on and ops.PROFILER.only is None):
+        return ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=out, out_ci_off=out_ci_off)
+    main = torch.cuda.current_stream()
+    ent = _SIDE.get(x.device)
+    if ent is None:
+        ent = _SIDE[x.device] = [torch.cuda.Stream(device=x.device), False]
+    side = ent[0]
+    # the result is allocated on the main stream (its consumers live there); inputs are pinned to the side stream's timeline
+    dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=dw, out_ci_off=out_ci_off)
+    for t in (x, dy, x2):
+        if t is not None:
+            t.record_stream(side)
+    ent[1] = True
+    return dw
+
+
+def wgrad_join():
+    """Make every weight gradient launched so far visible to the current stream (called before gradients leave a backward)."""
+    for dev, ent in _SIDE.items():
+        if ent[1]:
+            torch.cuda.current_stream(dev).wait_stream(ent[0])
+            ent[1] = False
 
 
 # ------------------------------------------------------------------------------------------------ stem
@@ -212,6 +248,7 @@ class BottleneckFn(torch.autograd.Function):
             addend, abits = dout, k3                # identity shortcut: dout * relu'(out), gated inside the dgrad epilogue
         dx, dw1, dg1, db1, _ = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
                                            addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=k1)
+        wgrad_join()
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
 
 
@@ -333,6 +370,7 @@ class PPMFn(torch.autograd.Function):
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None
         dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None
+        wgrad_join()
         return (dx4, None, *gstage, dwb, dgb, dbb, dwf, dbias)
 
 

@@ -16,6 +16,7 @@ w = torch.randn(a.cout, a.cin, a.k, a.k, device='cuda') * 0.02
 wf, wb = ops.weight_prep(w, dt)
 dy = torch.randn(a.B, a.hw, a.hw, a.cout, device='cuda').to(dt)
 add = torch.randn(a.B, a.hw, a.hw, a.cin, device='cuda').to(dt)
+bits = torch.randint(0, 256, (add.numel() // 8,), dtype=torch.uint8, device='cuda')
 def timeit(fn):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,6 +30,7 @@ es = 2
 for name, fn, byts in [('fwd', lambda: ops.conv2d_fwd(x, wf, spec, want_stats=True), M * (a.cin + a.cout) * es),
                        ('dgrad', lambda: ops.conv2d_bwd_data(dy, wb, spec, (a.hw, a.hw)), M * (a.cin + a.cout) * es),
                        ('dgrad+add', lambda: ops.conv2d_bwd_data(dy, wb, spec, (a.hw, a.hw), addend=add), M * (2 * a.cin + a.cout) * es),
+                       ('dgrad+add+bits', lambda: ops.conv2d_bwd_data(dy, wb, spec, (a.hw, a.hw), addend=add, addend_mask=bits), M * (2 * a.cin + a.cout) * es),
                        ('wgrad', lambda: ops.conv2d_bwd_weight(x, dy, spec), M * (a.cin + a.cout) * es)]:
     ms = timeit(fn)
     print('%-10s %8.3f ms  %8.1f TFLOP/s  %6.2f TB/s (activation bytes only)' % (name, ms, gf / ms, byts / ms / 1e9))
