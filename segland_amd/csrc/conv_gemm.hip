@@ -258,10 +258,12 @@ struct EpiGeom {
 };
 
 // accumulators of the wave rows belonging to `pass` -> LDS staging tile (rounded to T), in the row-major layout the store phase reads
-template <typename T, int BM, int BN, int WM, int WN>
+// SPLIT: the half-tile kernel's wave layout (wave rows/columns interleaved over the two operand halves, see conv_gemm_p8_kernel).
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int pass, int wm, int wn, int lane, unsigned char* smem) {
   using G = EpiGeom<T, BM, BN, WM, WN>;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  static_assert(!SPLIT || (G::NPASS == 1 && TM == 4 && TN == 2), "split layout: one pass, 4x2 accumulator blocks per wave");
   const int fhalf = lane >> 5;
   if (wm / (WM / G::NPASS) != pass) return;
   const int lrow = (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
@@ -271,7 +273,9 @@ __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN /
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        unsigned char* dst = smem + (lrow + i * 32) * G::PITCH + (wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf) * (int)sizeof(T);
+        const int row = SPLIT ? (i >> 1) * (BM / 2) + wm * (BM / 4) + (i & 1) * 32 + (lane & 31) : lrow + i * 32;
+        const int col = SPLIT ? j * (BN / 2) + wn * (BN / 8) + 8 * q + 4 * fhalf : wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf;
+        unsigned char* dst = smem + row * G::PITCH + col * (int)sizeof(T);
         if constexpr (sizeof(T) == 2) {
           typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
           typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -288,7 +292,7 @@ __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN /
 // Branch-free store phase for the two shapes of epilogue that carry almost all of the traffic, on tiles that lie completely
 // inside M:  MODE 1 = store the staged tile as is (+ BN statistic partials when requested),  MODE 2 = add the (optionally
 // bit-gated) addend and store.  No per-row predicates, one pointer increment per row, operand loads batched CH rows deep.
-template <typename T, int BM, int BN, int WM, int WN, int MODE>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                    int lane, int tid, unsigned char* smem) {
   using G = EpiGeom<T, BM, BN, WM, WN>;
@@ -316,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   };
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
-    epi_stage_acc<T, BM, BN, WM, WN>(acc, pass, wm, wn, lane, smem);
+    epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
     __syncthreads();
     const size_t goff = ((size_t)(bm * BM + pass * ROWS + r0) * p.N + ncol) * sizeof(T);
     unsigned char* o = (unsigned char*)p.out + goff;
@@ -415,32 +419,30 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                       int lane, int tid, unsigned char* smem);
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
   const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend;
-  if (full && !shaped && !p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 1>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-  else if (full && !shaped && !p.stat_partial) conv_epilogue_fast<T, BM, BN, WM, WN, 2>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-  else conv_epilogue_generic<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  if (full && !shaped && !p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  else if (full && !shaped && !p.stat_partial) conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  else conv_epilogue_generic<T, BM, BN, WM, WN, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT>
 __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                       int lane, int tid, unsigned char* smem) {
   using G = EpiGeom<T, BM, BN, WM, WN>;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int EPC = 16 / sizeof(T);
   constexpr int NT = 64 * WM * WN;
   constexpr int CPR = BN / EPC;              // 16-byte chunks per tile row
   constexpr int RS = NT / CPR;               // rows covered per sweep of the block
   constexpr int ROWS = BM / G::NPASS;
   static_assert(NT % CPR == 0 && CPR <= 64, "store-phase mapping");
-  const int fhalf = lane >> 5;
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
   float bias[EPC], scl[EPC], ssum[EPC], ssq[EPC];
@@ -449,27 +451,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
   T* out = (T*)p.out;
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
-    if (wm / (WM / G::NPASS) == pass) {
-      const int lrow = (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            unsigned char* dst = smem + (lrow + i * 32) * G::PITCH + (wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf) * (int)sizeof(T);
-            if constexpr (sizeof(T) == 2) {
-              typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-              typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-              uint2 v;
-              v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 0], acc[i][j][4 * q + 1]}, bf16x2_t));
-              v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}, bf16x2_t));
-              *(uint2*)dst = v;
-            } else {
-              *(float4*)dst = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-            }
-          }
-    }
+    epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
     __syncthreads();
     // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
     // flight together instead of one load -> use -> store latency chain per row
@@ -945,9 +927,181 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
   return 0;
 }
 
-int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3 (default): glds, 256-row 8-wave tiles where M allows
+
+// ---------------------------------------------------------------------------------------------------------------
+// v5 (bf16, N % 256 == 0): 256x256 tile, K-tile of 64 elements = 128-BYTE operand rows, LDS = 2 K-tiles x 4 half-tile slots
+// {A0, A1, B0, B1} of 16 KiB (128 rows x 128 B).  tools/micro/glds_bw.hip: the LDS-DMA path delivers 30-50 % more bytes/s when
+// each row request is a full 128-byte line than with the 64-byte rows of the v4 ring, and v4 sits exactly on that limit.
+// A K-tile is computed as 4 phases, one output quadrant each -- (A0,B0) (A0,B1) (A1,B1) (A1,B0) -- so a slot is free again
+// after at most two phases and is refilled with the same half of the K-tile two steps ahead:
+//   P0: issue B0(i+1)            P1: issue A0(i+2)            P3: issue A1(i+2), B1(i+2)
+// The A fragments of a half (8 x 16 B per lane) stay in registers for its two phases and are refilled in place (A1 during P1, the
+// next K-tile's A0 during P3); B fragments stream through a 4-deep register ring, three k-steps ahead.  One counted wait per
+// K-tile (end of P2: everything but the A0 just issued has landed) and three barriers (after P0, P2, P3).
+// Wave (wm, wn) of the 2 x 4 grid owns rows {h*128 + wm*64 ..+63} and columns {h*128 + wn*32 ..+31} of both halves h.
+constexpr int P8_SLOT = 128 * 128;
+constexpr int P8_RING = 9 * P8_SLOT;          // A0 x2, A1 x2, B1 x2, B0 x3
+constexpr int P8_LDS = EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES > P8_RING ? EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES : P8_RING;
+
+__global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / p.gridN, bn = bid % p.gridN;
+  const int taps = p.KH * p.KW;
+  const int CT = p.C1 + p.C2;
+  const int nk = taps * (CT / 64);
+  const int sgn = p.mode == 0 ? 1 : -1;
+
+  // ---- load side: instruction j of this wave fills rows wave*16 + j*8 + (lane>>3) of a half-tile slot, 16 B per lane
+  const int lr = lane >> 3, lpos = lane & 7;
+  int rbase[2][2]; unsigned vmask[2][2]; int rsw[2];
+  const unsigned char* wptr[2][2];
+  const size_t wpitch = (size_t)taps * CT * sizeof(T);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rsw[j] = (lpos ^ (((j * 8 + lr) >> 1) & 7)) * 16;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = h * 128 + wave * 16 + j * 8 + lr;
+      const int m = bm * BM + row;
+      rbase[h][j] = 0; vmask[h][j] = 0;
+      if (m < p.M) {
+        const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
+        const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
+        const int ry = p.mode == 0 ? yd * p.stride - p.pad : yd + p.pad;
+        const int rx = p.mode == 0 ? xd * p.stride - p.pad : xd + p.pad;
+        rbase[h][j] = (b * p.Hs + ry) * p.Ws + rx;
+        unsigned mk = 0;
+        for (int t = 0; t < taps; ++t) {
+          const int ky = t / p.KW, kx = t - ky * p.KW;
+          const int ys = ry + sgn * ky * p.dil, xs = rx + sgn * kx * p.dil;
+          if ((unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws) mk |= 1u << t;
+        }
+        vmask[h][j] = mk;
+      }
+      wptr[h][j] = (const unsigned char*)p.wt + (size_t)(bn * BN + row) * wpitch + rsw[j];
+    }
+  const unsigned char* zsrc = g_zero_page + lpos * 16;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // slot map: A0 -> 0,1 (K-tile parity)   A1 -> 2,3   B1 -> 4,5   B0 -> 6,7,8 (K-tile mod 3: it is read in the first AND the last phase)
+  auto issueA = [&](int h, int tap, int ct, int par) {
+    const unsigned dst = lds_base + (h * 2 + par) * P8_SLOT + wave * 2048;
+    const int c0 = ct * 64;
+    const unsigned char* base; unsigned pitchb;
+    if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
+    else           { base = (const unsigned char*)p.src2 + (size_t)(c0 - p.C1) * sizeof(T); pitchb = p.C2 * (unsigned)sizeof(T); }
+    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int delta = sgn * (ky * p.dil * p.Ws + kx * p.dil);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = (vmask[h][j] >> tap) & 1u;
+      const unsigned char* src = base + (size_t)((unsigned)(rbase[h][j] + delta)) * pitchb + rsw[j];
+      glds16_asm(ok ? src : zsrc, dst + j * 1024);
+    }
+  };
+  auto issueB = [&](int h, int tap, int ct, int slot) {
+    const unsigned dst = lds_base + slot * P8_SLOT + wave * 2048;
+    const size_t koff = ((size_t)tap * CT + ct * 64) * sizeof(T);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_asm(wptr[h][j] + koff, dst + j * 1024);
+  };
+  auto adv = [&](int& tap, int& ct) { if (++tap == taps) { tap = 0; ++ct; } };
+
+  // ---- fragment side: lane (l31, fh) reads row base + l31, 16-byte chunk 2*ks + fh (swizzled) of a slot
+  const int l31 = lane & 31, fh = lane >> 5;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + fh) ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned char* fa = smem + wm * (64 * 128);
+  const unsigned char* fb = smem + wn * (32 * 128);
+  auto ldA = [&](int par, int h, int i2, int ks) { return *(const uint4*)(fa + (h * 2 + par) * P8_SLOT + i2 * 4096 + foff[ks]); };
+  auto ldB = [&](int slot, int ks) { return *(const uint4*)(fb + slot * P8_SLOT + foff[ks]); };
+
+  f32x16_t acc[4][2];                         // [half*2 + 32-row block][column half]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- prologue.  Global issue order is K-tile by K-tile: B0(s), A0(s), A1(s), B1(s); the loop continues it with
+  // B0(i+2) in P0(i), A0(i+2) in P1(i), A1(i+2) and B1(i+2) in P3(i).
+  int tap2 = 0, ct2 = 0;                      // K-tile i+2 (after the prologue)
+  issueB(0, 0, 0, 6); issueA(0, 0, 0, 0); issueA(1, 0, 0, 0); issueB(1, 0, 0, 4);
+  adv(tap2, ct2);
+  if (nk > 1) { issueB(0, tap2, ct2, 7); issueA(0, tap2, ct2, 1); issueA(1, tap2, ct2, 1); issueB(1, tap2, ct2, 5); wait_vmcnt<8>(); } else wait_vmcnt<0>();
+  adv(tap2, ct2);
+  __builtin_amdgcn_s_barrier();
+  uint4 a[4][2], b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, 0, ks); a[ks][1] = ldA(0, 0, 1, ks); }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) b[q] = ldB(6, q);
+
+  int s3 = 0;                                 // i mod 3
+  for (int i = 0; i < nk; ++i) {
+    const int par = i & 1;
+    const int b0cur = 6 + s3, b0nxt = 6 + (s3 == 2 ? 0 : s3 + 1), b0nn = 6 + (s3 == 0 ? 2 : s3 - 1);   // B0 slots of K-tiles i, i+1, i+2
+    const bool more2 = i + 2 < nk;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int ph = q >> 2, ks = q & 3;
+      const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
+      if (ks == 0 && more2) {
+        if (ph == 0) issueB(0, tap2, ct2, b0nn);
+        if (ph == 1) issueA(0, tap2, ct2, par);
+        if (ph == 3) { issueA(1, tap2, ct2, par); issueB(1, tap2, ct2, 4 + par); }
+      }
+      {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
+        const int q3 = q + 3;
+        if (q3 < 16) { const int p3 = q3 >> 2; b[q3 & 3] = ldB((p3 == 1 || p3 == 2) ? 4 + par : b0cur, q3 & 3); }
+        else         b[q3 & 3] = ldB(b0nxt, q3 - 16);
+      }
+      Mma<T>::run(b[q & 3], a[ks][0], acc[ih * 2 + 0][jh]);
+      Mma<T>::run(b[q & 3], a[ks][1], acc[ih * 2 + 1][jh]);
+      if (ph == 1) { a[ks][0] = ldA(par, 1, 0, ks); a[ks][1] = ldA(par, 1, 1, ks); }           // A1 of this K-tile
+      if (ph == 3) { a[ks][0] = ldA(par ^ 1, 0, 0, ks); a[ks][1] = ldA(par ^ 1, 0, 1, ks); }   // A0 of the next K-tile
+      if (ks == 3) {
+        // end of P2: B0(i+1), A0(i+1) must have landed (read in P3); end of P3: A1(i+1), B1(i+1) (read from P0(i+1) on)
+        if (ph == 2) { if (more2) wait_vmcnt<8>(); else if (i + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+        if (ph == 3) { if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+        if (ph != 1) __builtin_amdgcn_s_barrier();
+      }
+    }
+    adv(tap2, ct2);
+    s3 = s3 == 2 ? 0 : s3 + 1;
+  }
+  __syncthreads();
+  conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+int launch_p8(ConvGemmParams& p, hipStream_t st) {
+  p.gridM = cdiv(p.M, 256);
+  p.gridN = p.N / 256;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_gemm_p8_kernel, dim3(p.gridM * p.gridN), dim3(512), P8_LDS, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
+  return 0;
+}
+
+int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3: glds 256-row 8-wave tiles, 4: 64-byte-row ring, 5 (default): half-tile slots with 128-byte rows where N % 256 == 0
 static int conv_variant() {
-  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '4') ? e[0] - '0' : 4; }
+  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '5') ? e[0] - '0' : 5; }
   return g_conv_variant;
 }
 
@@ -988,6 +1142,10 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   }
   // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
   const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
+  if constexpr (sizeof(T) == 2) {
+    // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
+    if (big && v >= 5 && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
+  }
   if (big && v >= 4) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
     if (n256) return launch_ring<T, 256, 256, 2, 4, 64, 4>(p, st);
@@ -1041,6 +1199,7 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
   if (v == 1) return 1000000 + 128000 + (n128 ? 128 : 64);
   const bool big = block_rows(M, ktot) == 256;
+  if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
   if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
   if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));
   if (v >= 4 && n128 && M >= 128 * 512) return 4128128;
