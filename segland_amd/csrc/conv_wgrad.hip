@@ -23,6 +23,7 @@ struct WgradParams {
   int M;             // B*Ho*Wo
   int rows_per_split;  // multiple of 32
   int gridN, gridC, taps, splits;
+  int pair;          // 1: a row is a PAIR of consecutive pixels (64-channel layers, see plan()); Cout, C1, M are the paired sizes
 };
 
 constexpr int KM = 32;  // reduction rows per LDS stage
@@ -288,10 +289,11 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 
   // Output-pixel coordinates of this lane's x rows for the NEXT stage to be issued, advanced incrementally (stages are
   // issued in order, KM rows apart): no integer divisions inside the loop.
+  const int pxr = p.pair ? 2 : 1;             // pixels per stage row
   int qb[IB], qy[IB], qx[IB];
 #pragma unroll
   for (int j = 0; j < IB; ++j) {
-    const int m = m_begin + (wave * IB + j) * RPI_B + b_rin;
+    const int m = (m_begin + (wave * IB + j) * RPI_B + b_rin) * pxr;
     const int hw = p.Ho * p.Wo;
     qb[j] = m / hw; const int rem = m - qb[j] * hw; qy[j] = rem / p.Wo; qx[j] = rem - qy[j] * p.Wo;
   }
@@ -309,17 +311,22 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
       const int ins = wave * IB + j, r = ins * RPI_B + b_rin, m = m0 + r;
       const void* src = (const void*)zsrc;
       if (m < m_end) {
-        const int ce = xoff + (b_pos ^ ((r & 3) << 2)) * EPC;
-        if (ident) src = (const void*)(xbase + (size_t)m * xpitch + ce);
+        const int sc = b_pos ^ ((r & 3) << 2);                 // source chunk of this lane inside the stage row
+        if (ident) src = (const void*)(xbase + (size_t)m * xpitch + xoff + sc * EPC);
         else {
-          const int ys = qy[j] * p.stride - p.pad + ky * p.dil, xs = qx[j] * p.stride - p.pad + kx * p.dil;
+          // paired rows: the first half of the row's chunks is pixel 2m, the second half pixel 2m+1 (same image row, Wo is even)
+          constexpr int CPP = RB_B / 32;
+          const int par = p.pair ? sc / CPP : 0;
+          const int ce = p.pair ? (sc % CPP) * EPC : xoff + sc * EPC;
+          const int pitch = p.pair ? xpitch / 2 : xpitch;
+          const int ys = qy[j] * p.stride - p.pad + ky * p.dil, xs = (qx[j] + par) * p.stride - p.pad + kx * p.dil;
           if ((unsigned)ys < (unsigned)p.H && (unsigned)xs < (unsigned)p.W)
-            src = (const void*)(xbase + ((size_t)(qb[j] * p.H + ys) * p.W + xs) * xpitch + ce);
+            src = (const void*)(xbase + ((size_t)(qb[j] * p.H + ys) * p.W + xs) * pitch + ce);
         }
       }
       wglds16_asm(src, lb + ins * 1024);
       if (!ident) {                       // advance KM rows
-        qx[j] += KM;
+        qx[j] += KM * pxr;
         while (qx[j] >= p.Wo) { qx[j] -= p.Wo; ++qy[j]; }
         while (qy[j] >= p.Ho) { qy[j] -= p.Ho; ++qb[j]; }
       }
@@ -468,6 +475,18 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __
   }
 }
 
+// paired rows (plan(): 64-channel layers): slab = [2*Cout][taps][2*Cin]; the weight gradient is the sum of the two parity-diagonal blocks
+__global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits, int dw_cin_total, int dw_ci_off) {
+  const long long total = (long long)Cout * Cin * taps, slab = 4 * total;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(e % taps), c = (int)((e / taps) % Cin), n = (int)(e / ((long long)taps * Cin));
+    const size_t o0 = ((size_t)n * taps + t) * (2 * Cin) + c, o1 = ((size_t)(Cout + n) * taps + t) * (2 * Cin) + Cin + c;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < splits; ++k) { s0 += ws[(size_t)k * slab + o0]; s1 += ws[(size_t)k * slab + o1]; }
+    dw[((size_t)n * dw_cin_total + dw_ci_off + c) * taps + t] = s0 + s1;
+  }
+}
+
 int g_use_tr = -1;
 int use_tr() {
   if (g_use_tr < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); g_use_tr = (e && e[0] == '0') ? 0 : 1; }
@@ -480,9 +499,33 @@ int wgrad_variant() {
   return g_wgrad_variant;
 }
 
-struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; bool glds; size_t ws_bytes; };
+struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; bool glds, pair; size_t ws_bytes; };
 
+WgradPlan plan_shape(const SlConvDesc* d, long long M);
+
+// 64-channel layers (layer1, the stem GEMM): the 128-wide glds tiles do not fit them and the 64-wide register-staged kernel runs at
+// ~75 TFLOP/s.  Reading two consecutive pixels as ONE row doubles both channel counts ([M][64] is bit-identical to [M/2][128]):
+// the paired problem runs on the glds kernel and the true gradient is the sum of the two parity-diagonal blocks of its result
+// (half of the MFMA work is discarded -- still 2-3x faster).  3x3 layers gather the pair per lane, so they need Cin == 64 (one tile).
 WgradPlan plan(const SlConvDesc* d) {
+  const int c2 = d->Cin - d->C1;
+  const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
+  const bool ident = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+  const long long M = (long long)d->B * d->Ho * d->Wo;
+  if (wgrad_variant() >= 2 && !all128 && c2 == 0 && d->dtype == SL_BF16 && M % 2 == 0 && d->Wo % 2 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0 &&
+      ((ident && M >= (1 << 19)) || (!ident && d->Cin == 64 && d->stride == 1))) {    // measured: short 1x1 problems are faster on the 64-wide kernel
+    SlConvDesc d2 = *d;
+    d2.Cout = 2 * d->Cout; d2.Cin = d2.C1 = 2 * d->Cin;
+    WgradPlan pl = plan_shape(&d2, M / 2);
+    pl.pair = true;
+    return pl;
+  }
+  WgradPlan pl = plan_shape(d, M);
+  pl.pair = false;
+  return pl;
+}
+
+WgradPlan plan_shape(const SlConvDesc* d, long long M) {
   WgradPlan pl;
   const int c2 = d->Cin - d->C1;
   const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
@@ -497,7 +540,6 @@ WgradPlan plan(const SlConvDesc* d) {
   }
   pl.gridN = d->Cout / pl.bnn; pl.gridC = d->Cin / pl.bcc; pl.taps = d->KH * d->KW;
   const long long tiles = (long long)pl.gridN * pl.gridC * pl.taps;
-  const long long M = (long long)d->B * d->Ho * d->Wo;
   const double slab = (double)d->Cout * pl.taps * d->Cin * sizeof(float);
   // split-K factor: balance the block count over the 256 CUs (time ~ number of block waves) against the slab
   // traffic (written once, read once by the reduce), at >= 128 reduction rows per split and <= 1 GiB of slabs.
@@ -594,6 +636,8 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.M = d->B * d->Ho * d->Wo; p.rows_per_split = pl.rows_per_split;
   p.gridN = pl.gridN; p.gridC = pl.gridC; p.taps = pl.taps; p.splits = pl.splits;
+  p.pair = pl.pair ? 1 : 0;
+  if (pl.pair) { p.Cout = 2 * d->Cout; p.C1 = 2 * d->Cin; p.M /= 2; }
   hipStream_t st = (hipStream_t)stream;
   int e;
   if (d->dtype == SL_F32) e = launch_wgrad<float, false>(pl, p, st);
@@ -601,7 +645,10 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
   else e = launch_wgrad<bf16_t, false>(pl, p, st);
   if (e) return e;
   SL_REQUIRE(pl.taps <= 49, "conv bwd_weight: kernel window larger than 7x7");
-  if (pl.taps == 1) {
+  if (pl.pair) {
+    const long long total = (long long)d->Cout * d->Cin * pl.taps;
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
+  } else if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off);
   } else {

@@ -141,7 +141,7 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
 # Weight gradients have no consumer until the optimizer: they run on a second HIP stream so that their MFMA-bound
 # kernels fill the matrix pipes while the main stream is in HBM-bound phases (BN backward, conv epilogues).
 _SIDE = {}
-_WGRAD_STREAM = os.environ.get('SEGLAND_WGRAD_STREAM', '1') != '0'
+_WGRAD_STREAM = os.environ.get('SEGLAND_WGRAD_STREAM', '0') == '1'     # measured: +1 % with the v4 conv kernel, 0 with v5 -> opt-in
 
 
 def wgrad_async(x, dy, spec, x2=None, out=None, out_ci_off=0):
