@@ -172,7 +172,7 @@ int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, float* pooled, void* work
 /* dx[b,y,x,c] = dcat[b,y,x, cat_off + c] + sum over levels/bins covering (y,x) of dpooled/bin_area.
  * dcat has row pitch cat_pitch channels (the dgrad of the virtual concat). */
 int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
-                    sl_stream_t stream);
+                    void* workspace, size_t workspace_bytes, sl_stream_t stream);   /* workspace: sl_ppm_workspace(d) */
 /* priors[b,y,x, l*Cs + c] = bilinear(stage_l)[b,y,x,c]; stage rows as above with Cs channels */
 int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* priors, sl_stream_t stream);
 int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,

@@ -97,39 +97,66 @@ __global__ void ppm_bins_kernel(PpmGeom g, const float* __restrict__ cells, floa
   }
 }
 
-template <typename T>
-__global__ void ppm_pool_bwd_kernel(PpmGeom g, const float* __restrict__ dpooled, const T* __restrict__ dcat, int cat_pitch, int cat_off,
-                                    T* __restrict__ dx) {
-  constexpr int V = Vec16<T>::N;
-  const int nv = g.C / V;
-  const long long total = (long long)g.B * g.H * g.W * nv;
+// Backward of the four adaptive poolings.  The gradient is constant on every cell of the common refinement of the bin grids, so it
+// is first tabulated per cell (a few hundred cells per image) and then added to the direct (concat) gradient in a pure streaming pass.
+//   gcell[b][cy][cx][c] = sum over levels of dpooled[bin containing the cell][c] / bin area
+__global__ void ppm_pool_bwd_cells_kernel(PpmGeom g, const float* __restrict__ dpooled, float* __restrict__ gcell) {
+  const long long total = (long long)g.B * g.ncy * g.ncx * g.C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % nv); long long r = i / nv;
-    const int xx = (int)(r % g.W); r /= g.W;
-    const int y = (int)(r % g.H); const int b = (int)(r / g.H);
+    const int c = (int)(i % g.C); long long r = i / g.C;
+    const int cx = (int)(r % g.ncx); r /= g.ncx;
+    const int cy = (int)(r % g.ncy); const int b = (int)(r / g.ncy);
+    const int y0 = g.yb[cy], y1 = g.yb[cy + 1], x0 = g.xb[cx], x1 = g.xb[cx + 1];
+    float acc = 0.f;
+    for (int l = 0; l < g.nlevels; ++l) {
+      const int s = g.sizes[l];
+      for (int ii = 0; ii < s; ++ii) {
+        const int ys = d_bin_start(ii, g.H, s), ye = d_bin_end(ii, g.H, s);
+        if (y0 < ys || y1 > ye) continue;
+        for (int j = 0; j < s; ++j) {
+          const int xs = d_bin_start(j, g.W, s), xe = d_bin_end(j, g.W, s);
+          if (x0 < xs || x1 > xe) continue;
+          acc += dpooled[((size_t)g.rowoff[l] + (size_t)(b * s + ii) * s + j) * g.C + c] * (1.f / (float)((ye - ys) * (xe - xs)));
+        }
+      }
+    }
+    gcell[i] = acc;
+  }
+}
+
+// dx[b][y][x][:] = dcat[b][y][x][cat_off ..] + gcell[b][cell(y)][cell(x)][:]      one block per image row
+template <typename T>
+__global__ __launch_bounds__(256) void ppm_pool_bwd_kernel(PpmGeom g, const float* __restrict__ gcell, const T* __restrict__ dcat, int cat_pitch, int cat_off,
+                                                           T* __restrict__ dx) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ int cxs[4096];
+  const int by = blockIdx.x, b = by / g.H, y = by - b * g.H;
+  int cy = 0;
+  while (cy + 1 < g.ncy && y >= g.yb[cy + 1]) ++cy;
+  for (int xx = threadIdx.x; xx < g.W; xx += 256) {
+    int cx = 0;
+    while (cx + 1 < g.ncx && xx >= g.xb[cx + 1]) ++cx;
+    cxs[xx] = cx;
+  }
+  __syncthreads();
+  const int nv = g.C / V;
+  const float* gc = gcell + ((size_t)b * g.ncy + cy) * g.ncx * g.C;
+  const size_t row = (size_t)by * g.W;
+  for (int i = threadIdx.x; i < g.W * nv; i += 256) {
+    const int xx = i / nv, v = i - xx * nv;
     float acc[V];
-    if (dcat) unpack16<T>(*(const uint4*)(dcat + ((size_t)(b * g.H + y) * g.W + xx) * cat_pitch + cat_off + v * V), acc);
+    if (dcat) unpack16<T>(*(const uint4*)(dcat + (row + xx) * cat_pitch + cat_off + v * V), acc);
     else {
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[k] = 0.f;
     }
-    for (int l = 0; l < g.nlevels; ++l) {
-      const int s = g.sizes[l];
-      const int i0 = (y * s) / g.H, j0 = (xx * s) / g.W;
-      for (int ii = max(0, i0 - 1); ii <= min(s - 1, i0 + 1); ++ii) {
-        const int ys = d_bin_start(ii, g.H, s), ye = d_bin_end(ii, g.H, s);
-        if (y < ys || y >= ye) continue;
-        for (int j = max(0, j0 - 1); j <= min(s - 1, j0 + 1); ++j) {
-          const int xs = d_bin_start(j, g.W, s), xe = d_bin_end(j, g.W, s);
-          if (xx < xs || xx >= xe) continue;
-          const float* t = dpooled + ((size_t)g.rowoff[l] + (size_t)(b * s + ii) * s + j) * g.C + v * V;
-          const float inv = 1.f / (float)((ye - ys) * (xe - xs));
+    const float* t = gc + (size_t)cxs[xx] * g.C + v * V;
 #pragma unroll
-          for (int k = 0; k < V; ++k) acc[k] += t[k] * inv;
-        }
-      }
+    for (int k = 0; k < V; k += 4) {
+      const float4 q = *(const float4*)(t + k);
+      acc[k] += q.x; acc[k + 1] += q.y; acc[k + 2] += q.z; acc[k + 3] += q.w;
     }
-    *(uint4*)(dx + (size_t)i * V) = pack16<T>(acc);
+    *(uint4*)(dx + ((row + xx) * nv + v) * V) = pack16<T>(acc);
   }
 }
 
@@ -413,16 +440,21 @@ extern "C" int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, float* pooled,
 }
 
 extern "C" int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, int cat_pitch, int cat_off, void* dx,
-                               sl_stream_t stream) {
+                               void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   PpmGeom g;
   if (int e = make_geom(d, g)) return e;
-  SL_REQUIRE(dpooled && dx, "ppm_pool_bwd: null buffer");
+  SL_REQUIRE(dpooled && dx && workspace, "ppm_pool_bwd: null buffer");
   SL_REQUIRE(!dcat || (cat_pitch >= cat_off + g.C && cat_pitch % 8 == 0 && cat_off % 8 == 0), "ppm_pool_bwd: bad concat geometry");
+  SL_REQUIRE(g.W <= 4096, "ppm_pool_bwd: W > 4096");
+  const size_t need = (size_t)g.B * g.ncy * g.ncx * g.C * sizeof(float);
+  if (workspace_bytes < need) { sl_set_error("ppm_pool_bwd: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
+  float* gcell = (float*)workspace;
+  hipLaunchKernelGGL(ppm_pool_bwd_cells_kernel, dim3(gs_blocks((long long)g.B * g.ncy * g.ncx * g.C)), dim3(256), 0, st, g, (const float*)dpooled, gcell);
   if (d->dtype == SL_BF16)
-    hipLaunchKernelGGL(ppm_pool_bwd_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.C / 8)), dim3(256), 0, st, g, (const float*)dpooled, (const bf16_t*)dcat, cat_pitch, cat_off, (bf16_t*)dx);
+    hipLaunchKernelGGL(ppm_pool_bwd_kernel<bf16_t>, dim3(g.B * g.H), dim3(256), 0, st, g, (const float*)gcell, (const bf16_t*)dcat, cat_pitch, cat_off, (bf16_t*)dx);
   else if (d->dtype == SL_F32)
-    hipLaunchKernelGGL(ppm_pool_bwd_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * g.W * g.C / 4)), dim3(256), 0, st, g, (const float*)dpooled, (const float*)dcat, cat_pitch, cat_off, (float*)dx);
+    hipLaunchKernelGGL(ppm_pool_bwd_kernel<float>, dim3(g.B * g.H), dim3(256), 0, st, g, (const float*)gcell, (const float*)dcat, cat_pitch, cat_off, (float*)dx);
   else SL_REQUIRE(false, "ppm_pool_bwd: bad dtype");
   SL_LAUNCH_CHECK("ppm_pool_bwd_kernel");
   return 0;

@@ -329,7 +329,9 @@ def ppm_pool_bwd(dpooled, x_shape, dtype, sizes, dcat=None, cat_off=0):
     assert dpooled.dtype == torch.float32
     dx = torch.empty((B, H, W, Cn), dtype=dtype, device=dpooled.device)
     pitch = dcat.shape[-1] if dcat is not None else 0
-    check(_lib.lib().sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _s()), 'ppm_pool_bwd')
+    L = _lib.lib()
+    ws = workspace(L.sl_ppm_workspace(C.byref(d)), dpooled.device)
+    check(L.sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _p(ws), ws.numel(), _s()), 'ppm_pool_bwd')
     return dx
 
 
