@@ -257,6 +257,10 @@ int sl_upsample_argmax(const float* logits, int B, int K, int h, int w, int H, i
  * (int64 counts; caller zeroes hist). */
 int sl_iou_hist(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* hist,
                 sl_stream_t stream);
+/* eval_base.py:171-177 / utils/pyt_utils.py:182-200: cm[t*K + p] += 1 over pixels with target != ignore_index (int64 counts, K <= 64;
+ * caller zeroes cm). */
+int sl_confusion_matrix(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* cm,
+                        sl_stream_t stream);
 /* networks/pspnet.py:7-15 masked_average_pooling (dead code upstream; prototype-init utility here):
  * proto[c] = mean_b( sum_hw f*m / (sum_hw m + 1e-5) ), m = bilinear(mask, align_corners=True) at feature size.
  * feature: NHWC dtype [B][h][w][C]; mask: float [B][H][W]. */

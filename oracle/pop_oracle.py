@@ -12,6 +12,7 @@ tests/golden/make_golden.py, which also asserts oracle == reference there).
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -325,6 +326,37 @@ def intersection_and_union(output, target, K, ignore_index=255):
         return torch.bincount(v, minlength=K).to(torch.float32)
     a_i, a_o, a_t = hist(inter), hist(output), hist(target)
     return a_i, a_o + a_t - a_i, a_t
+
+
+def confusion_matrix(gt_label, pred_label, class_num):
+    """utils/pyt_utils.py:182-200 get_confusion_matrix: bincount of gt*K + pred over the pixels the caller kept (numpy int arrays)."""
+    index = (np.asarray(gt_label).astype(np.int64) * class_num + np.asarray(pred_label).astype(np.int64)).astype('int32')
+    count = np.bincount(index, minlength=class_num * class_num)[:class_num * class_num]
+    return count.reshape(class_num, class_num).astype(np.float64)
+
+
+def eval_confusion(logits, label, num_classes, ignore_label, pad_to_longside=False):
+    """eval_base.py:166-177 (eval_ft.py:166-181 when pad_to_longside): upsample(align_corners=True) -> argmax -> drop ignore -> confusion."""
+    h, w = label.shape[-2:]
+    if pad_to_longside:
+        side = max(h, w)
+        out = F.interpolate(logits, size=(side, side), mode='bilinear', align_corners=True)
+        gt = np.ones((label.shape[0], side, side), dtype=np.int64) * ignore_label
+        gt[:, :h, :w] = label.numpy()
+    else:
+        out = F.interpolate(logits, size=(h, w), mode='bilinear', align_corners=True)
+        gt = label.numpy().astype(np.int64)
+    pred = np.asarray(np.argmax(out.numpy(), axis=1), dtype=np.uint8)
+    keep = gt != ignore_label
+    return pred, confusion_matrix(gt[keep], pred[keep], num_classes)
+
+
+def miou_from_confusion(cm, n_base):
+    """eval_base.py:193-199."""
+    pos, res, tp = cm.sum(1), cm.sum(0), np.diag(cm)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = tp / (pos + res - tp)
+    return iou, np.nanmean(iou[:n_base + 1]), np.nanmean(iou[n_base + 1:]), np.nanmean(iou)
 
 
 def param_groups(model, lr, scale=10.0):

@@ -170,6 +170,24 @@ __global__ __launch_bounds__(256) void iou_hist_kernel(const uint8_t* __restrict
   for (int i = threadIdx.x; i < 3 * K; i += 256) if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
+// cm[t][p] += 1 for every pixel whose label t != ignore (utils/pyt_utils.py:182-200 get_confusion_matrix over the kept pixels);
+// labels outside [0, K) are skipped (the reference would fold them into a neighbouring bin through t*K + p -- they cannot occur:
+// the eval drivers filter ignore first and K covers every class).
+__global__ __launch_bounds__(256) void confusion_kernel(const uint8_t* __restrict__ pred, const int64_t* __restrict__ tgt, long long n, int K,
+                                                        int ignore, unsigned long long* __restrict__ cm) {
+  extern __shared__ unsigned int hc[];
+  for (int i = threadIdx.x; i < K * K; i += 256) hc[i] = 0;
+  __syncthreads();
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+    const long long t = tgt[i];
+    if (t == ignore || t < 0 || t >= K) continue;
+    const int p = pred[i];
+    if (p < K) atomicAdd(&hc[(int)t * K + p], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K * K; i += 256) if (hc[i]) atomicAdd(&cm[i], (unsigned long long)hc[i]);
+}
+
 template <typename T>
 __global__ void masked_avg_pool_kernel(const T* __restrict__ feat, const float* __restrict__ mask, int B, int h, int w, int C, int H, int W,
                                        float sy, float sx, float* __restrict__ proto) {
@@ -274,6 +292,15 @@ extern "C" int sl_iou_hist(const uint8_t* pred, const int64_t* target, long long
   SL_REQUIRE(pred && target && hist && n > 0 && K >= 1 && K <= 256, "iou_hist: bad args");
   hipLaunchKernelGGL(iou_hist_kernel, dim3(ce_blocks(n)), dim3(256), 0, (hipStream_t)stream, pred, target, n, K, ignore_index, (unsigned long long*)hist);
   SL_LAUNCH_CHECK("iou_hist_kernel");
+  return 0;
+}
+
+extern "C" int sl_confusion_matrix(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* cm,
+                                   sl_stream_t stream) {
+  SL_REQUIRE(pred && target && cm && n > 0 && K >= 1 && K <= 64, "confusion_matrix: bad args");
+  hipLaunchKernelGGL(confusion_kernel, dim3(ce_blocks(n)), dim3(256), (size_t)K * K * sizeof(unsigned), (hipStream_t)stream, pred, target, n, K, ignore_index,
+                     (unsigned long long*)cm);
+  SL_LAUNCH_CHECK("confusion_kernel");
   return 0;
 }
 

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Generalised few-shot evaluation entry points (counterparts of the reference's eval_base.py / eval_ft.py) on the MI355X HIP path.
+
+    python -m segland_amd.eval_base --model pspnet_pop --backbone resnet50 --dataset synthetic --restore-from best.pth --save-path out
+    python -m segland_amd.eval_ft   ... --random-seed 123,234 --restore-from novel.pth      # loads novel_<seed>.pth per seed
+
+Per batch: logits (eval-mode forward, folded BN) -> upsample(align_corners=True) + argmax in ONE kernel (the H x W logits of
+eval_base.py:168 are never written) -> confusion-matrix kernel on the label grid; mIoU over base / novel / all classes from the
+accumulated matrix exactly as eval_base.py:193-199.  The unlabeled-test branch (GeoTIFF + .mat dumps, eval_base.py:178-191) needs
+rasterio and is row f-2 of SURVEY.md section 8.
+"""
+import argparse
+import os
+import os.path as osp
+
+import numpy as np
+import torch
+
+from . import dataset as dataset_pkg
+from . import networks
+from .drivers import compute_dtype, resolve, str2bool
+from .engine import Engine
+from .utils import pyt_utils as my_utils
+
+
+def get_parser():
+    """Flag names and defaults of eval_base.py:36-72 (+ --fp16 selecting bf16 MFMA, as in the training drivers)."""
+    p = argparse.ArgumentParser(description='SegLand evaluation on the MI355X HIP path')
+    p.add_argument('--dataset', type=str, default='synthetic')
+    p.add_argument('--data-dir', type=str, default='')
+    p.add_argument('--train-list', type=str, default='')
+    p.add_argument('--val-list', type=str, default='')
+    p.add_argument('--test-batch-size', type=int, default=1)
+    p.add_argument('--model', type=str, default='pspnet_pop')
+    p.add_argument('--restore-from', type=str, default='')
+    p.add_argument('--backbone', type=str, default='resnet101')
+    p.add_argument('--base-size', type=str, default='512,512')
+    p.add_argument('--num-workers', type=int, default=0)
+    p.add_argument('--save', type=str2bool, default='False')
+    p.add_argument('--os', type=int, default=8)
+    p.add_argument('--save-path', type=str, default='')
+    p.add_argument('--random-seed', type=str, default='123')
+    p.add_argument('--fold', type=int, default=0, choices=[0, 1, 2, 3])
+    p.add_argument('--shot', type=int, default=1)
+    p.add_argument('--fp16', action='store_true')
+    return p
+
+
+def confusion_of_batch(logits, label, num_classes, ignore_label, pad_to_longside=False):
+    """eval_base.py:166-177 (eval_ft.py:166-181 with pad_to_longside): prediction at the label grid and its confusion counts."""
+    from . import ops
+    h, w = label.shape[-2:]
+    if pad_to_longside:                     # eval_ft.py: upsample to a square of the long side, labels padded with ignore
+        side = max(h, w)
+        pad = torch.full((label.shape[0], side, side), ignore_label, dtype=label.dtype, device=label.device)
+        pad[:, :h, :w] = label
+        label, size = pad, (side, side)
+    else:
+        size = (h, w)
+    pred = ops.upsample_argmax(logits.float().contiguous(), size)
+    return pred, ops.confusion_matrix(pred, label.contiguous(), num_classes, ignore_label)
+
+
+def miou_from_confusion(cm, n_base):
+    """eval_base.py:193-199: per-class IoU = tp / (row + column - tp); base = classes 0..n_base, novel = the rest."""
+    cm = np.asarray(cm, dtype=np.float64)
+    pos, res, tp = cm.sum(1), cm.sum(0), np.diag(cm)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = tp / (pos + res - tp)
+    return iou, float(np.nanmean(iou[:n_base + 1])), float(np.nanmean(iou[n_base + 1:])) if len(iou) > n_base + 1 else float('nan'), float(np.nanmean(iou))
+
+
+def main(argv=None, ft=False):
+    parser = get_parser()
+    with Engine(custom_parser=parser, argv=argv) as engine:
+        args = engine.args
+        logger = None
+        if engine.is_main and args.save_path:
+            os.makedirs(args.save_path, exist_ok=True)
+            from datetime import datetime
+            logger = my_utils.get_logger('', args.save_path, datetime.now().strftime('%Y_%m_%d_%H_%M_%S'))
+        args.base_size = tuple(map(int, args.base_size.split(',')))
+        ds = resolve(dataset_pkg, args.dataset)
+        testset = ds.GFSSegVal(args.data_dir, args.val_list, args.fold, base_size=args.base_size, resize_label=False, use_novel=True, use_base=True)
+        test_loader, test_sampler = engine.get_test_loader(testset)
+        args.ignore_label = testset.ignore_label
+        args.base_classes, args.novel_classes = len(testset.base_classes), len(testset.novel_classes)
+        args.num_classes = testset.num_classes + 1                      # background counts as a class (eval_base.py:120)
+        if engine.distributed:
+            test_sampler.set_epoch(0)
+        assert args.os in (8, 16, 32)
+        model_cls = getattr(networks, args.model).GFSS_Model
+        seg_model = model_cls(n_base=args.base_classes, backbone=args.backbone, dilated=(args.os != 32), os=args.os,
+                              n_novel=args.novel_classes, is_ft=ft, compute_dtype=compute_dtype(args))
+        model = engine.data_parallel(seg_model.to(engine.device))
+        results = {}
+        for seed in map(int, args.random_seed.split(',')):
+            path = (args.restore_from[:-4] + '_%d.pth' % seed) if ft else args.restore_from       # eval_ft.py:154
+            if path and osp.exists(path):
+                my_utils.load_model(model, path)
+            model.eval()
+            cm = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=engine.device)
+            for image, label, _ in test_loader:
+                image, label = image.to(engine.device, non_blocking=True), label.to(engine.device, non_blocking=True)
+                with torch.no_grad():
+                    logits = model(image)
+                cm += confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)[1]
+            if engine.distributed:
+                cm = engine.all_reduce_tensor(cm, norm=False)
+            cmn = cm.cpu().numpy().astype(np.float64)
+            iou, base_miou, novel_miou, total_miou = miou_from_confusion(cmn, args.base_classes)
+            results[seed] = (base_miou, novel_miou, total_miou)
+            if engine.is_main:
+                if args.save_path:
+                    np.save(osp.join(args.save_path, 'cmatrix_%d.npy' % seed), cmn)
+                msg = ['>>>>>>> Current Seed %d: <<<<<<<' % seed, 'meanIoU---base: mIoU %.4f.' % base_miou,
+                       'meanIoU---novel: mIoU %.4f.' % novel_miou, 'meanIoU---total: mIoU %.4f.' % total_miou]
+                for m in msg:
+                    (logger.info if logger else print)(m)
+        return results
+
+
+if __name__ == '__main__':
+    main()

@@ -533,6 +533,13 @@ def iou_hist(pred_u8, target, K, ignore_index):
     return hist
 
 
+def confusion_matrix(pred_u8, target, K, ignore_index):
+    """[K][K] int64 counts, rows = ground truth, columns = prediction, pixels with target == ignore_index dropped."""
+    cm = torch.zeros((K, K), dtype=torch.int64, device=target.device)
+    check(_lib.lib().sl_confusion_matrix(_p(pred_u8), _p(target), target.numel(), K, ignore_index, _p(cm), _s()), 'confusion_matrix')
+    return cm
+
+
 def masked_avg_pool(feature_nhwc, mask):
     B, h, w, Cn = feature_nhwc.shape
     H, W = mask.shape[-2:]

@@ -337,7 +337,33 @@ def g10():
     save('g10_iou', inter=i, union=u, target=t)
 
 
-ALL = dict(g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+def g11():
+    """eval path: eval_base.py:166-199 on fixed logits / labels, both the plain and the eval_ft long-side variant."""
+    logits = fm.sym('g11/logits', (2, 12, 16, 12), 2.0)
+    label = (fm.uniform01('g11/label', 2 * 128 * 96) * 12).floor().long().reshape(2, 128, 96)
+    label[1, :9] = 255
+    for tag, pad in (('plain', False), ('ft', True)):
+        h, w = label.shape[-2:]
+        side = max(h, w)
+        size = (side, side) if pad else (h, w)
+        out = F.interpolate(logits, size=size, mode='bilinear', align_corners=True)
+        seg_pred = np.asarray(np.argmax(out.numpy(), axis=1), dtype=np.uint8)
+        seg_gt = label.numpy().astype(np.int64)
+        if pad:
+            pad_gt = np.ones((2, side, side), dtype=np.int64) * 255
+            pad_gt[:, :h, :w] = seg_gt
+            seg_gt = pad_gt
+        keep = seg_gt != 255
+        cm = ref_utils.get_confusion_matrix(seg_gt[keep], seg_pred[keep], 12)
+        pred_o, cm_o = po.eval_confusion(logits, label, 12, 255, pad_to_longside=pad)
+        assert np.array_equal(pred_o, seg_pred) and np.array_equal(cm, cm_o), 'g11 ' + tag
+        pos, res, tp = cm.sum(1), cm.sum(0), np.diag(cm)
+        iou = tp / (pos + res - tp)
+        same(torch.tensor(iou), torch.tensor(po.miou_from_confusion(cm, 7)[0]), 'g11 iou')
+        save('g11_eval_' + tag, pred=seg_pred, cm=cm, iou=iou, miou=np.array([np.nanmean(iou[:8]), np.nanmean(iou[8:]), np.nanmean(iou)]))
+
+
+ALL = dict(g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -56,3 +56,42 @@ def test_g8_loss_trajectory_fp32(hip):
         np.testing.assert_allclose(got, g['losses'][step], rtol=tol, atol=1e-5)
         np.testing.assert_allclose(float(norm), g['norms'][step], rtol=max(tol * 10, 5e-3))
     assert int(m.backbone.bn1.num_batches_tracked) == 3
+
+
+def test_g11_eval_path(hip):
+    """Fused upsample+argmax and the confusion-matrix kernel against the golden of eval_base.py:166-199 (bit-exact integers),
+    plain and eval_ft (long-side padded) variants."""
+    from conftest import golden
+    from oracle import formula as fm
+    from segland_amd.eval_base import confusion_of_batch, miou_from_confusion
+    logits = fm.sym('g11/logits', (2, 12, 16, 12), 2.0).cuda()
+    label = (fm.uniform01('g11/label', 2 * 128 * 96) * 12).floor().long().reshape(2, 128, 96)
+    label[1, :9] = 255
+    for tag, pad in (('plain', False), ('ft', True)):
+        g = golden('g11_eval_' + tag)
+        pred, cm = confusion_of_batch(logits, label.cuda(), 12, 255, pad_to_longside=pad)
+        assert np.array_equal(pred.cpu().numpy(), g['pred']), tag
+        assert np.array_equal(cm.cpu().numpy().astype(np.float64), g['cm']), tag
+        iou, b, n, t = miou_from_confusion(cm.cpu().numpy(), 7)
+        assert np.allclose(iou, g['iou'], equal_nan=True) and np.allclose([b, n, t], g['miou'])
+
+
+@pytest.mark.parametrize('ft', [False, True])
+def test_eval_entry_points(hip, tmp_path, ft):
+    """python -m segland_amd.eval_base / eval_ft on the synthetic set: runs end to end, writes cmatrix_<seed>.npy (eval_base.py:201)."""
+    import torch
+    from segland_amd import eval_base
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    torch.manual_seed(0)
+    m = GFSS_Model(n_base=7, backbone='resnet50', dilated=True, os=8, n_novel=4, is_ft=ft, pretrained_model=None)
+    ck = str(tmp_path / ('novel_123.pth' if ft else 'base.pth'))
+    # checkpoints of the reference carry the DataParallel/DDP `module.` prefix and are loaded into the wrapped model (eval_base.py:155)
+    torch.save({'module.' + k: v for k, v in m.state_dict().items()}, ck, _use_new_zipfile_serialization=False)
+    argv = ['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--base-size', '256,256', '--fp16',
+            '--restore-from', str(tmp_path / 'novel.pth') if ft else ck, '--save-path', str(tmp_path / 'out'), '--random-seed', '123']
+    res = eval_base.main(argv, ft=ft)
+    cm = np.load(str(tmp_path / 'out' / 'cmatrix_123.npy'))
+    assert cm.shape == (12, 12) and cm.sum() > 0 and 123 in res
+    from segland_amd.dataset.synthetic import GFSSegVal
+    ds = GFSSegVal(base_size=(256, 256), use_novel=True)
+    assert cm.sum() == sum(int((ds[i][1] != 255).sum()) for i in range(len(ds)))

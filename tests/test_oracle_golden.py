@@ -152,6 +152,19 @@ def test_g10_iou():
     assert np.array_equal(i.numpy(), g['inter']) and np.array_equal(u.numpy(), g['union']) and np.array_equal(t.numpy(), g['target'])
 
 
+def test_g11_eval_confusion():
+    """eval_base.py:166-199 / eval_ft.py:166-181: prediction mask, confusion matrix and IoU vector."""
+    logits = fm.sym('g11/logits', (2, 12, 16, 12), 2.0)
+    label = (fm.uniform01('g11/label', 2 * 128 * 96) * 12).floor().long().reshape(2, 128, 96)
+    label[1, :9] = 255
+    for tag, pad in (('plain', False), ('ft', True)):
+        g = golden('g11_eval_' + tag)
+        pred, cm = po.eval_confusion(logits, label, 12, 255, pad_to_longside=pad)
+        assert np.array_equal(pred, g['pred']) and np.array_equal(cm, g['cm'])
+        iou, b, n, t = po.miou_from_confusion(cm, 7)
+        assert np.allclose(iou, g['iou'], equal_nan=True) and np.allclose([b, n, t], g['miou'])
+
+
 def test_index_rules_match_aten():
     # adaptive-avg-pool bins and bilinear taps (both align modes) restated in closed form
     for n, s in [(64, 1), (64, 2), (64, 3), (64, 6), (12, 6), (12, 3), (16, 6), (32, 3)]:
