@@ -1058,7 +1058,9 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
     for (int q = 0; q < 16; ++q) {
       const int ph = q >> 2, ks = q & 3;
       const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
-      if (ks == 0 && more2) {
+      // the two waves of a SIMD (w, w + 4) run the same phase; their address/issue sections are placed two k-steps apart so that
+      // one wave's MFMAs cover the other's VALU + LDS-DMA issue (same per-wave issue order, so the vmcnt arithmetic is unchanged)
+      if ((ks == 0 || ks == 2) && more2 && (ks == 2) == (wm == 1)) {
         if (ph == 0) issueB(0, tap2, ct2, b0nn);
         if (ph == 1) issueA(0, tap2, ct2, par);
         if (ph == 3) { issueA(1, tap2, ct2, par); issueB(1, tap2, ct2, 4 + par); }
