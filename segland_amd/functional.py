@@ -15,14 +15,38 @@ from .ops import ConvSpec
 
 _nbt_pending = []       # num_batches_tracked buffers to bump once per forward
 
+# Staleness of the derived (GEMM-layout / compute-dtype) weight copies.  The tensor version counter alone is not enough: fused
+# optimizers (torch.optim.AdamW(fused=True), the drivers' default on the GPU) update parameters WITHOUT bumping `_version`.  A global
+# post-step hook on every torch optimizer advances an epoch that is part of the cache key of trainable weights; frozen weights
+# (requires_grad False: the ft_pop backbone) keep their copies across steps, load_state_dict still bumps their version.
+_OPT_EPOCH = [0]
+
+
+def _on_optimizer_step(optimizer, args, kwargs):
+    _OPT_EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step      # noqa: E402
+
+_register_post_step(_on_optimizer_step)
+
+
+def weights_changed():
+    """For code that mutates parameters behind torch's back (`.data` writes, custom optimizers that are not torch.optim subclasses)."""
+    _OPT_EPOCH[0] += 1
+
+
+def _wver(w):
+    return (w._version, _OPT_EPOCH[0] if w.requires_grad else 0)
+
 
 def prepared(w, dtype):
     """GEMM-layout copies of a conv weight in the compute dtype, refreshed when the parameter changes.
     The cache lives on the Parameter object itself (version counter + storage pointer + dtype as the key)."""
     ent = getattr(w, '_sl_prep', None)
-    if ent is None or ent[0] != w._version or ent[1] != dtype or ent[2] != w.data_ptr():
+    if ent is None or ent[0] != _wver(w) or ent[1] != dtype or ent[2] != w.data_ptr():
         wf, wb = ops.weight_prep(w, dtype)
-        ent = (w._version, dtype, w.data_ptr(), wf, wb)
+        ent = (_wver(w), dtype, w.data_ptr(), wf, wb)
         w._sl_prep = ent
     return ent[3], ent[4]
 
@@ -36,9 +60,14 @@ class _PrepPlan:
     def refresh(self, convs, dtypes):
         import struct
         ws = [c.weight for c in convs]
-        stale = [w for w, d in zip(ws, dtypes) if (getattr(w, '_sl_prep', None) is None or w._sl_prep[0] != w._version
+        stale = [w for w, d in zip(ws, dtypes) if (getattr(w, '_sl_prep', None) is None or w._sl_prep[0] != _wver(w)
                                                     or w._sl_prep[1] != d or w._sl_prep[2] != w.data_ptr())]
         if not stale:
+            return
+        if len(stale) * 4 < len(ws) and self.key is not None:   # a few trainable weights over a frozen backbone (ft_pop): per-conv launches
+            for w, d in zip(ws, dtypes):
+                if w._sl_prep[0] != _wver(w) or w._sl_prep[1] != d or w._sl_prep[2] != w.data_ptr():
+                    prepared(w, d)
             return
         key = tuple((w.data_ptr(), d) for w, d in zip(ws, dtypes))
         if key != self.key:                                   # (re)build buffers + the device table
@@ -54,7 +83,7 @@ class _PrepPlan:
             self.total, self.key = start, key
         ops.weight_prep_batched(self.table, len(self.items), self.total)
         for w, d, wf, wb in self.items:
-            w._sl_prep = (w._version, d, w.data_ptr(), wf, wb)
+            w._sl_prep = (_wver(w), d, w.data_ptr(), wf, wb)
 
 
 def refresh_weights(model):
@@ -387,7 +416,7 @@ def set_ppm_factorised(flag):
 def _stage_weights(dec):
     """Stage 1x1 weights stacked for the grouped GEMM: ([nl][Cs][Cf] forward, [nl][Cf][Cs] data gradient), float, cached per version."""
     ws = [st[1].weight for st in dec.stages]
-    key = tuple((w._version, w.data_ptr()) for w in ws)
+    key = tuple((_wver(w), w.data_ptr()) for w in ws)
     ent = getattr(dec, '_sl_stage_w', None)
     if ent is None or ent[0] != key:
         f = torch.stack([w.detach().view(w.shape[0], w.shape[1]) for w in ws]).float().contiguous()
@@ -399,11 +428,11 @@ def _stage_weights(dec):
 def _ppm_weights(w, Cs, nl, dtype):
     """Per-level 1x1 weights of the factorised prior path (float) + GEMM layouts of the x4 channel slice, cached on the Parameter."""
     ent = getattr(w, '_sl_ppm', None)
-    if ent is None or ent[0] != w._version or ent[1] != dtype or ent[2] != w.data_ptr():
+    if ent is None or ent[0] != _wver(w) or ent[1] != dtype or ent[2] != w.data_ptr():
         wq_f, wq_b = ops.ppm_wq_prep(w, Cs, nl)
         wf4, wb4 = ops.weight_prep_slice(w, dtype, nl * Cs, w.shape[1] - nl * Cs)
         N = w.shape[0]
-        ent = (w._version, dtype, w.data_ptr(), wq_f, wq_b, wf4, wb4)
+        ent = (_wver(w), dtype, w.data_ptr(), wq_f, wq_b, wf4, wb4)
         w._sl_ppm = ent
     return ent[3], ent[4], ent[5], ent[6]
 

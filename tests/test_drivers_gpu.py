@@ -95,3 +95,34 @@ def test_eval_entry_points(hip, tmp_path, ft):
     from segland_amd.dataset.synthetic import GFSSegVal
     ds = GFSSegVal(base_size=(256, 256), use_novel=True)
     assert cm.sum() == sum(int((ds[i][1] != 255).sum()) for i in range(len(ds)))
+
+
+def test_fused_optimizer_refreshes_weight_copies(hip):
+    """torch.optim.AdamW(fused=True) does not bump Parameter._version; the GEMM-layout weight copies must follow the step anyway
+    (functional._OPT_EPOCH).  Two identical models, one stepped by the fused and one by the foreach implementation, must agree after
+    the step -- and differ from the un-stepped output."""
+    import torch
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8).cuda().train()
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-2, fused=fused, foreach=None if fused else True)
+        g = torch.Generator().manual_seed(1)
+        img = torch.randn(2, 3, 128, 128, generator=g).cuda()
+        mask = torch.randint(0, 8, (2, 128, 128), generator=g).cuda()
+        m.eval()
+        with torch.no_grad():
+            before = m(img).float().clone()
+        m.train()
+        opt.zero_grad()
+        m(img, mask)['total_loss'].backward()
+        opt.step()
+        m.eval()
+        with torch.no_grad():
+            after = m(img).float().clone()
+        assert float((after - before).abs().max()) > 1e-3, 'the step did not reach the kernels (fused=%s)' % fused
+        outs.append(after)
+    err = float((outs[0] - outs[1]).norm() / outs[1].norm())
+    assert err < 5e-2, 'fused vs foreach AdamW after one step: %.3g' % err
