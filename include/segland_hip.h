@@ -100,8 +100,9 @@ int sl_weight_prep_slice(int dtype, const float* w_oihw, int Cout, int CinTot, i
 
 /* The same for n weights in ONE launch.  table_dev: device array of n 48-byte records
  *   { const float* src; void* w_fwd; void* w_bwd; int O, I, KHW, dtype; long long start; }
- * with `start` the running sum of O*I*KHW (ascending); total_elems the grand total. */
-int sl_weight_prep_batched(const void* table_dev, int n, long long total_elems, sl_stream_t stream);
+ * with `start` the running count of 64 x 32 channel tiles (O*I/2048) of the preceding records and total_tiles their grand total;
+ * O % 64 == 0, I % 32 == 0, KHW <= 9. */
+int sl_weight_prep_batched(const void* table_dev, int n, long long total_tiles, sl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ batch norm
  * nn.BatchNorm2d call sites: resnet.py:45,48,50,88,111; pspnet_pop.py:20,28 (eps 1e-5, momentum 0.1). */

@@ -1284,30 +1284,62 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, int Cout, int Ci
 namespace {
 struct PrepEntry { const float* src; void* wf; void* wb; int O, I, KHW, dtype; long long start; };
 
-// all conv weights of a model in ONE launch: entry table in device memory, elements concatenated in `start` order
-__global__ void weight_prep_batched_kernel(const PrepEntry* __restrict__ tab, int n, long long total) {
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    int lo = 0, hi = n - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= e) lo = mid; else hi = mid - 1; }
+// all conv weights of a model in ONE launch: entry table in device memory.  Every conv is cut into tiles of 64 output x 32 input
+// channels (all taps, <= 9).  A block stages one tile in LDS (converted), then writes
+// wf[o][t][i0..i0+31] (64-byte runs) and wb[i][t][o0..o0+63] (128-byte runs): both layouts leave the block coalesced, where the
+// element-wise version scattered 2-byte stores.
+constexpr int WP_O = 64, WP_I = 32;
+template <typename T>
+__device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long tile, unsigned char* smem) {
+  const int it_n = t.I / WP_I;
+  const int o0 = (int)(tile / it_n) * WP_O, i0 = (int)(tile % it_n) * WP_I;
+  const int KHW = t.KHW, row = WP_I * KHW;                 // contiguous source floats per output channel of the tile
+  T* lds = (T*)smem;                                       // [WP_O][row (+pad)]
+  const int pitch = row + 2;
+  for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
+    const int o = e / row, r = e - o * row;
+    lds[o * pitch + r] = from_f<T>(t.src[((size_t)(o0 + o) * t.I + i0) * KHW + r]);      // r = i*KHW + k
+  }
+  __syncthreads();
+  if (t.wf) {
+    T* wf = (T*)t.wf;
+    for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
+      const int i = e % WP_I, ok = e / WP_I, k = ok % KHW, o = ok / KHW;
+      wf[((size_t)(o0 + o) * KHW + k) * t.I + i0 + i] = lds[o * pitch + i * KHW + k];
+    }
+  }
+  if (t.wb) {
+    T* wb = (T*)t.wb;
+    for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
+      const int o = e % WP_O, ik = e / WP_O, k = ik % KHW, i = ik / KHW;
+      wb[((size_t)(i0 + i) * KHW + k) * t.O + o0 + o] = lds[o * pitch + i * KHW + k];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void weight_prep_batched_kernel(const PrepEntry* __restrict__ tab, int n, long long total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wp_smem[];
+  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    int lo = 0, hi = n - 1;                               // entry owning this tile: last one with start <= tile (block-uniform)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= tile) lo = mid; else hi = mid - 1; }
     const PrepEntry t = tab[lo];
-    const long long l = e - t.start;
-    const int k = (int)(l % t.KHW);
-    const long long oi = l / t.KHW;
-    const int i = (int)(oi % t.I), o = (int)(oi / t.I);
-    const float v = t.src[l];
-    const size_t fo = ((size_t)o * t.KHW + k) * t.I + i, bo = ((size_t)i * t.KHW + k) * t.O + o;
-    if (t.dtype == SL_BF16) { if (t.wf) ((bf16_t*)t.wf)[fo] = f2bf(v); if (t.wb) ((bf16_t*)t.wb)[bo] = f2bf(v); }
-    else                    { if (t.wf) ((float*)t.wf)[fo] = v;        if (t.wb) ((float*)t.wb)[bo] = v; }
+    if (t.dtype == SL_BF16) weight_prep_tile<bf16_t>(t, tile - t.start, wp_smem);
+    else                    weight_prep_tile<float>(t, tile - t.start, wp_smem);
   }
 }
 }  // namespace
 
-// table: device array of n entries {src, w_fwd, w_bwd (void*), O, I, KH*KW, dtype (int), start (int64)} = 48 bytes each
-extern "C" int sl_weight_prep_batched(const void* table_dev, int n, long long total_elems, sl_stream_t stream) {
-  SL_REQUIRE(table_dev && n > 0 && total_elems > 0, "weight_prep_batched: bad args");
+// table: device array of n entries {src, w_fwd, w_bwd (void*), O, I, KH*KW, dtype (int), start (int64)} = 48 bytes each;
+// start = running count of 64 x 32 channel tiles (O*I/2048) of the preceding entries, total_tiles their grand total.
+extern "C" int sl_weight_prep_batched(const void* table_dev, int n, long long total_tiles, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && n > 0 && total_tiles > 0, "weight_prep_batched: bad args");
   static_assert(sizeof(PrepEntry) == 48, "table layout is part of the ABI");
-  const int blocks = (int)((total_elems + 255) / 256 < 16384 ? (total_elems + 255) / 256 : 16384);
-  hipLaunchKernelGGL(weight_prep_batched_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const PrepEntry*)table_dev, n, total_elems);
+  const size_t lds = (size_t)WP_O * (WP_I * 9 + 2) * sizeof(float);      // taps <= 9 (1x1 and 3x3 convs), fp32 worst case
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)weight_prep_batched_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  const int blocks = (int)(total_tiles < 4096 ? total_tiles : 4096);
+  hipLaunchKernelGGL(weight_prep_batched_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, (const PrepEntry*)table_dev, n, total_tiles);
   SL_LAUNCH_CHECK("weight_prep_batched_kernel");
   return 0;
 }

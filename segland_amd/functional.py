@@ -77,7 +77,8 @@ class _PrepPlan:
                 wf = torch.empty((O, KH, KW, I), dtype=d, device=w.device)
                 wb = torch.empty((I, KH, KW, O), dtype=d, device=w.device)
                 rec += struct.pack('<QQQiiiiq', w.data_ptr(), wf.data_ptr(), wb.data_ptr(), O, I, KH * KW, ops.dt(d), start)
-                start += w.numel()
+                assert O % 64 == 0 and I % 32 == 0 and KH * KW <= 9
+                start += O * I // 2048
                 self.items.append((w, d, wf, wb))
             self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(ws[0].device)
             self.total, self.key = start, key
@@ -95,7 +96,8 @@ def refresh_weights(model):
         stage_convs = {id(st[1]) for st in model.decoder.stages}
         for m in list(model.backbone.modules()) + list(model.decoder.modules()) + list(model.classifier.modules()) + \
                 (list(model.classifier_n.modules()) if getattr(model, 'classifier_n', None) is not None else []):
-            if isinstance(m, torch.nn.Conv2d) and m.kernel_size[0] in (1, 3) and m.out_channels % 64 == 0:
+            if isinstance(m, torch.nn.Conv2d) and m.kernel_size[0] in (1, 3) and m.out_channels % 64 == 0 and m.in_channels % 32 == 0 \
+                    and not (_PPM_FACTORISED and m is model.decoder.bottleneck[0]):       # that one is consumed as slices (_ppm_weights)
                 convs.append(m)
                 dtypes.append(torch.float32 if id(m) in stage_convs else model.compute_dtype)     # PPM stage path is fp32
         plan.convs, plan.dtypes = convs, dtypes

@@ -261,6 +261,27 @@ def test_ppm_rows_gemm(hip, B, K, N):
         off += n
 
 
+def test_weight_prep_batched(hip):
+    """One-launch tiled weight prep == the per-conv kernel, bit for bit (bf16 and fp32 entries, 1x1 and 3x3, ragged channel counts)."""
+    from segland_amd import functional as sf
+    convs = [torch.nn.Conv2d(64, 128, 3, bias=False), torch.nn.Conv2d(96, 64, 1, bias=False), torch.nn.Conv2d(256, 192, 3, bias=False),
+             torch.nn.Conv2d(2048, 512, 1, bias=False)]
+    dts = [torch.bfloat16, torch.float32, torch.bfloat16, torch.float32]
+    for k, c in enumerate(convs):
+        c.weight.data = fm.sym('wp/%d' % k, tuple(c.weight.shape), 1.0)
+        c.to(DEV)
+    plan = sf._PrepPlan()
+    plan.refresh(convs, dts)
+    for c, d in zip(convs, dts):
+        wf, wb = ops_mod().weight_prep(c.weight, d)
+        assert torch.equal(c.weight._sl_prep[3], wf) and torch.equal(c.weight._sl_prep[4], wb)
+
+
+def ops_mod():
+    from segland_amd import ops
+    return ops
+
+
 def test_loss_golden_g3(hip):
     from segland_amd import ops
     g = golden('g3_loss')
