@@ -1128,7 +1128,10 @@ static int small_k() {
   if (v < 0) { const char* e = getenv("SEGLAND_CONV_SMALLK"); v = e ? atoi(e) : 0; }
   return v;
 }
-static int block_rows(long long M, int ktot) { return (conv_variant() >= 3 && M >= 256 * 96 && ktot > small_k()) ? 256 : 128; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int min_tiles256() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_MINTILES", 96); return v; }
+static int ring128_min() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_RING128_MIN", 512); return v; }
+static int block_rows(long long M, int ktot) { return (conv_variant() >= 3 && M >= 256LL * min_tiles256() && ktot > small_k()) ? 256 : 128; }
 
 template <typename T>
 int launch_gemm(ConvGemmParams& p, hipStream_t st) {
@@ -1159,7 +1162,7 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
     if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
     return launch_glds<T, 256, 64, 8, 1>(p, st);
   }
-  if (v >= 4 && n128 && p.M >= 128 * 512) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
+  if (v >= 4 && n128 && p.M >= 128LL * ring128_min()) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
   if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
   return launch_glds<T, 128, 64, 2, 2>(p, st);
 }
@@ -1204,7 +1207,7 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
   if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
   if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));
-  if (v >= 4 && n128 && M >= 128 * 512) return 4128128;
+  if (v >= 4 && n128 && M >= 128LL * ring128_min()) return 4128128;
   return 2000000 + 128000 + (n128 ? 128 : 64);
 }
 
