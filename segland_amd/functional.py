@@ -124,10 +124,38 @@ def _bn_coeffs(bn, part, count):
             raise ValueError('Expected more than 1 value per channel when training, got %d' % count)   # as F.batch_norm
         if bn.momentum is None:
             raise RuntimeError('segland_amd: cumulative-average BatchNorm (momentum=None) is not supported')
+        world = sync_world(bn)
+        if world:                                            # SyncBatchNorm: global sum / sum of squares / count (equal shards)
+            import torch.distributed as dist
+            tot = ops.colsum(part).contiguous()
+            dist.all_reduce(tot)
+            part, count = tot.unsqueeze(0), count * world
         out = ops.bn_finalize_train(part, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _nbt_pending.append(bn.num_batches_tracked)
         return out
     return _bn_eval_coeffs(bn)
+
+
+_SYNC_BN = os.environ.get('SEGLAND_SYNC_BN', '0')
+
+
+def set_sync_bn(mode):
+    """'0' (per-GPU statistics, default), '1' (synchronise nn.SyncBatchNorm modules when world_size > 1) or 'force' (also at world_size 1)."""
+    global _SYNC_BN
+    _SYNC_BN = str(mode)
+
+
+def sync_world(bn):
+    """World size if this BN synchronises its batch statistics over the process group, else 0.  Default: statistics are per GPU
+    (DESIGN.md section 6); SEGLAND_SYNC_BN=1 gives nn.SyncBatchNorm modules the reference's distributed semantics (train_base.py:175-176)
+    at the price of two small all-reduces per layer and direction."""
+    if _SYNC_BN == '0' or not bn.training or not isinstance(bn, torch.nn.SyncBatchNorm):
+        return 0
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    w = dist.get_world_size()
+    return w if (w > 1 or _SYNC_BN == 'force') else 0
 
 
 def conv_bn_fwd(x, conv, bn, relu, residual=None, x2=None, out=None, want_mask=False):
@@ -170,7 +198,7 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue."""
     dc, dres, dgamma, dbeta = ops.bn_bwd(dy, None if bits is not None else y_mask, c, mean, invstd, bn.weight, train=bn.training,
-                                         want_dres=want_dres, mask=bits)
+                                         want_dres=want_dres, mask=bits, sync_world=sync_world(bn))
     spec = spec_of(conv)
     dx = dw = None
     if need_dw:
@@ -236,7 +264,7 @@ class StemFn(torch.autograd.Function):
         img, c0, idx, mean, invstd, scale, shift = ctx.saved_tensors
         bn = ctx.net.bn1
         g0 = ops.stem_pool_relu_bwd(dp.contiguous(), idx, c0, scale, shift)
-        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training)
+        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training, sync_world=sync_world(bn))
         dw = ops.stem_conv_bwd_weight(img, dc0) if ctx.needs_input_grad[1] else None
         return None, dw, dgamma, dbeta, None, None
 
@@ -383,7 +411,7 @@ class PPMFn(torch.autograd.Function):
         if ctx.fact:
             N = bt[0].out_channels
             wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, nl, x4.dtype)
-            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training)
+            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training, sync_world=sync_world(bt[1]))
             spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
             dcat = ops.conv2d_bwd_data(dcb, wb4, spec4, (H, W))                     # gradient of the x4 half only: [B,H,W,Cf]
             cat_off = 0
@@ -411,7 +439,7 @@ class PPMFn(torch.autograd.Function):
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
             _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
-                                        out=dc_all[off:off + n])
+                                        out=dc_all[off:off + n], sync_world=sync_world(st[2]))
             dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1])) if need_w else None
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None

@@ -230,8 +230,10 @@ def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False)
     return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None):
-    """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given."""
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None, sync_world=0):
+    """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given.
+    sync_world > 0 (SyncBatchNorm semantics, torch/nn/modules/_functions.py): the two column sums that enter dx are all-reduced over
+    the process group and the element count is the global one; dgamma / dbeta stay local (DDP averages them like any gradient)."""
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     L = _lib.lib()
@@ -241,6 +243,14 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     o = _f32((5, Cn), x.device)
     check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
+    if sync_world and train:
+        import torch.distributed as dist
+        tot = colsum(part).contiguous()                     # local [2][C] sums
+        dist.all_reduce(tot)
+        og = _f32((5, Cn), x.device)
+        check(L.sl_bn_bwd_finalize(_p(tot), 1, Cn, rows * sync_world, _p(gamma), _p(mean), _p(invstd), 1, _p(og[0]), _p(og[1]), _p(og[2]), _p(og[3]),
+                                   _p(og[4]), _s()), 'bn_bwd_finalize(sync)')
+        o = torch.stack([o[0], o[1], og[2], og[3], og[4]])  # local dgamma/dbeta, global dx coefficients
     dx = out if out is not None else torch.empty_like(x)
     assert dx.numel() == x.numel() and dx.dtype == x.dtype
     dres = torch.empty_like(x) if want_dres else None

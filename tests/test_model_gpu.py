@@ -283,3 +283,40 @@ def test_g7_ft_fp32(hip):
     m.eval()
     with torch.no_grad():
         check(m(img), g['preds_all'], 1e-3, 'preds_all')
+
+
+def test_sync_bn_two_identical_shards(hip, monkeypatch):
+    """SEGLAND_SYNC_BN semantics (train_base.py:175-176 SyncBatchNorm) without a second GPU: with a fake all-reduce that doubles
+    the sums (two ranks holding the SAME shard) a SyncBatchNorm bottleneck on x must equal a plain-BN bottleneck on the batch
+    [x; x]: outputs, input gradient, running statistics (unbiased variance uses the GLOBAL count); dgamma/dbeta stay local,
+    i.e. half of the full-batch value (DDP would average the two ranks)."""
+    import torch.distributed as dist
+    from segland_amd import functional as sf
+    from segland_amd.networks.backbones.resnet import Bottleneck
+    ds = lambda: nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.BatchNorm2d(256))
+    dsy = lambda: nn.Sequential(nn.Conv2d(64, 256, 1, bias=False), nn.SyncBatchNorm(256))
+    torch.manual_seed(3)
+    full = Bottleneck(64, 64, 1, 1, ds(), norm_layer=nn.BatchNorm2d).to(DEV).train()
+    shard = Bottleneck(64, 64, 1, 1, dsy(), norm_layer=nn.SyncBatchNorm).to(DEV).train()
+    shard.load_state_dict(full.state_dict())
+    x = torch.randn(2, 16, 16, 64, device=DEV)
+    g = torch.randn(2, 16, 16, 256, device=DEV)
+    xf = torch.cat([x, x]).requires_grad_(True)
+    yf = full(xf)
+    yf.backward(torch.cat([g, g]))
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    monkeypatch.setattr(dist, 'get_world_size', lambda *a, **k: 2)
+    monkeypatch.setattr(dist, 'all_reduce', lambda t, *a, **k: t.mul_(2))
+    sf.set_sync_bn('1')
+    try:
+        xs = x.clone().requires_grad_(True)
+        ys = shard(xs)
+        ys.backward(g)
+    finally:
+        sf.set_sync_bn('0')
+    check(ys, yf[:2].detach().cpu().numpy(), 1e-5, 'sync-BN forward')
+    check_grad(xs.grad, xf.grad[:2].cpu().numpy(), 1e-4, 'sync-BN dx')
+    check(shard.bn2.running_var, full.bn2.running_var.cpu().numpy(), 1e-6, 'running_var (global count)')
+    check(shard.bn2.running_mean, full.bn2.running_mean.cpu().numpy(), 1e-6, 'running_mean')
+    check_grad(2 * shard.bn3.weight.grad, full.bn3.weight.grad.cpu().numpy(), 1e-4, 'dgamma is the local sum')
+    check_grad(2 * shard.conv2.weight.grad, full.conv2.weight.grad.cpu().numpy(), 1e-4, 'dw is the local sum')
