@@ -201,12 +201,17 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
                                          want_dres=want_dres, mask=bits, sync_world=sync_world(bn))
     spec = spec_of(conv)
     dx = dw = None
-    if need_dw:
-        dw = wgrad_async(x, dc, spec, x2=x2)      # side stream: overlaps the data gradient and the next BN backward
+    late = _WGRAD_STREAM and os.environ.get('SEGLAND_WGRAD_LATE', '1') == '1'
+    if need_dw and not late:
+        dw = wgrad_async(x, dc, spec, x2=x2)
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
         dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
                                  C1=(x.shape[3] if x2 is not None else None), out=dx_out)
+    if need_dw and late:
+        # side stream, released only AFTER the data gradient: the MFMA-bound wgrad then runs beside the HBM-bound BN backward of the
+        # previous layer (its waves fit next to the wgrad block on a CU) instead of time-slicing the CUs with the dgrad kernel
+        dw = wgrad_async(x, dc, spec, x2=x2)
     return dx, dw, dgamma, dbeta, dres
 
 
