@@ -320,3 +320,67 @@ def test_sync_bn_two_identical_shards(hip, monkeypatch):
     check(shard.bn2.running_mean, full.bn2.running_mean.cpu().numpy(), 1e-6, 'running_mean')
     check_grad(2 * shard.bn3.weight.grad, full.bn3.weight.grad.cpu().numpy(), 1e-4, 'dgamma is the local sum')
     check_grad(2 * shard.conv2.weight.grad, full.conv2.weight.grad.cpu().numpy(), 1e-4, 'dw is the local sum')
+
+
+@pytest.mark.parametrize('backbone,os_,H,W', [('resnet50', 16, 128, 160), ('resnet50', 32, 160, 128), ('resnet101', 8, 64, 96),
+                                               ('resnet50', 8, 136, 200), ('resnet50', 8, 72, 104)])
+def test_configs_vs_same_box_oracle(hip, backbone, os_, H, W):
+    """The other corners of the constructor surface (networks/backbones/__init__.py:8-43: os 16/32, ResNet-101) and image sizes that
+    are not multiples of the tile sizes (ragged row blocks, non-divisible pooling bins, odd feature maps), fp32 mode against the CPU
+    oracle evaluated on this machine: loss dict, logits (eval) and two gradients."""
+    from oracle import pop_oracle as po
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    tag = 'cfg/%s_%d_%dx%d' % (backbone, os_, H, W)
+    img = fm.formula_image(2, H, W, tag + '/img')
+    mask = fm.formula_mask(2, H, W, 8, tag + '/mask', ignore_rows=7)
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=backbone, pretrained_model=None, dilated=(os_ != 32), os=os_,
+                   compute_dtype=torch.float32)
+    fm.load_formula_weights(m)
+    m = m.to(DEV).train()
+    o = fm.load_formula_weights(po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), backbone=backbone, dilated=(os_ != 32), os=os_)).train()
+    d = m(img.to(DEV), mask.to(DEV))
+    d['total_loss'].backward()
+    do = o(img, mask)
+    do['total_loss'].backward()
+    for k in do:
+        assert abs(float(d[k]) - float(do[k])) <= 1e-3 * max(1.0, abs(float(do[k]))), (k, float(d[k]), float(do[k]))
+    check_grad(m.base_emb.grad, o.base_emb.grad.numpy(), 2e-2, 'd base_emb')
+    check_grad(m.classifier[4].weight.grad, o.classifier[4].weight.grad.numpy(), 2e-2, 'd classifier.4')
+    m.eval(); o.eval()
+    with torch.no_grad():
+        lg, lo = m(img.to(DEV)), o(img)
+    assert tuple(lg.shape) == tuple(lo.shape)
+    check(lg, lo.numpy(), 2e-3, 'eval logits')
+
+
+@pytest.mark.parametrize('B,H,W,os_', [(2, 72, 104, 8), (3, 96, 64, 16)])
+def test_ft_configs_vs_same_box_oracle(hip, B, H, W, os_):
+    """forward_novel / forward_all (pspnet_pop.py:136-243) at odd sizes, batch 3 and os 16 against the CPU oracle on this machine:
+    in-place pseudo-labels (<= a few numerically tied pixels), loss dict, novel-prototype gradient, eval logits."""
+    from oracle import pop_oracle as po
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    tag = 'ftcfg/%d_%dx%d_%d' % (B, H, W, os_)
+    kw = dict(n_base=7, is_ft=True, n_novel=4, backbone='resnet50', dilated=True, os=os_)
+    m = GFSS_Model(criterion=OrthLoss(255), pretrained_model=None, compute_dtype=torch.float32, **kw)
+    fm.load_formula_weights(m)
+    o = fm.load_formula_weights(po.PopOracle(criterion=po.OrthLossOracle(255), **kw))
+    m.init_cls_n(); po.init_cls_n(o)
+    m = m.to(DEV)
+    img, img_b = fm.formula_image(B, H, W, tag + '/img'), fm.formula_image(B, H, W, tag + '/img_b')
+    mask = fm.formula_mask(B, H, W, 4, tag + '/mask', ignore_rows=3, lo=8); mask[mask == 8] = 255
+    mask_b = fm.formula_mask(B, H, W, 8, tag + '/mask_b', ignore_rows=0)
+    mb_gpu, mb_cpu = mask_b.clone().to(DEV), mask_b.clone()
+    m.train_mode(); po.train_mode(o)
+    d = m(img.to(DEV), mask.to(DEV), img_b.to(DEV), mb_gpu)
+    d['total_loss'].backward()
+    do = o(img, mask, img_b, mb_cpu)
+    do['total_loss'].backward()
+    assert int((mb_gpu.cpu() != mb_cpu).sum()) <= 8, 'pseudo labels'
+    for k in do:
+        assert abs(float(d[k]) - float(do[k])) <= 2e-3 * max(1.0, abs(float(do[k]))), (k, float(d[k]), float(do[k]))
+    check_grad(m.novel_emb.grad, o.novel_emb.grad.numpy(), 2e-2, 'd novel_emb')
+    m.eval(); o.eval()
+    with torch.no_grad():
+        check(m(img.to(DEV)), o(img).numpy(), 2e-3, 'forward_all logits')
