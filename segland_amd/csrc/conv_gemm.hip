@@ -934,13 +934,13 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
 // each row request is a full 128-byte line than with the 64-byte rows of the v4 ring, and v4 sits exactly on that limit.
 // A K-tile is computed as 4 phases, one output quadrant each -- (A0,B0) (A0,B1) (A1,B1) (A1,B0) -- so a slot is free again
 // after at most two phases and is refilled with the same half of the K-tile two steps ahead:
-//   P0: issue B0(i+1)            P1: issue A0(i+2)            P3: issue A1(i+2), B1(i+2)
+//   P0: issue B0(i+2)            P1: issue A0(i+2)            P3: issue A1(i+2), B1(i+2)       (A0 and B0 have three slots, mod 3)
 // The A fragments of a half (8 x 16 B per lane) stay in registers for its two phases and are refilled in place (A1 during P1, the
-// next K-tile's A0 during P3); B fragments stream through a 4-deep register ring, three k-steps ahead.  One counted wait per
-// K-tile (end of P2: everything but the A0 just issued has landed) and three barriers (after P0, P2, P3).
+// next K-tile's A0 during P3); B fragments stream through a 4-deep register ring, three k-steps ahead (P3 re-uses the B0 fragments
+// of P0 from registers).  Two counted waits and two barriers per K-tile (after P2 and P3).
 // Wave (wm, wn) of the 2 x 4 grid owns rows {h*128 + wm*64 ..+63} and columns {h*128 + wn*32 ..+31} of both halves h.
 constexpr int P8_SLOT = 128 * 128;
-constexpr int P8_RING = 9 * P8_SLOT;          // A0 x2, A1 x2, B1 x2, B0 x3
+constexpr int P8_RING = 10 * P8_SLOT;         // A0 x3, A1 x2, B1 x2, B0 x3 = the whole 160 KiB
 constexpr int P8_LDS = EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES > P8_RING ? EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES : P8_RING;
 
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
@@ -993,9 +993,11 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
     }
   const unsigned char* zsrc = g_zero_page + lpos * 16;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  // slot map: A0 -> 0,1 (K-tile parity)   A1 -> 2,3   B1 -> 4,5   B0 -> 6,7,8 (K-tile mod 3: it is read in the first AND the last phase)
-  auto issueA = [&](int h, int tap, int ct, int par) {
-    const unsigned dst = lds_base + (h * 2 + par) * P8_SLOT + wave * 2048;
+  // slot map: A0 -> 0,1,2 (K-tile mod 3)   A1 -> 3,4 (parity)   B1 -> 5,6 (parity)   B0 -> 7,8,9 (K-tile mod 3).  The two halves that
+  // are read early AND late in a K-tile (B0: phases 0 and 3; A0: fragments of the NEXT K-tile are fetched in phase 3) get a third slot,
+  // which takes their re-issue off the barrier chain: two barriers per K-tile.
+  auto issueA = [&](int h, int tap, int ct, int slot) {
+    const unsigned dst = lds_base + slot * P8_SLOT + wave * 2048;
     const int c0 = ct * 64;
     const unsigned char* base; unsigned pitchb;
     if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + fh) ^ ((l31 >> 1) & 7)) << 4);
   const unsigned char* fa = smem + wm * (64 * 128);
   const unsigned char* fb = smem + wn * (32 * 128);
-  auto ldA = [&](int par, int h, int i2, int ks) { return *(const uint4*)(fa + (h * 2 + par) * P8_SLOT + i2 * 4096 + foff[ks]); };
+  auto ldA = [&](int slot, int i2, int ks) { return *(const uint4*)(fa + slot * P8_SLOT + i2 * 4096 + foff[ks]); };
   auto ldB = [&](int slot, int ks) { return *(const uint4*)(fb + slot * P8_SLOT + foff[ks]); };
 
   f32x16_t acc[4][2];                         // [half*2 + 32-row block][column half]
@@ -1038,21 +1040,22 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   // ---- prologue.  Global issue order is K-tile by K-tile: B0(s), A0(s), A1(s), B1(s); the loop continues it with
   // B0(i+2) in P0(i), A0(i+2) in P1(i), A1(i+2) and B1(i+2) in P3(i).
   int tap2 = 0, ct2 = 0;                      // K-tile i+2 (after the prologue)
-  issueB(0, 0, 0, 6); issueA(0, 0, 0, 0); issueA(1, 0, 0, 0); issueB(1, 0, 0, 4);
+  issueB(0, 0, 0, 7); issueA(0, 0, 0, 0); issueA(1, 0, 0, 3); issueB(1, 0, 0, 5);
   adv(tap2, ct2);
-  if (nk > 1) { issueB(0, tap2, ct2, 7); issueA(0, tap2, ct2, 1); issueA(1, tap2, ct2, 1); issueB(1, tap2, ct2, 5); wait_vmcnt<8>(); } else wait_vmcnt<0>();
+  if (nk > 1) { issueB(0, tap2, ct2, 8); issueA(0, tap2, ct2, 1); issueA(1, tap2, ct2, 4); issueB(1, tap2, ct2, 6); wait_vmcnt<8>(); } else wait_vmcnt<0>();
   adv(tap2, ct2);
   __builtin_amdgcn_s_barrier();
-  uint4 a[4][2], b[4];
+  uint4 a[4][2], b[4], b0k[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, 0, ks); a[ks][1] = ldA(0, 0, 1, ks); }
+  for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, ks); a[ks][1] = ldA(0, 1, ks); }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) b[q] = ldB(6, q);
+  for (int q = 0; q < 3; ++q) b[q] = ldB(7, q);
 
   int s3 = 0;                                 // i mod 3
   for (int i = 0; i < nk; ++i) {
     const int par = i & 1;
-    const int b0cur = 6 + s3, b0nxt = 6 + (s3 == 2 ? 0 : s3 + 1), b0nn = 6 + (s3 == 0 ? 2 : s3 - 1);   // B0 slots of K-tiles i, i+1, i+2
+    const int s3n = s3 == 2 ? 0 : s3 + 1, s3nn = s3 == 0 ? 2 : s3 - 1;                                   // (i+1) % 3, (i+2) % 3
+    const int b0cur = 7 + s3, b0nxt = 7 + s3n, b0nn = 7 + s3nn;                                         // B0 slots of K-tiles i, i+1, i+2
     const bool more2 = i + 2 < nk;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -1062,23 +1065,25 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       // one wave's MFMAs cover the other's VALU + LDS-DMA issue (same per-wave issue order, so the vmcnt arithmetic is unchanged)
       if ((ks == 0 || ks == 2) && more2 && (ks == 2) == (wm == 1)) {
         if (ph == 0) issueB(0, tap2, ct2, b0nn);
-        if (ph == 1) issueA(0, tap2, ct2, par);
-        if (ph == 3) { issueA(1, tap2, ct2, par); issueB(1, tap2, ct2, 4 + par); }
+        if (ph == 1) issueA(0, tap2, ct2, s3nn);
+        if (ph == 3) { issueA(1, tap2, ct2, 3 + par); issueB(1, tap2, ct2, 5 + par); }
       }
       {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
         const int q3 = q + 3;
-        if (q3 < 16) { const int p3 = q3 >> 2; b[q3 & 3] = ldB((p3 == 1 || p3 == 2) ? 4 + par : b0cur, q3 & 3); }
-        else         b[q3 & 3] = ldB(b0nxt, q3 - 16);
+        if (q3 < 12) { const int p3 = q3 >> 2; b[q3 & 3] = ldB((p3 == 1 || p3 == 2) ? 5 + par : b0cur, q3 & 3); }
+        else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P3 re-uses the B0 fragments of P0 from registers (b0k)
       }
-      Mma<T>::run(b[q & 3], a[ks][0], acc[ih * 2 + 0][jh]);
-      Mma<T>::run(b[q & 3], a[ks][1], acc[ih * 2 + 1][jh]);
-      if (ph == 1) { a[ks][0] = ldA(par, 1, 0, ks); a[ks][1] = ldA(par, 1, 1, ks); }           // A1 of this K-tile
-      if (ph == 3) { a[ks][0] = ldA(par ^ 1, 0, 0, ks); a[ks][1] = ldA(par ^ 1, 0, 1, ks); }   // A0 of the next K-tile
+      if (ph == 0) b0k[ks] = b[q & 3];
+      const uint4 bq = ph == 3 ? b0k[ks] : b[q & 3];
+      Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
+      Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
+      if (ph == 1) { a[ks][0] = ldA(3 + par, 0, ks); a[ks][1] = ldA(3 + par, 1, ks); }   // A1 of this K-tile
+      if (ph == 3) { a[ks][0] = ldA(s3n, 0, ks); a[ks][1] = ldA(s3n, 1, ks); }           // A0 of the next K-tile
       if (ks == 3) {
         // end of P2: B0(i+1), A0(i+1) must have landed (read in P3); end of P3: A1(i+1), B1(i+1) (read from P0(i+1) on)
         if (ph == 2) { if (more2) wait_vmcnt<8>(); else if (i + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
         if (ph == 3) { if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
-        if (ph != 1) __builtin_amdgcn_s_barrier();
+        if (ph >= 2) __builtin_amdgcn_s_barrier();
       }
     }
     adv(tap2, ct2);
