@@ -937,7 +937,7 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
 //   P0: issue B0(i+2)            P1: issue A0(i+2)            P3: issue A1(i+2), B1(i+2)       (A0 and B0 have three slots, mod 3)
 // The A fragments of a half (8 x 16 B per lane) stay in registers for its two phases and are refilled in place (A1 during P1, the
 // next K-tile's A0 during P3); B fragments stream through a 4-deep register ring, three k-steps ahead (P3 re-uses the B0 fragments
-// of P0 from registers).  Two counted waits and two barriers per K-tile (after P2 and P3).
+// and P2 the B1 fragments of P1 from registers: 24 LDS fragment reads per 32 MFMAs).  Two counted waits and two barriers per K-tile.
 // Wave (wm, wn) of the 2 x 4 grid owns rows {h*128 + wm*64 ..+63} and columns {h*128 + wn*32 ..+31} of both halves h.
 constexpr int P8_SLOT = 128 * 128;
 constexpr int P8_RING = 10 * P8_SLOT;         // A0 x3, A1 x2, B1 x2, B0 x3 = the whole 160 KiB
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   if (nk > 1) { issueB(0, tap2, ct2, 8); issueA(0, tap2, ct2, 1); issueA(1, tap2, ct2, 4); issueB(1, tap2, ct2, 6); wait_vmcnt<8>(); } else wait_vmcnt<0>();
   adv(tap2, ct2);
   __builtin_amdgcn_s_barrier();
-  uint4 a[4][2], b[4], b0k[4];
+  uint4 a[4][2], b[4], b0k[4], b1k[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, ks); a[ks][1] = ldA(0, 1, ks); }
 #pragma unroll
@@ -1070,11 +1070,12 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       }
       {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
         const int q3 = q + 3;
-        if (q3 < 12) { const int p3 = q3 >> 2; b[q3 & 3] = ldB((p3 == 1 || p3 == 2) ? 5 + par : b0cur, q3 & 3); }
-        else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P3 re-uses the B0 fragments of P0 from registers (b0k)
+        if (q3 < 8) { const int p3 = q3 >> 2; b[q3 & 3] = ldB(p3 == 1 ? 5 + par : b0cur, q3 & 3); }
+        else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P2 / P3 re-use the B1 / B0 fragments of P1 / P0 from registers
       }
       if (ph == 0) b0k[ks] = b[q & 3];
-      const uint4 bq = ph == 3 ? b0k[ks] : b[q & 3];
+      if (ph == 1) b1k[ks] = b[q & 3];
+      const uint4 bq = ph == 3 ? b0k[ks] : (ph == 2 ? b1k[ks] : b[q & 3]);
       Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
       Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
       if (ph == 1) { a[ks][0] = ldA(3 + par, 0, ks); a[ks][1] = ldA(3 + par, 1, ks); }   // A1 of this K-tile
