@@ -50,33 +50,36 @@ def make_bottleneck(inplanes, planes, stride, dilation, with_ds, last_relu=True)
     return m
 
 
-def make_resnet(layers, dilated=True, os=8):
+def make_resnet(layers, dilated=True, os=8, multi_grid=False, relu_l3=True, relu_l4=True):
     # networks/backbones/resnet.py:81-121
     net = _Holder()
     net.conv1 = _conv(3, 64, 7, stride=2, pad=3)
     net.bn1 = nn.BatchNorm2d(64)
     state = {'inplanes': 64}
 
-    def stage(planes, n, stride=1, dilation=1):
+    def stage(planes, n, stride=1, dilation=1, grid=1, last_relu=True):
+        # resnet.py:105-121: block i gets dilation * grid[i % len(grid)]; only the LAST block may drop its final ReLU
+        mg = (lambda i: grid[i % len(grid)]) if isinstance(grid, tuple) else (lambda i: 1)
         blocks = []
         need_ds = stride != 1 or state['inplanes'] != planes * 4
-        blocks.append(make_bottleneck(state['inplanes'], planes, stride, dilation, need_ds))
+        blocks.append(make_bottleneck(state['inplanes'], planes, stride, dilation * mg(0), need_ds))
         state['inplanes'] = planes * 4
-        for _ in range(1, n):
-            blocks.append(make_bottleneck(state['inplanes'], planes, 1, dilation, False))
+        for i in range(1, n):
+            blocks.append(make_bottleneck(state['inplanes'], planes, 1, dilation * mg(i), False, last_relu=True if i != n - 1 else last_relu))
         return nn.Sequential(*blocks)
 
+    grid = (1, 2, 4) if multi_grid else (1, 1, 1)
     net.layer1 = stage(64, layers[0])
     net.layer2 = stage(128, layers[1], stride=2)
     if dilated and os == 8:      # resnet.py:95-97
-        net.layer3 = stage(256, layers[2], stride=1, dilation=2)
-        net.layer4 = stage(512, layers[3], stride=1, dilation=4)
+        net.layer3 = stage(256, layers[2], stride=1, dilation=2, last_relu=relu_l3)
+        net.layer4 = stage(512, layers[3], stride=1, dilation=4, grid=grid, last_relu=relu_l4)
     elif dilated:                # resnet.py:98-100
-        net.layer3 = stage(256, layers[2], stride=2)
-        net.layer4 = stage(512, layers[3], stride=1, dilation=2)
+        net.layer3 = stage(256, layers[2], stride=2, last_relu=relu_l3)
+        net.layer4 = stage(512, layers[3], stride=1, dilation=2, grid=grid, last_relu=relu_l4)
     else:                        # resnet.py:101-103
-        net.layer3 = stage(256, layers[2], stride=2)
-        net.layer4 = stage(512, layers[3], stride=2)
+        net.layer3 = stage(256, layers[2], stride=2, last_relu=relu_l3)
+        net.layer4 = stage(512, layers[3], stride=2, last_relu=relu_l4)
     return net
 
 
@@ -105,7 +108,7 @@ class PopOracle(nn.Module):
     """Same constructor surface / state_dict keys as networks/pspnet_pop.py:37-74."""
 
     def __init__(self, n_base, criterion=None, is_ft=False, n_novel=0, backbone='resnet50',
-                 dilated=True, os=8, d_model=D_MODEL, feat_channels=2048, _custom_backbone=None):
+                 dilated=True, os=8, d_model=D_MODEL, feat_channels=2048, _custom_backbone=None, multi_grid=False, relu_l3=True, relu_l4=True):
         super().__init__()
         if is_ft:   # pspnet_pop.py:54-56 -- own parameters are registered before child modules
             self.base_emb = nn.Parameter(torch.zeros(n_base, d_model), requires_grad=False)
@@ -113,7 +116,7 @@ class PopOracle(nn.Module):
         else:       # pspnet_pop.py:67-69
             self.base_emb = nn.Parameter(torch.zeros(n_base, d_model), requires_grad=True)
             self.novel_emb = None
-        self.backbone = _custom_backbone if _custom_backbone is not None else make_resnet(RESNET_LAYERS[backbone], dilated, os)
+        self.backbone = _custom_backbone if _custom_backbone is not None else make_resnet(RESNET_LAYERS[backbone], dilated, os, multi_grid, relu_l3, relu_l4)
         self.decoder = make_ppm(feat_channels, d_model)
         self.classifier = make_classifier(d_model)
         if is_ft:

@@ -363,7 +363,33 @@ def g11():
         save('g11_eval_' + tag, pred=seg_pred, cm=cm, iou=iou, miou=np.array([np.nanmean(iou[:8]), np.nanmean(iou[8:]), np.nanmean(iou)]))
 
 
-ALL = dict(g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+def g12():
+    """Constructor kwargs off the default path (networks/backbones/resnet.py:81-121): multi_grid=(1,2,4) dilations in layer4, relu_l3 /
+    relu_l4 = False (no final ReLU in the last block of the layer), at os 8 and os 16; full model, small tile."""
+    for tag, kw in (('a', dict(dilated=True, os=8, multi_grid=True, relu_l3=True, relu_l4=False)),
+                    ('b', dict(dilated=True, os=16, multi_grid=True, relu_l3=False, relu_l4=False))):
+        ref = ref_pop.GFSS_Model(n_base=7, criterion=RefOrthLoss(ignore_index=255), backbone='resnet50', pretrained_model=None, **kw)
+        ora = po.PopOracle(n_base=7, criterion=po.OrthLossOracle(ignore_index=255), backbone='resnet50', **kw)
+        assert list(ref.state_dict().keys()) == list(ora.state_dict().keys())
+        sd = fm.formula_state_dict(ref)
+        ref.load_state_dict(sd, strict=True); ora.load_state_dict(sd, strict=True)
+        img = fm.formula_image(2, 96, 128, 'g12%s/img' % tag)
+        mask = fm.formula_mask(2, 96, 128, 8, 'g12%s/mask' % tag, ignore_rows=5)
+        ref.train(); ora.train()
+        lr, lo = ref(img, mask), ora(img, mask)
+        lr['total_loss'].backward(); lo['total_loss'].backward()
+        for k in lr:
+            same(lr[k], lo[k], 'g12 ' + k)
+        same(ref.base_emb.grad, ora.base_emb.grad, 'g12 d_base_emb', 1e-6)
+        ref.eval(); ora.eval()
+        with torch.no_grad():
+            pe, po_ = ref(img), ora(img)
+        same(pe, po_, 'g12 eval logits', 1e-6)
+        save('g12_kwargs_' + tag, total=lr['total_loss'], seg=lr['seg_loss'], orth=lr['orth_loss'], d_base_emb=ref.base_emb.grad,
+             logits_eval=pe, rm_l4=ref.backbone.layer4[2].bn3.running_mean)
+
+
+ALL = dict(g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -384,3 +384,26 @@ def test_ft_configs_vs_same_box_oracle(hip, B, H, W, os_):
     m.eval(); o.eval()
     with torch.no_grad():
         check(m(img.to(DEV)), o(img).numpy(), 2e-3, 'forward_all logits')
+
+
+@pytest.mark.parametrize('tag,kw', [('a', dict(dilated=True, os=8, multi_grid=True, relu_l3=True, relu_l4=False)),
+                                    ('b', dict(dilated=True, os=16, multi_grid=True, relu_l3=False, relu_l4=False))])
+def test_g12_constructor_kwargs(hip, tag, kw):
+    """multi_grid (layer4 dilations 4/8/16 at os 8) and relu_l3 / relu_l4 = False against the reference's golden vectors, fp32."""
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    g = golden('g12_kwargs_' + tag)
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, compute_dtype=torch.float32, **kw)
+    fm.load_formula_weights(m)
+    m = m.to(DEV).train()
+    img = fm.formula_image(2, 96, 128, 'g12%s/img' % tag).to(DEV)
+    mask = fm.formula_mask(2, 96, 128, 8, 'g12%s/mask' % tag, ignore_rows=5).to(DEV)
+    d = m(img, mask)
+    d['total_loss'].backward()
+    np.testing.assert_allclose(d['total_loss'].item(), g['total'], rtol=1e-3)
+    np.testing.assert_allclose(d['seg_loss'].item(), g['seg'], rtol=1e-3)
+    check_grad(m.base_emb.grad, g['d_base_emb'], 2e-2, 'd base_emb')
+    check(m.backbone.layer4[2].bn3.running_mean, g['rm_l4'], 1e-3, 'running_mean layer4')
+    m.eval()
+    with torch.no_grad():
+        check(m(img), g['logits_eval'], 2e-3, 'eval logits')

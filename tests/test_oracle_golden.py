@@ -152,6 +152,27 @@ def test_g10_iou():
     assert np.array_equal(i.numpy(), g['inter']) and np.array_equal(u.numpy(), g['union']) and np.array_equal(t.numpy(), g['target'])
 
 
+G12 = {'a': dict(dilated=True, os=8, multi_grid=True, relu_l3=True, relu_l4=False),
+       'b': dict(dilated=True, os=16, multi_grid=True, relu_l3=False, relu_l4=False)}
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_g12_constructor_kwargs(tag):
+    """multi_grid / relu_l3 / relu_l4 (networks/backbones/resnet.py:81-121) through the oracle against the reference's vectors."""
+    g = golden('g12_kwargs_' + tag)
+    o = fm.load_formula_weights(po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), backbone='resnet50', **G12[tag])).train()
+    img = fm.formula_image(2, 96, 128, 'g12%s/img' % tag)
+    mask = fm.formula_mask(2, 96, 128, 8, 'g12%s/mask' % tag, ignore_rows=5)
+    d = o(img, mask)
+    d['total_loss'].backward()
+    close(d['total_loss'].detach(), g['total']); close(d['seg_loss'].detach(), g['seg']); close(d['orth_loss'].detach(), g['orth'])
+    close(o.base_emb.grad, g['d_base_emb'], rtol=1e-4, atol=1e-7)
+    close(o.backbone.layer4[2].bn3.running_mean, g['rm_l4'])
+    o.eval()
+    with torch.no_grad():
+        close(o(img), g['logits_eval'], rtol=1e-4, atol=1e-6)
+
+
 def test_g11_eval_confusion():
     """eval_base.py:166-199 / eval_ft.py:166-181: prediction mask, confusion matrix and IoU vector."""
     logits = fm.sym('g11/logits', (2, 12, 16, 12), 2.0)
