@@ -60,6 +60,35 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize('variant', [1, 2, 3, 4, 5])
+def test_conv_kernel_generations_agree(hip, variant):
+    """SEGLAND_CONV_VARIANT / SEGLAND_WGRAD_VARIANT (environment switches) select older kernel generations for A/B runs:
+    every generation must produce the same convolution (bf16 tolerance) on a 256-row-tile shape and on a ragged one."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    try:
+        hip.sl_debug_conv_variant(variant)
+        hip.sl_debug_wgrad_variant(1 if variant == 1 else 2)
+        for (B, H, W, Cin, Cout, k, st, pad, dil) in [(8, 64, 64, 256, 256, 3, 1, 2, 2), (7, 60, 64, 128, 512, 1, 1, 0, 1)]:
+            tag = 'gen%s' % ((B, H, W, Cin, Cout, k),)
+            x = rnd(fm.sym(tag + 'x', (B, Cin, H, W), 1.0), dtype).requires_grad_(True)
+            w = rnd(fm.sym(tag + 'w', (Cout, Cin, k, k), (3.0 / (Cin * k * k)) ** 0.5), dtype).requires_grad_(True)
+            y_ref = F.conv2d(x, w, None, st, pad, dil)
+            gy = rnd(fm.sym(tag + 'gy', tuple(y_ref.shape), 1.0), dtype)
+            y_ref.backward(gy)
+            spec = ops.ConvSpec(Cin, Cout, k, st, pad, dil)
+            wf, wb = ops.weight_prep(w.detach().to(DEV), dtype)
+            xg, gyg = nhwc(x.detach(), dtype), nhwc(gy, dtype)
+            y, part = ops.conv2d_fwd(xg, wf, spec, want_stats=True)
+            assert_close(nchw(y), y_ref, dtype, 'fwd v%d' % variant)
+            assert_close(part.sum(0).cpu()[0], y_ref.detach().sum((0, 2, 3)), dtype, 'stats v%d' % variant, scale=float(y_ref.abs().sum((0, 2, 3)).max()))
+            assert_close(nchw(ops.conv2d_bwd_data(gyg, wb, spec, (H, W))), x.grad, dtype, 'dgrad v%d' % variant)
+            assert_close(ops.conv2d_bwd_weight(xg, gyg, spec), w.grad, dtype, 'wgrad v%d' % variant)
+    finally:
+        hip.sl_debug_conv_variant(5)
+        hip.sl_debug_wgrad_variant(2)
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_dgrad_wgrad(hip, dtype, case):
