@@ -126,3 +126,17 @@ def test_fused_optimizer_refreshes_weight_copies(hip):
         outs.append(after)
     err = float((outs[0] - outs[1]).norm() / outs[1].norm())
     assert err < 5e-2, 'fused vs foreach AdamW after one step: %.3g' % err
+
+
+def test_overfits_one_batch_bf16_and_fp32(hip):
+    """End-to-end learning check (tools/overfit_check.py): 40 fused-AdamW steps on one fixed batch drive the segmentation loss from
+    ln 8 = 2.08 to < 0.4 in fp32 AND in bf16 mode (measured 0.17 / 0.15); a stale weight copy, a wrong BN statistic or a broken
+    gradient anywhere in the chain shows up here as a flat curve."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('overfit_check', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'overfit_check.py'))
+    oc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(oc)
+    for dt in (torch.bfloat16, torch.float32):
+        curve = oc.run(dt, steps=40)
+        assert 1.9 < curve[0] < 2.3, curve[0]
+        assert curve[-1] < 0.4 and all(v == v for v in curve), (str(dt), curve[-1])
