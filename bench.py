@@ -45,6 +45,7 @@ def parse():
     p.add_argument('--size', type=int, default=512)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-budget', type=float, default=40.0, help='seconds of CPU work allowed for the cpu_baseline sample')
+    p.add_argument('--torch-optimizer', action='store_true', help='torch.optim.AdamW(fused=True) instead of segland_amd.optim.AdamW')
     p.add_argument('--single-step', action='store_true', help='one AdamW step per iteration (the reference does two, train_base.py:262-264)')
     p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
     return p.parse_args()
@@ -58,9 +59,12 @@ def synthetic_batch(B, size, device, seed=0):
     return img.to(device), mask.to(device)
 
 
-def make_optimizer(model, lr=1e-3, wd=1e-4):
+def make_optimizer(model, lr=1e-3, wd=1e-4, torch_optimizer=False):
     from segland_amd.utils.pyt_utils import get_parameters
-    return torch.optim.AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd, fused=True)
+    if torch_optimizer:
+        return torch.optim.AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd, fused=True)
+    from segland_amd.optim import AdamW          # same update rule and state_dict, one launch over all parameters (csrc/optim.hip)
+    return AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd)
 
 
 def train_step(model, opt, img, mask, params, double_step):
@@ -68,9 +72,12 @@ def train_step(model, opt, img, mask, params, double_step):
     loss = model(img, mask)
     loss['total_loss'].backward()
     torch.nn.utils.clip_grad_norm_(params, 5.0)
-    opt.step()
-    if double_step:
+    if double_step and hasattr(opt, 'repeat_next'):
+        opt.step(repeat=2)                        # the reference's two steps on the same gradients, one pass over the state
+    else:
         opt.step()
+        if double_step:
+            opt.step()
     return loss
 
 
@@ -143,7 +150,7 @@ def main():
     torch.manual_seed(0)
     model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, dilated=True, os=8,
                        compute_dtype=dtype).to(dev).train()
-    opt = make_optimizer(model)
+    opt = make_optimizer(model, torch_optimizer=a.torch_optimizer)
     net = model
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,

@@ -1,0 +1,70 @@
+// AdamW over ALL parameters of a model in one launch (train_base.py:197-204 builds torch.optim.AdamW; its loop body steps it
+// twice per iteration, train_base.py:262-264).  HBM-bound: 16 B read + 12 B written per element and step; `repeat` consecutive steps on
+// the same gradient are applied in registers, so the reference's double step costs one pass instead of two.
+// Arithmetic = torch/csrc/.../fused_adam_utils.cuh (ADAMW, amsgrad off, maximize off): decoupled decay, lerp first moment,
+// bias-corrected step size, denom = sqrt(v)/sqrt(bc2) + eps.
+#include "common.h"
+
+namespace {
+
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long numel; float lr, wd; long long start; long long pad_; };
+static_assert(sizeof(AdamEntry) == 64, "table layout is part of the ABI");
+constexpr int AD_CHUNK = 4096;        // elements per block
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __restrict__ tab, int n, long long total_chunks, float b1, float b2, float eps,
+                                                          float bc1_0, float rs2_0, float bc1_1, float rs2_1, int repeat, const float* __restrict__ gscale) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= chunk) lo = mid; else hi = mid - 1; }
+    const AdamEntry t = tab[lo];
+    const long long base = (chunk - t.start) * AD_CHUNK;
+    const float decay = 1.f - t.lr * t.wd;
+    for (int k = threadIdx.x * 4; k < AD_CHUNK; k += 1024) {
+      const long long e = base + k;
+      if (e >= t.numel) break;
+      const int cnt = (int)((t.numel - e) < 4 ? (t.numel - e) : 4);
+      float p[4], g[4], m[4], v[4];
+      if (cnt == 4 && ((t.numel & 3) == 0)) {
+        const float4 P = *(const float4*)(t.p + e), G = *(const float4*)(t.g + e), M = *(const float4*)(t.m + e), V = *(const float4*)(t.v + e);
+        p[0] = P.x; p[1] = P.y; p[2] = P.z; p[3] = P.w; g[0] = G.x; g[1] = G.y; g[2] = G.z; g[3] = G.w;
+        m[0] = M.x; m[1] = M.y; m[2] = M.z; m[3] = M.w; v[0] = V.x; v[1] = V.y; v[2] = V.z; v[3] = V.w;
+      } else {
+        for (int j = 0; j < cnt; ++j) { p[j] = t.p[e + j]; g[j] = t.g[e + j]; m[j] = t.m[e + j]; v[j] = t.v[e + j]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = g[j] * gs;
+        for (int r = 0; r < repeat; ++r) {
+          const float bc1 = r == 0 ? bc1_0 : bc1_1, rs2 = r == 0 ? rs2_0 : rs2_1;
+          p[j] *= decay;
+          m[j] = m[j] + (gj - m[j]) * (1.f - b1);
+          v[j] = b2 * v[j] + (1.f - b2) * gj * gj;
+          const float denom = sqrtf(v[j]) / rs2 + eps;
+          p[j] -= (t.lr / bc1) * (m[j] / denom);
+        }
+      }
+      if (cnt == 4 && ((t.numel & 3) == 0)) {
+        *(float4*)(t.p + e) = make_float4(p[0], p[1], p[2], p[3]);
+        *(float4*)(t.m + e) = make_float4(m[0], m[1], m[2], m[3]);
+        *(float4*)(t.v + e) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        for (int j = 0; j < cnt; ++j) { t.p[e + j] = p[j]; t.m[e + j] = m[j]; t.v[e + j] = v[j]; }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
+                              float bias_correction1, float bias_correction2_sqrt, float bias_correction1_next, float bias_correction2_sqrt_next,
+                              int repeat, const float* grad_scale, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && n > 0 && total_chunks > 0 && (repeat == 1 || repeat == 2), "adamw_multi: bad args");
+  SL_REQUIRE(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f, "adamw_multi: bias corrections must be positive (step >= 1)");
+  const int blocks = (int)(total_chunks < 8192 ? total_chunks : 8192);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table_dev, n, total_chunks, beta1, beta2, eps,
+                     bias_correction1, bias_correction2_sqrt, bias_correction1_next, bias_correction2_sqrt_next, repeat, grad_scale);
+  SL_LAUNCH_CHECK("adamw_multi_kernel");
+  return 0;
+}

@@ -543,6 +543,10 @@ def iou_hist(pred_u8, target, K, ignore_index):
     return hist
 
 
+def adamw_multi(table, n, total_chunks, b1, b2, eps, bc1, rs2, bc1n, rs2n, repeat, grad_scale=None):
+    check(_lib.lib().sl_adamw_multi(_p(table), n, int(total_chunks), b1, b2, eps, bc1, rs2, bc1n, rs2n, int(repeat), _p(grad_scale), _s()), 'adamw_multi')
+
+
 def confusion_matrix(pred_u8, target, K, ignore_index):
     """[K][K] int64 counts, rows = ground truth, columns = prediction, pixels with target == ignore_index dropped."""
     cm = torch.zeros((K, K), dtype=torch.int64, device=target.device)

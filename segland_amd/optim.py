@@ -1,0 +1,64 @@
+"""AdamW with the interface and state_dict layout of torch.optim.AdamW, stepped by ONE hand-written kernel launch over all parameters
+(csrc/optim.hip).  `step(repeat=2)` applies the reference's two consecutive steps per iteration (train_base.py:262-264) in a single
+pass over the optimizer state.  Parameters / gradients must be contiguous fp32 tensors on the GPU (there is no CPU fallback)."""
+import math
+import struct
+
+import torch
+
+from . import ops
+
+
+class AdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **unused):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError('AdamW: invalid hyper-parameter')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._table, self._rec = None, None
+        self.repeat_next = 1          # drivers: set to 2 to fold the reference's second step() into the next one
+
+    @torch.no_grad()
+    def step(self, closure=None, repeat=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        repeat = self.repeat_next if repeat is None else repeat
+        self.repeat_next = 1
+        rec, n, start, step_t, hyper = bytearray(), 0, 0, None, None
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            hp = (b1, b2, group['eps'])
+            if hyper is not None and hp != hyper:
+                raise RuntimeError('segland_amd.optim.AdamW: betas / eps must be equal across parameter groups')
+            hyper = hp
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise RuntimeError('segland_amd.optim.AdamW: contiguous float32 GPU parameters and gradients only')
+                st = self.state[p]
+                if not st:
+                    st['step'] = torch.tensor(0.0)
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                t = int(st['step']) + 1
+                if step_t is not None and t != step_t:
+                    raise RuntimeError('segland_amd.optim.AdamW: all stepped parameters must share one step count')
+                step_t = t
+                st['step'] += repeat
+                rec += struct.pack('<QQQQqffqq', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                                   p.numel(), group['lr'], group['weight_decay'], start, 0)
+                start += (p.numel() + 4095) // 4096
+                n += 1
+        if n == 0:
+            return loss
+        dev = next(p for g in self.param_groups for p in g['params'] if p.grad is not None).device
+        if self._rec != rec:          # the caching allocator hands back the same gradient addresses step after step: usually no upload
+            # pinned staging + asynchronous copy: a pageable upload would synchronise the host with the GPU once per step
+            self._table, self._rec = torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True), bytes(rec)
+        table = self._table
+        b1, b2, eps = hyper
+        bc = [(1.0 - b1 ** (step_t + r), math.sqrt(1.0 - b2 ** (step_t + r))) for r in (0, 1)]
+        ops.adamw_multi(table, n, start, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat)
+        return loss

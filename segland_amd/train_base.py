@@ -23,8 +23,11 @@ def train_iteration(model, optimizer, loss_scaler, img, mask, double_step=True):
     """Loop body of train_base.py:250-264."""
     optimizer.zero_grad()
     loss_dict = model(img, mask)
+    fold = double_step and hasattr(optimizer, 'repeat_next')
+    if fold:
+        optimizer.repeat_next = 2     # segland_amd.optim.AdamW: both steps of the reference in one pass over the optimizer state
     grad_norm = loss_scaler(loss_dict['total_loss'], optimizer, clip_grad=5.0, parameters=model.parameters())
-    if double_step:
+    if double_step and not fold:
         optimizer.step()          # the reference's second step on the same gradients (SURVEY.md 0.6)
     return loss_dict, grad_norm
 
@@ -59,7 +62,11 @@ def main(argv=None):
         if args.freeze_backbone:
             my_utils.load_model(seg_model, args.restore_from, backbone_only=args.finetune, is_restore=not args.finetune)
         params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
-        optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay, fused=engine.use_cuda)
+        if engine.use_cuda:
+            from .optim import AdamW                                    # torch.optim.AdamW semantics / state_dict, one kernel launch per step
+            optimizer = AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
+        else:
+            optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
         model = engine.data_parallel(seg_model)
         loss_scaler = my_utils.NativeScalerWithGradNormCount()
         if engine.is_main:

@@ -290,6 +290,31 @@ def test_ppm_rows_gemm(hip, B, K, N):
         off += n
 
 
+@pytest.mark.parametrize('repeat', [1, 2])
+def test_adamw_multi_matches_torch(hip, repeat):
+    """One-launch AdamW (csrc/optim.hip) against torch.optim.AdamW over 3 iterations, two parameter groups (lr x10 / wd 0 as in
+    utils/pyt_utils.py:216-249), ragged sizes; repeat=2 = the reference's two steps per iteration (train_base.py:262-264)."""
+    from segland_amd.optim import AdamW
+    shapes = [(64, 3, 7, 7), (513,), (256, 64, 1, 1), (7, 512), (1,), (128, 128, 3, 3)]
+    mine = [fm.sym('adam/p%d' % i, s, 1.0).to(DEV).requires_grad_(True) for i, s in enumerate(shapes)]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    groups = lambda ps: [dict(params=ps[:3], lr=1e-3), dict(params=ps[3:], lr=1e-2, weight_decay=0.0)]
+    o1 = AdamW(groups(mine), lr=1e-3, weight_decay=1e-2)
+    o2 = torch.optim.AdamW(groups(ref), lr=1e-3, weight_decay=1e-2, foreach=True)
+    for it in range(3):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            g = fm.sym('adam/g%d_%d' % (it, i), tuple(a.shape), 0.5).to(DEV)
+            a.grad, b.grad = g.clone(), g.clone()
+        o1.step(repeat=repeat)
+        for _ in range(repeat):
+            o2.step()
+    for a, b in zip(mine, ref):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
+    s1, s2 = o1.state_dict(), o2.state_dict()
+    assert set(s1['state'][0]) == set(s2['state'][0]) and float(s1['state'][0]['step']) == float(s2['state'][0]['step']) == 3 * repeat
+    assert float((s1['state'][5]['exp_avg_sq'] - s2['state'][5]['exp_avg_sq']).abs().max()) < 1e-7
+
+
 def test_weight_prep_batched(hip):
     """One-launch tiled weight prep == the per-conv kernel, bit for bit (bf16 and fp32 entries, 1x1 and 3x3, ragged channel counts)."""
     from segland_amd import functional as sf
