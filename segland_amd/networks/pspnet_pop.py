@@ -40,6 +40,9 @@ def _classifier(d):
                          nn.Conv2d(d, 1, kernel_size=1, bias=False))
 
 
+_FEATURE_GRAPH = __import__('os').environ.get('SEGLAND_FEATURE_GRAPH', '1') != '0'
+
+
 class GFSS_Model(nn.Module):
     """Segmenter for Generalized Few-shot Semantic Segmentation (networks/pspnet_pop.py:37-243)."""
 
@@ -87,14 +90,57 @@ class GFSS_Model(nn.Module):
             return self.forward_all(img, mask)
         return self.forward_base(img, mask)
 
-    def _features(self, img):
-        if not img.is_cuda:
-            raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
+    def _features_eager(self, img):
         refresh_weights(self)
         x4 = self.backbone.base_forward(img)
         feat = self.decoder(x4)
         flush_num_batches_tracked()
         return feat
+
+    def _features(self, img):
+        if not img.is_cuda:
+            raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
+        if self.is_ft and self.training and _FEATURE_GRAPH and not torch.cuda.is_current_stream_capturing():
+            feat = self._features_graphed(img)
+            if feat is not None:
+                return feat
+        return self._features_eager(img)
+
+    def _features_graphed(self, img):
+        """ft_pop training: backbone + decoder are frozen and in eval mode (train_mode(), pspnet_pop.py:80-85), i.e. ~250 launches of a
+        fixed kernel sequence per step with a step time of a few ms -- launch-bound.  The sequence is captured once per input shape into
+        a HIP graph and replayed; any change of a frozen tensor (load_state_dict bumps the version counters) drops the graph."""
+        frozen = list(self.backbone.parameters()) + list(self.decoder.parameters())
+        if self.backbone.training or self.decoder.training or any(p.requires_grad for p in frozen):
+            return None
+        sig = (tuple(img.shape), img.dtype, img.device,
+               sum(p._version for p in frozen) + sum(b._version for b in self.backbone.buffers()) + sum(b._version for b in self.decoder.buffers()))
+        ent = self.__dict__.get('_sl_graph')
+        if ent is None or ent[0] != sig:
+            try:
+                static_in = img.detach().clone()
+                cur = torch.cuda.current_stream()
+                side = torch.cuda.Stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(2):                       # warm-up: weight copies, BN coefficients, workspaces, kernel attributes
+                        self._features_eager(static_in)
+                cur.wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph), torch.no_grad():
+                    static_out = self._features_eager(static_in)
+                ent = self.__dict__['_sl_graph'] = (sig, graph, static_in, static_out)
+            except Exception as e:                            # stay on the eager HIP path
+                import logging
+                logging.warning('segland_amd: HIP graph capture of the frozen feature extractor failed (%s); running eagerly', e)
+                self.__dict__['_sl_graph'] = (sig, None, None, None)
+                return None
+        _, graph, static_in, static_out = ent
+        if graph is None:
+            return None
+        static_in.copy_(img)
+        graph.replay()
+        return static_out.clone()
 
     def _head(self, feat):
         sb = F.normalize(self.base_emb.float(), p=2, dim=-1)

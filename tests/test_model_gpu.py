@@ -407,3 +407,24 @@ def test_g12_constructor_kwargs(hip, tag, kw):
     m.eval()
     with torch.no_grad():
         check(m(img), g['logits_eval'], 2e-3, 'eval logits')
+
+
+def test_ft_feature_graph_tracks_frozen_weights(hip):
+    """ft_pop mode replays the frozen backbone + decoder from a HIP graph (pspnet_pop._features_graphed): the replay must equal the
+    eager kernel sequence, for a second input too, and an in-place change of a frozen weight (version bump, as load_state_dict does)
+    must drop the graph."""
+    from segland_amd.networks import pspnet_pop as pp
+    m = build(True, 4, dtype=torch.float32, criterion=False)
+    m.init_cls_n()
+    m.train_mode()
+    img = fm.formula_image(2, 128, 128, 'graph/img').to(DEV)
+    img2 = fm.formula_image(2, 128, 128, 'graph/img2').to(DEV)
+    with torch.no_grad():
+        for x in (img, img2, img):
+            assert torch.equal(m._features(x), m._features_eager(x))
+        assert m.__dict__['_sl_graph'][1] is not None, 'graph capture did not happen'
+        g_before = m.__dict__['_sl_graph'][1]
+        m.backbone.layer4[2].conv3.weight.mul_(0.5)
+        f = m._features(img)
+        assert m.__dict__['_sl_graph'][1] is not g_before
+        assert torch.equal(f, m._features_eager(img))
