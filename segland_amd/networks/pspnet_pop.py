@@ -100,20 +100,22 @@ class GFSS_Model(nn.Module):
     def _features(self, img):
         if not img.is_cuda:
             raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
-        if self.is_ft and self.training and _FEATURE_GRAPH and not torch.cuda.is_current_stream_capturing():
+        if _FEATURE_GRAPH and not torch.cuda.is_current_stream_capturing() and ((self.is_ft and self.training) or (not self.training and not torch.is_grad_enabled())):
             feat = self._features_graphed(img)
             if feat is not None:
                 return feat
         return self._features_eager(img)
 
     def _features_graphed(self, img):
-        """ft_pop training: backbone + decoder are frozen and in eval mode (train_mode(), pspnet_pop.py:80-85), i.e. ~250 launches of a
-        fixed kernel sequence per step with a step time of a few ms -- launch-bound.  The sequence is captured once per input shape into
+        """ft_pop training (backbone + decoder frozen and in eval mode: train_mode(), pspnet_pop.py:80-85) and no-grad evaluation
+        (validate(), eval_base.py): ~250 launches of a fixed kernel sequence per call with a call time of a few ms -- launch-bound.  The sequence is captured once per input shape into
         a HIP graph and replayed; any change of a frozen tensor (load_state_dict bumps the version counters) drops the graph."""
         frozen = list(self.backbone.parameters()) + list(self.decoder.parameters())
-        if self.backbone.training or self.decoder.training or any(p.requires_grad for p in frozen):
+        trainable = any(p.requires_grad for p in frozen)
+        if self.backbone.training or self.decoder.training or (trainable and torch.is_grad_enabled()):
             return None
-        sig = (tuple(img.shape), img.dtype, img.device,
+        from ..functional import _OPT_EPOCH              # fused optimizers change trainable weights without a version bump
+        sig = (tuple(img.shape), img.dtype, img.device, _OPT_EPOCH[0] if trainable else 0,
                sum(p._version for p in frozen) + sum(b._version for b in self.backbone.buffers()) + sum(b._version for b in self.decoder.buffers()))
         ent = self.__dict__.get('_sl_graph')
         if ent is None or ent[0] != sig:
