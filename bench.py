@@ -71,10 +71,12 @@ def train_step(model, opt, img, mask, params, double_step):
     opt.zero_grad(set_to_none=True)
     loss = model(img, mask)
     loss['total_loss'].backward()
-    torch.nn.utils.clip_grad_norm_(params, 5.0)
-    if double_step and hasattr(opt, 'repeat_next'):
-        opt.step(repeat=2)                        # the reference's two steps on the same gradients, one pass over the state
+    if hasattr(opt, 'repeat_next'):
+        from segland_amd.optim import clip_coefficient
+        _, coef = clip_coefficient(params, 5.0)   # clip_grad_norm_(5.0): the coefficient is applied inside the optimizer kernel
+        opt.step(repeat=2 if double_step else 1, grad_scale=coef)      # the reference's two steps on the same gradients in one pass
     else:
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
         if double_step:
             opt.step()

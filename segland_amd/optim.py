@@ -18,7 +18,9 @@ class AdamW(torch.optim.Optimizer):
         self.repeat_next = 1          # drivers: set to 2 to fold the reference's second step() into the next one
 
     @torch.no_grad()
-    def step(self, closure=None, repeat=None):
+    def step(self, closure=None, repeat=None, grad_scale=None):
+        """grad_scale: optional 1-element float32 GPU tensor multiplied into every gradient inside the kernel (the clip_grad_norm_
+        coefficient, see clip_coefficient()) -- the gradients themselves are left unscaled."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -60,5 +62,16 @@ class AdamW(torch.optim.Optimizer):
         table = self._table
         b1, b2, eps = hyper
         bc = [(1.0 - b1 ** (step_t + r), math.sqrt(1.0 - b2 ** (step_t + r))) for r in (0, 1)]
-        ops.adamw_multi(table, n, start, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat)
+        ops.adamw_multi(table, n, start, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat, grad_scale=grad_scale)
         return loss
+
+
+def clip_coefficient(parameters, max_norm):
+    """(total_norm, coefficient) of torch.nn.utils.clip_grad_norm_(parameters, max_norm) WITHOUT scaling the gradients: the coefficient
+    min(1, max_norm / (total_norm + 1e-6)) is handed to AdamW.step(grad_scale=...) and applied inside the optimizer kernel."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.0), None
+    total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).to(torch.float32).reshape(1)
+    return total, coef

@@ -96,6 +96,11 @@ class NativeScalerWithGradNormCount:
         if not update_grad:
             return None
         params = [p for p in parameters if p.grad is not None]
+        if clip_grad is not None and hasattr(optimizer, 'repeat_next'):
+            from ..optim import clip_coefficient           # segland_amd.optim.AdamW applies the clip coefficient inside its kernel
+            norm, coef = clip_coefficient(params, clip_grad)
+            optimizer.step(grad_scale=coef)
+            return norm
         if clip_grad is not None:
             norm = torch.nn.utils.clip_grad_norm_(params, clip_grad)
         else:

@@ -301,11 +301,16 @@ def test_adamw_multi_matches_torch(hip, repeat):
     groups = lambda ps: [dict(params=ps[:3], lr=1e-3), dict(params=ps[3:], lr=1e-2, weight_decay=0.0)]
     o1 = AdamW(groups(mine), lr=1e-3, weight_decay=1e-2)
     o2 = torch.optim.AdamW(groups(ref), lr=1e-3, weight_decay=1e-2, foreach=True)
+    from segland_amd.optim import clip_coefficient
     for it in range(3):
         for i, (a, b) in enumerate(zip(mine, ref)):
             g = fm.sym('adam/g%d_%d' % (it, i), tuple(a.shape), 0.5).to(DEV)
             a.grad, b.grad = g.clone(), g.clone()
-        o1.step(repeat=repeat)
+        norm, coef = clip_coefficient(mine, 5.0)                 # clipping folded into the kernel vs clip_grad_norm_ + step
+        assert float(coef) < 1.0
+        o1.step(repeat=repeat, grad_scale=coef)
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, 5.0)
+        assert abs(float(norm) - float(norm_ref)) <= 1e-5 * float(norm_ref)
         for _ in range(repeat):
             o2.step()
     for a, b in zip(mine, ref):
