@@ -45,6 +45,8 @@ _COMMON = [
     ('--test-batch-size', dict(type=int, default=1, help='Number of images sent to the network in one validation step.')),
     ('--filter-novel', dict(action='store_true', default=False, help='filter images containing novel classes during training.')),
     ('--freeze-backbone', dict(action='store_true', default=False, help='freeze the backbone during training.')),
+    ('--allow-random-init', dict(action='store_true', default=False, help='continue with random weights when --restore-from does not exist '
+                                                                           '(the reference fails in torch.load; so does this build without the flag).')),
     ('--fp16', dict(action='store_true', default=False, help='mixed precision: bf16 MFMA with fp32 accumulate on MI355X '
                                                                 '(the reference uses fp16 autocast + GradScaler); default is exact-fp32 MFMA.')),
 ]
@@ -114,6 +116,19 @@ def save_checkpoint(model, path):
 
 def miou(inter, union):
     return np.nanmean((inter / union).cpu().numpy())
+
+
+def checkpoint_or_none(path, allow_random_init, what='--restore-from'):
+    """The path if it exists; None (random initialisation) only when explicitly allowed.  The reference raises inside torch.load for a
+    missing file (utils/pyt_utils.py:91); silently training / evaluating a random model is never what the caller meant."""
+    import os.path as osp
+    if path and osp.exists(str(path)):
+        return path
+    if allow_random_init:
+        import logging
+        logging.getLogger('Segmentation').error('%s=%r does not exist: continuing with RANDOM weights (--allow-random-init)', what, path)
+        return None
+    raise FileNotFoundError('%s=%r does not exist (pass --allow-random-init to run with random weights)' % (what, path))
 
 
 def resolve(dataset_pkg, name):

@@ -38,13 +38,16 @@ class Engine(object):
         self.args = self.parser.parse_args(argv)
         self.continue_state_object = self.args.continue_fpath
         self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
-        self.distributed = self.world_size > 1
+        # SEGLAND_FORCE_DDP=1: the DDP / RCCL code path also at world size 1 (tests and A/B timing on one GPU)
+        self.distributed = self.world_size > 1 or os.environ.get('SEGLAND_FORCE_DDP') == '1'
         self.local_rank = int(os.environ.get('LOCAL_RANK', self.args.local_rank))
         self.use_cuda = torch.cuda.is_available()
         if self.use_cuda:
             torch.cuda.set_device(self.local_rank)
         self.device = torch.device('cuda', self.local_rank) if self.use_cuda else torch.device('cpu')
         if self.distributed and not dist.is_initialized():
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29500')
             dist.init_process_group(backend='nccl' if self.use_cuda else 'gloo', init_method='env://')
         self.rank = dist.get_rank() if self.distributed else 0
         self.devices = list(range(self.world_size))

@@ -18,7 +18,7 @@ import torch
 
 from . import dataset as dataset_pkg
 from . import networks
-from .drivers import compute_dtype, resolve, str2bool
+from .drivers import checkpoint_or_none, compute_dtype, resolve, str2bool
 from .engine import Engine
 from .utils import pyt_utils as my_utils
 
@@ -43,6 +43,7 @@ def get_parser():
     p.add_argument('--fold', type=int, default=0, choices=[0, 1, 2, 3])
     p.add_argument('--shot', type=int, default=1)
     p.add_argument('--fp16', action='store_true')
+    p.add_argument('--allow-random-init', action='store_true', help='evaluate random weights when --restore-from does not exist')
     return p
 
 
@@ -96,7 +97,7 @@ def main(argv=None, ft=False):
         results = {}
         for seed in map(int, args.random_seed.split(',')):
             path = (args.restore_from[:-4] + '_%d.pth' % seed) if ft else args.restore_from       # eval_ft.py:154
-            if path and osp.exists(path):
+            if checkpoint_or_none(path, args.allow_random_init):
                 my_utils.load_model(model, path)
             model.eval()
             cm = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=engine.device)

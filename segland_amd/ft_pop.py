@@ -11,7 +11,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
-from .drivers import adjust_learning_rate_poly, build_parser, compute_dtype, resolve, save_checkpoint, validate
+from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
 from .utils import pyt_utils as my_utils
@@ -50,7 +50,7 @@ def main(argv=None):
             seg_model = getattr(networks, args.model).GFSS_Model(
                 n_base=args.base_classes, criterion=criterion, backbone=args.backbone, norm_layer=norm, dilated=(args.os != 32), os=args.os,
                 is_ft=True, n_novel=args.novel_classes, compute_dtype=compute_dtype(args))
-            if osp.exists(str(args.restore_from)):
+            if checkpoint_or_none(args.restore_from, args.allow_random_init):
                 my_utils.load_model(seg_model, args.restore_from, is_restore=True)
             seg_model.init_cls_n()
             params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)

@@ -120,11 +120,14 @@ def spec_of(conv):
 def _bn_coeffs(bn, part, count):
     """(mean, invstd, scale, shift) for this call; train mode also updates the running statistics."""
     if bn.training:
-        if count <= 1:
-            raise ValueError('Expected more than 1 value per channel when training, got %d' % count)   # as F.batch_norm
+        world = sync_world(bn)
+        # torch checks the GLOBAL count under SyncBatchNorm (nn/modules/_functions.py) and the local one under BatchNorm2d
+        # (F.batch_norm): with SEGLAND_SYNC_BN=1 a per-GPU batch of 1 (PPM level 1: B*1*1 values per channel) trains, without it raises
+        if count * max(world, 1) <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got %d (per-GPU batch 1 needs SEGLAND_SYNC_BN=1: '
+                             'the default BatchNorm statistics are per GPU)' % count)
         if bn.momentum is None:
             raise RuntimeError('segland_amd: cumulative-average BatchNorm (momentum=None) is not supported')
-        world = sync_world(bn)
         if world:                                            # SyncBatchNorm: global sum / sum of squares / count (equal shards)
             import torch.distributed as dist
             tot = ops.colsum(part).contiguous()
@@ -132,6 +135,8 @@ def _bn_coeffs(bn, part, count):
             part, count = tot.unsqueeze(0), count * world
         out = ops.bn_finalize_train(part, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _nbt_pending.append(bn.num_batches_tracked)
+        # the kernel wrote the running statistics through raw pointers (no tensor version bump): invalidate the eval-coefficient cache
+        bn.__dict__['_sl_rs_epoch'] = bn.__dict__.get('_sl_rs_epoch', 0) + 1
         return out
     return _bn_eval_coeffs(bn)
 
@@ -179,7 +184,8 @@ def conv_bn_infer(x, conv, bn, relu, residual=None, x2=None, out=None):
 def _bn_eval_coeffs(bn):
     """(mean, invstd, scale, shift) of a BN on its running statistics, cached on the module until any of its four tensors changes
     (58 tiny launches per frozen forward otherwise -- the ft_pop step is launch-bound)."""
-    key = (_wver(bn.weight), _wver(bn.bias), bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.eps)
+    key = (_wver(bn.weight), _wver(bn.bias), bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.eps,
+           bn.__dict__.get('_sl_rs_epoch', 0))      # train-mode forwards update the statistics behind the version counters
     ent = bn.__dict__.get('_sl_eval')
     if ent is None or ent[0] != key:
         ent = (key, ops.bn_finalize_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))

@@ -6,7 +6,6 @@ segland_amd.functional (StemFn, BottleneckFn).  Activations between blocks are N
 """
 import torch.nn as nn
 
-from .. import _compat  # noqa: F401
 from ...functional import BottleneckFn, StemFn, bottleneck_params
 
 

@@ -129,12 +129,15 @@ class GFSS_Model(nn.Module):
                         self._features_eager(static_in)
                 cur.wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph), torch.no_grad():
+                # thread_local: the drivers' DataLoader pin-memory thread calls hipHostMalloc / event queries concurrently; in the default
+                # 'global' mode those calls fail in THAT thread (killing the loader) and invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'), torch.no_grad():
                     static_out = self._features_eager(static_in)
                 ent = self.__dict__['_sl_graph'] = (sig, graph, static_in, static_out)
             except Exception as e:                            # stay on the eager HIP path
                 import logging
                 logging.warning('segland_amd: HIP graph capture of the frozen feature extractor failed (%s); running eagerly', e)
+                torch.cuda.synchronize()                      # a failed capture leaves work queued on the side stream: drain before the eager path
                 self.__dict__['_sl_graph'] = (sig, None, None, None)
                 return None
         _, graph, static_in, static_out = ent

@@ -10,24 +10,31 @@ from . import ops
 
 
 class AdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **unused):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, maximize=False, **unused):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError('AdamW: invalid hyper-parameter')
+        if amsgrad or maximize:
+            raise NotImplementedError('segland_amd.optim.AdamW: amsgrad / maximize are not implemented in the HIP kernel (use torch.optim.AdamW)')
+        bad = [k for k, v in unused.items() if k not in ('foreach', 'fused', 'capturable', 'differentiable') or k in ('capturable', 'differentiable') and v]
+        if bad:
+            raise TypeError('segland_amd.optim.AdamW: unsupported argument(s) %s' % ', '.join(bad))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
-        self._table, self._rec = None, None
+        self._tables = {}             # launch slot -> (record bytes, device table); parameters are launched grouped by their step count
         self.repeat_next = 1          # drivers: set to 2 to fold the reference's second step() into the next one
 
     @torch.no_grad()
     def step(self, closure=None, repeat=None, grad_scale=None):
         """grad_scale: optional 1-element float32 GPU tensor multiplied into every gradient inside the kernel (the clip_grad_norm_
-        coefficient, see clip_coefficient()) -- the gradients themselves are left unscaled."""
+        coefficient, see clip_coefficient()) -- the gradients themselves are left unscaled.
+        torch.optim.AdamW keeps a step count per parameter (a parameter that first receives a gradient later, or a resumed state_dict with
+        mixed counts): parameters are grouped by count, one launch per distinct count -- one launch in the usual case."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         repeat = self.repeat_next if repeat is None else repeat
         self.repeat_next = 1
-        rec, n, start, step_t, hyper = bytearray(), 0, 0, None, None
+        groups, hyper, dev = {}, None, None          # step count -> [record bytearray, n, chunk start]
         for group in self.param_groups:
             b1, b2 = group['betas']
             hp = (b1, b2, group['eps'])
@@ -39,30 +46,29 @@ class AdamW(torch.optim.Optimizer):
                     continue
                 if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     raise RuntimeError('segland_amd.optim.AdamW: contiguous float32 GPU parameters and gradients only')
+                dev = p.device
                 st = self.state[p]
                 if not st:
                     st['step'] = torch.tensor(0.0)
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 t = int(st['step']) + 1
-                if step_t is not None and t != step_t:
-                    raise RuntimeError('segland_amd.optim.AdamW: all stepped parameters must share one step count')
-                step_t = t
                 st['step'] += repeat
-                rec += struct.pack('<QQQQqffqq', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
-                                   p.numel(), group['lr'], group['weight_decay'], start, 0)
-                start += (p.numel() + 4095) // 4096
-                n += 1
-        if n == 0:
+                g = groups.setdefault(t, [bytearray(), 0, 0])
+                g[0] += struct.pack('<QQQQqffqq', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                                    p.numel(), group['lr'], group['weight_decay'], g[2], 0)
+                g[2] += (p.numel() + 4095) // 4096
+                g[1] += 1
+        if not groups:
             return loss
-        dev = next(p for g in self.param_groups for p in g['params'] if p.grad is not None).device
-        if self._rec != rec:          # the caching allocator hands back the same gradient addresses step after step: usually no upload
-            # pinned staging + asynchronous copy: a pageable upload would synchronise the host with the GPU once per step
-            self._table, self._rec = torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True), bytes(rec)
-        table = self._table
         b1, b2, eps = hyper
-        bc = [(1.0 - b1 ** (step_t + r), math.sqrt(1.0 - b2 ** (step_t + r))) for r in (0, 1)]
-        ops.adamw_multi(table, n, start, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat, grad_scale=grad_scale)
+        for slot, (step_t, (rec, n, total)) in enumerate(sorted(groups.items())):
+            ent = self._tables.get(slot)
+            if ent is None or ent[0] != rec:      # the caching allocator hands back the same gradient addresses step after step: usually no upload
+                # pinned staging + asynchronous copy: a pageable upload would synchronise the host with the GPU once per step
+                ent = self._tables[slot] = (bytes(rec), torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True))
+            bc = [(1.0 - b1 ** (step_t + r), math.sqrt(1.0 - b2 ** (step_t + r))) for r in (0, 1)]
+            ops.adamw_multi(ent[1], n, total, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat, grad_scale=grad_scale)
         return loss
 
 

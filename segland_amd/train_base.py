@@ -13,7 +13,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
-from .drivers import adjust_learning_rate_poly, build_parser, compute_dtype, miou, resolve, save_checkpoint, validate
+from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, miou, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
 from .utils import pyt_utils as my_utils
@@ -57,9 +57,9 @@ def main(argv=None):
         assert args.os in (8, 16, 32)
         model_cls = getattr(networks, args.model).GFSS_Model                    # `networks.<model>.GFSS_Model`
         seg_model = model_cls(n_base=args.base_classes, criterion=criterion, backbone=args.backbone, norm_layer=norm,
-                              pretrained_model=(args.restore_from if args.start_epoch == 0 and osp.exists(str(args.restore_from)) else None),
+                              pretrained_model=(checkpoint_or_none(args.restore_from, args.allow_random_init) if args.start_epoch == 0 else None),
                               dilated=(args.os != 32), os=args.os, compute_dtype=compute_dtype(args))
-        if args.freeze_backbone:
+        if args.freeze_backbone and checkpoint_or_none(args.restore_from, args.allow_random_init):
             my_utils.load_model(seg_model, args.restore_from, backbone_only=args.finetune, is_restore=not args.finetune)
         params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
         if engine.use_cuda:

@@ -18,7 +18,7 @@ def test_train_base_entry_point(hip, tmp_path):
     snap = str(tmp_path / 'snap')
     train_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--batch-size', '4', '--input-size', '128,128',
                      '--base-size', '128,128', '--num-epoch', '1', '--learning-rate', '1e-4', '--print-frequency', '4', '--snapshot-dir', snap,
-                     '--num-workers', '0', '--restore-from', '/nonexistent', '--fp16'])
+                     '--num-workers', '0', '--restore-from', '/nonexistent', '--allow-random-init', '--fp16'])
     ck = glob.glob(os.path.join(snap, 'epoch_1.pth'))
     assert ck, 'no checkpoint written'
     sd = torch.load(ck[0], map_location='cpu')
@@ -31,7 +31,7 @@ def test_ft_pop_entry_point(hip, tmp_path):
     snap = str(tmp_path / 'snap_ft')
     ft_pop.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--batch-size', '1', '--input-size', '128,128',
                  '--base-size', '128,128', '--num-epoch', '1', '--learning-rate', '1e-3', '--print-frequency', '5', '--snapshot-dir', snap,
-                 '--num-workers', '0', '--restore-from', '/nonexistent', '--random-seed', '123', '--freeze-backbone', '--fix-bn', '--update-base'])
+                 '--num-workers', '0', '--restore-from', '/nonexistent', '--allow-random-init', '--random-seed', '123', '--freeze-backbone', '--fix-bn', '--update-base'])
     assert glob.glob(os.path.join(snap, 'epoch_0_123.pth'))
 
 
