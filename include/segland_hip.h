@@ -221,6 +221,11 @@ int sl_rowdot_bwd(int dtype, const void* h, const float* w, const float* dz, voi
                   int C, sl_stream_t stream);
 /* out[c] = sum_blk partial[blk][c] */
 int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream);
+/* SyncBatchNorm (train_base.py:175-176: nn.SyncBatchNorm under DDP): the per-channel totals of the statistic partials are kept in double
+ * for the all-reduce over the process group (out[c] = sum_blk partial[blk][c], double), then handed to sl_bn_finalize_train /
+ * sl_bn_bwd_finalize as TWO float partial rows hi_lo[0][i] + hi_lo[1][i] == totals[i] to 48 bits. */
+int sl_colsum_f64(const float* partial, int nblk, int C, double* out, sl_stream_t stream);
+int sl_f64_split(const double* totals, int n, float* hi_lo, sl_stream_t stream);
 /* preds NCHW float [B][1+Kt][N]: channel 0 = z_bg[r], channel 1+k = a[k]*max(p,0) + b[k]*max(-p,0) */
 int sl_pop_combine_fwd(const float* proj, const float* z_bg, const float* a, const float* b, int Kt, float* preds,
                        int B, int N, sl_stream_t stream);

@@ -133,6 +133,32 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
   }
 }
 
+// SyncBatchNorm totals: the same column sum kept in double (all-reduced in double by the caller) ...
+__global__ __launch_bounds__(1024) void colsum_f64_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  double s = 0.0;
+  if (c < C) for (int r = rl; r < nblk; r += 16) s += (double)part[(size_t)r * C + c];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][cl];
+    out[c] = t;
+  }
+}
+// ... and handed back to the float partial-sum interface of the finalize kernels as two rows (hi, lo) whose double sum is the total
+__global__ void f64_split_kernel(const double* __restrict__ tot, int n, float* __restrict__ hi_lo) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double t = tot[i];
+  const float hi = (float)t;
+  hi_lo[i] = hi;
+  hi_lo[n + i] = (float)(t - (double)hi);
+}
+
 __global__ void pop_combine_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ zbg, const float* __restrict__ a,
                                        const float* __restrict__ b, int Kt, float* __restrict__ preds, int B, int N) {
   const long long R = (long long)B * N;
@@ -317,6 +343,20 @@ extern "C" int sl_colsum_finalize(const float* partial, int nblk, int C, float* 
   SL_REQUIRE(partial && out && nblk > 0 && C > 0, "colsum_finalize: bad args");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, out);
   SL_LAUNCH_CHECK("colsum_finalize_kernel");
+  return 0;
+}
+
+extern "C" int sl_colsum_f64(const float* partial, int nblk, int C, double* out, sl_stream_t stream) {
+  SL_REQUIRE(partial && out && nblk > 0 && C > 0, "colsum_f64: bad args");
+  hipLaunchKernelGGL(colsum_f64_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, out);
+  SL_LAUNCH_CHECK("colsum_f64_kernel");
+  return 0;
+}
+
+extern "C" int sl_f64_split(const double* totals, int n, float* hi_lo, sl_stream_t stream) {
+  SL_REQUIRE(totals && hi_lo && n > 0, "f64_split: bad args");
+  hipLaunchKernelGGL(f64_split_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, totals, n, hi_lo);
+  SL_LAUNCH_CHECK("f64_split_kernel");
   return 0;
 }
 

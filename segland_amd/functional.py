@@ -129,10 +129,7 @@ def _bn_coeffs(bn, part, count):
         if bn.momentum is None:
             raise RuntimeError('segland_amd: cumulative-average BatchNorm (momentum=None) is not supported')
         if world:                                            # SyncBatchNorm: global sum / sum of squares / count (equal shards)
-            import torch.distributed as dist
-            tot = ops.colsum(part).contiguous()
-            dist.all_reduce(tot)
-            part, count = tot.unsqueeze(0), count * world
+            part, count = ops.allreduce_partials(part), count * world
         out = ops.bn_finalize_train(part, count, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps)
         _nbt_pending.append(bn.num_batches_tracked)
         # the kernel wrote the running statistics through raw pointers (no tensor version bump): invalidate the eval-coefficient cache

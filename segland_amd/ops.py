@@ -244,11 +244,9 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
     if sync_world and train:
-        import torch.distributed as dist
-        tot = colsum(part).contiguous()                     # local [2][C] sums
-        dist.all_reduce(tot)
+        tot = allreduce_partials(part)                      # [2 (hi, lo)][2][C] global sums
         og = _f32((5, Cn), x.device)
-        check(L.sl_bn_bwd_finalize(_p(tot), 1, Cn, rows * sync_world, _p(gamma), _p(mean), _p(invstd), 1, _p(og[0]), _p(og[1]), _p(og[2]), _p(og[3]),
+        check(L.sl_bn_bwd_finalize(_p(tot), 2, Cn, rows * sync_world, _p(gamma), _p(mean), _p(invstd), 1, _p(og[0]), _p(og[1]), _p(og[2]), _p(og[3]),
                                    _p(og[4]), _s()), 'bn_bwd_finalize(sync)')
         o = torch.stack([o[0], o[1], og[2], og[3], og[4]])  # local dgamma/dbeta, global dx coefficients
     dx = out if out is not None else torch.empty_like(x)
@@ -459,6 +457,19 @@ def colsum(part):
     nblk, Cn = part.shape[0], part[0].numel()
     out = _f32(tuple(part.shape[1:]), part.device)
     check(_lib.lib().sl_colsum_finalize(_p(part), nblk, Cn, _p(out), _s()), 'colsum_finalize')
+    return out
+
+
+def allreduce_partials(part):
+    """SyncBatchNorm: [nblk][...] float statistic partials -> [2][...] float rows (hi, lo) of the GLOBAL totals: column sums in double,
+    ONE all-reduce (double) over the process group, split back for the finalize kernels (which add partial rows in double)."""
+    import torch.distributed as dist
+    nblk, n = part.shape[0], part[0].numel()
+    tot = torch.empty(tuple(part.shape[1:]), dtype=torch.float64, device=part.device)
+    check(_lib.lib().sl_colsum_f64(_p(part), nblk, n, _p(tot), _s()), 'colsum_f64')
+    dist.all_reduce(tot)
+    out = _f32((2,) + tuple(part.shape[1:]), part.device)
+    check(_lib.lib().sl_f64_split(_p(tot), n, _p(out), _s()), 'f64_split')
     return out
 
 
