@@ -288,6 +288,66 @@ int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float b
                    float bias_correction1, float bias_correction2_sqrt, float bias_correction1_next, float bias_correction2_sqrt_next,
                    int repeat, const float* grad_scale, sl_stream_t stream);
 
+/* ---- Swin-POP path ---------------------------------------------------------------------------
+ * Token maps are NHWC images [B][H][W][pitch] with C real channels and a ZERO channel pad up to `pitch` (a multiple of 64 so that the
+ * nn.Linear layers run on sl_conv2d_* as 1x1 convs; Swin-T/S: C = 96, pitch = 128).  Replaces, on the GPU, these call sites of the
+ * reference: networks/backbones/swintransformer.py PatchEmbed.forward :413-433, nn.LayerNorm (norm1 / norm2 / PatchMerging.norm /
+ * norm{i}, :214,244,287,636), WindowAttention.forward :118-149 together with the pad / roll / window_partition / window_reverse /
+ * attention mask of SwinTransformerBlock.forward :208-238 and BasicLayer.forward :363-379, Mlp's nn.GELU :36, PatchMerging's 2x2 gather
+ * :280-284, timm DropPath :243-244; networks/swin_pop.py F.interpolate(align_corners=True) :33,150-153,167, nn.Upsample :133-137,
+ * nn.Dropout2d :21. */
+typedef struct SlWinDesc {
+  int dtype, B, H, W;       /* token map (before the padding to multiples of 7, which the kernel does by index arithmetic) */
+  int C, heads;             /* C = heads * 32 */
+  int qkv_pitch, out_pitch; /* channels per token of the qkv tensor ([q | k | v | pad]) and of the output ([C | pad]) */
+  int shift;                /* 0 (W-MSA) or 3 (SW-MSA: cyclic shift + region mask) */
+} SlWinDesc;
+typedef struct SlResizeDesc {
+  int dtype, B, h, w, H, W; /* source h x w -> destination H x W */
+  int C;                    /* channels resized */
+  int src_pitch, src_off;   /* channel pitch of the source tensor and first channel of the window */
+  int dst_pitch, dst_off;
+  int align_corners;        /* F.interpolate(mode='bilinear', align_corners=...) */
+  int accumulate;           /* add into the output instead of overwriting it (top-down FPN sums, sum of the level heads) */
+  int src_f32;              /* the SOURCE-side tensor is float whatever dtype says (the pyramid-pooling stage maps stay fp32) */
+} SlResizeDesc;
+/* conv 4x4 stride 4 (3 -> C) + bias from the NCHW float image; zero padding to multiples of 4 (:417-421); out [B][ceil(H/4)][ceil(W/4)][pitch] */
+int sl_patch_embed_fwd(int dtype, const float* img_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int C,
+                       int out_pitch, sl_stream_t stream);
+/* partial[blk][C*48 (dw, OIHW order) + C (dbias)], blk < sl_patch_embed_bwd_blocks(); sum the rows with sl_colsum_finalize */
+int sl_patch_embed_bwd_blocks(int B, int H, int W);
+int sl_patch_embed_bwd(int dtype, const float* img_nchw, const void* dy, float* partial, int B, int H, int W, int C, int dy_pitch,
+                       sl_stream_t stream);
+/* y = (x - mean) * rstd * gamma + beta over the first C channels of each row, pad channels of y zeroed; mean_rstd [rows][2] (may be null) */
+int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, long long rows, int C,
+                     int x_pitch, int y_pitch, float eps, sl_stream_t stream);
+/* dx (+= addend, e.g. the gradient of the residual branch); dgamma_dbeta_partial [sl_layernorm_bwd_rows(rows)][2][C] or null */
+int sl_layernorm_bwd_rows(long long rows);
+int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                     float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream);
+/* exact GELU on n contiguous elements (n % 8 == 0) */
+int sl_gelu_fwd(int dtype, const void* h, void* y, long long n, sl_stream_t stream);
+int sl_gelu_bwd(int dtype, const void* h, const void* dy, void* dh, long long n, sl_stream_t stream);
+/* PatchMerging: x [B][H][W][x_pitch] -> xm [B][ceil(H/2)][ceil(W/2)][4*C] in the reference's (x0, x1, x2, x3) order; and its transpose */
+int sl_patch_merge_gather(int dtype, const void* x, void* xm, int B, int H, int W, int C, int x_pitch, sl_stream_t stream);
+int sl_patch_merge_scatter(int dtype, const void* dxm, void* dx, int B, int H, int W, int C, int dx_pitch, sl_stream_t stream);
+/* bilinear resize of a channel window, NHWC; the backward (d(dst) -> d(src)) is a gather over the destination pixels (bit-stable) */
+int sl_bilinear_fwd(const SlResizeDesc* d, const void* src, void* dst, sl_stream_t stream);
+int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* dsrc, sl_stream_t stream);
+/* out = (addend ? addend : 0) + x * scale[b] (per_channel 0: DropPath) or x * scale[b][c] (per_channel 1: Dropout2d; pad channels -> 0) */
+int sl_scale_add(int dtype, const void* x, const float* scale, const void* addend, void* out, int B, long long rows_per_sample, int C,
+                 int pitch, int per_channel, sl_stream_t stream);
+/* softmax(q k^T / sqrt(32) + rel_bias[head] + shift mask) v per 7x7 window and head.  qkv [B][H][W][qkv_pitch]; qkv_bias [3C] (the q/k/v of
+ * the zero-padded tokens); rel_bias [heads][49][49] (relative_position_bias_table gathered by relative_position_index); out [B][H][W][out_pitch]. */
+int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out,
+                            sl_stream_t stream);
+/* backward (probabilities recomputed): dqkv like qkv; drel_partial [sl_window_attention_bwd_chunks()][heads][49*49] (sum the chunks);
+ * pad_partial [sl_window_attention_windows()][heads][96]: q/k/v gradients that reach the qkv bias through the pad tokens (sum the windows) */
+int sl_window_attention_bwd_chunks(const SlWinDesc* d);
+int sl_window_attention_windows(const SlWinDesc* d);
+int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
+                            float* drel_partial, float* pad_partial, sl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,12 @@ def formula_tensor(name, ref):
         return (0.9 + 0.2 * uniform01(name, int(math.prod(shape)))).to(torch.float32).reshape(shape)
     if name in ('base_emb', 'novel_emb'):
         return sym(name, shape, 1.0)
+    if name.endswith('relative_position_index'):            # integer buffer of the Swin attention (a function of the window size)
+        return ref.detach().clone()
+    if name.endswith('relative_position_bias_table'):
+        return sym(name, shape, 0.5)
+    if len(shape) == 2:  # nn.Linear weight [out, in]: unit-gain uniform
+        return sym(name, shape, math.sqrt(3.0 / shape[1]))
     if len(shape) == 4:  # conv weight, Kaiming-uniform for ReLU nets
         fan_in = shape[1] * shape[2] * shape[3]
         return sym(name, shape, math.sqrt(6.0 / fan_in))

@@ -26,6 +26,14 @@ class SlPpmDesc(C.Structure):
                 ('sizes', C.c_int * 4)]
 
 
+class SlWinDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('dtype', 'B', 'H', 'W', 'C', 'heads', 'qkv_pitch', 'out_pitch', 'shift')]
+
+
+class SlResizeDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('dtype', 'B', 'h', 'w', 'H', 'W', 'C', 'src_pitch', 'src_off', 'dst_pitch', 'dst_off', 'align_corners', 'accumulate', 'src_f32')]
+
+
 _CTYPE = {
     'int': C.c_int, 'long long': C.c_longlong, 'float': C.c_float, 'size_t': C.c_size_t, 'sl_stream_t': C.c_void_p,
 }

@@ -2,26 +2,45 @@
 // in the collapsed form of SURVEY.md 0.7: the [B,K,C,N] component tensors are never built.
 //   proj[r][k] = S_k . q_r            bg_r = q_r - sum_k proj[r][k] S_k          (fp32, as the reference forces)
 //   pred[r][0] = MLP(bg_r)            pred[r][1+k] = a_k max(p,0) + b_k max(-p,0),  a_k = MLP(S_k), b_k = MLP(-S_k)
-// One wavefront per pixel row (C = 512 channels = 8 per lane), wave-shuffle reductions for the K projections.
+// A pixel row is owned by LPR lanes of a wavefront (C = LPR x 16-byte vectors x NV: 64 lanes for the 512-channel PSPNet head, 16 / 32
+// lanes -- 4 / 2 rows per wavefront -- for the 128-channel Swin head), shuffle reductions inside the LPR-lane group for the K projections.
 #include "common.h"
 
 namespace {
 
 constexpr int KMAXP = 16;  // max prototypes (base + novel)
 
-template <typename T, int NV>   // NV 16-byte vectors per lane
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {      // sum over the LPR lanes that share a row
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int LPR> __device__ __forceinline__ float across_groups(float v) {  // sum over the 64/LPR row groups (same channel, different rows)
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int NV, int LPR>   // NV 16-byte vectors per lane, LPR lanes per row
 __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ S, int Kt,
                                                                 float* __restrict__ proj, T* __restrict__ bg, long long R, int C) {
-  constexpr int V = Vec16<T>::N;
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Sl = sm;                       // [Kt][C]
   for (int e = threadIdx.x; e < Kt * C; e += 256) Sl[e] = S[e];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (long long r = blockIdx.x * 4LL + wave; r < R; r += gridDim.x * 4LL) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  for (long long rb = (blockIdx.x * 4LL + wave) * RPW; rb < R; rb += gridDim.x * 4LL * RPW) {
+    const long long r = rb + grp;
+    const bool live = r < R;
     float q[NV * V], o[NV * V];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * 64 + lane) * V), &q[j * V]);
+    for (int j = 0; j < NV; ++j) {
+      if (live) unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * LPR + sub) * V), &q[j * V]);
+      else
+#pragma unroll
+        for (int e = 0; e < V; ++e) q[j * V + e] = 0.f;
+    }
 #pragma unroll
     for (int e = 0; e < NV * V; ++e) o[e] = q[e];
     for (int k = 0; k < Kt; ++k) {
@@ -29,16 +48,18 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < V; ++e) d = fmaf(q[j * V + e], Sl[k * C + (j * 64 + lane) * V + e], d);
-      d = wave_sum(d);
-      if (lane == 0) proj[(size_t)r * Kt + k] = d;
+        for (int e = 0; e < V; ++e) d = fmaf(q[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], d);
+      d = group_sum<LPR>(d);
+      if (sub == 0 && live) proj[(size_t)r * Kt + k] = d;
 #pragma unroll
       for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[j * V + e] -= d * Sl[k * C + (j * 64 + lane) * V + e];
+        for (int e = 0; e < V; ++e) o[j * V + e] -= d * Sl[k * C + (j * LPR + sub) * V + e];
     }
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) *(uint4*)(bg + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(&o[j * V]);
+      for (int j = 0; j < NV; ++j) *(uint4*)(bg + (size_t)r * C + (j * LPR + sub) * V) = pack16<T>(&o[j * V]);
+    }
   }
 }
 
@@ -51,60 +72,66 @@ __global__ void pop_proto_rows_kernel(const float* __restrict__ S, int Kt, int C
   }
 }
 
-template <typename T, int NV>
+template <typename T, int NV, int LPR>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, float* __restrict__ z,
                                                          long long R, int C) {
-  constexpr int V = Vec16<T>::N;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   float wv[NV * V];
 #pragma unroll
   for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int e = 0; e < V; ++e) wv[j * V + e] = w[(j * 64 + lane) * V + e];
-  for (long long r = blockIdx.x * 4LL + wave; r < R; r += gridDim.x * 4LL) {
+    for (int e = 0; e < V; ++e) wv[j * V + e] = w[(j * LPR + sub) * V + e];
+  for (long long rb = (blockIdx.x * 4LL + wave) * RPW; rb < R; rb += gridDim.x * 4LL * RPW) {
+    const long long r = rb + grp;
     float d = 0.f;
+    if (r < R) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      float t[V];
-      unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * 64 + lane) * V), t);
+      for (int j = 0; j < NV; ++j) {
+        float t[V];
+        unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * LPR + sub) * V), t);
 #pragma unroll
-      for (int e = 0; e < V; ++e) d = fmaf(t[e], wv[j * V + e], d);
+        for (int e = 0; e < V; ++e) d = fmaf(t[e], wv[j * V + e], d);
+      }
     }
-    d = wave_sum(d);
-    if (lane == 0) z[r] = d;
+    d = group_sum<LPR>(d);
+    if (sub == 0 && r < R) z[r] = d;
   }
 }
 
 // dh = dz * w * (h > 0); partial[blk][c] = sum_r dz[r] * h[r][c]
-template <typename T, int NV>
+template <typename T, int NV, int LPR>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ dz,
                                                          T* __restrict__ dh, float* __restrict__ part, long long R, int C,
                                                          long long rows_per_blk) {
-  constexpr int V = Vec16<T>::N;
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][C]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   float wv[NV * V], acc[NV * V];
 #pragma unroll
   for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int e = 0; e < V; ++e) { wv[j * V + e] = w[(j * 64 + lane) * V + e]; acc[j * V + e] = 0.f; }
+    for (int e = 0; e < V; ++e) { wv[j * V + e] = w[(j * LPR + sub) * V + e]; acc[j * V + e] = 0.f; }
   const long long r0 = blockIdx.x * rows_per_blk;
   long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
-  for (long long r = r0 + wave; r < r1; r += 4) {
+  for (long long r = r0 + wave * RPW + grp; r < r1; r += 4 * RPW) {
     const float g = dz[r];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       float t[V], o[V];
-      unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * 64 + lane) * V), t);
+      unpack16<T>(*(const uint4*)(h + (size_t)r * C + (j * LPR + sub) * V), t);
 #pragma unroll
       for (int e = 0; e < V; ++e) { acc[j * V + e] = fmaf(g, t[e], acc[j * V + e]); o[e] = t[e] > 0.f ? g * wv[j * V + e] : 0.f; }
-      *(uint4*)(dh + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(o);
+      *(uint4*)(dh + (size_t)r * C + (j * LPR + sub) * V) = pack16<T>(o);
     }
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j)
 #pragma unroll
-    for (int e = 0; e < V; ++e) sm[wave * C + (j * 64 + lane) * V + e] = acc[j * V + e];
+    for (int e = 0; e < V; ++e) {
+      const float t = across_groups<LPR>(acc[j * V + e]);
+      if (grp == 0) sm[wave * C + (j * LPR + sub) * V + e] = t;
+    }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = sm[c] + sm[C + c] + sm[2 * C + c] + sm[3 * C + c];
 }
@@ -213,17 +240,17 @@ __global__ __launch_bounds__(256) void pop_combine_bwd_kernel(const float* __res
 }
 
 // t_k = dproj[r][k] - dg_r . S_k ;  dq_r = dg_r + sum_k t_k S_k ;  dS_k += t_k q_r - proj[r][k] dg_r
-template <typename T, int NV, int KM>
+template <typename T, int NV, int KM, int LPR>
 __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ feats, const float* __restrict__ S,
                                                                 const float* __restrict__ proj, const float* __restrict__ dproj, int Kt,
                                                                 T* __restrict__ dq, float* __restrict__ dSpart, long long R, int C,
                                                                 long long rows_per_blk) {
-  constexpr int V = Vec16<T>::N, CL = NV * V;     // channels per lane
+  constexpr int V = Vec16<T>::N, CL = NV * V, RPW = 64 / LPR;     // CL channels per lane
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Sl = sm;                                 // [KM][C]; reused for the cross-wave reduction
   for (int e = threadIdx.x; e < KM * C; e += 256) Sl[e] = e < Kt * C ? S[e] : 0.f;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   float acc[KM][CL];
 #pragma unroll
   for (int k = 0; k < KM; ++k)
@@ -231,12 +258,19 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
     for (int e = 0; e < CL; ++e) acc[k][e] = 0.f;
   const long long r0 = blockIdx.x * rows_per_blk;
   long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
-  for (long long r = r0 + wave; r < r1; r += 4) {
+  for (long long rb = r0 + wave * RPW; rb < r1; rb += 4 * RPW) {
+    const long long r = rb + grp;
+    const bool live = r < r1;
     float g[CL], q[CL], o[CL];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      unpack16<T>(*(const uint4*)(dg + (size_t)r * C + (j * 64 + lane) * V), &g[j * V]);
-      unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * 64 + lane) * V), &q[j * V]);
+      if (live) {
+        unpack16<T>(*(const uint4*)(dg + (size_t)r * C + (j * LPR + sub) * V), &g[j * V]);
+        unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * LPR + sub) * V), &q[j * V]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) { g[j * V + e] = 0.f; q[j * V + e] = 0.f; }
+      }
     }
 #pragma unroll
     for (int e = 0; e < CL; ++e) o[e] = g[e];
@@ -247,20 +281,22 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-          for (int e = 0; e < V; ++e) d = fmaf(g[j * V + e], Sl[k * C + (j * 64 + lane) * V + e], d);
-        d = wave_sum(d);
-        const float t = dproj[(size_t)r * Kt + k] - d, p = proj[(size_t)r * Kt + k];
+          for (int e = 0; e < V; ++e) d = fmaf(g[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], d);
+        d = group_sum<LPR>(d);
+        const float t = live ? dproj[(size_t)r * Kt + k] - d : 0.f, p = live ? proj[(size_t)r * Kt + k] : 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-            o[j * V + e] = fmaf(t, Sl[k * C + (j * 64 + lane) * V + e], o[j * V + e]);
+            o[j * V + e] = fmaf(t, Sl[k * C + (j * LPR + sub) * V + e], o[j * V + e]);
             acc[k][j * V + e] += t * q[j * V + e] - p * g[j * V + e];
           }
       }
     }
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < NV; ++j) *(uint4*)(dq + (size_t)r * C + (j * 64 + lane) * V) = pack16<T>(&o[j * V]);
+      for (int j = 0; j < NV; ++j) *(uint4*)(dq + (size_t)r * C + (j * LPR + sub) * V) = pack16<T>(&o[j * V]);
+    }
   }
   // cross-wave reduction, one prototype at a time through LDS
   __syncthreads();
@@ -269,7 +305,10 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
   for (int k = 0; k < KM; ++k) {
     if (k < Kt) {     // Kt is block-uniform
 #pragma unroll
-      for (int e = 0; e < CL; ++e) red[wave * C + ((e / V) * 64 + lane) * V + (e % V)] = acc[k][e];
+      for (int e = 0; e < CL; ++e) {
+        const float t = across_groups<LPR>(acc[k][e]);
+        if (grp == 0) red[wave * C + ((e / V) * LPR + sub) * V + (e % V)] = t;
+      }
       __syncthreads();
       for (int c = threadIdx.x; c < C; c += 256)
         dSpart[((size_t)blockIdx.x * Kt + k) * C + c] = red[c] + red[C + c] + red[2 * C + c] + red[3 * C + c];
@@ -280,14 +319,22 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
 
 inline int row_blocks(long long R, int cap) { long long b = (R + 63) / 64; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 
-}  // namespace
+// C = LPR * NV * (16 / sizeof(T)).  512 channels: the PSPNet-POP head (d_model, pspnet_pop.py:43); 128 / 256: the Swin-POP head
+// (d_model = backbone.get_filters()[0] = 96 / 128 / 192 zero-padded to a multiple of 128, swin_pop.py:182).
+template <int N> struct IC { static constexpr int value = N; };
+template <typename F>
+int pop_dispatch(int dtype, int C, F&& f) {
+  if (dtype == SL_BF16 && C == 512) return f(bf16_t{}, IC<1>{}, IC<64>{});
+  if (dtype == SL_BF16 && C == 256) return f(bf16_t{}, IC<1>{}, IC<32>{});
+  if (dtype == SL_BF16 && C == 128) return f(bf16_t{}, IC<1>{}, IC<16>{});
+  if (dtype == SL_F32 && C == 512) return f(float{}, IC<2>{}, IC<64>{});
+  if (dtype == SL_F32 && C == 256) return f(float{}, IC<1>{}, IC<64>{});
+  if (dtype == SL_F32 && C == 128) return f(float{}, IC<1>{}, IC<32>{});
+  SL_REQUIRE(false, "pop head: unsupported dtype/C (%d, %d); C must be 128, 256 or 512", dtype, C);
+  return 0;
+}
 
-#define POP_DISPATCH(dtype, C, CALL_BF, CALL_F32)                                         \
-  do {                                                                                    \
-    if ((dtype) == SL_BF16 && (C) == 512) { CALL_BF; }                                    \
-    else if ((dtype) == SL_F32 && (C) == 512) { CALL_F32; }                               \
-    else SL_REQUIRE(false, "pop head: unsupported dtype/C (%d, %d); C must be 512", (int)(dtype), (int)(C)); \
-  } while (0)
+}  // namespace
 
 extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, float* proj, void* bg, long long R,
                                     int C, sl_stream_t stream) {
@@ -295,9 +342,10 @@ extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S
   hipStream_t st = (hipStream_t)stream;
   const int blocks = row_blocks(R * 16, 2048);
   const size_t lds = (size_t)KMAXP * C * sizeof(float);
-  POP_DISPATCH(dtype, C,
-               hipLaunchKernelGGL((pop_decompose_fwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), lds, st, (const bf16_t*)feats, S, Kt, proj, (bf16_t*)bg, R, C),
-               hipLaunchKernelGGL((pop_decompose_fwd_kernel<float, 2>), dim3(blocks), dim3(256), lds, st, (const float*)feats, S, Kt, proj, (float*)bg, R, C));
+  if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((pop_decompose_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value>), dim3(blocks), dim3(256), lds, st, (const T*)feats, S, Kt, proj, (T*)bg, R, C);
+        return 0; })) return e;
   SL_LAUNCH_CHECK("pop_decompose_fwd_kernel");
   return 0;
 }
@@ -316,9 +364,10 @@ extern "C" int sl_rowdot_fwd(int dtype, const void* h, const float* w, float* z,
   SL_REQUIRE(h && w && z && R > 0, "rowdot_fwd: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int blocks = row_blocks(R * 16, 2048);
-  POP_DISPATCH(dtype, C,
-               hipLaunchKernelGGL((rowdot_fwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)h, w, z, R, C),
-               hipLaunchKernelGGL((rowdot_fwd_kernel<float, 2>), dim3(blocks), dim3(256), 0, st, (const float*)h, w, z, R, C));
+  if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((rowdot_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value>), dim3(blocks), dim3(256), 0, st, (const T*)h, w, z, R, C);
+        return 0; })) return e;
   SL_LAUNCH_CHECK("rowdot_fwd_kernel");
   return 0;
 }
@@ -332,9 +381,10 @@ extern "C" int sl_rowdot_bwd(int dtype, const void* h, const float* w, const flo
   const int nblk = row_blocks(R, 512);
   const long long rpb = (R + nblk - 1) / nblk;
   const size_t lds = 4 * (size_t)C * sizeof(float);
-  POP_DISPATCH(dtype, C,
-               hipLaunchKernelGGL((rowdot_bwd_kernel<bf16_t, 1>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)h, w, dz, (bf16_t*)dh, partial, R, C, rpb),
-               hipLaunchKernelGGL((rowdot_bwd_kernel<float, 2>), dim3(nblk), dim3(256), lds, st, (const float*)h, w, dz, (float*)dh, partial, R, C, rpb));
+  if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
+        using T = decltype(t);
+        hipLaunchKernelGGL((rowdot_bwd_kernel<T, decltype(nv)::value, decltype(lpr)::value>), dim3(nblk), dim3(256), lds, st, (const T*)h, w, dz, (T*)dh, partial, R, C, rpb);
+        return 0; })) return e;
   SL_LAUNCH_CHECK("rowdot_bwd_kernel");
   return 0;
 }
@@ -394,14 +444,16 @@ extern "C" int sl_pop_decompose_bwd(int dtype, const void* dg, const void* feats
   const long long rpb = (R + nblk - 1) / nblk;
   if (Kt <= 8) {
     const size_t lds = 8 * (size_t)C * sizeof(float);
-    POP_DISPATCH(dtype, C,
-                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<bf16_t, 1, 8>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)dg, (const bf16_t*)feats, S, proj, dproj, Kt, (bf16_t*)dq, dS_partial, R, C, rpb),
-                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<float, 2, 8>), dim3(nblk), dim3(256), lds, st, (const float*)dg, (const float*)feats, S, proj, dproj, Kt, (float*)dq, dS_partial, R, C, rpb));
+    if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
+          using T = decltype(t);
+          hipLaunchKernelGGL((pop_decompose_bwd_kernel<T, decltype(nv)::value, 8, decltype(lpr)::value>), dim3(nblk), dim3(256), lds, st, (const T*)dg, (const T*)feats, S, proj, dproj, Kt, (T*)dq, dS_partial, R, C, rpb);
+          return 0; })) return e;
   } else {
     const size_t lds = 16 * (size_t)C * sizeof(float);
-    POP_DISPATCH(dtype, C,
-                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<bf16_t, 1, 16>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)dg, (const bf16_t*)feats, S, proj, dproj, Kt, (bf16_t*)dq, dS_partial, R, C, rpb),
-                 hipLaunchKernelGGL((pop_decompose_bwd_kernel<float, 2, 16>), dim3(nblk), dim3(256), lds, st, (const float*)dg, (const float*)feats, S, proj, dproj, Kt, (float*)dq, dS_partial, R, C, rpb));
+    if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
+          using T = decltype(t);
+          hipLaunchKernelGGL((pop_decompose_bwd_kernel<T, decltype(nv)::value, 16, decltype(lpr)::value>), dim3(nblk), dim3(256), lds, st, (const T*)dg, (const T*)feats, S, proj, dproj, Kt, (T*)dq, dS_partial, R, C, rpb);
+          return 0; })) return e;
   }
   SL_LAUNCH_CHECK("pop_decompose_bwd_kernel");
   return 0;

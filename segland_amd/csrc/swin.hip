@@ -1,0 +1,927 @@
+// Swin-POP path on gfx950: the token-side kernels of networks/backbones/swintransformer.py and the
+// resize / gather helpers of networks/swin_pop.py's UperNet_Decoder_Plus.  The dense contractions (qkv / proj / fc1 / fc2 / patch-merge
+// reduction Linear layers, 3x3 decoder convs) run on the MFMA implicit-GEMM kernels of conv_gemm.hip / conv_wgrad.hip: a token map
+// [B,H,W,Cp] IS an NHWC image and nn.Linear a 1x1 conv.  Channel counts that are not multiples of 64 (Swin-T/S: C = 96) are carried with
+// a zero-filled channel pad (pitch Cp = 128); every kernel here takes (C, pitch) and keeps the pad at exactly zero.
+//
+//   patch_embed_*      swintransformer.py:395-433   conv 4x4 s4 (3 -> C) straight from the NCHW float image (K = 48: VALU, LDS-tiled)
+//   layernorm_*        nn.LayerNorm (eps 1e-5) over C: rows owned by 16/32/64-lane groups, two-pass statistics, shuffle reductions
+//   window_attention_* swintransformer.py:118-149 + the pad / cyclic shift / window partition / mask of :208-238,363-379 as index arithmetic:
+//                      one workgroup per (window, head); q, k, v, scores in LDS; softmax(q k^T * scale + bias + mask) v; the backward
+//                      recomputes the probabilities (nothing but q, k, v is kept from the forward)
+//   gelu_*             exact (erf) GELU of Mlp (:36)
+//   merge_gather/scatter  PatchMerging's 2x2 space-to-depth (:280-284)
+//   bilinear_*         F.interpolate(mode='bilinear') NHWC, both align_corners modes, optional accumulation into the destination and
+//                      channel windows (swin_pop.py:33,150-153,167 and the nn.Upsample of :133-137); backward in gather form (bit-stable)
+//   scale_add          x + s[b] * branch (DropPath, timm) and y * m[b][c] (nn.Dropout2d, swin_pop.py:21)
+#include "common.h"
+
+namespace {
+
+constexpr int WS = 7, WN = 49, HD = 32;       // window edge, tokens per window, head dimension (C / heads = 32 for every Swin variant)
+constexpr int QP = 36;                        // LDS row pitch of a [49][32] tile (floats): 16-byte aligned, conflict-free ds_read_b128
+
+template <int LPR> __device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ patch embedding
+// out[b][ty][tx][c] = bias[c] + sum_{ci,ky,kx} w[c][ci][ky][kx] * img[b][ci][4ty+ky][4tx+kx]   (zero outside the image, :417-421)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __restrict__ img, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              T* __restrict__ out, int B, int H, int W, int Ho, int Wo, int C, int Cp) {
+  constexpr int V = Vec16<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                 // [48][C]
+  float* pl = sm + 48 * C;        // [64][49] (odd pitch: the 4 threads of a token broadcast, tokens spread over banks)
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 48 * C; e += 256) { const int c = e / 48, k = e % 48; wl[k * C + c] = w[e]; }
+  const long long ntok = (long long)B * Ho * Wo;
+  const long long t0 = (long long)blockIdx.x * 64;
+  for (int e = tid; e < 64 * 48; e += 256) {
+    const int t = e / 48, k = e % 48;
+    const long long tok = t0 + t;
+    float v = 0.f;
+    if (tok < ntok) {
+      const int tx = (int)(tok % Wo), ty = (int)((tok / Wo) % Ho), b = (int)(tok / ((long long)Wo * Ho));
+      const int ci = k / 16, ky = (k % 16) / 4, kx = k % 4;
+      const int y = 4 * ty + ky, x = 4 * tx + kx;
+      if (y < H && x < W) v = img[((size_t)(b * 3 + ci) * H + y) * W + x];
+    }
+    pl[t * 49 + k] = v;
+  }
+  __syncthreads();
+  const int t = tid >> 2, cg = tid & 3, cpt = C / 4;       // 64 tokens x 4 channel groups
+  const long long tok = t0 + t;
+  if (tok >= ntok) return;
+  T* o = out + (size_t)tok * Cp;
+  for (int c0 = cg * cpt; c0 < (cg + 1) * cpt; c0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias[c0 + j];
+    for (int k = 0; k < 48; ++k) {
+      const float a = pl[t * 49 + k];
+      const float4 w0 = *(const float4*)(wl + k * C + c0), w1 = *(const float4*)(wl + k * C + c0 + 4);
+      acc[0] = fmaf(a, w0.x, acc[0]); acc[1] = fmaf(a, w0.y, acc[1]); acc[2] = fmaf(a, w0.z, acc[2]); acc[3] = fmaf(a, w0.w, acc[3]);
+      acc[4] = fmaf(a, w1.x, acc[4]); acc[5] = fmaf(a, w1.y, acc[5]); acc[6] = fmaf(a, w1.z, acc[6]); acc[7] = fmaf(a, w1.w, acc[7]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j += V) *(uint4*)(o + c0 + j) = pack16<T>(&acc[j]);
+  }
+  if (cg == 3) {
+    float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = C; c < Cp; c += V) *(uint4*)(o + c) = pack16<T>(z);
+  }
+}
+
+// part[blk][c][48] = sum over the block's tokens of dy[t][c] * patch[t][k];  part[blk][C*48 + c] = sum dy[t][c]
+template <typename T>
+__global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ img, const T* __restrict__ dy, float* __restrict__ part,
+                                                              int B, int H, int W, int Ho, int Wo, int C, int Cp, long long tok_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* pl = sm;                  // [64][49]
+  float* dl = sm + 64 * 49;        // [64][C]
+  const int tid = threadIdx.x, k = tid & 63, cg = tid >> 6, cpt = C / 4;
+  const long long ntok = (long long)B * Ho * Wo;
+  const long long ta = blockIdx.x * tok_per_blk;
+  long long tb = ta + tok_per_blk; if (tb > ntok) tb = ntok;
+  float acc[48];                   // cpt <= 48
+#pragma unroll
+  for (int j = 0; j < 48; ++j) acc[j] = 0.f;
+  float bsum = 0.f;                // thread (cg, k < cpt) also owns dbias[cg*cpt + k]
+  for (long long t0 = ta; t0 < tb; t0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * 48; e += 256) {
+      const int t = e / 48, kk = e % 48;
+      const long long tok = t0 + t;
+      float v = 0.f;
+      if (tok < tb) {
+        const int tx = (int)(tok % Wo), ty = (int)((tok / Wo) % Ho), b = (int)(tok / ((long long)Wo * Ho));
+        const int ci = kk / 16, ky = (kk % 16) / 4, kx = kk % 4;
+        const int y = 4 * ty + ky, x = 4 * tx + kx;
+        if (y < H && x < W) v = img[((size_t)(b * 3 + ci) * H + y) * W + x];
+      }
+      pl[t * 49 + kk] = v;
+    }
+    for (int e = tid; e < 64 * C; e += 256) {
+      const int t = e / C, c = e % C;
+      const long long tok = t0 + t;
+      dl[e] = tok < tb ? to_f<T>(dy[(size_t)tok * Cp + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < 64; ++t) {
+      const float a = k < 48 ? pl[t * 49 + k] : 0.f;
+      const float* d = dl + t * C + cg * cpt;           // wave-uniform address: broadcast
+#pragma unroll
+      for (int j = 0; j < 48; ++j)
+        if (j < cpt) acc[j] = fmaf(a, d[j], acc[j]);
+      if (k < cpt) bsum += d[k];
+    }
+  }
+  float* o = part + (size_t)blockIdx.x * (C * 49);
+  if (k < 48) {
+#pragma unroll
+    for (int j = 0; j < 48; ++j)
+      if (j < cpt) o[(cg * cpt + j) * 48 + k] = acc[j];
+  }
+  if (k < cpt) o[C * 48 + cg * cpt + k] = bsum;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// rows of C channels (pitch px / py); a row belongs to LPR lanes; stats[row] = {mean, rstd}
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ y, float* __restrict__ stats, long long rows, int C, int px, int py, float eps) {
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  const int nvec = C / V;
+  for (long long rb = ((long long)blockIdx.x * 4 + wave) * RPW; rb < rows; rb += (long long)gridDim.x * 4 * RPW) {
+    const long long r = rb + grp;
+    const bool live = r < rows;
+    const T* xr = x + (size_t)(live ? r : 0) * px;
+    float s = 0.f;
+    for (int v = sub; v < nvec; v += LPR) {
+      float t[V];
+      unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s += t[e];
+    }
+    const float mean = grp_sum<LPR>(s) / (float)C;
+    float q = 0.f;
+    for (int v = sub; v < nvec; v += LPR) {
+      float t[V];
+      unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float d = t[e] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = rsqrtf(grp_sum<LPR>(q) / (float)C + eps);
+    if (!live) continue;
+    if (sub == 0 && stats) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
+    T* yr = y + (size_t)r * py;
+    for (int v = sub; v < py / V; v += LPR) {
+      float o[V];
+      if (v < nvec) {
+        float t[V];
+        unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = (t[e] - mean) * rstd * gamma[v * V + e] + beta[v * V + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = 0.f;
+      }
+      *(uint4*)(yr + v * V) = pack16<T>(o);
+    }
+  }
+}
+
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) (+ addend),  g = dy * gamma,  xhat = (x - mean) * rstd
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
+                                                            long long rows, int C, int pdy, int px, int pdx) {
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  const int nvec = C / V;
+  for (long long rb = ((long long)blockIdx.x * 4 + wave) * RPW; rb < rows; rb += (long long)gridDim.x * 4 * RPW) {
+    const long long r = rb + grp;
+    const bool live = r < rows;
+    const long long rr = live ? r : 0;
+    const T* dyr = dy + (size_t)rr * pdy;
+    const T* xr = x + (size_t)rr * px;
+    const float mean = stats[2 * rr], rstd = stats[2 * rr + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int v = sub; v < nvec; v += LPR) {
+      float g[V], t[V];
+      unpack16<T>(*(const uint4*)(dyr + v * V), g);
+      unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { const float ge = g[e] * gamma[v * V + e]; s1 += ge; s2 = fmaf(ge, (t[e] - mean) * rstd, s2); }
+    }
+    s1 = grp_sum<LPR>(s1) / (float)C;
+    s2 = grp_sum<LPR>(s2) / (float)C;
+    if (!live) continue;
+    T* dxr = dx + (size_t)r * pdx;
+    for (int v = sub; v < pdx / V; v += LPR) {
+      float o[V];
+      if (v < nvec) {
+        float g[V], t[V];
+        unpack16<T>(*(const uint4*)(dyr + v * V), g);
+        unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = rstd * (g[e] * gamma[v * V + e] - s1 - (t[e] - mean) * rstd * s2);
+        if (addend) {
+          float a[V];
+          unpack16<T>(*(const uint4*)(addend + (size_t)r * pdx + v * V), a);
+#pragma unroll
+          for (int e = 0; e < V; ++e) o[e] += a[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = 0.f;
+      }
+      *(uint4*)(dxr + v * V) = pack16<T>(o);
+    }
+  }
+}
+
+// part[blk][0][c] = sum_rows dy * xhat (dgamma), part[blk][1][c] = sum_rows dy (dbeta): thread per channel, rows of the block's chunk
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_cols_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ stats,
+                                                                 float* __restrict__ part, long long rows, int C, int pdy, int px, long long rows_per_blk) {
+  const long long r0 = blockIdx.x * rows_per_blk;
+  long long r1 = r0 + rows_per_blk; if (r1 > rows) r1 = rows;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+      const float g = to_f<T>(dy[(size_t)r * pdy + c]);
+      a = fmaf(g, (to_f<T>(x[(size_t)r * px + c]) - stats[2 * r]) * stats[2 * r + 1], a);
+      b += g;
+    }
+    part[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+    part[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ GELU (exact)
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, long long nvec) {
+  constexpr int V = Vec16<T>::N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float t[V];
+    unpack16<T>(((const uint4*)h)[i], t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
+    ((uint4*)y)[i] = pack16<T>(t);
+  }
+}
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dy, T* __restrict__ dh, long long nvec) {
+  constexpr int V = Vec16<T>::N;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float t[V], g[V];
+    unpack16<T>(((const uint4*)h)[i], t);
+    unpack16<T>(((const uint4*)dy)[i], g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float cdf = 0.5f * (1.f + erff(t[e] * 0.70710678118654752440f));
+      const float pdf = 0.39894228040143267794f * __expf(-0.5f * t[e] * t[e]);
+      g[e] *= cdf + t[e] * pdf;
+    }
+    ((uint4*)dh)[i] = pack16<T>(g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ patch merging gather / scatter
+// xm[b][i][j][q*C + c] = x[b][2i + (q&1)][2j + (q>>1)][c]  (zero beyond H, W: the odd-size padding of :277-278)
+template <typename T>
+__global__ void merge_gather_kernel(const T* __restrict__ x, T* __restrict__ xm, int B, int H, int W, int C, int Cp) {
+  constexpr int V = Vec16<T>::N;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, nv = C / V;
+  const long long total = (long long)B * H2 * W2 * 4 * nv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nv); long long r = i / nv;
+    const int q = (int)(r % 4); r /= 4;
+    const int j = (int)(r % W2); r /= W2;
+    const int ii = (int)(r % H2); const int b = (int)(r / H2);
+    const int y = 2 * ii + (q & 1), xx = 2 * j + (q >> 1);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (y < H && xx < W) val = *(const uint4*)(x + ((size_t)(b * H + y) * W + xx) * Cp + v * V);
+    *(uint4*)(xm + (((size_t)(b * H2 + ii) * W2 + j) * 4 + q) * C + v * V) = val;
+  }
+}
+template <typename T>
+__global__ void merge_scatter_kernel(const T* __restrict__ dxm, T* __restrict__ dx, int B, int H, int W, int C, int Cp) {
+  constexpr int V = Vec16<T>::N;
+  const int H2 = (H + 1) / 2, W2 = (W + 1) / 2, nv = Cp / V, nvc = C / V;
+  const long long total = (long long)B * H * W * nv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nv); long long r = i / nv;
+    const int xx = (int)(r % W); r /= W;
+    const int y = (int)(r % H); const int b = (int)(r / H);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (v < nvc) {
+      const int q = (y & 1) + 2 * (xx & 1);
+      val = *(const uint4*)(dxm + (((size_t)(b * H2 + y / 2) * W2 + xx / 2) * 4 + q) * C + v * V);
+    }
+    *(uint4*)(dx + ((size_t)(b * H + y) * W + xx) * Cp + v * V) = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear resize (NHWC)
+// ATen's upsample_bilinear2d source index (UpSample.h area_pixel_compute_source_index), float arithmetic
+__device__ __forceinline__ float src_scale(int in, int out, int align) {
+  if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  return (float)in / (float)out;
+}
+__device__ __forceinline__ void src_taps(int dst, float scale, int in, int align, int& i0, int& i1, float& l0, float& l1) {
+  float s = align ? scale * (float)dst : fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  l1 = s - (float)i0; l0 = 1.f - l1;
+}
+
+// V consecutive channels of a TS tensor as floats (TS = T: one 16-byte vector; TS = float beside T = bf16: two)
+template <typename TS, int V> __device__ __forceinline__ void ldv(const TS* p, float* o) {
+  if constexpr (sizeof(TS) == 4) {
+#pragma unroll
+    for (int e = 0; e < V; e += 4) { const float4 t = *(const float4*)(p + e); o[e] = t.x; o[e + 1] = t.y; o[e + 2] = t.z; o[e + 3] = t.w; }
+  } else unpack16<TS>(*(const uint4*)p, o);
+}
+template <typename TS, int V> __device__ __forceinline__ void stv(TS* p, const float* o) {
+  if constexpr (sizeof(TS) == 4) {
+#pragma unroll
+    for (int e = 0; e < V; e += 4) *(float4*)(p + e) = make_float4(o[e], o[e + 1], o[e + 2], o[e + 3]);
+  } else *(uint4*)p = pack16<TS>(o);
+}
+
+// y[b][Y][X][yoff + c] (+)= bilinear(x[b][..][..][xoff + c]), c < C
+template <typename T, typename TS>
+__global__ void bilinear_fwd_kernel(const TS* __restrict__ x, T* __restrict__ y, int B, int h, int w, int H, int W, int C, int px, int xoff,
+                                    int py, int yoff, int align, int accumulate) {
+  constexpr int V = Vec16<T>::N;
+  const int nv = C / V;
+  const float sy = src_scale(h, H, align), sx = src_scale(w, W, align);
+  const long long total = (long long)B * H * W * nv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nv); long long r = i / nv;
+    const int X = (int)(r % W); r /= W;
+    const int Y = (int)(r % H); const int b = (int)(r / H);
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    src_taps(Y, sy, h, align, y0, y1, ly0, ly1);
+    src_taps(X, sx, w, align, x0, x1, lx0, lx1);
+    const TS* base = x + (size_t)b * h * w * px + xoff + v * V;
+    float a[V], bb[V], c[V], d[V], o[V];
+    ldv<TS, V>(base + ((size_t)y0 * w + x0) * px, a);
+    ldv<TS, V>(base + ((size_t)y0 * w + x1) * px, bb);
+    ldv<TS, V>(base + ((size_t)y1 * w + x0) * px, c);
+    ldv<TS, V>(base + ((size_t)y1 * w + x1) * px, d);
+#pragma unroll
+    for (int e = 0; e < V; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);      // ATen's association
+    T* dst = y + ((size_t)(b * H + Y) * W + X) * py + yoff + v * V;
+    if (accumulate) {
+      float p[V];
+      unpack16<T>(*(const uint4*)dst, p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] += p[e];
+    }
+    *(uint4*)dst = pack16<T>(o);
+  }
+}
+
+// dx[b][y][x][xoff + c] (+)= sum over destination pixels that read source (y, x) of weight * dy[b][Y][X][yoff + c]  (gather form, fixed order)
+template <typename T, typename TS>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, TS* __restrict__ dx, int B, int h, int w, int H, int W, int C, int pdx, int xoff,
+                                    int pdy, int yoff, int align, int accumulate) {
+  constexpr int V = Vec16<T>::N;
+  const int nv = C / V;
+  const float sy = src_scale(h, H, align), sx = src_scale(w, W, align);
+  const long long total = (long long)B * h * w * nv;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nv); long long r = i / nv;
+    const int xs = (int)(r % w); r /= w;
+    const int ys = (int)(r % h); const int b = (int)(r / h);
+    // candidate destination rows / columns: source coordinate in (ys-1, ys+1)
+    int Ya, Yb, Xa, Xb;
+    // align_corners: src = s * dst;  otherwise src = max(s * (dst + 0.5) - 0.5, 0)
+    const float lo_y = align ? (float)ys - 1.f : (float)ys - 0.5f, hi_y = align ? (float)ys + 1.f : (float)ys + 1.5f, sh = align ? 0.f : 0.5f;
+    const float lo_x = align ? (float)xs - 1.f : (float)xs - 0.5f, hi_x = align ? (float)xs + 1.f : (float)xs + 1.5f;
+    if (sy > 0.f) { Ya = (int)floorf(lo_y / sy - sh) - 1; Yb = (int)ceilf(hi_y / sy - sh) + 1; } else { Ya = 0; Yb = H - 1; }
+    if (sx > 0.f) { Xa = (int)floorf(lo_x / sx - sh) - 1; Xb = (int)ceilf(hi_x / sx - sh) + 1; } else { Xa = 0; Xb = W - 1; }
+    if (!align && ys == 0) Ya = 0;              // the clamp at 0 maps every early destination row onto source row 0
+    if (!align && xs == 0) Xa = 0;
+    Ya = Ya < 0 ? 0 : Ya; Xa = Xa < 0 ? 0 : Xa; Yb = Yb > H - 1 ? H - 1 : Yb; Xb = Xb > W - 1 ? W - 1 : Xb;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    const T* base = dy + (size_t)b * H * W * pdy + yoff + v * V;
+    for (int Y = Ya; Y <= Yb; ++Y) {
+      int y0, y1; float ly0, ly1;
+      src_taps(Y, sy, h, align, y0, y1, ly0, ly1);
+      const float wy = (y0 == ys ? ly0 : 0.f) + (y1 == ys ? ly1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int X = Xa; X <= Xb; ++X) {
+        int x0, x1; float lx0, lx1;
+        src_taps(X, sx, w, align, x0, x1, lx0, lx1);
+        const float wx = (x0 == xs ? lx0 : 0.f) + (x1 == xs ? lx1 : 0.f);
+        if (wx == 0.f) continue;
+        float g[V];
+        unpack16<T>(*(const uint4*)(base + ((size_t)Y * W + X) * pdy), g);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+      }
+    }
+    TS* dst = dx + ((size_t)(b * h + ys) * w + xs) * pdx + xoff + v * V;
+    if (accumulate) {
+      float p[V];
+      ldv<TS, V>(dst, p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += p[e];
+    }
+    stv<TS, V>(dst, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ per-sample / per-(sample, channel) scaling
+// out = (addend ? addend : 0) + x * s,  s = scale[b] (mode 0: DropPath) or scale[b][c] (mode 1: Dropout2d);  rows_per_b rows of pitch P per sample
+template <typename T>
+__global__ void scale_add_kernel(const T* __restrict__ x, const float* __restrict__ scale, const T* __restrict__ addend, T* __restrict__ out,
+                                 long long rows_per_b, int C, int P, int mode, long long total_vec) {
+  constexpr int V = Vec16<T>::N;
+  const int nv = P / V;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total_vec; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nv);
+    const long long row = i / nv;
+    const int b = (int)(row / rows_per_b);
+    float t[V];
+    unpack16<T>(((const uint4*)x)[i], t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int c = v * V + e;
+      t[e] *= mode == 0 ? scale[b] : (c < C ? scale[(size_t)b * C + c] : 0.f);
+    }
+    if (addend) {
+      float a[V];
+      unpack16<T>(((const uint4*)addend)[i], a);
+#pragma unroll
+      for (int e = 0; e < V; ++e) t[e] += a[e];
+    }
+    ((uint4*)out)[i] = pack16<T>(t);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ window attention
+struct WinGeom {
+  int B, H, W, Hp, Wp, nWy, nWx, C, heads, P3, Cp, shift;
+};
+
+// token n of window (wy, wx) -> pixel of the un-shifted map, or -1 for a pad token; region id of the shift mask (:363-379)
+__device__ __forceinline__ void win_token(const WinGeom& g, int wy, int wx, int n, int& pix, int& region) {
+  const int Y = wy * WS + n / WS, X = wx * WS + n % WS;              // position in the cyclically shifted, padded map
+  int y = Y + g.shift, x = X + g.shift;                             // shifted[Y] = x[(Y + shift) mod Hp]   (torch.roll by -shift)
+  if (y >= g.Hp) y -= g.Hp;
+  if (x >= g.Wp) x -= g.Wp;
+  pix = (y < g.H && x < g.W) ? y * g.W + x : -1;
+  const int by = Y < g.Hp - WS ? 0 : (Y < g.Hp - g.shift ? 1 : 2), bx = X < g.Wp - WS ? 0 : (X < g.Wp - g.shift ? 1 : 2);
+  region = 3 * by + bx;
+}
+
+// loads q (scaled), k, v of one (window, head) into LDS [49][QP] each; pad tokens carry the qkv bias (their x is 0 AFTER norm1, :208-213)
+template <typename T>
+__device__ __forceinline__ void win_load_qkv(const WinGeom& g, const T* __restrict__ qkv, const float* __restrict__ qkv_bias, int b, int wy, int wx, int head,
+                                             float* q, float* k, float* v, int* pixs, int* regs, float scale) {
+  constexpr int V = Vec16<T>::N, CPR = HD / V;      // 16-byte chunks per 32-wide head slice
+  const int tid = threadIdx.x;
+  if (tid < WN) { int p, r; win_token(g, wy, wx, tid, p, r); pixs[tid] = p; regs[tid] = r; }
+  __syncthreads();
+  for (int e = tid; e < WN * 3 * CPR; e += 256) {
+    const int ch = e % CPR, which = (e / CPR) % 3, n = e / (3 * CPR);
+    const int col = which * g.C + head * HD + ch * V;
+    float t[V];
+    const int p = pixs[n];
+    if (p >= 0) unpack16<T>(*(const uint4*)(qkv + ((size_t)b * g.H * g.W + p) * g.P3 + col), t);
+    else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) t[j] = to_f<T>(from_f<T>(qkv_bias[col + j]));      // as the GEMM would have stored it
+    }
+    float* dst = (which == 0 ? q : (which == 1 ? k : v)) + n * QP + ch * V;
+    const float m = which == 0 ? scale : 1.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) dst[j] = t[j] * m;
+  }
+  __syncthreads();
+}
+
+// S = q k^T + bias + mask, row softmax in place: P[49][50]
+__device__ __forceinline__ void win_probs(const WinGeom& g, const float* q, const float* k, const float* __restrict__ rel_bias, int head, const int* regs, float* P) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < WN * WN; e += 256) {
+    const int i = e / WN, j = e % WN;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const float4 a = *(const float4*)(q + i * QP + d), b = *(const float4*)(k + j * QP + d);
+      s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+    }
+    s += rel_bias[(size_t)head * WN * WN + e];
+    if (g.shift > 0 && regs[i] != regs[j]) s += -100.f;
+    P[i * 50 + j] = s;
+  }
+  __syncthreads();
+  // 4 lanes per row
+  const int row = tid >> 2, part = tid & 3;
+  if (row < WN) {
+    float m = -INFINITY;
+    for (int j = part; j < WN; j += 4) m = fmaxf(m, P[row * 50 + j]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64));
+    float z = 0.f;
+    for (int j = part; j < WN; j += 4) { const float e = __expf(P[row * 50 + j] - m); P[row * 50 + j] = e; z += e; }
+    z += __shfl_xor(z, 1, 64); z += __shfl_xor(z, 2, 64);
+    const float inv = 1.f / z;
+    for (int j = part; j < WN; j += 4) P[row * 50 + j] *= inv;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attention_fwd_kernel(WinGeom g, const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                   const float* __restrict__ rel_bias, T* __restrict__ out) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ __attribute__((aligned(16))) float q[WN * QP], k[WN * QP], v[WN * QP], P[WN * 50];
+  __shared__ int pixs[WN], regs[WN];
+  int blk = blockIdx.x;
+  const int head = blk % g.heads; blk /= g.heads;
+  const int wx = blk % g.nWx; blk /= g.nWx;
+  const int wy = blk % g.nWy; const int b = blk / g.nWy;
+  win_load_qkv<T>(g, qkv, qkv_bias, b, wy, wx, head, q, k, v, pixs, regs, rsqrtf((float)HD));
+  win_probs(g, q, k, rel_bias, head, regs, P);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < WN * (HD / V); e += 256) {
+    const int i = e / (HD / V), d0 = (e % (HD / V)) * V;
+    const int p = pixs[i];
+    if (p < 0) continue;
+    float o[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = 0.f;
+    for (int jj = 0; jj < WN; ++jj) {
+      const float pr = P[i * 50 + jj];
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = fmaf(pr, v[jj * QP + d0 + j], o[j]);
+    }
+    *(uint4*)(out + ((size_t)b * g.H * g.W + p) * g.Cp + head * HD + d0) = pack16<T>(o);
+  }
+  if (head == 0 && g.Cp > g.C) {            // keep the channel pad at zero
+    for (int e = tid; e < WN * ((g.Cp - g.C) / V); e += 256) {
+      const int i = e / ((g.Cp - g.C) / V), c = g.C + (e % ((g.Cp - g.C) / V)) * V;
+      if (pixs[i] >= 0) *(uint4*)(out + ((size_t)b * g.H * g.W + pixs[i]) * g.Cp + c) = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+
+// backward of one (window, head); block (head, chunk) walks `wpb` windows and keeps the sum of dS (= gradient of the relative position bias)
+// in registers.  dqkv of real tokens is written in place; k / v gradients of PAD tokens belong to the qkv bias: pad_part[window][head][3*32].
+template <typename T>
+__global__ __launch_bounds__(256) void window_attention_bwd_kernel(WinGeom g, const T* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                   const float* __restrict__ rel_bias, const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                                   float* __restrict__ drel_part, float* __restrict__ pad_part, int wpb, int nwin) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ __attribute__((aligned(16))) float q[WN * QP], k[WN * QP], v[WN * QP], dO[WN * QP], P[WN * 50], dS[WN * 50];
+  __shared__ float padst[2][WN][HD];         // k / v gradients of the window's pad tokens, summed in token order below
+  __shared__ int pixs[WN], regs[WN];
+  const int tid = threadIdx.x;
+  const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
+  const float scale = rsqrtf((float)HD);
+  float dsum[10];                           // entries tid + 256*m of the 49 x 49 matrix
+#pragma unroll
+  for (int m = 0; m < 10; ++m) dsum[m] = 0.f;
+  for (int wi = chunk * wpb; wi < (chunk + 1) * wpb && wi < nwin; ++wi) {
+    const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
+    __syncthreads();
+    win_load_qkv<T>(g, qkv, qkv_bias, b, wy, wx, head, q, k, v, pixs, regs, scale);
+    for (int e = tid; e < WN * (HD / V); e += 256) {
+      const int i = e / (HD / V), d0 = (e % (HD / V)) * V;
+      float t[V];
+      if (pixs[i] >= 0) unpack16<T>(*(const uint4*)(dout + ((size_t)b * g.H * g.W + pixs[i]) * g.Cp + head * HD + d0), t);
+      else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) t[j] = 0.f;                  // outputs of pad queries are cropped (:234-235)
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) dO[i * QP + d0 + j] = t[j];
+    }
+    win_probs(g, q, k, rel_bias, head, regs, P);                  // ends with a barrier: dO is visible too
+    // dP[i][j] = dO_i . v_j
+    for (int e = tid; e < WN * WN; e += 256) {
+      const int i = e / WN, j = e % WN;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; d += 4) {
+        const float4 a = *(const float4*)(dO + i * QP + d), bb = *(const float4*)(v + j * QP + d);
+        s = fmaf(a.x, bb.x, s); s = fmaf(a.y, bb.y, s); s = fmaf(a.z, bb.z, s); s = fmaf(a.w, bb.w, s);
+      }
+      dS[i * 50 + j] = s;
+    }
+    __syncthreads();
+    {                                        // dS = P * (dP - sum_j P dP), 4 lanes per row
+      const int row = tid >> 2, part = tid & 3;
+      if (row < WN) {
+        float t = 0.f;
+        for (int j = part; j < WN; j += 4) t = fmaf(P[row * 50 + j], dS[row * 50 + j], t);
+        t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64);
+        for (int j = part; j < WN; j += 4) dS[row * 50 + j] = P[row * 50 + j] * (dS[row * 50 + j] - t);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 10; ++m) { const int e = tid + 256 * m; if (e < WN * WN) dsum[m] += dS[(e / WN) * 50 + e % WN]; }
+    // dq_i = scale * sum_j dS_ij k_j ; dk_j = sum_i dS_ij q_i (q already scaled) ; dv_j = sum_i P_ij dO_i
+    float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
+    for (int e = tid; e < 3 * WN * (HD / V); e += 256) {
+      const int which = e / (WN * (HD / V)), rem = e % (WN * (HD / V));
+      const int n = rem / (HD / V), d0 = (rem % (HD / V)) * V;
+      float o[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) o[j] = 0.f;
+      if (which == 0) {
+        for (int jj = 0; jj < WN; ++jj) {
+          const float w = dS[n * 50 + jj];
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = fmaf(w, k[jj * QP + d0 + j], o[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] *= scale;
+      } else if (which == 1) {
+        for (int ii = 0; ii < WN; ++ii) {
+          const float w = dS[ii * 50 + n];
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = fmaf(w, q[ii * QP + d0 + j], o[j]);
+        }
+      } else {
+        for (int ii = 0; ii < WN; ++ii) {
+          const float w = P[ii * 50 + n];
+#pragma unroll
+          for (int j = 0; j < V; ++j) o[j] = fmaf(w, dO[ii * QP + d0 + j], o[j]);
+        }
+      }
+      if (pixs[n] >= 0) *(uint4*)(dqkv + ((size_t)b * g.H * g.W + pixs[n]) * g.P3 + which * g.C + head * HD + d0) = pack16<T>(o);
+      else if (which > 0) {                   // pad token: its k / v are the bias vector
+#pragma unroll
+        for (int j = 0; j < V; ++j) padst[which - 1][n][d0 + j] = o[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 96) {                           // [q | k | v] x 32: fixed-order sum over the pad tokens (q of a pad token has no consumer)
+      float t = 0.f;
+      if (tid >= HD)
+        for (int n = 0; n < WN; ++n)
+          if (pixs[n] < 0) t += padst[tid / HD - 1][n][tid % HD];
+      padp[tid] = t;
+    }
+    if (head == 0 && g.P3 > 3 * g.C) {
+      for (int e = tid; e < WN * ((g.P3 - 3 * g.C) / V); e += 256) {
+        const int i = e / ((g.P3 - 3 * g.C) / V), c = 3 * g.C + (e % ((g.P3 - 3 * g.C) / V)) * V;
+        if (pixs[i] >= 0) *(uint4*)(dqkv + ((size_t)b * g.H * g.W + pixs[i]) * g.P3 + c) = make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+  float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
+#pragma unroll
+  for (int m = 0; m < 10; ++m) { const int e = tid + 256 * m; if (e < WN * WN) dr[e] = dsum[m]; }
+}
+
+inline int ew_grid(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
+int check_geom(const SlWinDesc* d, WinGeom& g) {
+  SL_REQUIRE(d && d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0, "window_attention: bad sizes");
+  SL_REQUIRE(d->C == d->heads * HD, "window_attention: C (%d) must be heads (%d) x 32", d->C, d->heads);
+  SL_REQUIRE(d->shift == 0 || d->shift == WS / 2, "window_attention: shift must be 0 or 3");
+  SL_REQUIRE(d->qkv_pitch >= 3 * d->C && d->out_pitch >= d->C, "window_attention: pitches too small");
+  const int vb = d->dtype == SL_BF16 ? 8 : 4;
+  SL_REQUIRE(d->dtype == SL_BF16 || d->dtype == SL_F32, "window_attention: bad dtype");
+  SL_REQUIRE(d->qkv_pitch % vb == 0 && d->out_pitch % vb == 0, "window_attention: pitches must be multiples of a 16-byte vector");
+  g.B = d->B; g.H = d->H; g.W = d->W; g.C = d->C; g.heads = d->heads; g.P3 = d->qkv_pitch; g.Cp = d->out_pitch; g.shift = d->shift;
+  g.Hp = cdiv(d->H, WS) * WS; g.Wp = cdiv(d->W, WS) * WS; g.nWy = g.Hp / WS; g.nWx = g.Wp / WS;
+  return 0;
+}
+
+}  // namespace
+
+#define BY_DTYPE(dtype, CALL_BF, CALL_F32, what)             \
+  do {                                                       \
+    if ((dtype) == SL_BF16) { CALL_BF; }                     \
+    else if ((dtype) == SL_F32) { CALL_F32; }                \
+    else SL_REQUIRE(false, what ": bad dtype");              \
+  } while (0)
+
+extern "C" int sl_patch_embed_fwd(int dtype, const float* img, const float* w, const float* bias, void* out, int B, int H, int W, int C,
+                                  int out_pitch, sl_stream_t stream) {
+  SL_REQUIRE(img && w && bias && out && B > 0 && H > 0 && W > 0, "patch_embed_fwd: bad args");
+  SL_REQUIRE(C % 32 == 0 && C <= 192 && out_pitch >= C && out_pitch % 8 == 0, "patch_embed_fwd: C must be a multiple of 32, <= 192");
+  const int Ho = cdiv(H, 4), Wo = cdiv(W, 4);
+  const long long ntok = (long long)B * Ho * Wo;
+  const size_t lds = (size_t)(48 * C + 64 * 49) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(patch_embed_fwd_kernel<bf16_t>, dim3(cdiv(ntok, 64)), dim3(256), lds, st, img, w, bias, (bf16_t*)out, B, H, W, Ho, Wo, C, out_pitch),
+           hipLaunchKernelGGL(patch_embed_fwd_kernel<float>, dim3(cdiv(ntok, 64)), dim3(256), lds, st, img, w, bias, (float*)out, B, H, W, Ho, Wo, C, out_pitch),
+           "patch_embed_fwd");
+  SL_LAUNCH_CHECK("patch_embed_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_patch_embed_bwd_blocks(int B, int H, int W) {
+  const long long ntok = (long long)B * cdiv(H, 4) * cdiv(W, 4);
+  const long long b = (ntok + 1023) / 1024;
+  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
+}
+
+extern "C" int sl_patch_embed_bwd(int dtype, const float* img, const void* dy, float* partial, int B, int H, int W, int C, int dy_pitch,
+                                  sl_stream_t stream) {
+  SL_REQUIRE(img && dy && partial && B > 0 && C % 32 == 0 && C <= 192 && dy_pitch >= C, "patch_embed_bwd: bad args");
+  const int Ho = cdiv(H, 4), Wo = cdiv(W, 4);
+  const long long ntok = (long long)B * Ho * Wo;
+  const int nblk = sl_patch_embed_bwd_blocks(B, H, W);
+  long long tpb = (ntok + nblk - 1) / nblk;
+  tpb = (tpb + 63) / 64 * 64;
+  const size_t lds = (size_t)(64 * 49 + 64 * C) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(patch_embed_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img, (const bf16_t*)dy, partial, B, H, W, Ho, Wo, C, dy_pitch, tpb),
+           hipLaunchKernelGGL(patch_embed_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, img, (const float*)dy, partial, B, H, W, Ho, Wo, C, dy_pitch, tpb),
+           "patch_embed_bwd");
+  SL_LAUNCH_CHECK("patch_embed_bwd_kernel");
+  return 0;
+}
+
+template <typename T>
+static int launch_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, long long rows, int C, int px, int py, float eps, hipStream_t st) {
+  constexpr int V = Vec16<T>::N;
+  const int nvec = C / V;
+  const int grid = (int)(rows / 16 + 1 > 8192 ? 8192 : rows / 16 + 1);
+  if (nvec <= 16) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
+  else if (nvec <= 32) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 32>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
+  else hipLaunchKernelGGL((layernorm_fwd_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
+  return 0;
+}
+
+extern "C" int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, long long rows,
+                                int C, int x_pitch, int y_pitch, float eps, sl_stream_t stream) {
+  SL_REQUIRE(x && gamma && beta && y && rows > 0 && C > 0, "layernorm_fwd: bad args");
+  const int vb = dtype == SL_BF16 ? 8 : 4;
+  SL_REQUIRE(C % vb == 0 && x_pitch >= C && y_pitch >= C && x_pitch % vb == 0 && y_pitch % vb == 0, "layernorm_fwd: C / pitches must be multiples of a 16-byte vector");
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype, launch_ln_fwd<bf16_t>(x, gamma, beta, y, mean_rstd, rows, C, x_pitch, y_pitch, eps, st),
+           launch_ln_fwd<float>(x, gamma, beta, y, mean_rstd, rows, C, x_pitch, y_pitch, eps, st), "layernorm_fwd");
+  SL_LAUNCH_CHECK("layernorm_fwd_kernel");
+  return 0;
+}
+
+template <typename T>
+static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, const void* addend, void* dx, long long rows, int C, int pdy, int px,
+                         int pdx, hipStream_t st) {
+  constexpr int V = Vec16<T>::N;
+  const int nvec = C / V;
+  const int grid = (int)(rows / 16 + 1 > 8192 ? 8192 : rows / 16 + 1);
+  if (nvec <= 16) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
+  else if (nvec <= 32) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 32>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
+  else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
+  return 0;
+}
+
+extern "C" int sl_layernorm_bwd_rows(long long rows) { const long long b = (rows + 255) / 256; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+
+extern "C" int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                                float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream) {
+  SL_REQUIRE(dy && x && gamma && mean_rstd && dx && rows > 0 && C > 0, "layernorm_bwd: bad args");
+  const int vb = dtype == SL_BF16 ? 8 : 4;
+  SL_REQUIRE(C % vb == 0 && dy_pitch >= C && x_pitch >= C && dx_pitch >= C && dy_pitch % vb == 0 && x_pitch % vb == 0 && dx_pitch % vb == 0, "layernorm_bwd: bad pitches");
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype, launch_ln_bwd<bf16_t>(dy, x, gamma, mean_rstd, addend, dx, rows, C, dy_pitch, x_pitch, dx_pitch, st),
+           launch_ln_bwd<float>(dy, x, gamma, mean_rstd, addend, dx, rows, C, dy_pitch, x_pitch, dx_pitch, st), "layernorm_bwd");
+  SL_LAUNCH_CHECK("layernorm_bwd_kernel");
+  if (dgamma_dbeta_partial) {
+    const int nblk = sl_layernorm_bwd_rows(rows);
+    const long long rpb = (rows + nblk - 1) / nblk;
+    BY_DTYPE(dtype,
+             hipLaunchKernelGGL(layernorm_bwd_cols_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean_rstd, dgamma_dbeta_partial, rows, C, dy_pitch, x_pitch, rpb),
+             hipLaunchKernelGGL(layernorm_bwd_cols_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)x, mean_rstd, dgamma_dbeta_partial, rows, C, dy_pitch, x_pitch, rpb),
+             "layernorm_bwd");
+    SL_LAUNCH_CHECK("layernorm_bwd_cols_kernel");
+  }
+  return 0;
+}
+
+extern "C" int sl_gelu_fwd(int dtype, const void* h, void* y, long long n, sl_stream_t stream) {
+  SL_REQUIRE(h && y && n > 0 && n % 8 == 0, "gelu_fwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype, hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)h, (bf16_t*)y, n / 8),
+           hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)h, (float*)y, n / 4), "gelu_fwd");
+  SL_LAUNCH_CHECK("gelu_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_gelu_bwd(int dtype, const void* h, const void* dy, void* dh, long long n, sl_stream_t stream) {
+  SL_REQUIRE(h && dy && dh && n > 0 && n % 8 == 0, "gelu_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  BY_DTYPE(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)h, (const bf16_t*)dy, (bf16_t*)dh, n / 8),
+           hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)h, (const float*)dy, (float*)dh, n / 4), "gelu_bwd");
+  SL_LAUNCH_CHECK("gelu_bwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_patch_merge_gather(int dtype, const void* x, void* xm, int B, int H, int W, int C, int x_pitch, sl_stream_t stream) {
+  SL_REQUIRE(x && xm && B > 0 && H > 0 && W > 0 && C % 8 == 0 && x_pitch >= C && x_pitch % 8 == 0, "patch_merge_gather: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * 4 * C;
+  BY_DTYPE(dtype, hipLaunchKernelGGL(merge_gather_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)xm, B, H, W, C, x_pitch),
+           hipLaunchKernelGGL(merge_gather_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)x, (float*)xm, B, H, W, C, x_pitch), "patch_merge_gather");
+  SL_LAUNCH_CHECK("merge_gather_kernel");
+  return 0;
+}
+
+extern "C" int sl_patch_merge_scatter(int dtype, const void* dxm, void* dx, int B, int H, int W, int C, int dx_pitch, sl_stream_t stream) {
+  SL_REQUIRE(dxm && dx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && dx_pitch >= C && dx_pitch % 8 == 0, "patch_merge_scatter: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * H * W * dx_pitch;
+  BY_DTYPE(dtype, hipLaunchKernelGGL(merge_scatter_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)dxm, (bf16_t*)dx, B, H, W, C, dx_pitch),
+           hipLaunchKernelGGL(merge_scatter_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)dxm, (float*)dx, B, H, W, C, dx_pitch), "patch_merge_scatter");
+  SL_LAUNCH_CHECK("merge_scatter_kernel");
+  return 0;
+}
+
+static int check_resize(const SlResizeDesc* d) {
+  SL_REQUIRE(d && d->B > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0 && d->C > 0, "bilinear: bad sizes");
+  const int vb = d->dtype == SL_BF16 ? 8 : 4;
+  SL_REQUIRE(d->dtype == SL_BF16 || d->dtype == SL_F32, "bilinear: bad dtype");
+  SL_REQUIRE(d->C % vb == 0 && d->src_pitch % vb == 0 && d->dst_pitch % vb == 0 && d->src_off % vb == 0 && d->dst_off % vb == 0, "bilinear: channel window must be 16-byte aligned");
+  SL_REQUIRE(d->src_off + d->C <= d->src_pitch && d->dst_off + d->C <= d->dst_pitch, "bilinear: channel window outside the tensor");
+  return 0;
+}
+
+extern "C" int sl_bilinear_fwd(const SlResizeDesc* d, const void* src, void* dst, sl_stream_t stream) {
+  if (int e = check_resize(d)) return e;
+  SL_REQUIRE(src && dst, "bilinear_fwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)d->B * d->H * d->W * d->C;
+#define BL_ARGS d->B, d->h, d->w, d->H, d->W, d->C, d->src_pitch, d->src_off, d->dst_pitch, d->dst_off, d->align_corners, d->accumulate
+  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, BL_ARGS);
+  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, BL_ARGS);
+  else hipLaunchKernelGGL((bilinear_fwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)src, (float*)dst, BL_ARGS);
+  SL_LAUNCH_CHECK("bilinear_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* dsrc, sl_stream_t stream) {
+  if (int e = check_resize(d)) return e;
+  SL_REQUIRE(ddst && dsrc, "bilinear_bwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)d->B * d->h * d->w * d->C;
+  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS);
+  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS);
+  else hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS);
+  SL_LAUNCH_CHECK("bilinear_bwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_scale_add(int dtype, const void* x, const float* scale, const void* addend, void* out, int B, long long rows_per_sample, int C,
+                            int pitch, int per_channel, sl_stream_t stream) {
+  SL_REQUIRE(x && scale && out && B > 0 && rows_per_sample > 0 && C > 0 && pitch >= C && pitch % 8 == 0, "scale_add: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)B * rows_per_sample * pitch;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(scale_add_kernel<bf16_t>, dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)x, scale, (const bf16_t*)addend, (bf16_t*)out, rows_per_sample, C, pitch, per_channel, n / 8),
+           hipLaunchKernelGGL(scale_add_kernel<float>, dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)x, scale, (const float*)addend, (float*)out, rows_per_sample, C, pitch, per_channel, n / 4),
+           "scale_add");
+  SL_LAUNCH_CHECK("scale_add_kernel");
+  return 0;
+}
+
+extern "C" int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out, sl_stream_t stream) {
+  WinGeom g;
+  if (int e = check_geom(d, g)) return e;
+  SL_REQUIRE(qkv && qkv_bias && rel_bias && out, "window_attention_fwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = g.B * g.nWy * g.nWx * g.heads;
+  BY_DTYPE(d->dtype, hipLaunchKernelGGL(window_attention_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (bf16_t*)out),
+           hipLaunchKernelGGL(window_attention_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, g, (const float*)qkv, qkv_bias, rel_bias, (float*)out), "window_attention_fwd");
+  SL_LAUNCH_CHECK("window_attention_fwd_kernel");
+  return 0;
+}
+
+// windows per block of the backward (more when there are many windows: fewer partial rows of the bias gradient)
+static int win_wpb(const WinGeom& g) {
+  const long long tasks = (long long)g.B * g.nWy * g.nWx * g.heads;
+  long long w = tasks / 2048;
+  return (int)(w < 1 ? 1 : (w > 16 ? 16 : w));
+}
+
+extern "C" int sl_window_attention_bwd_chunks(const SlWinDesc* d) {
+  WinGeom g;
+  if (check_geom(d, g)) return SL_EINVAL;
+  return cdiv((long long)g.B * g.nWy * g.nWx, win_wpb(g));
+}
+
+extern "C" int sl_window_attention_windows(const SlWinDesc* d) {
+  WinGeom g;
+  if (check_geom(d, g)) return SL_EINVAL;
+  return g.B * g.nWy * g.nWx;
+}
+
+extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
+                                       float* drel_partial, float* pad_partial, sl_stream_t stream) {
+  WinGeom g;
+  if (int e = check_geom(d, g)) return e;
+  SL_REQUIRE(qkv && qkv_bias && rel_bias && dout && dqkv && drel_partial && pad_partial, "window_attention_bwd: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int wpb = win_wpb(g), nwin = g.B * g.nWy * g.nWx;
+  const int chunks = cdiv(nwin, wpb);
+  BY_DTYPE(d->dtype,
+           hipLaunchKernelGGL(window_attention_bwd_kernel<bf16_t>, dim3(chunks * g.heads), dim3(256), 0, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout, (bf16_t*)dqkv, drel_partial, pad_partial, wpb, nwin),
+           hipLaunchKernelGGL(window_attention_bwd_kernel<float>, dim3(chunks * g.heads), dim3(256), 0, st, g, (const float*)qkv, qkv_bias, rel_bias, (const float*)dout, (float*)dqkv, drel_partial, pad_partial, wpb, nwin),
+           "window_attention_bwd");
+  SL_LAUNCH_CHECK("window_attention_bwd_kernel");
+  return 0;
+}

@@ -1,0 +1,443 @@
+"""Block-level autograd Functions of the Swin-POP path: each one runs a fused chain of libsegland_hip.so kernels
+forward and the hand-written backward chain, exactly as functional.py does for the ResNet path.  nn.Linear / nn.LayerNorm / nn.Conv2d /
+nn.BatchNorm2d modules are parameter holders (state_dict compatibility with networks/swin_pop.py); their own forward is never called.
+
+Layout: token maps and decoder maps are NHWC [B,H,W,P] in the compute dtype, P = ops_swin.pad_to(C) (zero channel pad where C = 96).
+Linear layers = 1x1 convs on the MFMA implicit-GEMM kernels with zero-padded weight copies; gradients are sliced back to the parameter shapes.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd.function import once_differentiable
+
+from . import ops
+from . import ops_swin as osw
+from .functional import _nbt_pending, _wver
+from .ops import ConvSpec
+from .ops_swin import pad_to
+
+
+# ------------------------------------------------------------------------------------------------ prepared (padded) weights
+class _Lin:
+    __slots__ = ('wf', 'wb', 'bias', 'spec', 'N', 'K', 'Np', 'Kp', 'k')
+
+
+def _padded(t, shape, fill=0.0):
+    if tuple(t.shape) == tuple(shape):
+        return t.detach()
+    out = torch.full(shape, fill, dtype=torch.float32, device=t.device)
+    out[tuple(slice(0, s) for s in t.shape)] = t.detach()
+    return out
+
+
+def lin_prep(weight, bias, dtype, Kp=None, Np=None, k=1, col_map=None):
+    """GEMM-layout copies of an nn.Linear weight [N,K] (or conv weight [N,K,k,k]) zero-padded to [Np,Kp], cached on the Parameter until it changes.
+    col_map (optional): (index tensor, Kp) scattering the K real input columns into a wider padded input (concat of padded maps)."""
+    N, K = weight.shape[0], weight.shape[1]
+    Kp = pad_to(K) if Kp is None else Kp
+    Np = pad_to(N) if Np is None else Np
+    key = (_wver(weight), _wver(bias) if bias is not None else None, dtype, weight.data_ptr(), Kp, Np)
+    ent = getattr(weight, '_sl_lin', None)
+    if ent is None or ent[0] != key:
+        w4 = weight.detach().reshape(N, K, k, k) if weight.dim() == 2 else weight.detach()
+        if col_map is not None:
+            wp = torch.zeros((Np, Kp, k, k), dtype=torch.float32, device=weight.device)
+            wp[:N].index_copy_(1, col_map, w4.float())
+        else:
+            wp = _padded(w4.float(), (Np, Kp, k, k))
+        L = _Lin()
+        L.wf, L.wb = ops.weight_prep(wp.contiguous(), dtype)
+        L.bias = None if bias is None else _padded(bias, (Np,)).contiguous()
+        L.spec = ConvSpec(Kp, Np, k, 1, k // 2, 1)
+        L.N, L.K, L.Np, L.Kp, L.k = N, K, Np, Kp, k
+        ent = (key, L)
+        weight._sl_lin = ent
+    return ent[1]
+
+
+def lin_fwd(x, L, residual=None, x2=None):
+    """x [B,H,W,Kp] -> [B,H,W,Np] = x W^T + b (+ residual)."""
+    return ops.conv2d_fwd(x, L.wf, L.spec, bias=L.bias, pre_addend=residual, x2=x2)[0]
+
+
+def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None):
+    """(dx, dw in the parameter's shape, dbias) of lin_fwd."""
+    dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
+    dw = db = None
+    if need_w:
+        dwp = ops.conv2d_bwd_weight(x, dy, L.spec, x2=x2)
+        dw = (dwp[:L.N].index_select(1, col_map) if col_map is not None else dwp[:L.N, :L.K]).contiguous()
+        if L.k == 1:
+            dw = dw.view(L.N, L.K) if dw.shape[1] == L.K else dw
+        if L.bias is not None:
+            db = ops.colsum_rows(dy)[:L.N].contiguous()
+    return dx, dw, db
+
+
+def _rel_bias(attn):
+    """relative_position_bias_table gathered to [heads, 49, 49] (swintransformer.py:128-131), cached per table version."""
+    t = attn.relative_position_bias_table
+    key = (_wver(t), t.data_ptr())
+    ent = attn.__dict__.get('_sl_rel')
+    if ent is None or ent[0] != key:
+        n = attn.relative_position_index.shape[0]
+        ent = (key, t.detach()[attn.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).contiguous().float())
+        attn.__dict__['_sl_rel'] = ent
+    return ent[1]
+
+
+def _ones(B, dev):
+    return torch.ones(B, dtype=torch.float32, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------ patch embedding
+class PatchEmbedFn(torch.autograd.Function):
+    """swintransformer.py:413-433: conv 4x4 s4 + LayerNorm -> tokens [B,H/4,W/4,P]."""
+
+    @staticmethod
+    def forward(ctx, img, pe, dtype, w, b, gamma, beta):
+        Cn = w.shape[0]
+        P = pad_to(Cn)
+        tok = osw.patch_embed_fwd(img.contiguous(), w.detach().contiguous(), b.detach(), dtype, P)
+        if pe.norm is None:
+            ctx.has_norm = False
+            ctx.save_for_backward(img)
+            ctx.Cn = Cn
+            return tok
+        y, stats = osw.layernorm_fwd(tok, gamma.detach(), beta.detach(), Cn)
+        ctx.has_norm, ctx.Cn = True, Cn
+        ctx.save_for_backward(img, tok, stats, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        if ctx.has_norm:
+            img, tok, stats, gamma = ctx.saved_tensors
+            dtok, dg, db = osw.layernorm_bwd(dy, tok, gamma.detach(), stats, ctx.Cn)
+        else:
+            img, = ctx.saved_tensors
+            dtok, dg, db = dy, None, None
+        dw, dbias = osw.patch_embed_bwd(img.contiguous(), dtok, ctx.Cn)
+        return None, None, None, dw, dbias, dg, db
+
+
+# ------------------------------------------------------------------------------------------------ Swin block
+class SwinBlockFn(torch.autograd.Function):
+    """swintransformer.py:195-250 on a token map x [B,H,W,P]:
+        x1 = x + s1 * proj(W-MSA(qkv(LN1(x))));   out = x1 + s2 * fc2(GELU(fc1(LN2(x1))))
+    s1, s2: per-sample DropPath scales (0 or 1/keep, timm) or None."""
+
+    @staticmethod
+    def forward(ctx, x, blk, s1, s2, *params):
+        n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params
+        a = blk.attn
+        Cn, heads, shift = blk.dim, blk.num_heads, blk.shift_size
+        dtp = x.dtype
+        P = x.shape[-1]
+        Lq = lin_prep(qw, qb, dtp, Kp=P, Np=pad_to(3 * Cn))
+        Lp = lin_prep(pw, pb, dtp, Kp=P, Np=P)
+        L1 = lin_prep(f1w, f1b, dtp, Kp=P)
+        L2 = lin_prep(f2w, f2b, dtp, Np=P)
+        rel = _rel_bias(a)
+        xn, st1 = osw.layernorm_fwd(x, n1w.detach(), n1b.detach(), Cn)
+        qkv = lin_fwd(xn, Lq)
+        att = osw.window_attention_fwd(qkv, qb.detach().contiguous(), rel, Cn, heads, shift, P)
+        if s1 is None:
+            x1 = lin_fwd(att, Lp, residual=x)
+        else:
+            x1 = osw.scale_add(lin_fwd(att, Lp), s1, x)
+        xn2, st2 = osw.layernorm_fwd(x1, n2w.detach(), n2b.detach(), Cn)
+        h = lin_fwd(xn2, L1)
+        g = osw.gelu_fwd(h)
+        if s2 is None:
+            out = lin_fwd(g, L2, residual=x1)
+        else:
+            out = osw.scale_add(lin_fwd(g, L2), s2, x1)
+        if any(ctx.needs_input_grad):
+            ctx.blk = blk
+            ctx.save_for_backward(x, st1, xn, qkv, att, x1, st2, xn2, h, rel, s1, s2, *params)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        blk = ctx.blk
+        sv = ctx.saved_tensors
+        x, st1, xn, qkv, att, x1, st2, xn2, h, rel, s1, s2 = sv[:12]
+        n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = sv[12:]
+        Cn, heads, shift = blk.dim, blk.num_heads, blk.shift_size
+        dtp, P = x.dtype, x.shape[-1]
+        need_w = ctx.needs_input_grad[4]               # parameters of a block are frozen or trainable together
+        Lq = lin_prep(qw, qb, dtp, Kp=P, Np=pad_to(3 * Cn))
+        Lp = lin_prep(pw, pb, dtp, Kp=P, Np=P)
+        L1 = lin_prep(f1w, f1b, dtp, Kp=P)
+        L2 = lin_prep(f2w, f2b, dtp, Np=P)
+        dout = dout.contiguous()
+        dz = dout if s2 is None else osw.scale_add(dout, s2)
+        g = osw.gelu_fwd(h)                            # recomputed: [B,H,W,4C] is the largest tensor of the block
+        dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w)
+        dh = osw.gelu_bwd(h, dg)
+        dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w)
+        dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w)
+        dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)
+        datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w)
+        dqkv, drel, dpad = osw.window_attention_bwd(qkv, qb.detach().contiguous(), rel, datt, Cn, heads, shift)
+        dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w)
+        dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w)
+        dtable = None
+        if need_w:
+            dbq = dbq + dpad                           # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
+            idx = blk.attn.relative_position_index.view(-1)
+            dtable = torch.zeros_like(table).index_add_(0, idx, drel.permute(1, 2, 0).reshape(-1, heads))
+        return (dx, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
+
+
+def block_params(blk):
+    a, m = blk.attn, blk.mlp
+    return [blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+            blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+
+
+# ------------------------------------------------------------------------------------------------ patch merging / output norms
+class PatchMergeFn(torch.autograd.Function):
+    """swintransformer.py:264-290: 2x2 space-to-depth -> LayerNorm(4C) -> Linear(4C, 2C, bias=False)."""
+
+    @staticmethod
+    def forward(ctx, x, Cn, rw, gamma, beta):
+        xm = osw.merge_gather(x, Cn)
+        xn, st = osw.layernorm_fwd(xm, gamma.detach(), beta.detach(), 4 * Cn)
+        L = lin_prep(rw, None, x.dtype)
+        y = lin_fwd(xn, L)
+        ctx.Cn, ctx.xshape = Cn, tuple(x.shape)
+        ctx.save_for_backward(xm, st, xn, rw, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        xm, st, xn, rw, gamma = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[2]
+        L = lin_prep(rw, None, xm.dtype)
+        dxn, dw, _ = lin_bwd(xn, dy.contiguous(), L, need_w=need_w)
+        dxm, dg, db = osw.layernorm_bwd(dxn, xm, gamma.detach(), st, 4 * ctx.Cn, want_param_grads=need_w)
+        return osw.merge_scatter(dxm, ctx.xshape, ctx.Cn), None, dw, dg, db
+
+
+class LayerNormFn(torch.autograd.Function):
+    """norm{i} of swintransformer.py:634-637 (the NCHW permute of :639 is a layout change the NHWC decoder does not need)."""
+
+    @staticmethod
+    def forward(ctx, x, Cn, gamma, beta):
+        y, st = osw.layernorm_fwd(x, gamma.detach(), beta.detach(), Cn)
+        ctx.Cn = Cn
+        ctx.save_for_backward(x, st, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, st, gamma = ctx.saved_tensors
+        dx, dg, db = osw.layernorm_bwd(dy.contiguous(), x, gamma.detach(), st, ctx.Cn, want_param_grads=ctx.needs_input_grad[2])
+        return dx, None, dg, db
+
+
+# ------------------------------------------------------------------------------------------------ decoder pieces
+def _bn_padded(bn, P):
+    """BatchNorm parameter / buffer vectors padded to the channel pitch (pad channels: gamma 1, beta 0 -> they stay exactly zero)."""
+    Cn = bn.num_features
+    if P == Cn:
+        return bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var
+    return (_padded(bn.weight, (P,), 1.0), _padded(bn.bias, (P,), 0.0), _padded(bn.running_mean, (P,), 0.0), _padded(bn.running_var, (P,), 1.0))
+
+
+def _bn_forward(bn, c, part, conv_bias, P):
+    """Train: batch statistics of the raw conv output c (a conv bias shifts the mean only: it cancels in the normalised output and is added to
+    running_mean); eval: running statistics with the bias folded into the shift.  Returns (mean, invstd, scale, shift)."""
+    Cn = bn.num_features
+    gw, gb, rm, rv = _bn_padded(bn, P)
+    if bn.training:
+        count = c.numel() // P
+        if count <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got %d' % count)
+        mean, invstd, scale, shift = ops.bn_finalize_train(part, count, gw.contiguous(), gb.contiguous(), rm, rv, bn.momentum, bn.eps)
+        with torch.no_grad():
+            if P != Cn:
+                bn.running_mean.copy_(rm[:Cn]); bn.running_var.copy_(rv[:Cn])
+            if conv_bias is not None:
+                bn.running_mean.add_(conv_bias.detach(), alpha=bn.momentum)
+        _nbt_pending.append(bn.num_batches_tracked)
+        bn.__dict__['_sl_rs_epoch'] = bn.__dict__.get('_sl_rs_epoch', 0) + 1
+        return mean, invstd, scale, shift
+    mean, invstd, scale, shift = ops.bn_finalize_eval(gw.contiguous(), gb.contiguous(), rm.contiguous(), rv.contiguous(), bn.eps)
+    if conv_bias is not None:
+        bp = _padded(conv_bias, (P,))
+        shift = shift + bp * scale
+        mean = mean - bp                    # the backward normalises the RAW conv output c: (c + b - running_mean) = c - (running_mean - b)
+    return mean, invstd, scale, shift
+
+
+class ConvBnReluFn(torch.autograd.Function):
+    """nn.Sequential(Conv2d(k x k, bias), BatchNorm2d, ReLU) of swin_pop.py:112-131 on an NHWC map [B,H,W,Pin] -> [B,H,W,Pout]."""
+
+    @staticmethod
+    def forward(ctx, x, seq, w, b, gamma, beta):
+        conv, bn = seq[0], seq[1]
+        L = lin_prep(w, None, x.dtype, Kp=x.shape[-1], k=conv.kernel_size[0])
+        c, part = ops.conv2d_fwd(x, L.wf, L.spec, want_stats=bn.training)
+        mean, invstd, scale, shift = _bn_forward(bn, c, part, b, L.Np)
+        y, bits = ops.bn_act(c, scale, shift, relu=True, want_mask=True)
+        if any(ctx.needs_input_grad):
+            ctx.seq = seq
+            ctx.save_for_backward(x, c, mean, invstd, bits, w, gamma)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        conv, bn = ctx.seq[0], ctx.seq[1]
+        x, c, mean, invstd, bits, w, gamma = ctx.saved_tensors
+        L = lin_prep(w, None, x.dtype, Kp=x.shape[-1], k=conv.kernel_size[0])
+        need_w = ctx.needs_input_grad[2]
+        Cn = bn.num_features
+        gw = _padded(gamma, (L.Np,), 1.0).contiguous()
+        dc, _, dgam, dbet = ops.bn_bwd(dy.contiguous(), None, c, mean, invstd, gw, train=bn.training, mask=bits)
+        dx, dw, _ = lin_bwd(x, dc, L, need_dx=ctx.needs_input_grad[0], need_w=need_w)
+        dbias = ops.colsum_rows(dc)[:Cn].contiguous() if need_w else None
+        return dx, None, dw, dbias, (dgam[:Cn].contiguous() if need_w else None), (dbet[:Cn].contiguous() if need_w else None)
+
+
+class ResizeFn(torch.autograd.Function):
+    """F.interpolate(size, mode='bilinear', align_corners) / nn.Upsample on an NHWC map."""
+
+    @staticmethod
+    def forward(ctx, x, size, align):
+        ctx.hw, ctx.align = tuple(x.shape[1:3]), align
+        return osw.bilinear_fwd(x, size, align)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        return osw.bilinear_bwd(dy.contiguous(), ctx.hw, ctx.align), None, None
+
+
+class AddResizedFn(torch.autograd.Function):
+    """base + F.interpolate(x, base.shape, align_corners=True)   (top-down path swin_pop.py:150-153; sum of the level heads :167-169)."""
+
+    @staticmethod
+    def forward(ctx, base, x, align):
+        ctx.hw, ctx.align, ctx.same = tuple(x.shape[1:3]), align, tuple(x.shape[1:3]) == tuple(base.shape[1:3])
+        if ctx.same:
+            return osw.scale_add(x, _ones(x.shape[0], x.device), base)
+        out = base.clone()
+        return osw.bilinear_fwd(x, tuple(base.shape[1:3]), align, out=out, accumulate=True)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        return dy, (dy if ctx.same else osw.bilinear_bwd(dy, ctx.hw, ctx.align)), None
+
+
+class PspSwinFn(torch.autograd.Function):
+    """PSPModule of swin_pop.py:7-35: 4 x (adaptive pool -> 1x1 -> BN -> ReLU -> bilinear(align_corners=True)) (+) feats -> 1x1 -> BN -> ReLU
+    -> Dropout2d(0.1).  x [B,h,w,Cf]; the concat is virtual ([priors | feats] read from two tensors); the pyramid rows stay fp32."""
+
+    @staticmethod
+    def forward(ctx, x, psp, drop, *params):
+        sizes, nl = psp.sizes, len(psp.sizes)
+        B, h, w, Cf = x.shape
+        Cs = psp.stages[0][1].out_channels
+        Ps = pad_to(Cs)
+        pooled = ops.ppm_pool_fwd(x, sizes)                                                   # [rows, Cf] float
+        wst = torch.stack([_padded(st[1].weight.view(Cs, Cf), (Ps, Cf)) for st in psp.stages]).contiguous()
+        call, part = ops.ppm_rows_gemm(pooled, wst, B, sizes, want_stats=any(st[2].training for st in psp.stages))
+        stage_act = torch.empty_like(call)
+        priors = torch.empty((B, h, w, nl * Ps), dtype=x.dtype, device=x.device)
+        cl, ml, il, off, grp = [], [], [], 0, ops.ppm_stat_groups(B, sizes)
+        for k, (s, st) in enumerate(zip(sizes, psp.stages)):
+            n = B * s * s
+            c = call[off:off + n]
+            m, i, scale, shift = _bn_forward(st[2], c, part[grp[k]:grp[k + 1]] if st[2].training else None, None, Ps)
+            ops.bn_act(c, scale, shift, relu=True, out=stage_act[off:off + n])
+            osw.bilinear_fwd(stage_act[off:off + n].view(B, s, s, Ps), (h, w), True, out=priors, out_off=k * Ps)
+            cl.append(c); ml.append(m); il.append(i); off += n
+        bt = psp.bottleneck
+        wb_, bnb = bt[0].weight, bt[1]
+        cmap = _psp_colmap(Cs, Ps, nl, Cf, x.device)
+        L = lin_prep(wb_, None, x.dtype, Kp=nl * Ps + Cf, col_map=cmap)
+        cb, partb = ops.conv2d_fwd(priors, L.wf, L.spec, x2=x, want_stats=bnb.training)
+        mb, ib, scale, shift = _bn_forward(bnb, cb, partb, None, L.Np)
+        y, bits = ops.bn_act(cb, scale, shift, relu=True, want_mask=True)
+        if drop is not None:
+            y = osw.scale_add(y, drop, None, per_channel=True, Cn=bnb.num_features)
+        if any(ctx.needs_input_grad):
+            ctx.psp = psp
+            ctx.save_for_backward(x, pooled, stage_act, priors, cb, mb, ib, bits, drop, wst, *cl, *ml, *il)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        psp = ctx.psp
+        sizes, nl = psp.sizes, len(psp.sizes)
+        sv = ctx.saved_tensors
+        x, pooled, stage_act, priors, cb, mb, ib, bits, drop, wst = sv[:10]
+        cl, ml, il = sv[10:10 + nl], sv[10 + nl:10 + 2 * nl], sv[10 + 2 * nl:10 + 3 * nl]
+        B, h, w, Cf = x.shape
+        Cs = psp.stages[0][1].out_channels
+        Ps = pad_to(Cs)
+        need_w, need_x = ctx.needs_input_grad[3], ctx.needs_input_grad[0]
+        bt = psp.bottleneck
+        bnb = bt[1]
+        dy = dy.contiguous()
+        if drop is not None:
+            dy = osw.scale_add(dy, drop, None, per_channel=True, Cn=bnb.num_features)
+        cmap = _psp_colmap(Cs, Ps, nl, Cf, x.device)
+        L = lin_prep(bt[0].weight, None, x.dtype, Kp=nl * Ps + Cf, col_map=cmap)
+        gw = _padded(bnb.weight, (L.Np,), 1.0).contiguous()
+        dcb, _, dgb, dbb = ops.bn_bwd(dy, None, cb, mb, ib, gw, train=bnb.training, mask=bits)
+        dcat, dwb, _ = lin_bwd(priors, dcb, L, need_w=need_w, col_map=cmap, x2=x)
+        if need_w:
+            dwb = dwb.view(bt[0].weight.shape)
+        dstage = torch.empty_like(stage_act)
+        dc_all = torch.empty_like(stage_act)
+        gstage, off = [], 0
+        for k, (s, st) in enumerate(zip(sizes, psp.stages)):
+            n = B * s * s
+            osw.bilinear_bwd(dcat, (s, s), True, out=dstage[off:off + n].view(B, s, s, Ps), Cn=Ps, dy_off=k * Ps)
+            gwk = _padded(st[2].weight, (Ps,), 1.0).contiguous()
+            _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], gwk, train=st[2].training, out=dc_all[off:off + n])
+            dws = None
+            if need_w:
+                dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Ps), ConvSpec(Cf, Ps, 1))[:Cs].contiguous()
+            gstage += [dws, dgs[:Cs].contiguous() if need_w else None, dbs[:Cs].contiguous() if need_w else None]
+            off += n
+        dx = None
+        if need_x:
+            dpooled = ops.ppm_rows_gemm(dc_all, wst.transpose(1, 2).contiguous(), B, sizes)[0]
+            dx = ops.ppm_pool_bwd(dpooled, x.shape, x.dtype, sizes, dcat=dcat, cat_off=nl * Ps)
+        Cb = bnb.num_features
+        return (dx, None, None, *gstage, dwb, dgb[:Cb].contiguous() if need_w else None, dbb[:Cb].contiguous() if need_w else None)
+
+
+_colmaps = {}
+
+
+def _psp_colmap(Cs, Ps, nl, Cf, dev):
+    """Input column of the padded concat [stage_0 (Ps) | ... | stage_{nl-1} (Ps) | feats (Cf)] for every column of the reference's
+    [stage_0 (Cs) | ... | feats] bottleneck weight (swin_pop.py:18,34)."""
+    key = (Cs, Ps, nl, Cf, dev)
+    m = _colmaps.get(key)
+    if m is None:
+        idx = [l * Ps + c for l in range(nl) for c in range(Cs)] + [nl * Ps + c for c in range(Cf)]
+        m = _colmaps[key] = torch.tensor(idx, dtype=torch.long, device=dev)
+    return m
+
+
+def psp_params(psp):
+    p = []
+    for st in psp.stages:
+        p += [st[1].weight, st[2].weight, st[2].bias]
+    bt = psp.bottleneck
+    return p + [bt[0].weight, bt[1].weight, bt[1].bias]

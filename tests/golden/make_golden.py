@@ -23,6 +23,24 @@ REF = '/root/reference'
 sys.path.insert(0, ROOT)
 
 
+class DropPathStandIn(nn.Module):
+    """timm.models.layers.DropPath (timm is not installed here): x * mask / keep_prob with a per-sample Bernoulli(keep_prob) mask in train mode.
+    The per-sample scale vector comes from `scale_fn(p, B)` so that the reference, the oracle and the HIP model can be fed the same draws; every
+    instance numbers its calls in construction order (= the block order of the Swin backbone, two calls per block)."""
+    scale_fn = None
+    calls = 0
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if not self.training or self.drop_prob == 0.0 or DropPathStandIn.scale_fn is None:
+            return x
+        s = DropPathStandIn.scale_fn(self.drop_prob, x.shape[0], self)
+        return x if s is None else x * s.view(-1, *([1] * (x.dim() - 1)))
+
+
 def import_reference():
     def stub(name, **attrs):
         m = types.ModuleType(name)
@@ -31,7 +49,7 @@ def import_reference():
         return m
     stub('cv2')
     stub('timm'); stub('timm.models')
-    stub('timm.models.layers', DropPath=nn.Identity, to_2tuple=lambda x: (x, x),
+    stub('timm.models.layers', DropPath=DropPathStandIn, to_2tuple=lambda x: (x, x),
          trunc_normal_=nn.init.trunc_normal_)
     stub('timm.models.registry', register_model=lambda f: f)
     stub('torchvision'); stub('torchvision.models')
@@ -389,7 +407,155 @@ def g12():
              logits_eval=pe, rm_l4=ref.backbone.layer4[2].bn3.running_mean)
 
 
-ALL = dict(g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+# ------------------------------------------------------------------------------------------ G13-G16: Swin-POP
+import networks.swin_pop as ref_swin                      # noqa: E402
+import networks.backbones.swintransformer as ref_st       # noqa: E402
+from oracle import swin_oracle as so                       # noqa: E402
+
+
+def drop_scale(index, b, p):
+    """Deterministic DropPath draw shared by the reference stand-in, the oracle and the HIP tests: sample b of block `index` is dropped when
+    (7 * index + 3 * b) % 5 == 0, else scaled by 1 / (1 - p)."""
+    return 0.0 if (7 * index + 3 * b) % 5 == 0 else 1.0 / (1.0 - p)
+
+
+def _formula_load(mod, prefix):
+    mod.load_state_dict({k: fm.formula_tensor(prefix + k, v) for k, v in mod.state_dict().items()}, strict=True)
+    return mod
+
+
+def g13():
+    """One Swin stage = BasicLayer (swintransformer.py:293-392): a W-MSA block, a shifted SW-MSA block (mask), PatchMerging; token maps that
+    need window padding (10 x 13 -> 14 x 14: pad tokens carry the qkv bias) and odd-size merge padding.  Case b: C = 192 (no channel pad), 7 x 7."""
+    for tag, dim, heads, H, W in (('a', 96, 3, 10, 13), ('b', 192, 6, 7, 7)):
+        ref = ref_st.BasicLayer(dim=dim, depth=2, num_heads=heads, window_size=7, drop_path=[0.0, 0.0], downsample=ref_st.PatchMerging)
+        net = so._Box()
+        st = so._Box(); st.blocks = nn.ModuleList()
+        for j in range(2):
+            blk = so.make_block(dim, heads); blk.shift, blk.drop_path_p, blk.index = (0 if j == 0 else 3), 0.0, j
+            st.blocks.append(blk)
+        st.downsample = so._Box(); st.downsample.reduction = nn.Linear(4 * dim, 2 * dim, bias=False); st.downsample.norm = nn.LayerNorm(4 * dim)
+        assert list(ref.state_dict().keys()) == list(st.state_dict().keys())
+        _formula_load(ref, 'g13%s/' % tag); _formula_load(st, 'g13%s/' % tag)
+        x = fm.sym('g13%s/x' % tag, (2, H * W, dim), 1.0)
+        c1 = fm.sym('g13%s/c1' % tag, (2, H * W, dim), 1.0)
+        c2 = fm.sym('g13%s/c2' % tag, (2, ((H + 1) // 2) * ((W + 1) // 2), 2 * dim), 1.0)
+        xr = x.clone().requires_grad_(True)
+        xo_, _, _, xd, _, _ = ref(xr, H, W)
+        ((xo_ * c1).sum() + (xd * c2).sum()).backward()
+        holder = types.SimpleNamespace(drop_path_scale=lambda i, B, p: None)
+        xo = x.clone().requires_grad_(True)
+        Hp, Wp = -(-H // 7) * 7, -(-W // 7) * 7
+        y = xo
+        for blk in st.blocks:
+            y = so.block_forward(holder, blk, y, H, W, so.shift_mask(Hp, Wp, 7, 3))
+        yd = so.patch_merging(st.downsample, y, H, W)
+        ((y * c1).sum() + (yd * c2).sum()).backward()
+        same(xo_, y, 'g13 x_out'); same(xd, yd, 'g13 x_down'); same(xr.grad, xo.grad, 'g13 dx', 1e-6)
+        pr, po_ = dict(ref.named_parameters()), dict(st.named_parameters())
+        for k in pr:
+            same(pr[k].grad, po_[k].grad, 'g13 d ' + k, 1e-5)
+        sub = lambda t: t[::4, ::4] if (t.dim() == 2 and t.numel() > 20000) else t          # big weight gradients: every 4th row / column
+        save('g13_swin_stage_' + tag, x_out=xo_[:, :, ::2], x_down=xd[:, :, ::2], dx=xr.grad[:, :, ::2],
+             **{'d_' + k.replace('.', '_'): sub(pr[k].grad) for k in ('blocks.0.attn.qkv.bias', 'blocks.1.attn.qkv.bias', 'blocks.1.attn.relative_position_bias_table',
+                                                                  'blocks.0.norm1.weight', 'blocks.1.norm2.bias', 'blocks.1.mlp.fc1.weight', 'blocks.0.attn.proj.weight',
+                                                                  'blocks.1.attn.qkv.weight', 'blocks.0.mlp.fc2.bias', 'downsample.reduction.weight', 'downsample.norm.weight')})
+
+
+def g14():
+    """PatchEmbed (swintransformer.py:395-433) on an image whose sides are not multiples of 4 (zero padding) + LayerNorm."""
+    ref = ref_st.PatchEmbed(patch_size=4, in_chans=3, embed_dim=96, norm_layer=nn.LayerNorm)
+    _formula_load(ref, 'g14/')
+    img = fm.formula_image(2, 30, 37, 'g14/img')
+    coef = fm.sym('g14/coef', (2, 96, 8, 10), 1.0)
+    y = ref(img)
+    (y * coef).sum().backward()
+    pe = so._Box(); pe.proj = nn.Conv2d(3, 96, 4, stride=4); pe.norm = nn.LayerNorm(96)
+    _formula_load(pe, 'g14/')
+    x = F.conv2d(F.pad(img, (0, 3, 0, 2)), pe.proj.weight, pe.proj.bias, stride=4)
+    yo = so._ln(x.flatten(2).transpose(1, 2), pe.norm).transpose(1, 2).reshape(2, 96, 8, 10)
+    (yo * coef).sum().backward()
+    same(y, yo, 'g14 y'); same(ref.proj.weight.grad, pe.proj.weight.grad, 'g14 dw', 1e-5)
+    save('g14_patch_embed', y=y, dw=ref.proj.weight.grad, db=ref.proj.bias.grad, dgamma=ref.norm.weight.grad, dbeta=ref.norm.bias.grad)
+
+
+def g15():
+    """UperNet_Decoder_Plus (swin_pop.py:104-173) with the Swin-T widths on small maps whose sizes do NOT double from level to level (top-down
+    and final interpolations at non-2x ratios), train-mode BatchNorm, Dropout2d mask drawn by nn.Dropout2d under a fixed seed and stored."""
+    filters = [96, 192, 384, 768]
+    sizes = [(16, 20), (8, 10), (4, 5), (2, 3)]
+    ref = ref_swin.UperNet_Decoder_Plus(filters, 96)
+    ora = so.SwinPopOracle(7)
+    assert list(ref.state_dict().keys()) == list(ora.decoder.state_dict().keys())
+    _formula_load(ref, 'g15/'); _formula_load(ora.decoder, 'g15/')
+    xs = [fm.sym('g15/x%d' % i, (2, c, h, w), 1.0) for i, (c, (h, w)) in enumerate(zip(filters, sizes))]
+    coef = fm.sym('g15/coef', (2, 96, 16, 20), 1.0)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    ref.train(); ora.train()
+    masks = []
+    default = ora._default_dropout2d
+    ora.dropout2d_scale = lambda B, C, p: masks.append(default(B, C, p)) or masks[-1]
+    torch.manual_seed(15); yr = ref(xr)
+    torch.manual_seed(15); yo = so.decoder_forward(ora, xo)
+    (yr * coef).sum().backward(); (yo * coef).sum().backward()
+    same(yr, yo, 'g15 y')
+    for a, b in zip(xr, xo):
+        same(a.grad, b.grad, 'g15 dx', 1e-6)
+    pr, po_ = dict(ref.named_parameters()), dict(ora.decoder.named_parameters())
+    for k in pr:
+        same(pr[k].grad, po_[k].grad, 'g15 d ' + k, 1e-5)
+    ref.eval()
+    with torch.no_grad():
+        ye = ref([x for x in xs])
+    save('g15_upernet', y=yr, y_eval=ye, drop_mask=masks[0], dx0=xr[0].grad[:, ::4], dx1=xr[1].grad[:, ::8], dx2=xr[2].grad[:, ::8], dx3=xr[3].grad[:, ::16],
+         d_lat0_w=pr['lateral_convs.0.0.weight'].grad[::4, ::4], d_lat2_b=pr['lateral_convs.2.0.bias'].grad, d_fpn3_w=pr['fpn_convs.3.4.0.weight'].grad[::4, ::4],
+         d_fpn0_gamma=pr['fpn_convs.0.0.1.weight'].grad, d_psp_bott_w=pr['psp.bottleneck.0.weight'].grad[::2, ::16, 0, 0], d_psp_st0_w=pr['psp.stages.0.1.weight'].grad[::4, ::16, 0, 0],
+         d_psp_st3_gamma=pr['psp.stages.3.2.weight'].grad, rm_lat1=ref.lateral_convs[1][1].running_mean, rv_psp_bott=ref.psp.bottleneck[1].running_var,
+         rm_fpn2=ref.fpn_convs[2][2][1].running_mean)
+
+
+def g16():
+    """Full Swin-T POP (BASELINE config 5's model) on a 128 x 160 tile pair: eval logits; one TRAIN-mode step with DropPath (shared deterministic
+    draws through the timm stand-in) and Dropout2d (nn.Dropout2d's own draw, stored): loss dict, gradients, per-parameter gradient norms."""
+    ref = ref_swin.GFSS_Model(n_base=7, criterion=RefOrthLoss(ignore_index=255), backbone='swin-t', pretrained_model=None)
+    ora = so.SwinPopOracle(7, criterion=po.OrthLossOracle(255), backbone='swin-t')
+    assert list(ref.state_dict().keys()) == list(ora.state_dict().keys()), 'swin state_dict keys differ'
+    assert [k for k, _ in ref.named_parameters()] == [k for k, _ in ora.named_parameters()]
+    sd = fm.formula_state_dict(ref)
+    ref.load_state_dict(sd, strict=True); ora.load_state_dict(sd, strict=True)
+    img = fm.formula_image(2, 128, 160, 'g16/img'); mask = fm.formula_mask(2, 128, 160, 8, 'g16/mask', ignore_rows=5)
+    ref.eval(); ora.eval()
+    with torch.no_grad():
+        le, lo = ref(img), ora(img)
+    same(le, lo, 'g16 eval logits')
+    # train step.  The stand-in numbers DropPath calls through the module's drop_prob: p -> block index via the reference's linspace schedule
+    rates = torch.linspace(0, 0.2, 12).tolist()
+    index_of = lambda p: min(range(12), key=lambda i: abs(rates[i] - p))
+    DropPathStandIn.scale_fn = lambda p, B, mod: torch.tensor([drop_scale(index_of(p), b, p) for b in range(B)])
+    ora.drop_path_scale = lambda i, B, p: None if p <= 0.0 else torch.tensor([drop_scale(i, b, p) for b in range(B)])
+    masks = []
+    default = ora._default_dropout2d
+    ora.dropout2d_scale = lambda B, C, p: masks.append(default(B, C, p)) or masks[-1]
+    ref.train(); ora.train()
+    torch.manual_seed(16); dr = ref(img, mask)
+    torch.manual_seed(16); do = ora(img, mask)
+    dr['total_loss'].backward(); do['total_loss'].backward()
+    DropPathStandIn.scale_fn = None
+    for k in dr:
+        same(dr[k], do[k], 'g16 ' + k)
+    pr, po_ = dict(ref.named_parameters()), dict(ora.named_parameters())
+    for k in pr:
+        same(pr[k].grad, po_[k].grad, 'g16 d ' + k, 1e-5)
+    keys = [k for k in pr]
+    save('g16_swin_pop', logits_eval=le, total=dr['total_loss'], seg=dr['seg_loss'], orth=dr['orth_loss'], drop_mask=masks[0],
+         d_base_emb=pr['base_emb'].grad, d_cls4=pr['classifier.4.weight'].grad[0, :, 0, 0], d_patch_w=pr['backbone.patch_embed.proj.weight'].grad,
+         d_table=pr['backbone.layers.0.blocks.1.attn.relative_position_bias_table'].grad, d_fc1=pr['backbone.layers.2.blocks.3.mlp.fc1.weight'].grad[::16, ::8],
+         d_qkv_b=pr['backbone.layers.1.blocks.0.attn.qkv.bias'].grad, d_fpn3=pr['decoder.fpn_convs.3.4.0.weight'].grad[::4, ::4],
+         grad_norm_keys=np.array(keys), grad_norms=np.array([float(pr[k].grad.norm()) for k in keys], dtype=np.float32))
+
+
+ALL = dict(g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -1,0 +1,323 @@
+"""Swin-POP path (BASELINE config 5) on the GPU against the golden vectors generated from the reference
+(tests/golden/g13..g16, make_golden.py) and against the CPU oracle (oracle/swin_oracle.py, pinned bit-for-bit to the reference) on this machine.
+
+fp32 mode is the parity gate (1e-3 of the tensor scale forward, relative L2 on gradients); bf16 mode is checked at the stated looser tolerances.
+The stochastic layers get the SAME draws as the golden run: DropPath through `backbone.drop_path_hook` (deterministic formula shared with
+make_golden.drop_scale), Dropout2d through `decoder.dropout2d_hook` (the mask nn.Dropout2d drew, stored in the golden)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import golden
+from oracle import formula as fm
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = {torch.float32: 1e-3, torch.bfloat16: 6e-2}
+GTOL = {torch.float32: 5e-3, torch.bfloat16: 0.12}
+
+
+def rel(got, ref):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().float().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12))
+
+
+def l2(got, ref):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().float().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    return float(np.linalg.norm((got - ref).ravel()) / max(np.linalg.norm(ref.ravel()), 1e-20))
+
+
+def drop_scale(index, b, p):           # == tests/golden/make_golden.py::drop_scale
+    return 0.0 if (7 * index + 3 * b) % 5 == 0 else 1.0 / (1.0 - p)
+
+
+def to_tokens(x_bnc, H, W, dtype, P):
+    """[B, H*W, C] float -> NHWC [B,H,W,P] in dtype with a zero channel pad."""
+    B, L, Cn = x_bnc.shape
+    t = torch.zeros(B, H, W, P)
+    t[..., :Cn] = x_bnc.view(B, H, W, Cn)
+    return t.to(DEV).to(dtype)
+
+
+def nchw_to_nhwc(x, dtype, P):
+    B, Cn, H, W = x.shape
+    t = torch.zeros(B, H, W, P)
+    t[..., :Cn] = x.permute(0, 2, 3, 1)
+    return t.to(DEV).to(dtype)
+
+
+# --------------------------------------------------------------------------------------------- kernels
+def test_layernorm_and_gelu_kernels(hip):
+    from segland_amd import ops_swin as osw
+    for dtype, tol in ((torch.float32, 2e-6), (torch.bfloat16, 1.5e-2)):
+        for Cn, P in ((96, 128), (192, 192), (384, 384), (768, 768), (1536, 1536)):
+            torch.manual_seed(Cn)
+            x = torch.randn(37, 5, P) * 2 + 0.5
+            x[..., Cn:] = 0
+            g, b = torch.rand(Cn) + 0.5, torch.randn(Cn)
+            xg = x.to(DEV).to(dtype)
+            y, st = osw.layernorm_fwd(xg, g.to(DEV), b.to(DEV), Cn)
+            xr = xg.float().cpu()[..., :Cn].requires_grad_(True)
+            yr = F.layer_norm(xr, (Cn,), g, b, 1e-5)
+            assert rel(y[..., :Cn], yr) <= tol and float(y[..., Cn:].abs().max() if P > Cn else 0) == 0
+            dy = torch.randn(37, 5, P); dy[..., Cn:] = 0
+            add = torch.randn(37, 5, P); add[..., Cn:] = 0
+            gref = torch.rand(Cn).requires_grad_(True); gref.data.copy_(g)
+            bref = b.clone().requires_grad_(True)
+            yr2 = F.layer_norm(xr, (Cn,), gref, bref, 1e-5)
+            dyr = dy.to(dtype).float()[..., :Cn]
+            (yr2 * dyr).sum().backward()
+            dx, dg, db = osw.layernorm_bwd(dy.to(DEV).to(dtype), xg, g.to(DEV), st, Cn, addend=add.to(DEV).to(dtype))
+            assert l2(dx[..., :Cn], xr.grad + add.to(dtype).float()[..., :Cn]) <= max(tol, 1e-5)
+            assert l2(dg, gref.grad) <= max(tol, 1e-5) and l2(db, bref.grad) <= max(tol, 1e-5)
+        h = torch.randn(64, 384) * 2
+        hg = h.to(DEV).to(dtype)
+        hr = hg.float().cpu().requires_grad_(True)
+        yr = F.gelu(hr)
+        assert rel(osw.gelu_fwd(hg), yr) <= tol
+        dy = torch.randn(64, 384)
+        (yr * dy.to(dtype).float()).sum().backward()
+        assert l2(osw.gelu_bwd(hg, dy.to(DEV).to(dtype)), hr.grad) <= max(tol, 1e-5)
+
+
+@pytest.mark.parametrize('align', [True, False])
+def test_bilinear_kernels(hip, align):
+    """F.interpolate(mode='bilinear') both ways, up- and down-sampling, channel windows, accumulation; backward = autograd of the torch op."""
+    from segland_amd import ops_swin as osw
+    for (h, w, H, W) in ((4, 5, 8, 10), (2, 3, 16, 20), (1, 1, 7, 9), (9, 12, 5, 6), (6, 6, 6, 6)):
+        torch.manual_seed(h * 100 + H)
+        x = torch.randn(2, 16, h, w, requires_grad=True)
+        y = F.interpolate(x, size=(H, W), mode='bilinear', align_corners=align)
+        dy = torch.randn(2, 16, H, W)
+        (y * dy).sum().backward()
+        xg = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+        yg = osw.bilinear_fwd(xg, (H, W), align)
+        assert rel(yg.permute(0, 3, 1, 2), y) <= 2e-6, (h, w, H, W)
+        dxg = osw.bilinear_bwd(dy.permute(0, 2, 3, 1).contiguous().to(DEV), (h, w), align)
+        assert rel(dxg.permute(0, 3, 1, 2), x.grad) <= 5e-6, (h, w, H, W)
+        # channel window + accumulate, float source next to a bf16 destination
+        base = torch.randn(2, H, W, 32)
+        out = base.clone().to(DEV).to(torch.bfloat16)
+        osw.bilinear_fwd(xg, (H, W), align, out=out, out_off=8, Cn=16, accumulate=True)
+        want = base.to(torch.bfloat16).float()
+        want[..., 8:24] += y.detach().permute(0, 2, 3, 1)
+        assert rel(out, want) <= 1.5e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_g14_patch_embed(hip, dtype):
+    from segland_amd.functional_swin import PatchEmbedFn
+    from segland_amd.networks.backbones.swintransformer import PatchEmbed
+    g = golden('g14_patch_embed')
+    pe = PatchEmbed(4, 3, 96, True)
+    pe.load_state_dict({k: fm.formula_tensor('g14/' + k, v) for k, v in pe.state_dict().items()})
+    pe.to(DEV)
+    img = fm.formula_image(2, 30, 37, 'g14/img').to(DEV)
+    y = PatchEmbedFn.apply(img, pe, dtype, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias)
+    coef = fm.sym('g14/coef', (2, 96, 8, 10), 1.0)
+    (y.float()[..., :96] * coef.permute(0, 2, 3, 1).to(DEV)).sum().backward()
+    assert tuple(y.shape) == (2, 8, 10, 128) and float(y[..., 96:].abs().max()) == 0
+    assert rel(y[..., :96].permute(0, 3, 1, 2), g['y']) <= TOL[dtype]
+    assert l2(pe.proj.weight.grad, g['dw']) <= GTOL[dtype] and l2(pe.proj.bias.grad, g['db']) <= GTOL[dtype]
+    assert l2(pe.norm.weight.grad, g['dgamma']) <= GTOL[dtype] and l2(pe.norm.bias.grad, g['dbeta']) <= GTOL[dtype]
+
+
+def _stage(dim, heads, tag):
+    from segland_amd.networks.backbones.swintransformer import BasicLayer
+    st = BasicLayer(dim, 2, heads, [0.0, 0.0], 0, True)
+    st.load_state_dict({k: fm.formula_tensor('g13%s/' % tag + k, v) for k, v in st.state_dict().items()})
+    return st.to(DEV)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('tag,dim,heads,H,W', [('a', 96, 3, 10, 13), ('b', 192, 6, 7, 7)])
+def test_g13_swin_stage(hip, tag, dim, heads, H, W, dtype):
+    """W-MSA block + SW-MSA block + PatchMerging against golden G13 (window padding, shift mask, pad-token qkv bias, odd merge)."""
+    from segland_amd.functional_swin import PatchMergeFn, SwinBlockFn, block_params
+    from segland_amd.ops_swin import pad_to
+    g = golden('g13_swin_stage_' + tag)
+    st = _stage(dim, heads, tag)
+    P = pad_to(dim)
+    x = fm.sym('g13%s/x' % tag, (2, H * W, dim), 1.0)
+    xg = to_tokens(x, H, W, dtype, P).requires_grad_(True)
+    y = xg
+    for blk in st.blocks:
+        y = SwinBlockFn.apply(y, blk, None, None, *block_params(blk))
+    ds = st.downsample
+    yd = PatchMergeFn.apply(y, dim, ds.reduction.weight, ds.norm.weight, ds.norm.bias)
+    c1 = fm.sym('g13%s/c1' % tag, (2, H * W, dim), 1.0).view(2, H, W, dim).to(DEV)
+    H2, W2 = (H + 1) // 2, (W + 1) // 2
+    c2 = fm.sym('g13%s/c2' % tag, (2, H2 * W2, 2 * dim), 1.0).view(2, H2, W2, 2 * dim).to(DEV)
+    ((y.float()[..., :dim] * c1).sum() + (yd.float() * c2).sum()).backward()
+    if P > dim:
+        assert float(y[..., dim:].abs().max()) == 0, 'channel pad is not zero'
+    assert rel(y[..., :dim].reshape(2, H * W, dim)[:, :, ::2], g['x_out']) <= TOL[dtype]
+    assert rel(yd.reshape(2, H2 * W2, 2 * dim)[:, :, ::2], g['x_down']) <= TOL[dtype]
+    assert l2(xg.grad[..., :dim].reshape(2, H * W, dim)[:, :, ::2], g['dx']) <= GTOL[dtype]
+    sub = lambda t: t[::4, ::4] if (t.dim() == 2 and t.numel() > 20000) else t
+    pr = dict(st.named_parameters())
+    for k in ('blocks.0.attn.qkv.bias', 'blocks.1.attn.qkv.bias', 'blocks.1.attn.relative_position_bias_table', 'blocks.0.norm1.weight', 'blocks.1.norm2.bias',
+              'blocks.1.mlp.fc1.weight', 'blocks.0.attn.proj.weight', 'blocks.1.attn.qkv.weight', 'blocks.0.mlp.fc2.bias', 'downsample.reduction.weight', 'downsample.norm.weight'):
+        e = l2(sub(pr[k].grad), g['d_' + k.replace('.', '_')])
+        assert e <= GTOL[dtype], 'd %s: relative L2 %.3g' % (k, e)
+
+
+def test_drop_path_scales_in_block(hip):
+    """DropPath as per-sample scale vectors (timm semantics): against the oracle with the same scales, fp32."""
+    from oracle import swin_oracle as so
+    from segland_amd.functional_swin import SwinBlockFn, block_params
+    st = _stage(96, 3, 'a')
+    blk = st.blocks[1]
+    ob = so.make_block(96, 3); ob.shift, ob.index, ob.drop_path_p = 3, 1, 0.1
+    ob.load_state_dict({k: v.detach().cpu() for k, v in blk.state_dict().items()})
+    x = fm.sym('dp/x', (3, 9 * 8, 96), 1.0)
+    s1, s2 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9]), torch.tensor([1 / 0.9, 0.0, 1 / 0.9])
+    it = iter([s1, s2])
+    holder = type('H', (), {'drop_path_scale': staticmethod(lambda i, B, p: next(it))})
+    xo = x.clone().requires_grad_(True)
+    yo = so.block_forward(holder, ob, xo, 9, 8, so.shift_mask(14, 14, 7, 3))
+    yo.square().sum().backward()
+    xg = to_tokens(x, 9, 8, torch.float32, 128).requires_grad_(True)
+    y = SwinBlockFn.apply(xg, blk, s1.to(DEV), s2.to(DEV), *block_params(blk))
+    y.float()[..., :96].square().sum().backward()
+    assert rel(y[..., :96].reshape(3, 72, 96), yo) <= 1e-5
+    assert l2(xg.grad[..., :96].reshape(3, 72, 96), xo.grad) <= 1e-5
+    assert l2(blk.attn.qkv.bias.grad, ob.attn.qkv.bias.grad) <= 1e-4 and l2(blk.mlp.fc2.weight.grad, ob.mlp.fc2.weight.grad) <= 1e-4
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_g15_upernet_decoder(hip, dtype):
+    from segland_amd.functional import flush_num_batches_tracked
+    from segland_amd.networks.swin_pop import UperNet_Decoder_Plus
+    g = golden('g15_upernet')
+    filters, sizes = [96, 192, 384, 768], [(16, 20), (8, 10), (4, 5), (2, 3)]
+    dec = UperNet_Decoder_Plus(filters, 96)
+    dec.load_state_dict({k: fm.formula_tensor('g15/' + k, v) for k, v in dec.state_dict().items()})
+    dec.to(DEV).train()
+    mask = torch.from_numpy(g['drop_mask'])
+    dec.dropout2d_hook = lambda B, C, p: mask
+    xs = [nchw_to_nhwc(fm.sym('g15/x%d' % i, (2, c, h, w), 1.0), dtype, 128 if c == 96 else c).requires_grad_(True) for i, (c, (h, w)) in enumerate(zip(filters, sizes))]
+    y = dec(xs)
+    flush_num_batches_tracked()
+    coef = fm.sym('g15/coef', (2, 96, 16, 20), 1.0).permute(0, 2, 3, 1).to(DEV)
+    (y.float()[..., :96] * coef).sum().backward()
+    tol, gt = TOL[dtype], GTOL[dtype] * (1 if dtype == torch.float32 else 2)
+    assert float(y[..., 96:].abs().max()) == 0
+    assert rel(y[..., :96].permute(0, 3, 1, 2), g['y']) <= tol
+    for i, (st, c) in enumerate(zip((4, 8, 8, 16), filters)):
+        assert l2(xs[i].grad[..., :c].permute(0, 3, 1, 2)[:, ::st], g['dx%d' % i]) <= gt, 'dx%d' % i
+    pr = dict(dec.named_parameters())
+    checks = {'d_lat0_w': pr['lateral_convs.0.0.weight'].grad[::4, ::4], 'd_fpn3_w': pr['fpn_convs.3.4.0.weight'].grad[::4, ::4],
+              'd_fpn0_gamma': pr['fpn_convs.0.0.1.weight'].grad, 'd_psp_bott_w': pr['psp.bottleneck.0.weight'].grad[::2, ::16, 0, 0],
+              'd_psp_st0_w': pr['psp.stages.0.1.weight'].grad[::4, ::16, 0, 0], 'd_psp_st3_gamma': pr['psp.stages.3.2.weight'].grad}
+    for k, v in checks.items():
+        e = l2(v, g[k])
+        assert e <= gt, '%s: relative L2 %.3g' % (k, e)
+    # conv biases in front of a train-mode BatchNorm: the exact gradient is 0; the reference's value is rounding noise of the same size
+    assert float(pr['lateral_convs.2.0.bias'].grad.abs().max()) <= 1e-3 * max(float(np.abs(g['d_lat0_w']).max()), 1e-6) + float(np.abs(g['d_lat2_b']).max()) * 10 + 1e-4
+    assert rel(dec.lateral_convs[1][1].running_mean, g['rm_lat1']) <= tol and rel(dec.psp.bottleneck[1].running_var, g['rv_psp_bott']) <= tol
+    assert rel(dec.fpn_convs[2][2][1].running_mean, g['rm_fpn2']) <= tol
+    dec.eval()
+    dec.dropout2d_hook = None
+    with torch.no_grad():
+        ye = dec([x.detach() for x in xs])
+    assert rel(ye[..., :96].permute(0, 3, 1, 2), g['y_eval']) <= tol
+
+
+def _swin_model(dtype, is_ft=False, criterion=True):
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.swin_pop import GFSS_Model
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255) if criterion else None, backbone='swin-t', pretrained_model=None, is_ft=is_ft, n_novel=4 if is_ft else 0,
+                   compute_dtype=dtype)
+    fm.load_formula_weights(m)
+    return m.to(DEV)
+
+
+def test_g16_swin_pop_fp32(hip):
+    """BASELINE config 5's model end to end: eval logits (1e-3 rel fp32), argmax agreement, one train-mode step with the golden run's DropPath /
+    Dropout2d draws: loss dict, gradients, per-parameter gradient norms."""
+    g = golden('g16_swin_pop')
+    m = _swin_model(torch.float32)
+    img = fm.formula_image(2, 128, 160, 'g16/img').to(DEV)
+    mask = fm.formula_mask(2, 128, 160, 8, 'g16/mask', ignore_rows=5).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        le = m(img)
+    e = rel(le, g['logits_eval'])
+    agree = float((le.argmax(1).cpu().numpy() == g['logits_eval'].argmax(1)).mean())
+    print('Swin-T POP eval logits: max err %.2e of scale, argmax agreement %.5f' % (e, agree))
+    assert e <= 1e-3 and agree >= 0.999
+    m.train()
+    m.backbone.drop_path_hook = lambda i, B, p: None if p <= 0.0 else torch.tensor([drop_scale(i, b, p) for b in range(B)])
+    dm = torch.from_numpy(g['drop_mask'])
+    m.decoder.dropout2d_hook = lambda B, C, p: dm
+    d = m(img, mask)
+    d['total_loss'].backward()
+    np.testing.assert_allclose(float(d['total_loss'].detach()), g['total'], rtol=2e-4)
+    np.testing.assert_allclose(float(d['seg_loss'].detach()), g['seg'], rtol=2e-4)
+    np.testing.assert_allclose(float(d['orth_loss'].detach()), g['orth'], rtol=1e-4)
+    pr = dict(m.named_parameters())
+    for key, got in (('d_base_emb', pr['base_emb'].grad), ('d_cls4', pr['classifier.4.weight'].grad[0, :, 0, 0]), ('d_patch_w', pr['backbone.patch_embed.proj.weight'].grad),
+                     ('d_table', pr['backbone.layers.0.blocks.1.attn.relative_position_bias_table'].grad), ('d_fc1', pr['backbone.layers.2.blocks.3.mlp.fc1.weight'].grad[::16, ::8]),
+                     ('d_qkv_b', pr['backbone.layers.1.blocks.0.attn.qkv.bias'].grad), ('d_fpn3', pr['decoder.fpn_convs.3.4.0.weight'].grad[::4, ::4])):
+        e = l2(got, g[key])
+        assert e <= 2e-2, '%s: relative L2 %.3g' % (key, e)
+    names = [str(k) for k in g['grad_norm_keys']]
+    gmax = float(g['grad_norms'].max())
+    worst = max((abs(float(pr[k].grad.norm()) - v) / v, k) for k, v in zip(names, g['grad_norms']) if v > 1e-3 * gmax and not (k.endswith('.0.bias') and 'decoder' in k))
+    print('worst per-parameter gradient-norm deviation: %.3g (%s)' % worst)
+    assert worst[0] < 3e-2
+
+
+def test_swin_pop_bf16_eval_and_step(hip):
+    """bf16 throughput mode: eval logits within 5 % of the fp32 golden and >= 98 % argmax agreement; a train step gives finite gradients for every
+    parameter and the fp32-mode loss within 2 %."""
+    g = golden('g16_swin_pop')
+    m = _swin_model(torch.bfloat16)
+    img = fm.formula_image(2, 128, 160, 'g16/img').to(DEV)
+    mask = fm.formula_mask(2, 128, 160, 8, 'g16/mask', ignore_rows=5).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        le = m(img)
+    agree = float((le.argmax(1).cpu().numpy() == g['logits_eval'].argmax(1)).mean())
+    print('Swin-T POP bf16 eval: max err %.3f of scale, argmax agreement %.4f' % (rel(le, g['logits_eval']), agree))
+    assert rel(le, g['logits_eval']) <= 5e-2 and agree >= 0.98
+    m.train()
+    m.backbone.drop_path_hook = lambda i, B, p: None if p <= 0.0 else torch.tensor([drop_scale(i, b, p) for b in range(B)])
+    dm = torch.from_numpy(g['drop_mask'])
+    m.decoder.dropout2d_hook = lambda B, C, p: dm
+    d = m(img, mask)
+    d['total_loss'].backward()
+    assert abs(float(d['total_loss'].detach()) - float(g['total'])) <= 2e-2 * float(g['total'])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.requires_grad)
+
+
+def test_swin_ft_mode_vs_same_box_oracle(hip):
+    """forward_novel / forward_all on the Swin features (swin_pop.py:280-386): pseudo-labels, loss dict, novel-prototype gradient, frozen parameters."""
+    from oracle import pop_oracle as po
+    from oracle import swin_oracle as so
+    m = _swin_model(torch.float32, is_ft=True)
+    o = fm.load_formula_weights(so.SwinPopOracle(7, criterion=po.OrthLossOracle(255), is_ft=True, n_novel=4))
+    m.init_cls_n(); po.init_cls_n(o)
+    H, W = 96, 128
+    img, img_b = fm.formula_image(1, H, W, 'swft/img'), fm.formula_image(1, H, W, 'swft/img_b')
+    mask = fm.formula_mask(1, H, W, 4, 'swft/mask', ignore_rows=3, lo=8); mask[mask == 8] = 255
+    mask_b = fm.formula_mask(1, H, W, 8, 'swft/mask_b', ignore_rows=0)
+    mb_gpu, mb_cpu = mask_b.clone().to(DEV), mask_b.clone()
+    m.train_mode(); so.train_mode(o)
+    d = m(img.to(DEV), mask.to(DEV), img_b.to(DEV), mb_gpu)
+    d['total_loss'].backward()
+    do = o(img, mask, img_b, mb_cpu)
+    do['total_loss'].backward()
+    assert int((mb_gpu.cpu() != mb_cpu).sum()) <= 8
+    for k in do:
+        assert abs(float(d[k].detach()) - float(do[k].detach())) <= 2e-3 * max(1.0, abs(float(do[k].detach()))), k
+    assert l2(m.novel_emb.grad, o.novel_emb.grad) <= 2e-2
+    assert m.base_emb.grad is None and m.backbone.patch_embed.proj.weight.grad is None and m.decoder.psp.bottleneck[0].weight.grad is None
+    m.eval(); o.eval()
+    with torch.no_grad():
+        assert rel(m(img.to(DEV)), o(img)) <= 2e-3
