@@ -214,11 +214,17 @@ def test_g15_upernet_decoder(hip, dtype):
     checks = {'d_lat0_w': pr['lateral_convs.0.0.weight'].grad[::4, ::4], 'd_fpn3_w': pr['fpn_convs.3.4.0.weight'].grad[::4, ::4],
               'd_fpn0_gamma': pr['fpn_convs.0.0.1.weight'].grad, 'd_psp_bott_w': pr['psp.bottleneck.0.weight'].grad[::2, ::16, 0, 0],
               'd_psp_st0_w': pr['psp.stages.0.1.weight'].grad[::4, ::16, 0, 0], 'd_psp_st3_gamma': pr['psp.stages.3.2.weight'].grad}
+    if dtype != torch.float32:
+        # pyramid level 1x1 with batch 2: BatchNorm over TWO samples maps them to -+1 whatever the input, its input gradient is ~0 and what
+        # is left is rounding noise (0.6 relative in bf16); the exact-fp32 mode passes at 5e-3
+        checks.pop('d_psp_st0_w')
     for k, v in checks.items():
         e = l2(v, g[k])
         assert e <= gt, '%s: relative L2 %.3g' % (k, e)
-    # conv biases in front of a train-mode BatchNorm: the exact gradient is 0; the reference's value is rounding noise of the same size
-    assert float(pr['lateral_convs.2.0.bias'].grad.abs().max()) <= 1e-3 * max(float(np.abs(g['d_lat0_w']).max()), 1e-6) + float(np.abs(g['d_lat2_b']).max()) * 10 + 1e-4
+    # conv biases in front of a train-mode BatchNorm: the exact gradient is 0 (BN removes the mean); the reference's value is its own rounding
+    # noise (5e-6 here), ours the column sum of the stored BN-input gradient: bounded relative to the weight gradients of the same layer
+    bnoise = float(pr['lateral_convs.2.0.bias'].grad.abs().max()) / float(pr['lateral_convs.2.0.weight'].grad.abs().max())
+    assert bnoise <= (1e-5 if dtype == torch.float32 else 2e-2), bnoise
     assert rel(dec.lateral_convs[1][1].running_mean, g['rm_lat1']) <= tol and rel(dec.psp.bottleneck[1].running_var, g['rv_psp_bott']) <= tol
     assert rel(dec.fpn_convs[2][2][1].running_mean, g['rm_fpn2']) <= tol
     dec.eval()
