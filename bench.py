@@ -29,7 +29,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_TILE = {'resnet50': 1170.7, 'resnet101': 1636.1}      # fwd+bwd, reference algorithm
+GFLOP_PER_TILE = {'resnet50': 1170.7, 'resnet101': 1636.1, 'swin-t': 197.4}      # fwd+bwd, reference algorithm
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_F32_TFLOPS = 157.3
 
@@ -39,8 +39,9 @@ def parse():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=5)
-    p.add_argument('--batch', type=int, default=16, help='tiles per GPU')
-    p.add_argument('--backbone', default='resnet50')
+    p.add_argument('--model', default='pspnet_pop', choices=['pspnet_pop', 'swin_pop'], help='swin_pop: BASELINE config 5 (Swin-T + UperNet_Decoder_Plus + POP head, 8 tiles per GPU)')
+    p.add_argument('--batch', type=int, default=None, help='tiles per GPU (default 16; swin_pop: 8)')
+    p.add_argument('--backbone', default=None)
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--size', type=int, default=512)
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -95,7 +96,7 @@ def usable_cpus():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(budget_s, backbone):
+def cpu_baseline(budget_s, backbone, model='pspnet_pop'):
     """CPU port (oracle) of the same loop body, on a BOUNDED sample: batch 2 at 256x256 first (1/4 of the pixels of
     config C1); if that step takes < budget/8 the full C1 sample (batch 2, 512x512) is timed too and reported instead.
     tiles/s is always in units of 512x512 tiles (a 256x256 tile counts 1/4)."""
@@ -103,7 +104,11 @@ def cpu_baseline(budget_s, backbone):
     torch.manual_seed(0)
     threads = usable_cpus()
     torch.set_num_threads(threads)
-    m = po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), backbone=backbone).train()
+    if model == 'swin_pop':
+        from oracle import swin_oracle as so
+        m = so.SwinPopOracle(7, criterion=po.OrthLossOracle(255), backbone=backbone).train()
+    else:
+        m = po.PopOracle(n_base=7, criterion=po.OrthLossOracle(255), backbone=backbone).train()
     groups, _ = po.param_groups(m, lr=1e-5)
     opt = torch.optim.AdamW(groups, lr=1e-5, weight_decay=1e-4)
 
@@ -126,12 +131,16 @@ def cpu_baseline(budget_s, backbone):
     except Exception:
         pass
     return {'value': 2.0 * (size * size) / (512.0 * 512.0) / t, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle/pop_oracle.py train_step (train_base.py:250-264 body), %s fp32, batch 2 at %dx%d, %.2f s/step after warm-up, '
+            'sample': ('oracle/swin_oracle.py' if model == 'swin_pop' else 'oracle/pop_oracle.py') + ' train_step (train_base.py:250-264 body), %s fp32, batch 2 at %dx%d, %.2f s/step after warm-up, '
                       '%d threads (cgroup/affinity limit) on %s' % (backbone, size, size, t, threads, cpu)}
 
 
 def main():
     a = parse()
+    if a.batch is None:
+        a.batch = 8 if a.model == 'swin_pop' else 16
+    if a.backbone is None:
+        a.backbone = 'swin-t' if a.model == 'swin_pop' else 'resnet50'
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -146,12 +155,13 @@ def main():
 
     from segland_amd import ops
     from segland_amd.loss.criterion import OrthLoss
-    from segland_amd.networks.pspnet_pop import GFSS_Model
+    from segland_amd import networks
 
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     torch.manual_seed(0)
-    model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, dilated=True, os=8,
-                       compute_dtype=dtype).to(dev).train()
+    GFSS_Model = getattr(networks, a.model).GFSS_Model
+    kw = dict(dilated=True, os=8) if a.model == 'pspnet_pop' else {}
+    model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, compute_dtype=dtype, **kw).to(dev).train()
     opt = make_optimizer(model, torch_optimizer=a.torch_optimizer)
     net = model
     if use_ddp:
@@ -207,10 +217,10 @@ def main():
         value = tiles / dt_s
         peak = PEAK_BF16_TFLOPS if a.dtype == 'bf16' else PEAK_F32_TFLOPS
         out = {
-            'metric': '512x512 tiles/sec fwd+bwd PSPNet-POP', 'value': round(value, 3), 'unit': 'tiles/s',
+            'metric': '512x512 tiles/sec fwd+bwd ' + ('PSPNet-POP' if a.model == 'pspnet_pop' else 'Swin-POP'), 'value': round(value, 3), 'unit': 'tiles/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt_s / a.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
-            'config': {'workload': 'PSPNet-POP %s %s, batch %d/GPU, %dx%d, 8 logit channels, train_base.py loop body '
+            'config': {'workload': ('PSPNet-POP' if a.model == 'pspnet_pop' else 'Swin-POP') + ' %s %s, batch %d/GPU, %dx%d, 8 logit channels, train_base.py loop body '
                                    '(fwd+loss+bwd+clip+AdamW x%d), %d x MI355X' % (a.backbone, a.dtype, a.batch, a.size, a.size, 2 if double else 1, world),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
@@ -233,7 +243,7 @@ def main():
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the timed steps (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone)
+            out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone, a.model)
         print(json.dumps(out), flush=True)
     if use_ddp:
         dist.destroy_process_group()

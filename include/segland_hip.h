@@ -314,15 +314,14 @@ typedef struct SlResizeDesc {
 /* conv 4x4 stride 4 (3 -> C) + bias from the NCHW float image; zero padding to multiples of 4 (:417-421); out [B][ceil(H/4)][ceil(W/4)][pitch] */
 int sl_patch_embed_fwd(int dtype, const float* img_nchw, const float* w_oihw, const float* bias, void* out, int B, int H, int W, int C,
                        int out_pitch, sl_stream_t stream);
-/* partial[blk][C*48 (dw, OIHW order) + C (dbias)], blk < sl_patch_embed_bwd_blocks(); sum the rows with sl_colsum_finalize */
-int sl_patch_embed_bwd_blocks(int B, int H, int W);
-int sl_patch_embed_bwd(int dtype, const float* img_nchw, const void* dy, float* partial, int B, int H, int W, int C, int dy_pitch,
-                       sl_stream_t stream);
+/* weight gradient of the patch embedding: col [B*ceil(H/4)*ceil(W/4)][64] = the 48 patch values of every token (k = ci*16 + ky*4 + kx) + 16
+ * zeros, then dW = sl_conv2d_bwd_weight(col as [1,1,T,64], dy as [1,1,T,pitch]) on the MFMA kernel */
+int sl_patch_im2col(int dtype, const float* img_nchw, void* col, int B, int H, int W, sl_stream_t stream);
 /* y = (x - mean) * rstd * gamma + beta over the first C channels of each row, pad channels of y zeroed; mean_rstd [rows][2] (may be null) */
 int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, long long rows, int C,
                      int x_pitch, int y_pitch, float eps, sl_stream_t stream);
-/* dx (+= addend, e.g. the gradient of the residual branch); dgamma_dbeta_partial [sl_layernorm_bwd_rows(rows)][2][C] or null */
-int sl_layernorm_bwd_rows(long long rows);
+/* dx (+= addend, e.g. the gradient of the residual branch); dgamma_dbeta_partial [sl_layernorm_bwd_rows(dtype, rows, C, dx_pitch)][2][C] or null */
+int sl_layernorm_bwd_rows(int dtype, long long rows, int C, int dx_pitch);
 int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
                      float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream);
 /* exact GELU on n contiguous elements (n % 8 == 0) */

@@ -21,6 +21,8 @@ namespace {
 constexpr int WS = 7, WN = 49, HD = 32;       // window edge, tokens per window, head dimension (C / heads = 32 for every Swin variant)
 constexpr int QP = 36;                        // LDS row pitch of a [49][32] tile (floats): 16-byte aligned, conflict-free ds_read_b128
 
+inline int ew_grid(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
 template <int LPR> __device__ __forceinline__ float grp_sum(float v) {
 #pragma unroll
   for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -76,57 +78,27 @@ __global__ __launch_bounds__(256) void patch_embed_fwd_kernel(const float* __res
   }
 }
 
-// part[blk][c][48] = sum over the block's tokens of dy[t][c] * patch[t][k];  part[blk][C*48 + c] = sum dy[t][c]
+// col[t][k] = img patch value k = ci*16 + ky*4 + kx of token t (k < 48), zero for k in [48, 64): the weight gradient of the patch embedding is
+// then the MFMA weight-gradient GEMM dW[c][k] = sum_t dy[t][c] * col[t][k] (sl_conv2d_bwd_weight on [1,1,T,64] x [1,1,T,P])
 template <typename T>
-__global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __restrict__ img, const T* __restrict__ dy, float* __restrict__ part,
-                                                              int B, int H, int W, int Ho, int Wo, int C, int Cp, long long tok_per_blk) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* pl = sm;                  // [64][49]
-  float* dl = sm + 64 * 49;        // [64][C]
-  const int tid = threadIdx.x, k = tid & 63, cg = tid >> 6, cpt = C / 4;
-  const long long ntok = (long long)B * Ho * Wo;
-  const long long ta = blockIdx.x * tok_per_blk;
-  long long tb = ta + tok_per_blk; if (tb > ntok) tb = ntok;
-  float acc[48];                   // cpt <= 48
+__global__ void patch_im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int H, int W, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo * 16;          // 16 groups of 4 consecutive k (= one kernel row of one input channel)
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int gq = (int)(i % 16); const long long tok = i / 16;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gq < 12) {
+      const int tx = (int)(tok % Wo), ty = (int)((tok / Wo) % Ho), b = (int)(tok / ((long long)Wo * Ho));
+      const int ci = gq / 4, ky = gq % 4, y = 4 * ty + ky;
+      if (y < H) {
+        const float* src = img + ((size_t)(b * 3 + ci) * H + y) * W + 4 * tx;
 #pragma unroll
-  for (int j = 0; j < 48; ++j) acc[j] = 0.f;
-  float bsum = 0.f;                // thread (cg, k < cpt) also owns dbias[cg*cpt + k]
-  for (long long t0 = ta; t0 < tb; t0 += 64) {
-    __syncthreads();
-    for (int e = tid; e < 64 * 48; e += 256) {
-      const int t = e / 48, kk = e % 48;
-      const long long tok = t0 + t;
-      float v = 0.f;
-      if (tok < tb) {
-        const int tx = (int)(tok % Wo), ty = (int)((tok / Wo) % Ho), b = (int)(tok / ((long long)Wo * Ho));
-        const int ci = kk / 16, ky = (kk % 16) / 4, kx = kk % 4;
-        const int y = 4 * ty + ky, x = 4 * tx + kx;
-        if (y < H && x < W) v = img[((size_t)(b * 3 + ci) * H + y) * W + x];
+        for (int kx = 0; kx < 4; ++kx) if (4 * tx + kx < W) v[kx] = src[kx];
       }
-      pl[t * 49 + kk] = v;
     }
-    for (int e = tid; e < 64 * C; e += 256) {
-      const int t = e / C, c = e % C;
-      const long long tok = t0 + t;
-      dl[e] = tok < tb ? to_f<T>(dy[(size_t)tok * Cp + c]) : 0.f;
-    }
-    __syncthreads();
-    for (int t = 0; t < 64; ++t) {
-      const float a = k < 48 ? pl[t * 49 + k] : 0.f;
-      const float* d = dl + t * C + cg * cpt;           // wave-uniform address: broadcast
+    T* o = col + (size_t)tok * 64 + gq * 4;
 #pragma unroll
-      for (int j = 0; j < 48; ++j)
-        if (j < cpt) acc[j] = fmaf(a, d[j], acc[j]);
-      if (k < cpt) bsum += d[k];
-    }
+    for (int kx = 0; kx < 4; ++kx) o[kx] = from_f<T>(v[kx]);
   }
-  float* o = part + (size_t)blockIdx.x * (C * 49);
-  if (k < 48) {
-#pragma unroll
-    for (int j = 0; j < 48; ++j)
-      if (j < cpt) o[(cg * cpt + j) * 48 + k] = acc[j];
-  }
-  if (k < cpt) o[C * 48 + cg * cpt + k] = bsum;
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
@@ -176,14 +148,29 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) (+ addend),  g = dy * gamma,  xhat = (x - mean) * rstd
-template <typename T, int LPR>
+// dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) (+ addend),  g = dy * gamma,  xhat = (x - mean) * rstd.
+// NV > 0: the lane's (at most NV) channel vectors also accumulate the column sums part[blk][0][c] = sum_rows dy * xhat (dgamma) and
+// part[blk][1][c] = sum_rows dy (dbeta) in registers -- no second pass over dy and x; NV = 0: rows wider than NV_MAX * LPR vectors
+// leave the column sums to layernorm_bwd_cols_kernel.
+template <int LPR> __device__ __forceinline__ float grp_across(float v) {      // same channel, the 64/LPR rows of a wavefront
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
-                                                            long long rows, int C, int pdy, int px, int pdx) {
-  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
+                                                            float* __restrict__ part, long long rows, int C, int pdy, int px, int pdx) {
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR, NA = NV > 0 ? NV : 1;
+  extern __shared__ __attribute__((aligned(16))) float red[];           // [4][2][C] when NV > 0
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   const int nvec = C / V;
+  float ag[NA][V], ab[NA][V];
+#pragma unroll
+  for (int j = 0; j < NA; ++j)
+#pragma unroll
+    for (int e = 0; e < V; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
   for (long long rb = ((long long)blockIdx.x * 4 + wave) * RPW; rb < rows; rb += (long long)gridDim.x * 4 * RPW) {
     const long long r = rb + grp;
     const bool live = r < rows;
@@ -203,14 +190,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     s2 = grp_sum<LPR>(s2) / (float)C;
     if (!live) continue;
     T* dxr = dx + (size_t)r * pdx;
-    for (int v = sub; v < pdx / V; v += LPR) {
+#pragma unroll
+    for (int j = 0; j < (NV > 0 ? NV : 64); ++j) {
+      const int v = sub + j * LPR;
+      if (v >= pdx / V) break;
       float o[V];
       if (v < nvec) {
         float g[V], t[V];
         unpack16<T>(*(const uint4*)(dyr + v * V), g);
         unpack16<T>(*(const uint4*)(xr + v * V), t);
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = rstd * (g[e] * gamma[v * V + e] - s1 - (t[e] - mean) * rstd * s2);
+        for (int e = 0; e < V; ++e) {
+          const float xh = (t[e] - mean) * rstd;
+          o[e] = rstd * (g[e] * gamma[v * V + e] - s1 - xh * s2);
+          if (NV > 0) { ag[j < NA ? j : 0][e] = fmaf(g[e], xh, ag[j < NA ? j : 0][e]); ab[j < NA ? j : 0][e] += g[e]; }
+        }
         if (addend) {
           float a[V];
           unpack16<T>(*(const uint4*)(addend + (size_t)r * pdx + v * V), a);
@@ -222,6 +216,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < V; ++e) o[e] = 0.f;
       }
       *(uint4*)(dxr + v * V) = pack16<T>(o);
+    }
+  }
+  if (NV > 0 && part) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int v = sub + j * LPR;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float a = grp_across<LPR>(ag[j][e]), b = grp_across<LPR>(ab[j][e]);
+        if (grp == 0 && v < nvec) { red[(wave * 2 + 0) * C + v * V + e] = a; red[(wave * 2 + 1) * C + v * V + e] = b; }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+      const int which = i / C, c = i % C;
+      part[((size_t)blockIdx.x * 2 + which) * C + c] = red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c] + red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c];
     }
   }
 }
@@ -672,7 +682,6 @@ __global__ __launch_bounds__(256) void window_attention_bwd_kernel(WinGeom g, co
   for (int m = 0; m < 10; ++m) { const int e = tid + 256 * m; if (e < WN * WN) dr[e] = dsum[m]; }
 }
 
-inline int ew_grid(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 
 int check_geom(const SlWinDesc* d, WinGeom& g) {
   SL_REQUIRE(d && d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0, "window_attention: bad sizes");
@@ -712,27 +721,14 @@ extern "C" int sl_patch_embed_fwd(int dtype, const float* img, const float* w, c
   return 0;
 }
 
-extern "C" int sl_patch_embed_bwd_blocks(int B, int H, int W) {
-  const long long ntok = (long long)B * cdiv(H, 4) * cdiv(W, 4);
-  const long long b = (ntok + 1023) / 1024;
-  return (int)(b < 1 ? 1 : (b > 512 ? 512 : b));
-}
-
-extern "C" int sl_patch_embed_bwd(int dtype, const float* img, const void* dy, float* partial, int B, int H, int W, int C, int dy_pitch,
-                                  sl_stream_t stream) {
-  SL_REQUIRE(img && dy && partial && B > 0 && C % 32 == 0 && C <= 192 && dy_pitch >= C, "patch_embed_bwd: bad args");
+extern "C" int sl_patch_im2col(int dtype, const float* img, void* col, int B, int H, int W, sl_stream_t stream) {
+  SL_REQUIRE(img && col && B > 0 && H > 0 && W > 0, "patch_im2col: bad args");
   const int Ho = cdiv(H, 4), Wo = cdiv(W, 4);
-  const long long ntok = (long long)B * Ho * Wo;
-  const int nblk = sl_patch_embed_bwd_blocks(B, H, W);
-  long long tpb = (ntok + nblk - 1) / nblk;
-  tpb = (tpb + 63) / 64 * 64;
-  const size_t lds = (size_t)(64 * 49 + 64 * C) * sizeof(float);
+  const long long n = (long long)B * Ho * Wo * 16;
   hipStream_t st = (hipStream_t)stream;
-  BY_DTYPE(dtype,
-           hipLaunchKernelGGL(patch_embed_bwd_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img, (const bf16_t*)dy, partial, B, H, W, Ho, Wo, C, dy_pitch, tpb),
-           hipLaunchKernelGGL(patch_embed_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, img, (const float*)dy, partial, B, H, W, Ho, Wo, C, dy_pitch, tpb),
-           "patch_embed_bwd");
-  SL_LAUNCH_CHECK("patch_embed_bwd_kernel");
+  BY_DTYPE(dtype, hipLaunchKernelGGL(patch_im2col_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, st, img, (bf16_t*)col, B, H, W, Ho, Wo),
+           hipLaunchKernelGGL(patch_im2col_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, st, img, (float*)col, B, H, W, Ho, Wo), "patch_im2col");
+  SL_LAUNCH_CHECK("patch_im2col_kernel");
   return 0;
 }
 
@@ -759,31 +755,49 @@ extern "C" int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   return 0;
 }
 
+constexpr int LN_BWD_BLOCKS = 512;      // partial rows of the fused column sums (grid-stride over the rows)
+
+// fused column sums need every lane's channel vectors in registers: up to 3 per lane (C <= 3 * 64 * 8 = 1536 in bf16, 768 in fp32)
+
 template <typename T>
-static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, const void* addend, void* dx, long long rows, int C, int pdy, int px,
-                         int pdx, hipStream_t st) {
+static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, const void* addend, void* dx, float* part, long long rows, int C,
+                         int pdy, int px, int pdx, hipStream_t st) {
   constexpr int V = Vec16<T>::N;
-  const int nvec = C / V;
-  const int grid = (int)(rows / 16 + 1 > 8192 ? 8192 : rows / 16 + 1);
-  if (nvec <= 16) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
-  else if (nvec <= 32) hipLaunchKernelGGL((layernorm_bwd_kernel<T, 32>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
-  else hipLaunchKernelGGL((layernorm_bwd_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, rows, C, pdy, px, pdx);
-  return 0;
+  const int nvec = C / V, nvp = pdx / V;
+  long long want = rows / 16 + 1;
+  const bool fused = part != nullptr && nvp <= 192;
+  const int grid = (int)(fused ? (want > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : want) : (want > 8192 ? 8192 : want));
+  const size_t lds = fused ? (size_t)8 * C * sizeof(float) : 0;
+#define LN_BWD(LPR, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, NV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, part, rows, C, pdy, px, pdx)
+  if (fused) {
+    if (nvp <= 16) LN_BWD(16, 1); else if (nvp <= 32) LN_BWD(32, 1); else if (nvp <= 64) LN_BWD(64, 1); else if (nvp <= 128) LN_BWD(64, 2); else LN_BWD(64, 3);
+  } else {
+    if (nvec <= 16) LN_BWD(16, 0); else if (nvec <= 32) LN_BWD(32, 0); else LN_BWD(64, 0);
+  }
+#undef LN_BWD
+  return fused ? grid : 0;
 }
 
-extern "C" int sl_layernorm_bwd_rows(long long rows) { const long long b = (rows + 255) / 256; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
+extern "C" int sl_layernorm_bwd_rows(int dtype, long long rows, int C, int dx_pitch) {
+  const int vb = dtype == SL_BF16 ? 8 : 4;
+  if (dx_pitch / vb <= 192) { const long long want = rows / 16 + 1; return (int)(want > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : want); }
+  const long long b = (rows + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
 
 extern "C" int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
                                 float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream) {
   SL_REQUIRE(dy && x && gamma && mean_rstd && dx && rows > 0 && C > 0, "layernorm_bwd: bad args");
   const int vb = dtype == SL_BF16 ? 8 : 4;
+  SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "layernorm_bwd: bad dtype");
   SL_REQUIRE(C % vb == 0 && dy_pitch >= C && x_pitch >= C && dx_pitch >= C && dy_pitch % vb == 0 && x_pitch % vb == 0 && dx_pitch % vb == 0, "layernorm_bwd: bad pitches");
   hipStream_t st = (hipStream_t)stream;
-  BY_DTYPE(dtype, launch_ln_bwd<bf16_t>(dy, x, gamma, mean_rstd, addend, dx, rows, C, dy_pitch, x_pitch, dx_pitch, st),
-           launch_ln_bwd<float>(dy, x, gamma, mean_rstd, addend, dx, rows, C, dy_pitch, x_pitch, dx_pitch, st), "layernorm_bwd");
+  const bool fused = dgamma_dbeta_partial && dx_pitch / vb <= 192;
+  if (dtype == SL_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st);
+  else launch_ln_bwd<float>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st);
   SL_LAUNCH_CHECK("layernorm_bwd_kernel");
-  if (dgamma_dbeta_partial) {
-    const int nblk = sl_layernorm_bwd_rows(rows);
+  if (dgamma_dbeta_partial && !fused) {
+    const int nblk = sl_layernorm_bwd_rows(dtype, rows, C, dx_pitch);
     const long long rpb = (rows + nblk - 1) / nblk;
     BY_DTYPE(dtype,
              hipLaunchKernelGGL(layernorm_bwd_cols_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x, mean_rstd, dgamma_dbeta_partial, rows, C, dy_pitch, x_pitch, rpb),

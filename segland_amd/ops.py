@@ -256,6 +256,9 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     return dx, dres, o[0], o[1]
 
 
+_zeros_cache = {}
+
+
 def colsum_rows(t):
     """Per-channel sum over all rows of an NHWC tensor (conv bias gradient) via the BN reduce kernel (S1 with no mask)."""
     Cn = t.shape[-1]
@@ -263,7 +266,9 @@ def colsum_rows(t):
     L = _lib.lib()
     nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
     part = _f32((nblk, 2, Cn), t.device)
-    z = _f32((2, Cn), t.device, zero=True)
+    z = _zeros_cache.get((Cn, t.device))
+    if z is None:
+        z = _zeros_cache[(Cn, t.device)] = _f32((2, Cn), t.device, zero=True)          # read-only (mean 0, invstd 0): shared by every call
     check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
     return colsum(part)[0].contiguous()
 

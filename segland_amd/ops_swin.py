@@ -27,14 +27,14 @@ def patch_embed_fwd(img, w, bias, dtype, pitch):
 
 
 def patch_embed_bwd(img, dy, Cn):
-    """(dw [C,3,4,4], dbias [C]) float."""
+    """(dw [C,3,4,4], dbias [C]) float: im2col of the 4x4 patches + the MFMA weight-gradient GEMM (the same route as the ResNet stem)."""
     B, _, H, W = img.shape
-    L = _lib.lib()
-    nblk = L.sl_patch_embed_bwd_blocks(B, H, W)
-    part = _f32((nblk, Cn * 49), img.device)
-    check(L.sl_patch_embed_bwd(dt(dy), _p(img), _p(dy), _p(part), B, H, W, Cn, dy.shape[-1], _s()), 'patch_embed_bwd')
-    tot = ops.colsum(part)
-    return tot[:Cn * 48].view(Cn, 3, 4, 4), tot[Cn * 48:]
+    ntok = B * ((H + 3) // 4) * ((W + 3) // 4)
+    P = dy.shape[-1]
+    col = torch.empty((1, 1, ntok, 64), dtype=dy.dtype, device=img.device)
+    check(_lib.lib().sl_patch_im2col(dt(dy), _p(img), _p(col), B, H, W, _s()), 'patch_im2col')
+    dwp = ops.conv2d_bwd_weight(col, dy.view(1, 1, ntok, P), ops.ConvSpec(64, P, 1))
+    return dwp[:Cn, :48, 0, 0].reshape(Cn, 3, 4, 4), ops.colsum_rows(dy)[:Cn].contiguous()
 
 
 # --------------------------------------------------------------------------------------------- LayerNorm
@@ -55,7 +55,7 @@ def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, d
     rows = x.numel() // px
     dx = torch.empty(x.shape[:-1] + (pdx,), dtype=x.dtype, device=x.device)
     L = _lib.lib()
-    part = _f32((L.sl_layernorm_bwd_rows(rows), 2, Cn), x.device) if want_param_grads else None
+    part = _f32((L.sl_layernorm_bwd_rows(dt(x), rows, Cn, pdx), 2, Cn), x.device) if want_param_grads else None
     check(L.sl_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(stats), _p(addend), _p(dx), _p(part), rows, Cn, pdy, px, pdx, _s()), 'layernorm_bwd')
     if not want_param_grads:
         return dx, None, None
