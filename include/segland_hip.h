@@ -259,6 +259,11 @@ int sl_pseudo_label(const float* logits, int K2, int h, int w, int64_t* mask, in
 /* argmax over channels of the upsampled (align_corners=True) logits -> uint8 labels (eval_base.py:168-169) */
 int sl_upsample_argmax(const float* logits, int B, int K, int h, int w, int H, int W, uint8_t* labels,
                        sl_stream_t stream);
+/* eval_base.py:168,189-190: the upsampled logits themselves (the 'outputs' array of the per-tile .mat probability dumps), NCHW float */
+int sl_upsample_logits(const float* logits, int B, int K, int h, int w, int H, int W, float* out, sl_stream_t stream);
+/* fusemat.py:35-52: argmax over classes of the mean of n_models probability maps [K][hw] (mats_dev: device array of n_models float pointers),
+ * summed in list order like the reference's in-place `mats[idx] += prob` */
+int sl_fuse_argmax(const void* mats_dev, int n_models, int K, long long hw, uint8_t* labels, sl_stream_t stream);
 /* utils/pyt_utils.py:293-305 intersectionAndUnionGPU: hist[0..K) inter, [K..2K) pred area, [2K..3K) target area
  * (int64 counts; caller zeroes hist). */
 int sl_iou_hist(const uint8_t* pred, const int64_t* target, long long n, int K, int ignore_index, long long* hist,
@@ -346,6 +351,18 @@ int sl_window_attention_bwd_chunks(const SlWinDesc* d);
 int sl_window_attention_windows(const SlWinDesc* d);
 int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
                             float* drel_partial, float* pad_partial, sl_stream_t stream);
+
+/* ---- OpenEarthMap tile preparation ------------------------------------------------------------
+ * dataset/base_dataset.py crop :140-174, pad :88-104, random_flip :106-110, fixed_random_rotate :134-138, normalize :29-34, totensor
+ * :36-43 and the label re-indexing of dataset/oem.py:113-133 / oem_ft.py:197 for a batch of decoded tiles in one launch.
+ * tiles_dev: device array of B 32-byte records { const uint8_t* img [H][W][3]; const uint8_t* lbl [H][W] or null; int H, W, h_off, w_off; };
+ * flip_rot_dev: device int[2*B] = {flip (0/1), k of np.rot90}; crops must be square when any k is odd.  mean3 / std3: HOST pointers (in the
+ * reversed channel order normalize() applies them in).  label_lut_dev: 256-entry table or null (identity).  out_img [B][3][crop_h][crop_w]
+ * float, out_lbl [B][crop_h][crop_w] int64 (may be null).  Pixels beyond the tile are the padding: image value 0 BEFORE normalisation,
+ * label ignore_label. */
+int sl_augment_batch(const void* tiles_dev, const int* flip_rot_dev, int B, int crop_h, int crop_w, const double* mean3_host,
+                     const double* std3_host, int ignore_label, const uint8_t* label_lut_dev, float* out_img, long long* out_lbl,
+                     sl_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -154,6 +154,34 @@ __global__ void upsample_argmax_kernel(UpGeom g, const float* __restrict__ lg, u
   }
 }
 
+// probability-map dump of eval_base.py:168,189-190: the full-resolution logits F.interpolate(align_corners=True) produced, NCHW float
+__global__ void upsample_logits_kernel(UpGeom g, const float* __restrict__ lg, float* __restrict__ out) {
+  const long long total = (long long)g.B * g.H * g.W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % g.W); const long long r = i / g.W;
+    const int Y = (int)(r % g.H), b = (int)(r / g.H);
+    float v[KMAXC];
+    pixel_logits(g, lg, b, Y, X, v);
+    const size_t plane = (size_t)g.H * g.W;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) if (k < g.K) out[((size_t)b * g.K + k) * plane + (size_t)Y * g.W + X] = v[k];
+  }
+}
+
+// fusemat.py:35-52: mats[idx] += prob in list order, argmax(mat / n, axis=0): float sum in the same order, first maximum wins (np.argmax)
+__global__ void fuse_argmax_kernel(const float* const* __restrict__ mats, int n, int K, long long hw, uint8_t* __restrict__ out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < hw; i += (long long)gridDim.x * blockDim.x) {
+    int best = 0; float bv = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float s = mats[0][(size_t)k * hw + i];
+      for (int m = 1; m < n; ++m) s += mats[m][(size_t)k * hw + i];
+      s = s / (float)n;
+      if (k == 0 || s > bv) { bv = s; best = k; }
+    }
+    out[i] = (uint8_t)best;
+  }
+}
+
 __global__ __launch_bounds__(256) void iou_hist_kernel(const uint8_t* __restrict__ pred, const int64_t* __restrict__ tgt, long long n, int K,
                                                        int ignore, unsigned long long* __restrict__ hist) {
   __shared__ unsigned int h[3 * 256];
@@ -284,6 +312,21 @@ extern "C" int sl_upsample_argmax(const float* logits, int B, int K, int h, int 
   const UpGeom g = make_up(B, K, h, w, H, W);
   hipLaunchKernelGGL(upsample_argmax_kernel<false>, dim3(ce_blocks((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, logits, labels, (int64_t*)nullptr, 0);
   SL_LAUNCH_CHECK("upsample_argmax_kernel");
+  return 0;
+}
+
+extern "C" int sl_upsample_logits(const float* logits, int B, int K, int h, int w, int H, int W, float* out, sl_stream_t stream) {
+  SL_REQUIRE(logits && out && K >= 1 && K <= KMAXC && B > 0, "upsample_logits: bad args");
+  const UpGeom g = make_up(B, K, h, w, H, W);
+  hipLaunchKernelGGL(upsample_logits_kernel, dim3(ce_blocks((long long)B * H * W)), dim3(256), 0, (hipStream_t)stream, g, logits, out);
+  SL_LAUNCH_CHECK("upsample_logits_kernel");
+  return 0;
+}
+
+extern "C" int sl_fuse_argmax(const void* mats_dev, int n_models, int K, long long hw, uint8_t* labels, sl_stream_t stream) {
+  SL_REQUIRE(mats_dev && labels && n_models >= 1 && K >= 1 && K <= 255 && hw > 0, "fuse_argmax: bad args");
+  hipLaunchKernelGGL(fuse_argmax_kernel, dim3(ce_blocks(hw)), dim3(256), 0, (hipStream_t)stream, (const float* const*)mats_dev, n_models, K, hw, labels);
+  SL_LAUNCH_CHECK("fuse_argmax_kernel");
   return 0;
 }
 

@@ -1,3 +1,4 @@
-"""Datasets of the drivers.  `synthetic` ships with the build (benchmarks, smoke runs, tests); `oem` (OpenEarthMap
-GeoTIFF tiles, dataset/oem.py + oem_ft.py of the reference) is row f-2 of SURVEY.md section 8 -- next, not built yet."""
-from . import synthetic, synthetic_ft  # noqa: F401
+"""Datasets of the drivers.  `synthetic` (ready float tiles) and `synthetic_raw` (raw uint8 tiles through the GPU tile preparation) ship with
+the build for benchmarks, smoke runs and tests; `oem` reads OpenEarthMap GeoTIFF tiles (dataset/oem.py of the reference; needs rasterio, which
+this image does not have -- the readers raise without it) and prepares them on the GPU."""
+from . import oem, synthetic, synthetic_ft, synthetic_raw  # noqa: F401

@@ -91,6 +91,23 @@ def compute_dtype(args):
     return torch.bfloat16 if args.fp16 else torch.float32
 
 
+def batch_to_device(batch, dataset, device, cache={}):
+    """(img, mask) on the device from a loader batch: ready tensors (synthetic), or raw uint8 tiles + the reference's random draws that the GPU
+    crops / pads / flips / rotates / normalises / re-indexes in one launch (dataset/augment.py)."""
+    if not getattr(dataset, 'raw_tiles', False):
+        return batch[0].to(device, non_blocking=True), batch[1].to(device, non_blocking=True)
+    tiles, params, _ = batch
+    if hasattr(dataset, 'crop_size'):
+        key, make = (id(dataset), 'train'), lambda: dataset.augmenter(device)
+    else:                                  # validation: whole tiles, one augmenter per tile size
+        size = tuple(tiles[0][0].shape[:2])
+        key, make = (id(dataset), size), lambda: dataset.augmenter(device, size)
+    aug = cache.get(key)
+    if aug is None:
+        aug = cache[key] = make()
+    return aug.prepare(tiles, params)
+
+
 def validate(model, dataloader, num_classes, ignore_label, device):
     """train_base.py:316-340 / ft_pop.py:312-336: logits -> upsample(align_corners=True) -> argmax -> IoU histogram,
     with the upsample+argmax fused in one HIP kernel (no H x W logits) and the histogram in another."""
@@ -98,8 +115,8 @@ def validate(model, dataloader, num_classes, ignore_label, device):
     model.eval()
     inter = torch.zeros(num_classes, device=device)
     union = torch.zeros(num_classes, device=device)
-    for img, mask, _ in dataloader:
-        img, mask = img.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+    for batch in dataloader:
+        img, mask = batch_to_device(batch, dataloader.dataset, device)
         with torch.no_grad():
             logits = model(img)
             pred = ops.upsample_argmax(logits.float().contiguous(), mask.shape[1:])
@@ -112,6 +129,26 @@ def validate(model, dataloader, num_classes, ignore_label, device):
 def save_checkpoint(model, path):
     """Legacy (non-zipfile) serialisation and `module.`-prefixed keys, exactly the reference's on-disk format."""
     torch.save(model.state_dict(), path, _use_new_zipfile_serialization=False)
+
+
+def save_training_state(model, optimizer, path, epoch, best=0.0, best_epoch=0):
+    """Everything a true resume needs (the reference saves the bare model state_dict only, train_base.py:286-292, and parses
+    `-c/--continue` without using it, engine.py:62-65): model weights in the reference's `module.`-prefixed format under 'state_dict' (so
+    utils.pyt_utils.load_model reads this file too), the optimizer state (torch.optim layout), the finished epoch and the best validation score."""
+    torch.save({'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': int(epoch), 'best': float(best), 'best_epoch': int(best_epoch)},
+               path, _use_new_zipfile_serialization=False)
+
+
+def load_training_state(model, optimizer, path):
+    """-> (epoch to continue with, best, best_epoch).  `model` is the wrapped model (its keys carry `module.`)."""
+    ckpt = torch.load(path, map_location='cpu')
+    if 'optimizer' not in ckpt or 'state_dict' not in ckpt:
+        raise RuntimeError('%s is not a training state written by save_training_state (a bare state_dict restores weights only: use --restore-from)' % path)
+    model.load_state_dict(ckpt['state_dict'], strict=True)
+    optimizer.load_state_dict(ckpt['optimizer'])
+    from .functional import weights_changed
+    weights_changed()                      # the derived GEMM-layout weight copies follow the loaded parameters
+    return int(ckpt['epoch']), float(ckpt.get('best', 0.0)), int(ckpt.get('best_epoch', 0))
 
 
 def miou(inter, union):

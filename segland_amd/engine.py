@@ -77,8 +77,13 @@ class Engine(object):
             sampler = torch.utils.data.distributed.DistributedSampler(dataset)
             batch_size = max(1, batch_size // self.world_size)          # engine.py:86 of the reference
             num_workers = num_workers // self.world_size if train else num_workers
+        raw = getattr(dataset, 'raw_tiles', False)           # OpenEarthMap readers: workers decode, the GPU prepares the batch (dataset/augment.py)
+        collate = None
+        if raw:
+            from .dataset.oem import raw_collate as collate
         loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, drop_last=train,
-                                             shuffle=(train and sampler is None), pin_memory=self.use_cuda, sampler=sampler)
+                                             shuffle=(train and sampler is None), pin_memory=self.use_cuda and not raw, sampler=sampler,
+                                             collate_fn=collate)
         return loader, sampler
 
     def get_train_loader(self, train_dataset):

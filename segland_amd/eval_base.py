@@ -43,6 +43,8 @@ def get_parser():
     p.add_argument('--fold', type=int, default=0, choices=[0, 1, 2, 3])
     p.add_argument('--shot', type=int, default=1)
     p.add_argument('--fp16', action='store_true')
+    p.add_argument('--save-prob', action='store_true', help="dump the upsampled logits of every tile as <save-path>/prob_<seed>/<id>.mat ({'outputs': [1,K,H,W]}, "
+                   'eval_base.py:189-190) for segland_amd.fusemat, plus the predicted label map as a palette PNG')
     p.add_argument('--allow-random-init', action='store_true', help='evaluate random weights when --restore-from does not exist')
     return p
 
@@ -60,6 +62,27 @@ def confusion_of_batch(logits, label, num_classes, ignore_label, pad_to_longside
         size = (h, w)
     pred = ops.upsample_argmax(logits.float().contiguous(), size)
     return pred, ops.confusion_matrix(pred, label.contiguous(), num_classes, ignore_label)
+
+
+def dump_probabilities(logits, size, pred, ids, out_dir):
+    """eval_base.py:168,180-190 without the GeoTIFF profile (rasterio): per tile `<id>.mat` = {'outputs': [1,K,H,W] logits upsampled with
+    align_corners=True} (the input of fusemat.py) and `<id>.png`, the argmax as a palette image."""
+    import scipy.io
+    from . import ops
+    from .fusemat import COLORMAP
+    os.makedirs(out_dir, exist_ok=True)
+    up = ops.upsample_logits(logits.float().contiguous(), tuple(size)).cpu().numpy()
+    pred = pred.cpu().numpy()
+    for b in range(up.shape[0]):
+        name = str(ids[b].item() if hasattr(ids[b], 'item') else ids[b])
+        scipy.io.savemat(osp.join(out_dir, name + '.mat'), {'outputs': up[b:b + 1]})
+        try:
+            from PIL import Image
+            img = Image.fromarray(pred[b][:size[0], :size[1]], 'P')
+            img.putpalette(np.resize(COLORMAP, (256, 3)))
+            img.save(osp.join(out_dir, name + '.png'))
+        except ImportError:
+            pass
 
 
 def miou_from_confusion(cm, n_base):
@@ -101,11 +124,14 @@ def main(argv=None, ft=False):
                 my_utils.load_model(model, path)
             model.eval()
             cm = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=engine.device)
-            for image, label, _ in test_loader:
+            for image, label, ids in test_loader:
                 image, label = image.to(engine.device, non_blocking=True), label.to(engine.device, non_blocking=True)
                 with torch.no_grad():
                     logits = model(image)
-                cm += confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)[1]
+                pred, cmb = confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)
+                cm += cmb
+                if args.save_prob and args.save_path:
+                    dump_probabilities(logits, label.shape[-2:], pred, ids, osp.join(args.save_path, 'prob_%d' % seed))
             if engine.distributed:
                 cm = engine.all_reduce_tensor(cm, norm=False)
             cmn = cm.cpu().numpy().astype(np.float64)

@@ -553,6 +553,29 @@ def upsample_argmax(logits, size):
     return out
 
 
+def upsample_logits(logits, size):
+    """F.interpolate(logits, size, mode='bilinear', align_corners=True) -- the array eval_base.py:189-190 dumps per tile."""
+    B, K, h, w = logits.shape
+    out = _f32((B, K, size[0], size[1]), logits.device)
+    check(_lib.lib().sl_upsample_logits(_p(logits), B, K, h, w, size[0], size[1], _p(out), _s()), 'upsample_logits')
+    return out
+
+
+def fuse_argmax(mats):
+    """argmax over classes of the mean of probability maps (list of [K,H,W] float GPU tensors), fusemat.py:35-52 -> uint8 [H,W]."""
+    K, H, W = mats[0].shape
+    for m in mats:
+        if tuple(m.shape) != (K, H, W) or m.dtype != torch.float32:
+            raise RuntimeError('fuse_argmax: every probability map must be float32 [%d,%d,%d]' % (K, H, W))
+    import struct
+    table = torch.frombuffer(bytearray(struct.pack('<%dQ' % len(mats), *[m.data_ptr() for m in mats])), dtype=torch.uint8).to(mats[0].device)
+    out = torch.empty((H, W), dtype=torch.uint8, device=mats[0].device)
+    for m in mats:
+        _p(m)
+    check(_lib.lib().sl_fuse_argmax(_p(table), len(mats), K, H * W, _p(out), _s()), 'fuse_argmax')
+    return out
+
+
 def iou_hist(pred_u8, target, K, ignore_index):
     hist = torch.zeros((3, K), dtype=torch.int64, device=target.device)
     check(_lib.lib().sl_iou_hist(_p(pred_u8), _p(target), target.numel(), K, ignore_index, _p(hist), _s()), 'iou_hist')

@@ -13,7 +13,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
-from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, miou, resolve, save_checkpoint, validate
+from .drivers import adjust_learning_rate_poly, batch_to_device, build_parser, load_training_state, save_training_state, checkpoint_or_none, compute_dtype, miou, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
 from .utils import pyt_utils as my_utils
@@ -72,7 +72,12 @@ def main(argv=None):
         if engine.is_main:
             os.makedirs(args.snapshot_dir, exist_ok=True)
 
-        it, best, best_epoch = args.start_epoch * len(train_loader), 0.0, 0
+        best, best_epoch = 0.0, 0
+        if engine.continue_state_object:                                # -c / --continue FILE (engine.py:62-65 parses it; the reference never uses it)
+            args.start_epoch, best, best_epoch = load_training_state(model, optimizer, engine.continue_state_object)
+            if engine.is_main:
+                logger.info('continuing from %s: epoch %d, best mIoU %.4f', engine.continue_state_object, args.start_epoch, best)
+        it = args.start_epoch * len(train_loader)
         for epoch in range(args.start_epoch, args.num_epoch):
             if args.random_seed > 0:
                 my_utils.set_seed(args.random_seed + epoch)
@@ -84,9 +89,9 @@ def main(argv=None):
                 model.train()
             lr = adjust_learning_rate_poly(optimizer, args.learning_rate, epoch, args.num_epoch, args.power,
                                            split=-1 if args.freeze_backbone else 0)      # per EPOCH (train_base.py:248)
-            for i, (img, mask, _) in enumerate(train_loader):
+            for i, batch in enumerate(train_loader):
                 it += 1
-                img, mask = img.to(engine.device, non_blocking=True), mask.to(engine.device, non_blocking=True)
+                img, mask = batch_to_device(batch, trainset, engine.device)
                 loss_dict, grad_norm = train_iteration(model, optimizer, loss_scaler, img, mask, double_step=not args.single_step)
                 if i % args.print_frequency == 0:
                     vals = engine.reduce_loss_dict(loss_dict)
@@ -96,6 +101,7 @@ def main(argv=None):
             e1 = epoch + 1
             if engine.is_main and (e1 % 10 == 0 or e1 >= args.num_epoch):
                 save_checkpoint(model, osp.join(args.snapshot_dir, 'epoch_%d.pth' % e1))
+                save_training_state(model, optimizer, osp.join(args.snapshot_dir, 'state_%d.pth' % e1), e1, best, best_epoch)
             if e1 > 35 and (e1 % 10 == 0 or epoch == args.num_epoch - 1):
                 inter, union = validate(model, test_loader, args.base_classes + 1, args.ignore_label, engine.device)
                 inter, union = engine.all_reduce_tensor(inter, norm=False), engine.all_reduce_tensor(union, norm=False)

@@ -555,7 +555,126 @@ def g16():
          grad_norm_keys=np.array(keys), grad_norms=np.array([float(pr[k].grad.norm()) for k in keys], dtype=np.float32))
 
 
-ALL = dict(g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+# ------------------------------------------------------------------------------------------ G17: OEM tile preparation
+def g17():
+    """dataset/base_dataset.py crop / pad / random_flip / fixed_random_rotate / normalize / totensor in the order of oem.py:70-75 on synthetic
+    tiles (smaller than, equal to and larger than the crop), with the reference's own random draws under fixed seeds; the label re-indexing of
+    oem.py:113-133 through GFSSegVal.__getitem__ fed by a rasterio stand-in.  OpenCV is absent: cv2.copyMakeBorder (constant border) is its
+    numpy equivalent here, nothing else of cv2 is on this path."""
+    import importlib.util
+    import random
+    from oracle import data_oracle as do
+
+    def copy_make_border(src, top, bottom, left, right, border_type, value=0):
+        v = value[0] if isinstance(value, (tuple, list)) else value
+        pads = ((top, bottom), (left, right)) + (((0, 0),) if src.ndim == 3 else ())
+        return np.pad(src, pads, constant_values=v)
+    sys.modules['cv2'].copyMakeBorder = copy_make_border
+    sys.modules['cv2'].BORDER_CONSTANT = 0
+    arrays = {}
+    rio = types.ModuleType('rasterio')
+    rio.open = lambda path: types.SimpleNamespace(read=lambda: arrays[path])
+    sys.modules['rasterio'] = rio
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location('ref_dataset.' + name, os.path.join(REF, 'dataset', name + '.py'), submodule_search_locations=None)
+        mod = importlib.util.module_from_spec(spec)
+        mod.__package__ = 'ref_dataset'
+        sys.modules['ref_dataset.' + name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    pkg = types.ModuleType('ref_dataset'); pkg.__path__ = [os.path.join(REF, 'dataset')]
+    sys.modules['ref_dataset'] = pkg
+    base = load('base_dataset')
+    oem = load('oem')
+    out = {}
+    for tag, (H, W) in (('small', (50, 70)), ('exact', (64, 64)), ('large', (100, 90))):
+        img = (fm.uniform01('g17/%s/img' % tag, H * W * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(H, W, 3).numpy()
+        lab = (fm.uniform01('g17/%s/lab' % tag, H * W) * 12).floor().to(torch.uint8).reshape(H, W).numpy()
+        lab[:7] = 255
+        ds = base.BaseDataset(mode='train', crop_size=(64, 64), ignore_label=255, base_size=(1024, 1024))
+        ds.mean, ds.std = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]                 # oem.py:26-27
+        for rep in range(3):
+            seed = 100 * rep + H
+            random.seed(seed); np.random.seed(seed)
+            i, l = ds.crop(img, lab)
+            i, l = ds.pad(ds.crop_size, i, l)
+            i, l = ds.random_flip(i, l)
+            i, l = ds.fixed_random_rotate(i, l)
+            i = ds.normalize(i)
+            it, lt = ds.totensor(i, l)
+            random.seed(seed); np.random.seed(seed)
+            prm = do.draw_train_params(lab, (64, 64), 255)
+            io, lo = do.prepare_tile(img, lab, (64, 64), *prm)
+            assert np.array_equal(it.numpy(), io) and np.array_equal(lt.numpy(), lo), 'g17 %s %d' % (tag, rep)
+            out['%s_%d_img' % (tag, rep)] = it.numpy()[:, ::3, ::3]
+            out['%s_%d_lbl' % (tag, rep)] = lt.numpy().astype(np.uint8)
+            out['%s_%d_prm' % (tag, rep)] = np.array([prm[0], prm[1], int(prm[2]), prm[3]], dtype=np.int32)
+    # non-trivial mean / std (BaseDataset defaults, base_dataset.py:9) through normalize + totensor only
+    ds = base.BaseDataset(mode='val', crop_size=(64, 64))
+    img = (fm.uniform01('g17/norm/img', 40 * 48 * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(40, 48, 3).numpy()
+    it = ds.totensor(ds.normalize(img))
+    io, _ = do.prepare_tile(img, None, (40, 48), 0, 0, False, 0, mean=ds.mean, std=ds.std)
+    assert np.array_equal(it.numpy(), io), 'g17 normalize'
+    out['norm_img'] = it.numpy()
+    # label re-indexing: GFSSegVal.__getitem__ (oem.py:98-137) on a tile holding every class, 0 and 255
+    lab = (fm.uniform01('g17/remap/lab', 32 * 32) * 13).floor().to(torch.uint8).reshape(32, 32).numpy()
+    lab[lab == 12] = 255
+    rgb = np.zeros((3, 32, 32), dtype=np.uint8)
+    arrays.update({'R/images/t.tif': rgb, 'R/labels/t.tif': lab[None]})
+    lst = os.path.join('/tmp', 'g17_val_list.txt')
+    open(lst, 'w').write('t\n')
+    real_exists = os.path.exists
+    os.path.exists = lambda p: True if p == 'R/labels/t.tif' else real_exists(p)
+    try:
+        for ub, un in ((True, True), (True, False), (False, True)):
+            dv = oem.GFSSegVal('R', lst, 0, base_size=(32, 32), resize_label=False, use_novel=un, use_base=ub)
+            _, lt, _ = dv[0]
+            lut = do.remap_lut(dv.base_classes, dv.novel_classes, use_base=ub, use_novel=un)
+            assert np.array_equal(lt.numpy(), lut[lab].astype(np.int64)), 'g17 remap'
+            out['remap_%d%d' % (ub, un)] = lt.numpy().astype(np.uint8)
+    finally:
+        os.path.exists = real_exists
+    save('g17_oem_tiles', **out)
+
+
+# ------------------------------------------------------------------------------------------ G18: probability-map fusion (SURVEY 8 f-3)
+def g18():
+    """fusemat.py executed as the script it is (placeholders of its fusion_list / output_path replaced by temporary directories holding three
+    models' .mat dumps of two tiles); its PNGs (nearest-neighbour x16) give back the fused 64 x 64 label maps, which the numpy restatement must equal."""
+    import scipy.io
+    import tempfile
+    from PIL import Image
+    from oracle import data_oracle as do
+    tmp = tempfile.mkdtemp(prefix='g18_')
+    dirs = [os.path.join(tmp, 'm%d' % m) for m in range(3)]
+    maps = {}
+    for m, d in enumerate(dirs):
+        os.makedirs(d)
+        for tile in ('a', 'b'):
+            arr = fm.sym('g18/m%d/%s' % (m, tile), (1, 8, 64, 64), 3.0).numpy()
+            if tile == 'b':
+                arr[:, :, :8] = np.round(arr[:, :, :8])          # exact ties between classes: first maximum must win
+            scipy.io.savemat(os.path.join(d, tile + '.mat'), {'outputs': arr})
+            maps.setdefault(tile, []).append(arr[0])
+    out_dir = os.path.join(tmp, 'out')
+    src = open(os.path.join(REF, 'fusemat.py')).read()
+    src = src.replace("'PATH_OF_PROBABILITY_MAPS_FOR_FUSION_1'", repr(dirs[0])).replace("'PATH_OF_PROBABILITY_MAPS_FOR_FUSION_2'", repr(dirs[1]))
+    src = src.replace("'PATH_OF_PROBABILITY_MAPS_FOR_FUSION_3',\n        '...'", repr(dirs[2])).replace("'PATH_OF_OUTPUT_PROBABILITY_MAPS'", repr(out_dir))
+    import scipy as _scipy
+    exec(compile(src, 'fusemat.py', 'exec'), {'__name__': '__main__'})
+    res = {}
+    for tile in ('a', 'b'):
+        png = np.array(Image.open(os.path.join(out_dir, tile + '.png')))
+        assert png.shape == (1024, 1024)
+        lab = png[::16, ::16]
+        assert np.array_equal(np.repeat(np.repeat(lab, 16, 0), 16, 1), png)
+        assert np.array_equal(lab, do.fuse_probability_maps(maps[tile])), 'g18 ' + tile
+        res['fused_' + tile] = lab.astype(np.uint8)
+    save('g18_fusion', **res)
+
+
+ALL = dict(g18=g18, g17=g17, g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

@@ -80,6 +80,33 @@ def test_checkpoint_format_roundtrip(tmp_path):
     o.load_state_dict({k[7:]: v for k, v in sd.items()}, strict=True)
 
 
+def test_torchvision_keyed_resnet_loads_as_pretrained_backbone(tmp_path):
+    """Row f-4: an ImageNet ResNet-50 checkpoint in torchvision's key layout (conv1 / bn1 / layer{1..4}.{i}.conv{1,2,3} / bn{1,2,3} /
+    downsample.{0,1} + the classification head fc.*) through get_backbone(pretrained_model=...) -> utils.pyt_utils.load_model
+    (networks/backbones/__init__.py:41-42, utils/pyt_utils.py:86-135): every backbone tensor is taken, fc.* is reported as unexpected and dropped."""
+    import logging
+    from segland_amd.networks.backbones import get_backbone
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    torch.manual_seed(7)
+    # torchvision.models.resnet50().state_dict(): same names and shapes as our backbone (stride-2 convs live in conv2 there too) plus fc
+    donor = get_backbone(norm_layer=torch.nn.BatchNorm2d, backbone='resnet50', dilated=False, os=32)
+    sd = {k: torch.randn_like(v) if v.dtype.is_floating_point else v.clone() for k, v in donor.state_dict().items()}
+    assert len(sd) == 318 and 'layer4.2.bn3.running_var' in sd and 'layer1.0.downsample.0.weight' in sd         # 320 torchvision entries minus fc.*
+    sd['fc.weight'], sd['fc.bias'] = torch.randn(1000, 2048), torch.randn(1000)
+    path = str(tmp_path / 'resnet50-imagenet.pth')
+    torch.save(sd, path, _use_new_zipfile_serialization=False)
+    seen = []
+    h = logging.Handler(); h.emit = lambda r: seen.append(r.getMessage())
+    logging.getLogger().addHandler(h)
+    try:
+        m = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=path, dilated=True, os=8)
+    finally:
+        logging.getLogger().removeHandler(h)
+    for k, v in m.backbone.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    assert any('Unexpected key' in s and 'fc.weight' in s for s in seen) and not any('Missing key' in s for s in seen)
+
+
 def test_gpu_only_model_fails_loudly_on_cpu():
     from segland_amd.networks.pspnet_pop import GFSS_Model
     m = GFSS_Model(n_base=7, backbone='resnet50', pretrained_model=None, dilated=True, os=8)

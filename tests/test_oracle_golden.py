@@ -265,3 +265,45 @@ def test_g8_trajectory_and_param_groups():
         losses, norm = po.train_step(m, opt, img, mask, clip_grad=5.0, double_step=True)
         close([losses['total_loss'], losses['seg_loss'], losses['orth_loss']], g['losses'][step], rtol=2e-3, atol=1e-5)
         close(norm, g['norms'][step], rtol=5e-3)
+
+
+def test_g17_tile_preparation_oracle():
+    """Row f-2: the numpy restatement of dataset/base_dataset.py / oem.py against the golden produced by the reference's own code (same seeds
+    -> same crops), plus the host-side draw / lookup-table helpers of the product against the oracle's."""
+    import random
+    from oracle import data_oracle as do
+    from segland_amd.dataset import augment as aug
+    g = golden('g17_oem_tiles')
+    for tag, (H, W) in (('small', (50, 70)), ('exact', (64, 64)), ('large', (100, 90))):
+        img = (fm.uniform01('g17/%s/img' % tag, H * W * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(H, W, 3).numpy()
+        lab = (fm.uniform01('g17/%s/lab' % tag, H * W) * 12).floor().to(torch.uint8).reshape(H, W).numpy()
+        lab[:7] = 255
+        for rep in range(3):
+            seed = 100 * rep + H
+            random.seed(seed); np.random.seed(seed)
+            prm = do.draw_train_params(lab, (64, 64), 255)
+            random.seed(seed); np.random.seed(seed)
+            assert aug.draw_train_params(lab, (64, 64), 255) == prm
+            assert [prm[0], prm[1], int(prm[2]), prm[3]] == g['%s_%d_prm' % (tag, rep)].tolist()
+            io, lo = do.prepare_tile(img, lab, (64, 64), *prm)
+            assert np.array_equal(io[:, ::3, ::3], g['%s_%d_img' % (tag, rep)]) and np.array_equal(lo.astype(np.uint8), g['%s_%d_lbl' % (tag, rep)])
+    for ub, un in ((True, True), (True, False), (False, True)):
+        lut = do.remap_lut(set(range(1, 8)), set(range(8, 12)), ub, un)
+        assert np.array_equal(lut, aug.remap_lut(set(range(1, 8)), set(range(8, 12)), ub, un))
+        lab = (fm.uniform01('g17/remap/lab', 32 * 32) * 13).floor().to(torch.uint8).reshape(32, 32).numpy()
+        lab[lab == 12] = 255
+        assert np.array_equal(lut[lab], g['remap_%d%d' % (ub, un)])
+
+
+def test_g18_fusion_oracle():
+    """Row f-3: numpy restatement of fusemat.py:35-52 against the label maps the reference script itself produced (golden G18)."""
+    from oracle import data_oracle as do
+    g = golden('g18_fusion')
+    for tile in ('a', 'b'):
+        maps = []
+        for m in range(3):
+            arr = fm.sym('g18/m%d/%s' % (m, tile), (1, 8, 64, 64), 3.0).numpy()
+            if tile == 'b':
+                arr[:, :, :8] = np.round(arr[:, :, :8])
+            maps.append(arr[0])
+        assert np.array_equal(do.fuse_probability_maps(maps), g['fused_' + tile])

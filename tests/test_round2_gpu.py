@@ -442,3 +442,127 @@ def test_per_gpu_batch_one_needs_sync_bn(hip, monkeypatch):
     finally:
         sf.set_sync_bn('0')
     assert bool(torch.isfinite(d['total_loss'])) and bool(torch.isfinite(m.base_emb.grad).all())
+
+
+# --------------------------------------------------------------------------------------------- f-2: OEM tile preparation on the GPU
+def test_g17_tile_preparation_gpu(hip):
+    """csrc/augment.hip against golden G17 (dataset/base_dataset.py:29-175 + oem.py:113-133 executed by the reference): bit-exact float
+    images and integer labels for tiles smaller than / equal to / larger than the crop, every flip / rot90 combination, a batch in one launch."""
+    from oracle import data_oracle as do
+    from segland_amd.dataset.augment import TileAugmenter, remap_lut
+    g = golden('g17_oem_tiles')
+    aug = TileAugmenter((64, 64), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 255, device=DEV)
+    tiles, params, want = [], [], []
+    for tag, (H, W) in (('small', (50, 70)), ('exact', (64, 64)), ('large', (100, 90))):
+        img = (fm.uniform01('g17/%s/img' % tag, H * W * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(H, W, 3).numpy()
+        lab = (fm.uniform01('g17/%s/lab' % tag, H * W) * 12).floor().to(torch.uint8).reshape(H, W).numpy()
+        lab[:7] = 255
+        for rep in range(3):
+            p = g['%s_%d_prm' % (tag, rep)].tolist()
+            tiles.append((img, lab)); params.append((p[0], p[1], bool(p[2]), p[3])); want.append((tag, rep))
+    out, lab_out = aug.prepare(tiles, params)
+    for b, (tag, rep) in enumerate(want):
+        assert np.array_equal(out[b].cpu().numpy()[:, ::3, ::3], g['%s_%d_img' % (tag, rep)]), (tag, rep)
+        assert np.array_equal(lab_out[b].cpu().numpy().astype(np.uint8), g['%s_%d_lbl' % (tag, rep)]), (tag, rep)
+    # every flip / rotation against the oracle, with a re-indexing table and a non-trivial mean / std
+    lut = remap_lut(set(range(1, 8)), set(range(8, 12)), True, True)
+    aug2 = TileAugmenter((48, 48), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), 255, lut=lut, device=DEV)
+    img = (fm.uniform01('g17x/img', 60 * 52 * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(60, 52, 3).numpy()
+    lab = (fm.uniform01('g17x/lab', 60 * 52) * 12).floor().to(torch.uint8).reshape(60, 52).numpy()
+    prm = [(5, 3, f, k) for f in (False, True) for k in range(4)] + [(20, 10, True, 1)]
+    o2, l2 = aug2.prepare([(img, lab)] * len(prm), prm)
+    for b, p in enumerate(prm):
+        io, lo = do.prepare_tile(img, lab, (48, 48), *p, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225))
+        assert np.array_equal(o2[b].cpu().numpy(), io), p
+        assert np.array_equal(l2[b].cpu().numpy(), lut[lo.astype(np.uint8)].astype(np.int64)), p
+    # normalize() with the BaseDataset default statistics on a whole (uncropped) tile, as stored by the reference
+    img = (fm.uniform01('g17/norm/img', 40 * 48 * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(40, 48, 3).numpy()
+    aug3 = TileAugmenter((40, 48), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225), 255, device=DEV)
+    o3, l3 = aug3.prepare([(img, None)], [(0, 0, False, 0)])
+    assert l3 is None and np.array_equal(o3[0].cpu().numpy(), g['norm_img'])
+
+
+def test_oem_reader_needs_rasterio(hip):
+    from segland_amd.dataset import oem
+    try:
+        import rasterio  # noqa: F401
+        pytest.skip('rasterio is installed here')
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match='rasterio'):
+        oem.GFSSegVal('/data', '/data/val.txt', 0)
+
+
+def test_train_base_on_raw_tiles_with_workers(hip, tmp_path):
+    """Row f-2 through the driver: DataLoader workers hand over raw uint8 tiles + the reference's random draws (synthetic_raw mirrors the OEM
+    reader's sample format), one augment launch per batch on the GPU, training and the end-of-run validation on whole tiles."""
+    import glob
+    from segland_amd import train_base
+    snap = str(tmp_path / 'snap_raw')
+    train_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_raw', '--batch-size', '4', '--input-size', '128,128',
+                     '--base-size', '160,160', '--num-epoch', '36', '--start-epoch', '35', '--learning-rate', '1e-4', '--print-frequency', '8', '--snapshot-dir', snap,
+                     '--num-workers', '2', '--restore-from', '/nonexistent', '--allow-random-init', '--fp16'])
+    assert glob.glob(os.path.join(snap, 'epoch_36.pth')) and glob.glob(os.path.join(snap, 'best.pth'))
+
+
+# --------------------------------------------------------------------------------------------- f-3: probability dumps and their fusion
+def test_g18_fusion_and_probability_dump(hip, tmp_path):
+    """sl_fuse_argmax bit-exact against golden G18 (the reference's fusemat.py run on three models' dumps, ties included); sl_upsample_logits
+    against F.interpolate(align_corners=True) (eval_base.py:168); then the whole tool chain: eval_base --save-prob twice -> segland_amd.fusemat."""
+    import scipy.io
+    from PIL import Image
+    from segland_amd import eval_base, fusemat, ops
+    g = golden('g18_fusion')
+    for tile in ('a', 'b'):
+        maps = []
+        for m in range(3):
+            arr = fm.sym('g18/m%d/%s' % (m, tile), (1, 8, 64, 64), 3.0)
+            if tile == 'b':
+                arr[:, :, :8] = torch.round(arr[:, :, :8])
+            maps.append(arr[0].contiguous().to(DEV))
+        assert np.array_equal(ops.fuse_argmax(maps).cpu().numpy(), g['fused_' + tile]), tile
+    lg = fm.sym('up/logits', (2, 12, 16, 20), 2.0)
+    up = ops.upsample_logits(lg.to(DEV), (100, 130)).cpu()
+    ref = F.interpolate(lg, size=(100, 130), mode='bilinear', align_corners=True)
+    assert float((up - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    outs = []
+    for run in range(2):
+        torch.manual_seed(run)
+        m = GFSS_Model(n_base=7, backbone='resnet50', dilated=True, os=8, pretrained_model=None)
+        ck = str(tmp_path / ('base%d.pth' % run))
+        torch.save({'module.' + k: v for k, v in m.state_dict().items()}, ck, _use_new_zipfile_serialization=False)
+        out = str(tmp_path / ('out%d' % run))
+        eval_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--base-size', '128,128', '--restore-from', ck,
+                        '--save-path', out, '--random-seed', '123', '--save-prob'])
+        outs.append(os.path.join(out, 'prob_123'))
+    mats = [scipy.io.loadmat(os.path.join(outs[r], '0.mat'))['outputs'] for r in range(2)]
+    assert mats[0].shape[0] == 1 and mats[0].shape[2:] == (128, 128) and not np.array_equal(mats[0], mats[1])
+    res = fusemat.fuse(outs, str(tmp_path / 'fused'), size=(256, 256))
+    from oracle import data_oracle as do
+    assert np.array_equal(res['0.mat'], do.fuse_probability_maps([mats[0][0], mats[1][0]]))
+    png = np.array(Image.open(str(tmp_path / 'fused' / '0.png')))
+    assert png.shape == (256, 256) and np.array_equal(png[::2, ::2], res['0.mat'])
+
+
+# --------------------------------------------------------------------------------------------- f-4: true resume
+def test_continue_resumes_training_state(hip, tmp_path):
+    """`-c/--continue FILE` (parsed and ignored by the reference, engine.py:62-65): two epochs in one run == one epoch, save, continue for the
+    second -- weights, AdamW moments and step counts bit-identical (per-epoch seeding, deterministic kernels)."""
+    from segland_amd import train_base
+    common = ['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--batch-size', '4', '--input-size', '128,128', '--base-size', '128,128',
+              '--learning-rate', '1e-4', '--print-frequency', '100', '--num-workers', '0', '--restore-from', '/nonexistent', '--allow-random-init', '--random-seed', '11']
+    a, b = str(tmp_path / 'full'), str(tmp_path / 'split')
+    train_base.main(common + ['--num-epoch', '2', '--snapshot-dir', a])
+    torch.manual_seed(11)                       # the model is built before set_seed(random_seed + epoch): same initial weights for the split run
+    train_base.main(common + ['--num-epoch', '1', '--snapshot-dir', b])
+    # num-epoch enters the poly LR schedule: continue with the 2-epoch schedule from the state of epoch 1
+    st = torch.load(os.path.join(b, 'state_1.pth'), map_location='cpu')
+    assert st['epoch'] == 1 and 'optimizer' in st and all(k.startswith('module.') for k in st['state_dict'])
+    train_base.main(common + ['--num-epoch', '2', '--snapshot-dir', b, '-c', os.path.join(b, 'state_1.pth')])
+    fa, fb = torch.load(os.path.join(a, 'state_2.pth'), map_location='cpu'), torch.load(os.path.join(b, 'state_2.pth'), map_location='cpu')
+    # epoch 1 of the split run used lr_poly(epoch 0, max 1) == lr_poly(epoch 0, max 2) == base lr, so both runs saw the same schedule
+    for k in fa['state_dict']:
+        assert torch.equal(fa['state_dict'][k], fb['state_dict'][k]), k
+    sa, sb = fa['optimizer']['state'], fb['optimizer']['state']
+    assert sa.keys() == sb.keys() and all(float(sa[i]['step']) == float(sb[i]['step']) and torch.equal(sa[i]['exp_avg'], sb[i]['exp_avg']) for i in sa)
