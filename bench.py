@@ -146,12 +146,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if a.gpus > 1 and world == 1:
+        raise SystemExit('bench.py --gpus %d must be launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py '
+                         '--gpus %d ...` (one rank per GPU); a single process would measure one GPU' % (a.gpus, a.gpus, a.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     use_ddp = world > 1 or os.environ.get('SEGLAND_FORCE_DDP') == '1'       # the env knob exercises DDP/RCCL on one GPU
     if use_ddp:
         dist.init_process_group('nccl', init_method='env://')       # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == max(world, 1), 'process group has %d ranks, launcher said %d' % (dist.get_world_size(), world)
+    assert a.gpus == world or world == 1, '--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run --nproc-per-node %d' % (a.gpus, world, a.gpus)
+    if rank == 0:
+        print('bench: world size %d (%s), rank 0 on cuda:%d' % (world, 'RCCL/DDP' if use_ddp else 'single process', local), file=sys.stderr, flush=True)
 
     from segland_amd import ops
     from segland_amd.loss.criterion import OrthLoss

@@ -80,7 +80,8 @@ def dump_probabilities(logits, size, pred, ids, out_dir):
             from PIL import Image
             img = Image.fromarray(pred[b][:size[0], :size[1]], 'P')
             img.putpalette(np.resize(COLORMAP, (256, 3)))
-            img.save(osp.join(out_dir, name + '.png'))
+            os.makedirs(out_dir + '_png', exist_ok=True)           # next to, not inside, the .mat directory fusemat walks
+            img.save(osp.join(out_dir + '_png', name + '.png'))
         except ImportError:
             pass
 

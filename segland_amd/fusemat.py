@@ -21,7 +21,9 @@ def collect(fusion_list):
     fns, mats = [], []
     for path in fusion_list:
         for root, _, files in os.walk(path):
-            for f in files:
+            for f in sorted(files):
+                if not f.endswith('.mat'):
+                    continue
                 prob = scipy.io.loadmat(os.path.join(root, f))['outputs'][0]
                 if f not in fns:
                     fns.append(f); mats.append([prob])
