@@ -14,6 +14,7 @@
 //   bilinear_*         F.interpolate(mode='bilinear') NHWC, both align_corners modes, optional accumulation into the destination and
 //                      channel windows (swin_pop.py:33,150-153,167 and the nn.Upsample of :133-137); backward in gather form (bit-stable)
 //   scale_add          x + s[b] * branch (DropPath, timm) and y * m[b][c] (nn.Dropout2d, swin_pop.py:21)
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -571,6 +572,479 @@ __global__ __launch_bounds__(256) void window_attention_fwd_kernel(WinGeom g, co
   }
 }
 
+// ---- MFMA forward (bf16): one WAVEFRONT per (window, head); the 4 waves of a block take 4 consecutive windows of one head (shared bias tile).
+//   S^T[key][query] = K Q^T     v_mfma_f32_32x32x16_bf16, operands straight from global memory (a lane's 16 bytes = 8 consecutive d of its token)
+//   softmax over the keys       keys live in the lane's REGISTERS (D layout: lane = column = query), so max / sum are in-lane + one xor-32 shuffle
+//   O^T[d][query]   = V^T P^T   the probability registers ARE the second MFMA operand (the MFMA k index may be any permutation as long as both
+//                               operands use it: element e of k-step s <-> key 32*ib + 16*s + 8*(e>>2) + 4*(lane>>5) + (e&3) is exactly the D layout's
+//                               row of register 8*s + e); only V needs a transposed copy ([d][key] in LDS)
+constexpr int VTP = 68;                       // bf16 pitch of the V^T rows: 136 bytes -> conflict-free ds_read_b64 over 32 rows
+constexpr int BLP = 52;                       // float pitch of the bias rows (16-byte aligned float4 reads)
+
+__device__ __forceinline__ uint4 win_frag(const WinGeom& g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias, int b, int wy, int wx,
+                                          int head, int which, int n, int dofs) {
+  if (n >= WN) return make_uint4(0, 0, 0, 0);
+  int pix, reg;
+  win_token(g, wy, wx, n, pix, reg);
+  const int col = which * g.C + head * HD + dofs;
+  if (pix >= 0) return *(const uint4*)(qkv + ((size_t)b * g.H * g.W + pix) * g.P3 + col);
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = qkv_bias[col + e];
+  return pack16<bf16_t>(f);
+}
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+__device__ __forceinline__ f32x16_t mfma16(const uint4& first_rows_to_regs, const uint4& second_rows_to_lanes, f32x16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8v, first_rows_to_regs), __builtin_bit_cast(bf16x8v, second_rows_to_lanes), c, 0, 0, 0);
+}
+
+// region ids of the 64 (49 real) window tokens packed 4 bits each: word w holds tokens 8w .. 8w+7 (wave-uniform after the reduction)
+__device__ __forceinline__ void win_pack_regions(const WinGeom& g, int wy, int wx, int lane, unsigned (&pk)[8]) {
+  int pix, reg = 0;
+  if (lane < WN) win_token(g, wy, wx, lane, pix, reg);
+  unsigned v = (unsigned)reg << (4 * (lane & 7));
+  v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
+#pragma unroll
+  for (int w = 0; w < 8; ++w) pk[w] = __shfl(v, 8 * w, 64);
+}
+
+// scores -> probabilities in place (acc[ib][jb][r]: key 32*ib + (r&3) + 8*(r>>2) + 4*hf, query 32*jb + (lane&31)); returns nothing, rows of invalid
+// queries hold finite garbage
+__device__ __forceinline__ void win_softmax_regs(const WinGeom& g, f32x16_t (&acc)[2][2], const float* biasl, const unsigned (&pk)[8], int lane, float scale) {
+  const int l31 = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
+    const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int i0 = 32 * ib + 8 * m + 4 * hf;
+        const float4 bv = *(const float4*)(biasl + jc * BLP + i0);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = i0 + e;
+          float sc = acc[ib][jb][4 * m + e] * scale + bb[e];
+          if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+          sc = i < WN ? sc : -INFINITY;
+          acc[ib][jb][4 * m + e] = sc;
+          mx = fmaxf(mx, sc);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float z = 0.f;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float e = __expf(acc[ib][jb][r] - mx); acc[ib][jb][r] = e; z += e; }
+    z += __shfl_xor(z, 32, 64);
+    const float inv = 1.f / z;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ib][jb][r] *= inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void window_attention_fwd_mfma_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                        const float* __restrict__ rel_bias, bf16_t* __restrict__ out, int nwin) {
+  __shared__ __attribute__((aligned(16))) float biasl[WN * BLP + 16];
+  __shared__ __attribute__((aligned(16))) bf16_t vt[4][HD * VTP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int head = blockIdx.x % g.heads, wi = (blockIdx.x / g.heads) * 4 + wave;
+  for (int e = tid; e < WN * WN; e += 256) biasl[(e / WN) * BLP + e % WN] = rel_bias[(size_t)head * WN * WN + e];
+  __syncthreads();
+  if (wi >= nwin) return;
+  const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
+  // V^T into LDS: chunk c = (key, 8 consecutive d); key columns 49..63 zeroed (their probabilities are 0, LDS garbage could be NaN)
+  bf16_t* vtw = vt[wave];
+  for (int c = lane; c < WN * 4; c += 64) {
+    const int key = c >> 2, d0 = (c & 3) * 8;
+    const uint4 v = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 2, key, d0);
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vtw[(d0 + e) * VTP + key] = (bf16_t)((w4[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+  }
+  for (int e = lane; e < HD * (64 - WN); e += 64) vtw[(e / (64 - WN)) * VTP + WN + e % (64 - WN)] = 0;
+  unsigned pk[8];
+  win_pack_regions(g, wy, wx, lane, pk);
+  // S^T = K Q^T
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ib][jb][r] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    uint4 kf[2], qf[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      kf[rb] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 1, 32 * rb + l31, 16 * s2 + 8 * hf);
+      qf[rb] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 0, 32 * rb + l31, 16 * s2 + 8 * hf);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = mfma16(kf[ib], qf[jb], acc[ib][jb]);
+  }
+  win_softmax_regs(g, acc, biasl, pk, lane, rsqrtf((float)HD));
+  __builtin_amdgcn_wave_barrier();            // the wave's own LDS writes of V^T are complete before its reads (same wave: program order + lgkmcnt)
+  // O^T = V^T P^T
+  f32x16_t o[2];
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[jb][r] = 0.f;
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16_t* vr = vtw + l31 * VTP + 32 * ib + 16 * s2 + 4 * hf;
+      const uint2 lo = *(const uint2*)vr, hi = *(const uint2*)(vr + 8);
+      const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        float pv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = acc[ib][jb][8 * s2 + e];
+        o[jb] = mfma16(vf, pack16<bf16_t>(pv), o[jb]);
+      }
+    }
+#pragma unroll
+  for (int jb = 0; jb < 2; ++jb) {
+    const int j = 32 * jb + l31;
+    if (j >= WN) continue;
+    int pix, reg;
+    win_token(g, wy, wx, j, pix, reg);
+    if (pix < 0) continue;
+    bf16_t* dst = out + ((size_t)b * g.H * g.W + pix) * g.Cp + head * HD + 4 * hf;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+      uint2 v;
+      v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){o[jb][4 * m + 0], o[jb][4 * m + 1]}, bf16x2_t));
+      v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){o[jb][4 * m + 2], o[jb][4 * m + 3]}, bf16x2_t));
+      *(uint2*)(dst + 8 * m) = v;
+    }
+    if (head == 0 && g.Cp > g.C && hf == 0)
+      for (int c = g.C; c < g.Cp; c += 8) *(uint4*)(out + ((size_t)b * g.H * g.W + pix) * g.Cp + c) = make_uint4(0, 0, 0, 0);
+  }
+}
+
+// ---- MFMA backward (bf16): one wavefront per (window, head), probabilities recomputed.  Two register layouts of the 64 x 64 score matrix:
+//   T-layout (lane = query, registers = keys):  S^T = K Q^T, dP^T = V dO^T  ->  softmax, row sums, dS^T;  dQ^T[d][query] = K^T dS  (dS^T registers
+//            are the second MFMA operand, K^T [d][key] comes from LDS);  the sum of dS over the wave's windows = gradient of the position bias
+//   N-layout (lane = key, registers = queries): S = Q K^T, dP = dO V^T with the row max / sum / dot of the T-layout handed over through LDS ->
+//            P, dS;  dK^T[d][key] = Q^T dS^T,  dV^T[d][key] = dO^T P^T  (Q^T, dO^T [d][query] from LDS)
+// Pad tokens' k / v gradients (they ARE the qkv bias) are summed over the pad keys with shuffles and go to pad_part.
+__device__ __forceinline__ void lds_transposed(const WinGeom& g, const bf16_t* __restrict__ src, int pitch, int col0, const float* __restrict__ qkv_bias, int bias_col0,
+                                               int b, int wy, int wx, int lane, bf16_t* dst) {
+  // dst[d][token] (pitch VTP) = src[token][col0 + d]; pad tokens: qkv bias (bias_col0 >= 0) or zero; token columns 49..63 zero
+  for (int c = lane; c < WN * 4; c += 64) {
+    const int n = c >> 2, d0 = (c & 3) * 8;
+    int pix, reg;
+    win_token(g, wy, wx, n, pix, reg);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (pix >= 0) v = *(const uint4*)(src + ((size_t)b * g.H * g.W + pix) * pitch + col0 + d0);
+    else if (bias_col0 >= 0) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = qkv_bias[bias_col0 + d0 + e];
+      v = pack16<bf16_t>(f);
+    }
+    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[(d0 + e) * VTP + n] = (bf16_t)((w4[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+  }
+  for (int e = lane; e < HD * (64 - WN); e += 64) dst[(e / (64 - WN)) * VTP + WN + e % (64 - WN)] = 0;
+}
+
+__device__ __forceinline__ uint4 lds_tfrag(const bf16_t* t, int l31, int hf, int blk, int s2) {     // first-operand fragment: row l31, k in D-layout order
+  const bf16_t* r = t + l31 * VTP + 32 * blk + 16 * s2 + 4 * hf;
+  const uint2 lo = *(const uint2*)r, hi = *(const uint2*)(r + 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__device__ __forceinline__ uint4 regs_frag(const f32x16_t& a, int s2) {
+  float pv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pv[e] = a[8 * s2 + e];
+  return pack16<bf16_t>(pv);
+}
+
+__device__ __forceinline__ void store_dT(bf16_t* base, const f32x16_t& o, int hf, float mul) {        // registers = d (quads of 4), one token per lane
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    uint2 v;
+    v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){o[4 * m + 0] * mul, o[4 * m + 1] * mul}, bf16x2_t));
+    v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){o[4 * m + 2] * mul, o[4 * m + 3] * mul}, bf16x2_t));
+    *(uint2*)(base + 8 * m + 4 * hf) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                        const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                                        float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
+  float* biast = biasl + WN * BLP + 16;                     // [49][52] (+16): bias[key][query]
+  bf16_t* tbase = (bf16_t*)(biast + WN * BLP + 16);         // per wave: K^T, Q^T, dO^T [32][68] each
+  float* mzbase = (float*)(tbase + 4 * 3 * HD * VTP);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
+  for (int e = tid; e < WN * WN; e += 256) {
+    const float v = rel_bias[(size_t)head * WN * WN + e];
+    biasl[(e / WN) * BLP + e % WN] = v;
+    biast[(e % WN) * BLP + e / WN] = v;
+  }
+  __syncthreads();
+  bf16_t* kt = tbase + wave * 3 * HD * VTP;
+  bf16_t* qt = kt + HD * VTP;
+  bf16_t* dot = qt + HD * VTP;
+  float* mz = mzbase + wave * 256;
+  const float scale = rsqrtf((float)HD);
+  f32x16_t dsum[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsum[ib][jb][r] = 0.f;
+
+  for (int t = 0; t < wpw; ++t) {
+    const int wi = (chunk * wpw + t) * 4 + wave;
+    if (wi >= nwin) break;
+    const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
+    // natural-layout fragments (token rows, 8 consecutive d per lane)
+    uint4 kf[2][2], qf[2][2], vf[2][2], gf[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int n = 32 * rb + l31, dofs = 16 * s2 + 8 * hf;
+        qf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 0, n, dofs);
+        kf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 1, n, dofs);
+        vf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 2, n, dofs);
+        uint4 gv = make_uint4(0, 0, 0, 0);
+        if (n < WN) { int pix, reg; win_token(g, wy, wx, n, pix, reg); if (pix >= 0) gv = *(const uint4*)(dout + ((size_t)b * g.H * g.W + pix) * g.Cp + head * HD + dofs); }
+        gf[rb][s2] = gv;                                      // outputs of pad queries are cropped: zero gradient
+      }
+    lds_transposed(g, qkv, g.P3, 1 * g.C + head * HD, qkv_bias, 1 * g.C + head * HD, b, wy, wx, lane, kt);
+    lds_transposed(g, qkv, g.P3, 0 * g.C + head * HD, qkv_bias, 0 * g.C + head * HD, b, wy, wx, lane, qt);
+    lds_transposed(g, dout, g.Cp, head * HD, qkv_bias, -1, b, wy, wx, lane, dot);
+    unsigned pk[8];
+    win_pack_regions(g, wy, wx, lane, pk);
+    // ---------------- T-layout
+    f32x16_t st[2][2], dp[2][2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[ib][jb][r] = 0.f; dp[ib][jb][r] = 0.f; }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          st[ib][jb] = mfma16(kf[ib][s2], qf[jb][s2], st[ib][jb]);
+          dp[ib][jb] = mfma16(vf[ib][s2], gf[jb][s2], dp[ib][jb]);
+        }
+    // softmax with the row max / sum kept for the N-layout
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
+      const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int i0 = 32 * ib + 8 * m + 4 * hf;
+          const float4 bv = *(const float4*)(biasl + jc * BLP + i0);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float sc = st[ib][jb][4 * m + e] * scale + bb[e];
+            if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+            sc = (i0 + e) < WN ? sc : -INFINITY;
+            st[ib][jb][4 * m + e] = sc;
+            mx = fmaxf(mx, sc);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float z = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = __expf(st[ib][jb][r] - mx); st[ib][jb][r] = e; z += e; }
+      z += __shfl_xor(z, 32, 64);
+      const float inv = 1.f / z;
+      float rs = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[ib][jb][r] *= inv; rs = fmaf(st[ib][jb][r], dp[ib][jb][r], rs); }
+      rs += __shfl_xor(rs, 32, 64);
+      if (hf == 0) { mz[4 * j + 0] = mx; mz[4 * j + 1] = inv; mz[4 * j + 2] = rs; }
+      // dS^T in place of dP^T; pad / nonexistent queries have dO = 0 -> dP = 0, rs = 0 -> dS = 0
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dp[ib][jb][r] = st[ib][jb][r] * (dp[ib][jb][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][jb][r] : 0.f; }
+    }
+    // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
+    {
+      f32x16_t oq[2];
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oq[jb][r] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const uint4 a = lds_tfrag(kt, l31, hf, ib, s2);
+#pragma unroll
+          for (int jb = 0; jb < 2; ++jb) oq[jb] = mfma16(a, regs_frag(dp[ib][jb], s2), oq[jb]);
+        }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        const int j = 32 * jb + l31;
+        if (j >= WN) continue;
+        int pix, reg;
+        win_token(g, wy, wx, j, pix, reg);
+        if (pix < 0) continue;
+        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3;
+        store_dT(dst + head * HD, oq[jb], hf, scale);
+        if (head == 0 && g.P3 > 3 * g.C && hf == 0)
+          for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
+      }
+    }
+    // ---------------- N-layout (lane = key)
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[ib][jb][r] = 0.f; dp[ib][jb][r] = 0.f; }
+    // here the FIRST index of st / dp is the query block (registers), the second the key block (lanes)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          st[jb][ib] = mfma16(qf[jb][s2], kf[ib][s2], st[jb][ib]);
+          dp[jb][ib] = mfma16(gf[jb][s2], vf[ib][s2], dp[jb][ib]);
+        }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const int i = 32 * ib + l31, ic = i < WN ? i : WN - 1;
+      const unsigned regk = (pk[ic >> 3] >> (4 * (ic & 7))) & 15u;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int j0 = 32 * jb + 8 * m + 4 * hf;
+          const float4 bv = *(const float4*)(biast + ic * BLP + j0);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            float sc = st[jb][ib][4 * m + e] * scale + bb[e];
+            if (g.shift > 0) { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; if (rq != regk) sc += -100.f; }
+            const float4 mzv = *(const float4*)(mz + 4 * (j < 64 ? j : 63));
+            const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
+            st[jb][ib][4 * m + e] = pr;                                            // P[query][key]
+            dp[jb][ib][4 * m + e] = pr * (dp[jb][ib][4 * m + e] - mzv.z);          // dS[query][key]
+          }
+        }
+    }
+    // dK^T[d][key] = sum_query Q^T[d][query] dS[query][key];  dV^T[d][key] = sum_query dO^T[d][query] P[query][key]
+    f32x16_t ok[2], ov[2];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ok[ib][r] = 0.f; ov[ib][r] = 0.f; }
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 aq = lds_tfrag(qt, l31, hf, jb, s2), ag = lds_tfrag(dot, l31, hf, jb, s2);
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          ok[ib] = mfma16(aq, regs_frag(dp[jb][ib], s2), ok[ib]);
+          ov[ib] = mfma16(ag, regs_frag(st[jb][ib], s2), ov[ib]);
+        }
+      }
+    float padk[16], padv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
+    bool anypad = false;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const int i = 32 * ib + l31;
+      int pix = -2, reg;
+      if (i < WN) win_token(g, wy, wx, i, pix, reg);
+      if (pix >= 0) {
+        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3 + head * HD;
+        store_dT(dst + 1 * g.C, ok[ib], hf, scale);
+        store_dT(dst + 2 * g.C, ov[ib], hf, 1.f);
+      } else if (pix == -1) {
+        anypad = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { padk[r] += ok[ib][r] * scale; padv[r] += ov[ib][r]; }
+      }
+    }
+    float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
+    if (__any(anypad)) {
+      // fixed-order sum over the window's pad keys through LDS (the Q^T / dO^T tiles of this wave are consumed): [half][key lane][16 d-registers]
+      float* sk = (float*)qt;
+      float* sv = (float*)dot;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sk[(hf * 32 + l31) * 17 + r] = padk[r]; sv[(hf * 32 + l31) * 17 + r] = padv[r]; }
+      if (lane < HD) {
+        const int d = lane, h2 = (d >> 2) & 1, r = 4 * (d >> 3) + (d & 3);       // d = 8*(r>>2) + 4*half + (r&3)
+        float tk = 0.f, tv = 0.f;
+        for (int l = 0; l < 32; ++l) { tk += sk[(h2 * 32 + l) * 17 + r]; tv += sv[(h2 * 32 + l) * 17 + r]; }
+        padp[d] = 0.f; padp[HD + d] = tk; padp[2 * HD + d] = tv;
+      }
+    } else {
+      for (int e = lane; e < 96; e += 64) padp[e] = 0.f;
+    }
+  }
+  // gradient of the position bias: the 4 waves' sums through LDS (the K^T / Q^T / dO^T area is free now), then one partial row per block
+  __syncthreads();
+  float* tile = (float*)tbase;                                 // [64 queries][64 keys] floats = 16 KiB <= 4 * 3 * 32 * 68 * 2 bytes
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = 32 * jb + l31, i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (w == 0) tile[j * 64 + i] = dsum[ib][jb][r]; else tile[j * 64 + i] += dsum[ib][jb][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
+  for (int e = tid; e < WN * WN; e += 256) dr[e] = tile[(e / WN) * 64 + e % WN];
+}
+
 // backward of one (window, head); block (head, chunk) walks `wpb` windows and keeps the sum of dS (= gradient of the relative position bias)
 // in registers.  dqkv of real tokens is written in place; k / v gradients of PAD tokens belong to the qkv bias: pad_part[window][head][3*32].
 template <typename T>
@@ -893,12 +1367,24 @@ extern "C" int sl_scale_add(int dtype, const void* x, const float* scale, const 
   return 0;
 }
 
+static int attn_valu() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_VALU"); v = (e && e[0] == '1') ? 1 : 0; } return v; }
+extern "C" void sl_debug_attn_valu(int v);
+static int g_attn_valu_override = -1;
+extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
+static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && !(g_attn_valu_override >= 0 ? g_attn_valu_override : attn_valu()); }
+
 extern "C" int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out, sl_stream_t stream) {
   WinGeom g;
   if (int e = check_geom(d, g)) return e;
   SL_REQUIRE(qkv && qkv_bias && rel_bias && out, "window_attention_fwd: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  const int grid = g.B * g.nWy * g.nWx * g.heads;
+  const int nwin = g.B * g.nWy * g.nWx;
+  if (use_attn_mfma(d->dtype)) {
+    hipLaunchKernelGGL(window_attention_fwd_mfma_kernel, dim3(cdiv(nwin, 4) * g.heads), dim3(256), 0, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (bf16_t*)out, nwin);
+    SL_LAUNCH_CHECK("window_attention_fwd_mfma_kernel");
+    return 0;
+  }
+  const int grid = nwin * g.heads;
   BY_DTYPE(d->dtype, hipLaunchKernelGGL(window_attention_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (bf16_t*)out),
            hipLaunchKernelGGL(window_attention_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, g, (const float*)qkv, qkv_bias, rel_bias, (float*)out), "window_attention_fwd");
   SL_LAUNCH_CHECK("window_attention_fwd_kernel");
@@ -911,11 +1397,13 @@ static int win_wpb(const WinGeom& g) {
   long long w = tasks / 2048;
   return (int)(w < 1 ? 1 : (w > 16 ? 16 : w));
 }
+static int win_wpw(const WinGeom& g) { return (win_wpb(g) + 3) / 4; }         // MFMA path: 4 waves per block, each walks wpw windows
 
 extern "C" int sl_window_attention_bwd_chunks(const SlWinDesc* d) {
   WinGeom g;
   if (check_geom(d, g)) return SL_EINVAL;
-  return cdiv((long long)g.B * g.nWy * g.nWx, win_wpb(g));
+  const long long nwin = (long long)g.B * g.nWy * g.nWx;
+  return use_attn_mfma(d->dtype) ? cdiv(nwin, 4 * win_wpw(g)) : cdiv(nwin, win_wpb(g));
 }
 
 extern "C" int sl_window_attention_windows(const SlWinDesc* d) {
@@ -930,7 +1418,18 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
   if (int e = check_geom(d, g)) return e;
   SL_REQUIRE(qkv && qkv_bias && rel_bias && dout && dqkv && drel_partial && pad_partial, "window_attention_bwd: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  const int wpb = win_wpb(g), nwin = g.B * g.nWy * g.nWx;
+  const int nwin = g.B * g.nWy * g.nWx;
+  if (use_attn_mfma(d->dtype)) {
+    const int wpw = win_wpw(g), chunks = cdiv(nwin, 4 * wpw);
+    const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(window_attention_bwd_mfma_kernel, dim3(chunks * g.heads), dim3(256), lds, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
+                       (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
+    SL_LAUNCH_CHECK("window_attention_bwd_mfma_kernel");
+    return 0;
+  }
+  const int wpb = win_wpb(g);
   const int chunks = cdiv(nwin, wpb);
   BY_DTYPE(d->dtype,
            hipLaunchKernelGGL(window_attention_bwd_kernel<bf16_t>, dim3(chunks * g.heads), dim3(256), 0, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout, (bf16_t*)dqkv, drel_partial, pad_partial, wpb, nwin),

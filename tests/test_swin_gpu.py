@@ -327,3 +327,65 @@ def test_swin_ft_mode_vs_same_box_oracle(hip):
     m.eval(); o.eval()
     with torch.no_grad():
         assert rel(m(img.to(DEV)), o(img)) <= 2e-3
+
+
+@pytest.mark.parametrize('shift', [0, 3])
+@pytest.mark.parametrize('Cn,heads,H,W', [(96, 3, 10, 13), (192, 6, 14, 14), (384, 12, 5, 9)])
+def test_window_attention_mfma_vs_valu(hip, Cn, heads, H, W, shift):
+    """The bf16 MFMA window-attention kernels (one wavefront per window and head, probabilities kept in registers between the two MFMA stages)
+    against the fp32-arithmetic VALU kernel on the same bf16 inputs, and both against a plain torch evaluation of swintransformer.py:118-149 +
+    :208-238 (pad, roll, partition, mask) on those inputs."""
+    from oracle import swin_oracle as so
+    from segland_amd import _lib
+    from segland_amd import ops_swin as osw
+    from segland_amd.ops_swin import pad_to
+    torch.manual_seed(Cn + H + shift)
+    B, P, P3 = 2, pad_to(Cn), pad_to(3 * Cn)
+    qkv = torch.zeros(B, H, W, P3)
+    qkv[..., :3 * Cn] = torch.randn(B, H, W, 3 * Cn)
+    bias = torch.randn(3 * Cn) * 0.5
+    relb = torch.randn(heads, 49, 49) * 0.5
+    qg = qkv.to(DEV).to(torch.bfloat16)
+    dout = torch.zeros(B, H, W, P); dout[..., :Cn] = torch.randn(B, H, W, Cn)
+    dg = dout.to(DEV).to(torch.bfloat16)
+    L = _lib.lib()
+    res = {}
+    for name, valu in (('valu', 1), ('mfma', 0)):
+        L.sl_debug_attn_valu(valu)
+        try:
+            out = osw.window_attention_fwd(qg, bias.to(DEV), relb.to(DEV), Cn, heads, shift, P)
+            grads = osw.window_attention_bwd(qg, bias.to(DEV), relb.to(DEV), dg, Cn, heads, shift)
+        finally:
+            L.sl_debug_attn_valu(-1)
+        res[name] = (out.float().cpu(), [t.float().cpu() for t in grads])
+    # torch evaluation on the bf16-rounded inputs (pad tokens carry the bf16-rounded bias, as the qkv GEMM would have stored it)
+    qr = qg.float().cpu()[..., :3 * Cn].requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    rr = relb.clone().requires_grad_(True)
+    Hp, Wp = -(-H // 7) * 7, -(-W // 7) * 7
+    brr = (br + (br.detach().to(torch.bfloat16).float() - br.detach())).view(1, 1, 1, -1).expand(B, Hp, Wp, 3 * Cn)
+    canvas = torch.cat([torch.cat([qr, brr[:, :H, W:]], 2), brr[:, H:]], 1) if (Hp > H or Wp > W) else qr
+    if shift:
+        canvas = torch.roll(canvas, (-shift, -shift), (1, 2))
+    xw = canvas.view(B, Hp // 7, 7, Wp // 7, 7, 3 * Cn).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49, 3, heads, 32)
+    q, k, v = xw[:, :, 0].transpose(1, 2), xw[:, :, 1].transpose(1, 2), xw[:, :, 2].transpose(1, 2)
+    att = (q * 32 ** -0.5) @ k.transpose(-2, -1) + rr.unsqueeze(0)
+    if shift:
+        m = so.shift_mask(Hp, Wp, 7, 3)
+        att = (att.view(B, -1, heads, 49, 49) + m[None, :, None]).view(-1, heads, 49, 49)
+    o = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, Hp // 7, Wp // 7, 7, 7, Cn).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, Cn)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    o = o[:, :H, :W]
+    (o * dg.float().cpu()[..., :Cn]).sum().backward()
+    want = (o.detach(), [qr.grad, rr.grad, br.grad])
+    for name in ('valu', 'mfma'):
+        out, (dqkv, drel, dpad) = res[name]
+        tol = 1.5e-2 if name == 'valu' else 2.5e-2
+        assert float(out[..., Cn:].abs().max() if P > Cn else 0) == 0
+        assert rel(out[..., :Cn], want[0]) <= tol, (name, rel(out[..., :Cn], want[0]))
+        assert l2(dqkv[..., :3 * Cn], want[1][0]) <= tol, (name, 'dqkv', l2(dqkv[..., :3 * Cn], want[1][0]))
+        assert l2(drel, want[1][1]) <= tol, (name, 'drel', l2(drel, want[1][1]))
+        if Hp > H or Wp > W:
+            # gradient of the qkv bias through the pad tokens only (the real tokens' share is the column sum of dqkv, added by the caller)
+            assert l2(dpad, want[1][2]) <= 3e-2, (name, 'dpad', l2(dpad, want[1][2]))
