@@ -1372,6 +1372,14 @@ extern "C" void sl_debug_attn_valu(int v);
 static int g_attn_valu_override = -1;
 extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
 static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && !(g_attn_valu_override >= 0 ? g_attn_valu_override : attn_valu()); }
+// The MFMA backward is correct (tests) but not yet faster than the VALU one: 256 VGPR + 256 AGPR and 104 spilled registers put one wave on a
+// SIMD (hipcc -Rpass-analysis=kernel-resource-usage); until its two score layouts are processed block by block it is opt-in.
+static int attn_bwd_mfma_env() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_MFMA"); v = (e && e[0] == '1') ? 1 : 0; } return v; }
+static bool use_attn_bwd_mfma(int dtype) {
+  if (dtype != SL_BF16) return false;
+  if (g_attn_valu_override >= 0) return g_attn_valu_override == 0;       // test hook: 0 = MFMA everywhere, 1 = VALU everywhere
+  return !attn_valu() && attn_bwd_mfma_env();
+}
 
 extern "C" int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out, sl_stream_t stream) {
   WinGeom g;
@@ -1403,7 +1411,7 @@ extern "C" int sl_window_attention_bwd_chunks(const SlWinDesc* d) {
   WinGeom g;
   if (check_geom(d, g)) return SL_EINVAL;
   const long long nwin = (long long)g.B * g.nWy * g.nWx;
-  return use_attn_mfma(d->dtype) ? cdiv(nwin, 4 * win_wpw(g)) : cdiv(nwin, win_wpb(g));
+  return use_attn_bwd_mfma(d->dtype) ? cdiv(nwin, 4 * win_wpw(g)) : cdiv(nwin, win_wpb(g));
 }
 
 extern "C" int sl_window_attention_windows(const SlWinDesc* d) {
@@ -1419,7 +1427,7 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
   SL_REQUIRE(qkv && qkv_bias && rel_bias && dout && dqkv && drel_partial && pad_partial, "window_attention_bwd: null buffer");
   hipStream_t st = (hipStream_t)stream;
   const int nwin = g.B * g.nWy * g.nWx;
-  if (use_attn_mfma(d->dtype)) {
+  if (use_attn_bwd_mfma(d->dtype)) {
     const int wpw = win_wpw(g), chunks = cdiv(nwin, 4 * wpw);
     const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
     static bool attr_set = false;
