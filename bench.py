@@ -37,8 +37,8 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
-    p.add_argument('--warmup', type=int, default=5)
+    p.add_argument('--steps', type=int, default=50)
+    p.add_argument('--warmup', type=int, default=10)
     p.add_argument('--model', default='pspnet_pop', choices=['pspnet_pop', 'swin_pop'], help='swin_pop: BASELINE config 5 (Swin-T + UperNet_Decoder_Plus + POP head, 8 tiles per GPU)')
     p.add_argument('--batch', type=int, default=None, help='tiles per GPU (default 16; swin_pop: 8)')
     p.add_argument('--backbone', default=None)
@@ -175,7 +175,8 @@ def main():
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
     params = [p for p in model.parameters() if p.requires_grad]
-    img, mask = synthetic_batch(a.batch, a.size, dev, seed=rank)
+    batches = [synthetic_batch(a.batch, a.size, dev, seed=rank * 16 + k) for k in range(4)]      # four resident batches, cycled: no step sees the previous one's tiles
+    img, mask = batches[0]
     double = not a.single_step
 
     # ---- warm-up; the last warm-up step is instrumented to find the dominant kernel shape
@@ -188,6 +189,7 @@ def main():
         train_step(net, opt, img, mask, params, double)
     torch.cuda.synchronize()
     table = ops.PROFILER.stop()
+    table_bytes = ops.PROFILER.stop_bytes()
     single = {k: v for k, v in table.items() if 'wgrad' not in k}     # families that are exactly one kernel per launch
     dominant = max(single.values(), key=lambda e: e['ms_total']) if single else None
 
@@ -197,9 +199,13 @@ def main():
     if use_ddp:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for k in range(a.steps):
+        img, mask = batches[k % len(batches)]
         train_step(net, opt, img, mask, params, double)
+        marks[k + 1].record()                          # per-step GPU time without a host synchronisation (median below)
     torch.cuda.synchronize()
     if use_ddp:
         dist.barrier()
@@ -232,20 +238,34 @@ def main():
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
         }
+        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
+        out['ms_per_step_median'] = round(per[len(per) // 2], 3)
+        out['value_at_median'] = round(a.batch * world / (per[len(per) // 2] * 1e-3), 1)
+        out['tflops_note'] = ('whole_step_tflops = tiles/s x the REFERENCE algorithm FLOPs per tile (%.1f GFLOP: what a plain implementation executes); '
+                              'executed_tflops = tiles/s x the FLOPs this build launches on the MFMA kernels (collapsed head, pooled-grid PPM: see DESIGN.md 3)' % GFLOP_PER_TILE.get(a.backbone, 0))
+        exec_gflop = sum(e['gflop'] for e in table.values())
+        out['executed_tflops'] = round(value * exec_gflop / max(a.batch, 1) / 1e3, 1)
+        fams = {}
+        for k_, e in table.items():
+            fams[k_] = {'tflops': round(e['gflop'] / max(e['ms_total'], 1e-9), 1), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls']}
+        for k_, e in table_bytes.items():
+            fams[k_] = {'gb_per_s': round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls'], 'gbytes_per_step': round(e['gbytes'], 3)}
+        out['families'] = fams               # one instrumented (un-timed) step: MFMA families in TFLOP/s, BatchNorm passes in algorithmic GB/s vs the 8 TB/s HBM peak
         if live:
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r1_traffic.json')      # PMC pass (tools/collect_traffic.py), bytes per launch
+            traffic, tsrc = None, None
+            tpath = os.path.join(ROOT, 'profiles', 'r2_traffic.json')      # PMC passes (tools/collect_traffic.py), bytes per launch
             if os.path.exists(tpath):
                 try:
                     t = json.load(open(tpath))
                     if t.get('kernel') == e['family']:
                         traffic = t.get('hbm_bytes_per_launch')
+                        tsrc = 'NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/r2_traffic.json (tools/collect_traffic.py)'
                 except Exception:
                     pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                               'traffic': traffic, 'kernel': e['family'], 'launches': e['calls'],
+                               'traffic': traffic, 'traffic_source': tsrc, 'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the timed steps (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}

@@ -48,10 +48,10 @@ class _Profiler:
     FAMILY = {5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
-        self.on, self.only, self.rec = False, None, {}
+        self.on, self.only, self.rec, self.rec_bytes = False, None, {}, {}
 
     def start(self, only=None):
-        self.on, self.only, self.rec = True, only, {}
+        self.on, self.only, self.rec, self.rec_bytes = True, only, {}, {}
 
     def family(self, kind, d):
         if kind == 'conv_wgrad':
@@ -77,6 +77,29 @@ class _Profiler:
         gflop = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW / 1e9
         shape = '%s B%d %dx%d %d->%d k%d s%d d%d' % (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
         self.rec.setdefault(fam, []).append((e0, e1, gflop, shape))
+
+    def begin_bytes(self, family, nbytes):
+        """HBM-bound kernel families (BatchNorm passes): algorithmic bytes instead of FLOPs; only in the instrumented (un-timed) step."""
+        if not self.on or self.only is not None:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return family, nbytes, e0, e1
+
+    def end_bytes(self, tok):
+        if tok is None:
+            return
+        family, nbytes, e0, e1 = tok
+        e1.record()
+        self.rec_bytes.setdefault(family, []).append((e0, e1, nbytes))
+
+    def stop_bytes(self):
+        """{family: {calls, ms_total, gbytes}} of the spans recorded since start(); call after stop() (which synchronises)."""
+        out = {}
+        for fam, evs in self.rec_bytes.items():
+            out[fam] = {'calls': len(evs), 'ms_total': sum(a.elapsed_time(b) for a, b, _ in evs), 'gbytes': sum(n for _, _, n in evs) / 1e9}
+        self.rec_bytes = {}
+        return out
 
     def stop(self):
         """{family: {calls, ms_total, gflop, shapes: {shape: [calls, ms, gflop]}}}"""
@@ -226,7 +249,9 @@ def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False)
     y = out if out is not None else torch.empty_like(x)
     assert y.numel() == x.numel() and y.dtype == x.dtype
     mask = torch.empty(x.numel() * x.element_size() // 16, dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    tok = PROFILER.begin_bytes('bn_act_fwd', x.numel() * x.element_size() * (2 + (residual is not None)) + (mask.numel() if mask is not None else 0))
     check(_lib.lib().sl_bn_act_fwd(dt(x), _p(x), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _p(mask), x.numel() // Cn, Cn, _s()), 'bn_act_fwd')
+    PROFILER.end_bytes(tok)
     return (y, mask) if want_mask else y
 
 
@@ -239,7 +264,11 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     L = _lib.lib()
     nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
     part = _f32((nblk, 2, Cn), x.device)
+    nb = x.numel() * x.element_size()
+    gate = (mask.numel() if mask is not None else (nb if y is not None else 0))
+    tok = PROFILER.begin_bytes('bn_bwd_reduce', 2 * nb + gate)
     check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
+    PROFILER.end_bytes(tok)
     o = _f32((5, Cn), x.device)
     check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
@@ -252,7 +281,9 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     dx = out if out is not None else torch.empty_like(x)
     assert dx.numel() == x.numel() and dx.dtype == x.dtype
     dres = torch.empty_like(x) if want_dres else None
+    tok = PROFILER.begin_bytes('bn_bwd_apply', (3 + (dres is not None)) * nb + gate)
     check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
+    PROFILER.end_bytes(tok)
     return dx, dres, o[0], o[1]
 
 

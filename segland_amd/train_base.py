@@ -84,7 +84,11 @@ def main(argv=None):
             if engine.distributed:
                 train_sampler.set_epoch(epoch)
             if args.freeze_backbone:
-                model.module.train_mode()
+                # train_base.py:244 passes backbone_only=args.finetune; pspnet_pop.GFSS_Model.train_mode() takes no argument there (the
+                # reference crashes), swin_pop's does (swin_pop.py:220)
+                import inspect
+                tm = model.module.train_mode
+                tm(backbone_only=args.finetune) if 'backbone_only' in inspect.signature(tm).parameters else tm()
             else:
                 model.train()
             lr = adjust_learning_rate_poly(optimizer, args.learning_rate, epoch, args.num_epoch, args.power,

@@ -389,3 +389,30 @@ def test_window_attention_mfma_vs_valu(hip, Cn, heads, H, W, shift):
         if Hp > H or Wp > W:
             # gradient of the qkv bias through the pad tokens only (the real tokens' share is the column sum of dqkv, added by the caller)
             assert l2(dpad, want[1][2]) <= 3e-2, (name, 'dpad', l2(dpad, want[1][2]))
+
+
+def test_swin_pop_through_the_drivers(hip, tmp_path):
+    """scripts/train_oem.sh / ft_oem.sh / evaluate_oem.sh with --model swin_pop --backbone swin-t (the authors' fine-tuning configuration,
+    scripts/ft_oem.sh:13-14) on the synthetic dataset: base training writes a reference-format checkpoint, ft_pop restores it and trains the
+    novel head on frozen Swin features, eval_ft reads the fine-tuned checkpoint and writes the confusion matrix."""
+    import glob
+    import os
+    from segland_amd import eval_base, ft_pop, train_base
+    snap = str(tmp_path / 'swin_base')
+    common = ['--model', 'swin_pop', '--backbone', 'swin-t', '--input-size', '128,128', '--base-size', '128,128', '--print-frequency', '8', '--num-workers', '0']
+    train_base.main(common + ['--dataset', 'synthetic', '--batch-size', '4', '--num-epoch', '1', '--learning-rate', '1e-4', '--snapshot-dir', snap,
+                              '--restore-from', '/nonexistent', '--allow-random-init', '--fp16'])
+    ck = os.path.join(snap, 'epoch_1.pth')
+    sd = torch.load(ck, map_location='cpu')
+    assert 'module.backbone.layers.2.blocks.5.attn.relative_position_bias_table' in sd and 'module.decoder.fpn_convs.3.4.0.weight' in sd
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    snap_ft = str(tmp_path / 'swin_ft')
+    ft_pop.main(common + ['--dataset', 'synthetic', '--batch-size', '1', '--num-epoch', '1', '--learning-rate', '1e-3', '--snapshot-dir', snap_ft, '--restore-from', ck,
+                          '--random-seed', '123', '--freeze-backbone', '--fix-bn'])
+    ft_ck = glob.glob(os.path.join(snap_ft, 'epoch_0_123.pth'))
+    assert ft_ck
+    novel = str(tmp_path / 'novel_123.pth')
+    os.replace(ft_ck[0], novel)
+    res = eval_base.main(['--model', 'swin_pop', '--backbone', 'swin-t', '--dataset', 'synthetic', '--base-size', '128,128', '--restore-from', str(tmp_path / 'novel.pth'),
+                          '--save-path', str(tmp_path / 'out'), '--random-seed', '123'], ft=True)
+    assert 123 in res and os.path.exists(str(tmp_path / 'out' / 'cmatrix_123.npy'))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 PMC passes of bench.py (FETCH_SIZE, WRITE_SIZE -- separate runs, as MI355X_MICROARCH.md prescribes)
-into profiles/r1_traffic.json: HBM-side bytes per launch of the dominant kernel.
+into profiles/r2_traffic.json: HBM-side bytes per launch of the dominant kernel.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o b -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o b -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
@@ -28,5 +28,5 @@ w_kib, nw = per_launch(write_dir, 'WRITE_SIZE', needle)
 out = {'kernel': label, 'launches_profiled': [nf, nw], 'fetch_kib_per_launch_raw': f_kib, 'write_kib_per_launch_raw': w_kib,
        'fetch_correction': 2.0, 'hbm_bytes_per_launch': int(f_kib * 1024 * 2.0 + w_kib * 1024),
        'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 3 --warmup 1'}
-json.dump(out, open(sys.argv[5] if len(sys.argv) > 5 else 'profiles/r1_traffic.json', 'w'), indent=1)
+json.dump(out, open(sys.argv[5] if len(sys.argv) > 5 else 'profiles/r2_traffic.json', 'w'), indent=1)
 print(json.dumps(out))
