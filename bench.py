@@ -68,13 +68,13 @@ def make_optimizer(model, lr=1e-3, wd=1e-4, torch_optimizer=False):
     return AdamW(get_parameters(model, lr=lr), lr=lr, weight_decay=wd)
 
 
-def train_step(model, opt, img, mask, params, double_step):
+def train_step(model, opt, img, mask, params, double_step, grad_div=1):
     opt.zero_grad(set_to_none=True)
     loss = model(img, mask)
     loss['total_loss'].backward()
     if hasattr(opt, 'repeat_next'):
         from segland_amd.optim import clip_coefficient
-        _, coef = clip_coefficient(params, 5.0)   # clip_grad_norm_(5.0): the coefficient is applied inside the optimizer kernel
+        _, coef = clip_coefficient(params, 5.0, grad_div)   # clip_grad_norm_(5.0): the coefficient is applied inside the optimizer kernel
         opt.step(repeat=2 if double_step else 1, grad_scale=coef)      # the reference's two steps on the same gradients in one pass
     else:
         torch.nn.utils.clip_grad_norm_(params, 5.0)
@@ -171,9 +171,14 @@ def main():
     model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, compute_dtype=dtype, **kw).to(dev).train()
     opt = make_optimizer(model, torch_optimizer=a.torch_optimizer)
     net = model
+    grad_div = 1
     if use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
+        if not a.torch_optimizer and os.environ.get('SEGLAND_DDP_PLAIN') != '1':
+            from segland_amd.engine import enable_inplace_bucket_gradients      # sum-only all-reduce, gradients written into the bucket views
+            enable_inplace_bucket_gradients(net)
+            grad_div = world
     params = [p for p in model.parameters() if p.requires_grad]
     batches = [synthetic_batch(a.batch, a.size, dev, seed=rank * 16 + k) for k in range(4)]      # four resident batches, cycled: no step sees the previous one's tiles
     img, mask = batches[0]
@@ -183,10 +188,10 @@ def main():
     for i in range(a.warmup):
         if i == a.warmup - 1:
             ops.PROFILER.start()
-        train_step(net, opt, img, mask, params, double)
+        train_step(net, opt, img, mask, params, double, grad_div)
     if a.warmup == 0:
         ops.PROFILER.start()
-        train_step(net, opt, img, mask, params, double)
+        train_step(net, opt, img, mask, params, double, grad_div)
     torch.cuda.synchronize()
     table = ops.PROFILER.stop()
     table_bytes = ops.PROFILER.stop_bytes()
@@ -204,7 +209,7 @@ def main():
     marks[0].record()
     for k in range(a.steps):
         img, mask = batches[k % len(batches)]
-        train_step(net, opt, img, mask, params, double)
+        train_step(net, opt, img, mask, params, double, grad_div)
         marks[k + 1].record()                          # per-step GPU time without a host synchronisation (median below)
     torch.cuda.synchronize()
     if use_ddp:

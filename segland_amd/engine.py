@@ -31,6 +31,32 @@ class ModuleWrapper(nn.Module):
         return self.module(*a, **k)
 
 
+def _allreduce_sum_hook(state, bucket):
+    """DDP communication hook: all-reduce (SUM) of the flat bucket, no division (the optimizer kernel applies 1 / world_size)."""
+    fut = dist.all_reduce(bucket.buffer(), group=state, async_op=True).get_future()
+    return fut.then(lambda f: f.value()[0])
+
+
+def _cache_bucket_views(optimizer, args, kwargs):
+    # before every optimizer step the gradients ARE DDP's bucket views (gradient_as_bucket_view): remember them for the next backward
+    for group in optimizer.param_groups:
+        for p in group['params']:
+            if p.grad is not None:
+                p._sl_gview = p.grad
+
+
+_hook_registered = []
+
+
+def enable_inplace_bucket_gradients(ddp, process_group=None):
+    """Sum-only all-reduce hook + bucket-view cache on `ddp` (see functional.grad_dst).  Gradients arrive SUMMED over the ranks."""
+    ddp.register_comm_hook(process_group, _allreduce_sum_hook)
+    if not _hook_registered:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        _hook_registered.append(register_optimizer_step_pre_hook(_cache_bucket_views))
+    return ddp
+
+
 class Engine(object):
     def __init__(self, custom_parser=None, argv=None):
         self.parser = custom_parser if custom_parser is not None else argparse.ArgumentParser()
@@ -50,6 +76,7 @@ class Engine(object):
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29500')
             dist.init_process_group(backend='nccl' if self.use_cuda else 'gloo', init_method='env://')
         self.rank = dist.get_rank() if self.distributed else 0
+        self.grad_div = 1
         self.devices = list(range(self.world_size))
 
     def inject_default_parser(self):
@@ -62,14 +89,23 @@ class Engine(object):
     def is_main(self):
         return self.rank == 0
 
-    def data_parallel(self, model):
+    def data_parallel(self, model, sum_gradients=False):
+        """sum_gradients=True (segland_amd.optim.AdamW on the GPU): the all-reduce SUMS and the 1 / world_size of DDP's mean is folded into the
+        optimizer kernel's gradient scale (`self.grad_div`, handed to NativeScalerWithGradNormCount) -- together with the in-place gradient
+        writes of functional.grad_dst this removes DDP's per-parameter copy and scale kernels.  Otherwise: stock DDP averaging."""
         model = model.to(self.device)
+        self.grad_div = 1
         if not self.distributed:
             return ModuleWrapper(model)
         kw = dict(find_unused_parameters=False, gradient_as_bucket_view=True, broadcast_buffers=False, bucket_cap_mb=64)
         if self.use_cuda:
-            return nn.parallel.DistributedDataParallel(model, device_ids=[self.local_rank], output_device=self.local_rank, **kw)
-        return nn.parallel.DistributedDataParallel(model, **kw)
+            ddp = nn.parallel.DistributedDataParallel(model, device_ids=[self.local_rank], output_device=self.local_rank, **kw)
+        else:
+            ddp = nn.parallel.DistributedDataParallel(model, **kw)
+        if sum_gradients:
+            enable_inplace_bucket_gradients(ddp)
+            self.grad_div = self.world_size
+        return ddp
 
     def _loader(self, dataset, batch_size, num_workers, train):
         sampler = None

@@ -107,6 +107,25 @@ def refresh_weights(model):
         plan.refresh(plan.convs, plan.dtypes)
 
 
+# ---- gradients written in place into DDP's bucket views --------------------------------------------------------------------------------
+# Under DistributedDataParallel(gradient_as_bucket_view=True) a parameter's .grad is a view into the flat bucket the RCCL all-reduce runs on.
+# The engine caches those views on the parameters (`_sl_gview`, refreshed before every optimizer step); a block backward that finds one
+# lets its kernels write the gradient THERE and hands autograd a fresh alias of it: AccumulateGrad adopts the alias without a copy and
+# DDP's reducer, seeing `grad.is_alias_of(bucket_view)`, neither copies nor (with the engine's sum-only comm hook) scales it -- the ~290
+# per-parameter copy / scale kernels of a plain DDP step disappear.  Correct whatever the cache holds: DDP compares storages itself and
+# falls back to its copy when the view is stale (the one iteration after it rebuilt its buckets).
+def grad_dst(p):
+    v = getattr(p, '_sl_gview', None)
+    if v is None or v.shape != p.shape or v.dtype != torch.float32 or not v.is_contiguous() or p.grad is not None:
+        return None                                    # p.grad set already (gradient accumulation): autograd must ADD, so no in-place write
+    return v
+
+
+def grad_alias(t, dst):
+    """What a backward returns for a gradient it wrote into `dst` (a cached bucket view): a new tensor object on the same storage."""
+    return t.detach() if (dst is not None and t is dst) else t
+
+
 def flush_num_batches_tracked():
     if _nbt_pending:
         torch._foreach_add_(_nbt_pending, 1)
@@ -200,13 +219,15 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue."""
+    gw, gg, gb = (grad_dst(conv.weight), grad_dst(bn.weight), grad_dst(bn.bias)) if need_dw else (None, None, None)
     dc, dres, dgamma, dbeta = ops.bn_bwd(dy, None if bits is not None else y_mask, c, mean, invstd, bn.weight, train=bn.training,
-                                         want_dres=want_dres, mask=bits, sync_world=sync_world(bn))
+                                         want_dres=want_dres, mask=bits, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb)
+    dgamma, dbeta = grad_alias(dgamma, gg), grad_alias(dbeta, gb)
     spec = spec_of(conv)
     dx = dw = None
     late = _WGRAD_STREAM and os.environ.get('SEGLAND_WGRAD_LATE', '1') == '1'
     if need_dw and not late:
-        dw = wgrad_async(x, dc, spec, x2=x2)
+        dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
         dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
@@ -214,7 +235,7 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     if need_dw and late:
         # side stream, released only AFTER the data gradient: the MFMA-bound wgrad then runs beside the HBM-bound BN backward of the
         # previous layer (its waves fit next to the wgrad block on a CU) instead of time-slicing the CUs with the dgrad kernel
-        dw = wgrad_async(x, dc, spec, x2=x2)
+        dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
     return dx, dw, dgamma, dbeta, dres
 
 
@@ -272,9 +293,10 @@ class StemFn(torch.autograd.Function):
         img, c0, idx, mean, invstd, scale, shift = ctx.saved_tensors
         bn = ctx.net.bn1
         g0 = ops.stem_pool_relu_bwd(dp.contiguous(), idx, c0, scale, shift)
-        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training, sync_world=sync_world(bn))
+        gg, gb = grad_dst(bn.weight), grad_dst(bn.bias)
+        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb)
         dw = ops.stem_conv_bwd_weight(img, dc0) if ctx.needs_input_grad[1] else None
-        return None, dw, dgamma, dbeta, None, None
+        return None, dw, grad_alias(dgamma, gg), grad_alias(dbeta, gb), None, None
 
 
 # ------------------------------------------------------------------------------------------------ bottleneck
@@ -414,12 +436,15 @@ class PPMFn(torch.autograd.Function):
         spec_f = spec_of(bt[3])
         _, wbf = prepared(bt[3].weight, x4.dtype)
         dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
-        dwf = ops.conv2d_bwd_weight(ab, dfeat, spec_f) if need_w else None
+        gwf = grad_dst(bt[3].weight) if need_w else None
+        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf), gwf) if need_w else None
         dbias = ops.colsum_rows(dfeat) if need_w else None
         if ctx.fact:
             N = bt[0].out_channels
             wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, nl, x4.dtype)
-            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training, sync_world=sync_world(bt[1]))
+            ggb, gbb = (grad_dst(bt[1].weight), grad_dst(bt[1].bias)) if need_w else (None, None)
+            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training, sync_world=sync_world(bt[1]), dgamma_out=ggb, dbeta_out=gbb)
+            dgb, dbb = grad_alias(dgb, ggb), grad_alias(dbb, gbb)
             spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
             dcat = ops.conv2d_bwd_data(dcb, wb4, spec4, (H, W))                     # gradient of the x4 half only: [B,H,W,Cf]
             cat_off = 0
@@ -427,7 +452,8 @@ class PPMFn(torch.autograd.Function):
             gq = ops.ppm_fact_scatter(dcb, x4.shape, sizes)
             dstage, _ = ops.ppm_rows_gemm(gq, wq_b, B, sizes)
             if need_w:
-                dwb = torch.empty_like(bt[0].weight, dtype=torch.float32)
+                gwb = grad_dst(bt[0].weight)
+                dwb = gwb if gwb is not None else torch.empty_like(bt[0].weight, dtype=torch.float32)
                 ops.conv2d_bwd_weight(x4, dcb, spec4, out=dwb, out_ci_off=nl * Cs)
                 dwq = torch.empty((nl, 9 * N, Cs), dtype=torch.float32, device=x4.device)
                 qspec, off = ConvSpec(Cs, 9 * N, 1), 0
@@ -438,6 +464,7 @@ class PPMFn(torch.autograd.Function):
                     off += n
             if need_w:
                 ops.ppm_dwq_scatter(dwq, dwb, Cs, nl)
+                dwb = grad_alias(dwb, gwb)
         else:
             dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
             dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
@@ -446,9 +473,11 @@ class PPMFn(torch.autograd.Function):
         gstage, off = [], 0
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
+            ggs, gbs, gws = (grad_dst(st[2].weight), grad_dst(st[2].bias), grad_dst(st[1].weight)) if need_w else (None, None, None)
             _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
-                                        out=dc_all[off:off + n], sync_world=sync_world(st[2]))
-            dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1])) if need_w else None
+                                        out=dc_all[off:off + n], sync_world=sync_world(st[2]), dgamma_out=ggs, dbeta_out=gbs)
+            dgs, dbs = grad_alias(dgs, ggs), grad_alias(dbs, gbs)
+            dws = grad_alias(ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1]), out=gws), gws) if need_w else None
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None
         dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None
@@ -519,12 +548,14 @@ def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x):
     dh2 = dh2.view(1, 1, R, Cn)
     _, w2b = prepared(cls[2].weight, X.dtype)
     dh1 = ops.conv2d_bwd_data(dh2, w2b, spec_of(cls[2]), (1, R), mask_src=h1)
-    dw2 = ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2])) if need_w else None
+    g2 = grad_dst(cls[2].weight) if need_w else None
+    dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2), g2) if need_w else None
     dX = None
     if need_x:
         _, w1b = prepared(cls[0].weight, X.dtype)
         dX = ops.conv2d_bwd_data(dh1, w1b, spec_of(cls[0]), (1, R)).view(R, Cn)
-    dw1 = ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0])) if need_w else None
+    g1 = grad_dst(cls[0].weight) if need_w else None
+    dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1), g1) if need_w else None
     return dX, dw1, dw2, (dw3.view_as(cls[4].weight) if need_w else None)
 
 

@@ -255,7 +255,7 @@ def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False)
     return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None, sync_world=0):
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None, sync_world=0, dgamma_out=None, dbeta_out=None):
     """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given.
     sync_world > 0 (SyncBatchNorm semantics, torch/nn/modules/_functions.py): the two column sums that enter dx are all-reduced over
     the process group and the element count is the global one; dgamma / dbeta stay local (DDP averages them like any gradient)."""
@@ -270,7 +270,10 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
     PROFILER.end_bytes(tok)
     o = _f32((5, Cn), x.device)
-    check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
+    # dgamma_out / dbeta_out: write the parameter gradients straight into the caller's buffers (DDP bucket views, functional.grad_dst)
+    dg = o[0] if dgamma_out is None else dgamma_out
+    db = o[1] if dbeta_out is None else dbeta_out
+    check(L.sl_bn_bwd_finalize(_p(part), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), int(train), _p(dg), _p(db), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
           'bn_bwd_finalize')
     if sync_world and train:
         tot = allreduce_partials(part)                      # [2 (hi, lo)][2][C] global sums
@@ -284,7 +287,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     tok = PROFILER.begin_bytes('bn_bwd_apply', (3 + (dres is not None)) * nb + gate)
     check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
     PROFILER.end_bytes(tok)
-    return dx, dres, o[0], o[1]
+    return dx, dres, dg, db
 
 
 _zeros_cache = {}

@@ -72,12 +72,18 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
-def clip_coefficient(parameters, max_norm):
+def clip_coefficient(parameters, max_norm, grad_div=1):
     """(total_norm, coefficient) of torch.nn.utils.clip_grad_norm_(parameters, max_norm) WITHOUT scaling the gradients: the coefficient
-    min(1, max_norm / (total_norm + 1e-6)) is handed to AdamW.step(grad_scale=...) and applied inside the optimizer kernel."""
+    min(1, max_norm / (total_norm + 1e-6)) is handed to AdamW.step(grad_scale=...) and applied inside the optimizer kernel.
+    grad_div > 1: the gradients hold the SUM over that many ranks (engine.enable_inplace_bucket_gradients); the norm is that of their mean
+    and the returned coefficient carries the 1 / grad_div as well."""
     grads = [p.grad for p in parameters if p.grad is not None]
     if not grads:
         return torch.tensor(0.0), None
     total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+    if grad_div != 1:
+        total = total / grad_div
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0).to(torch.float32).reshape(1)
+    if grad_div != 1:
+        coef = coef / grad_div
     return total, coef

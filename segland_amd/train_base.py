@@ -67,8 +67,8 @@ def main(argv=None):
             optimizer = AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
         else:
             optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
-        model = engine.data_parallel(seg_model)
-        loss_scaler = my_utils.NativeScalerWithGradNormCount()
+        model = engine.data_parallel(seg_model, sum_gradients=engine.use_cuda)      # our AdamW divides by the world size inside its kernel
+        loss_scaler = my_utils.NativeScalerWithGradNormCount(engine.grad_div)
         if engine.is_main:
             os.makedirs(args.snapshot_dir, exist_ok=True)
 

@@ -91,6 +91,9 @@ class NativeScalerWithGradNormCount:
     backward -> clip_grad_norm_ -> optimizer.step() exactly like GradScaler.step would."""
     state_dict_key = 'amp_scaler'
 
+    def __init__(self, grad_div=1):
+        self.grad_div = grad_div          # gradients are SUMS over this many ranks (Engine.data_parallel(sum_gradients=True))
+
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
         loss.backward(create_graph=create_graph)
         if not update_grad:
@@ -98,9 +101,11 @@ class NativeScalerWithGradNormCount:
         params = [p for p in parameters if p.grad is not None]
         if clip_grad is not None and hasattr(optimizer, 'repeat_next'):
             from ..optim import clip_coefficient           # segland_amd.optim.AdamW applies the clip coefficient inside its kernel
-            norm, coef = clip_coefficient(params, clip_grad)
+            norm, coef = clip_coefficient(params, clip_grad, self.grad_div)
             optimizer.step(grad_scale=coef)
             return norm
+        if self.grad_div != 1:
+            raise RuntimeError('summed DDP gradients need segland_amd.optim.AdamW (the 1 / world_size lives in its kernel)')
         if clip_grad is not None:
             norm = torch.nn.utils.clip_grad_norm_(params, clip_grad)
         else:

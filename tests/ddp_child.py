@@ -4,7 +4,7 @@ world_size-1 RCCL run of the PRODUCT: segland_amd.GFSS_Model on the HIP kernels,
 (DistributedDataParallel, gradient_as_bucket_view, engine.py:71 of the reference), stepped by segland_amd.optim.AdamW with the
 train_base.py:250-264 loop body.  The process group is created before any GPU work of this process.  Prints one JSON line.
 
-    python tests/ddp_child.py <sync_bn: 0|force> <port>
+    python tests/ddp_child.py <mode: 0 | force (SyncBN semantics) | inplace (sum-only all-reduce + gradients written into the bucket views)> <port>
 """
 import json
 import os
@@ -39,6 +39,17 @@ def main():
         img = fm.formula_image(4, 128, 128, 'ddp1/img').to(dev)
         mask = fm.formula_mask(4, 128, 128, 8, 'ddp1/mask', block=16, ignore_rows=6).to(dev)
 
+        inplace = sync == 'inplace'
+        hits = [0]
+        if inplace:
+            real = sf.grad_dst
+
+            def counted(p):
+                v = real(p)
+                hits[0] += v is not None
+                return v
+            sf.grad_dst = counted
+
         def run(wrapped, norm):
             torch.manual_seed(0)
             m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8,
@@ -46,14 +57,19 @@ def main():
             fm.load_formula_weights(m)
             m = m.to(dev).train()
             opt = AdamW(get_parameters(m, lr=1e-4), lr=1e-4, weight_decay=1e-4)
-            net = engine.data_parallel(m) if wrapped else m
+            net = engine.data_parallel(m, sum_gradients=inplace) if wrapped else m
             if wrapped:
                 assert isinstance(net, nn.parallel.DistributedDataParallel)
-            scaler = NativeScalerWithGradNormCount()
+            scaler = NativeScalerWithGradNormCount(engine.grad_div if wrapped else 1)
             losses = []
-            for _ in range(2):
+            for it in range(3 if inplace else 2):
+                hits[0] = 0
                 d, gn = train_iteration(net, opt, scaler, img, mask, double_step=True)
                 losses.append([float(d['total_loss']), float(gn)])
+            if wrapped and inplace:
+                out['inplace_writes_last_step'] = hits[0]
+                out['grads_alias_cached_views'] = sum(1 for p in m.parameters() if p.grad is not None and getattr(p, '_sl_gview', None) is not None
+                                                      and p.grad.data_ptr() == p._sl_gview.data_ptr())
             if wrapped:                        # gradients are views into DDP's flat buckets (gradient_as_bucket_view)
                 bucket_views = sum(1 for p in m.parameters() if p.grad is not None and p.grad._base is not None)
                 out['bucket_view_grads'] = bucket_views
@@ -64,8 +80,8 @@ def main():
 
         sf.set_sync_bn('0')
         ref_sd, ref_losses, ref_logits = run(False, nn.BatchNorm2d)
-        sf.set_sync_bn(sync)
-        sd, losses, logits = run(True, nn.SyncBatchNorm if sync != '0' else nn.BatchNorm2d)
+        sf.set_sync_bn(sync if sync in ('0', 'force') else '0')
+        sd, losses, logits = run(True, nn.SyncBatchNorm if sync == 'force' else nn.BatchNorm2d)
         sf.set_sync_bn('0')
         worst, worst_key = 0.0, ''
         for k in ref_sd:
