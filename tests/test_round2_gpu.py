@@ -346,7 +346,8 @@ def test_hip_model_under_rccl_ddp(hip, sync):
     assert r.returncode == 0 and line, 'child failed (rc %d):\n%s\n%s' % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     out = json.loads(line[-1][len('DDP_CHILD '):])
     print(out)
-    assert out['bucket_view_grads'] > 100, 'gradients are not DDP bucket views'
+    if sync != 'inplace':                      # in-place mode: the gradients are fresh aliases of the views (checked through grads_alias_cached_views)
+        assert out['bucket_view_grads'] > 100, 'gradients are not DDP bucket views'
     assert out['bn1_tracked'] == (3 if sync == 'inplace' else 2)
     tol = 2e-4 if sync == 'force' else 1e-6
     if sync == 'inplace':
