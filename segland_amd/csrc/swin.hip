@@ -766,6 +766,32 @@ __device__ __forceinline__ void lds_transposed(const WinGeom& g, const bf16_t* _
   for (int e = lane; e < HD * (64 - WN); e += 64) dst[(e / (64 - WN)) * VTP + WN + e % (64 - WN)] = 0;
 }
 
+constexpr int NTP = 40;                       // bf16 pitch of the natural [token][d] tiles: 80 bytes -> conflict-free ds_read_b128 over 32 rows
+// One pass over a (window, head) slice of src: rows < 49 of nat[token][d] (pitch NTP) and, when tr != nullptr, tr[d][token] (pitch VTP), both from the
+// same 16-byte global loads.  Pad tokens: the qkv bias (bias_col0 >= 0) or zero.  Rows / columns 49..63 are zeroed once per kernel by the caller.
+__device__ __forceinline__ void lds_fill(const WinGeom& g, const bf16_t* __restrict__ src, int pitch, int col0, const float* __restrict__ qkv_bias, int bias_col0,
+                                         int b, int wy, int wx, int lane, bf16_t* nat, bf16_t* tr) {
+  for (int c = lane; c < WN * 4; c += 64) {
+    const int n = c >> 2, d0 = (c & 3) * 8;
+    int pix, reg;
+    win_token(g, wy, wx, n, pix, reg);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (pix >= 0) v = *(const uint4*)(src + ((size_t)b * g.H * g.W + pix) * pitch + col0 + d0);
+    else if (bias_col0 >= 0) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = qkv_bias[bias_col0 + d0 + e];
+      v = pack16<bf16_t>(f);
+    }
+    *(uint4*)(nat + n * NTP + d0) = v;
+    if (tr) {
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tr[(d0 + e) * VTP + n] = (bf16_t)((w4[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+    }
+  }
+}
+
 __device__ __forceinline__ uint4 lds_tfrag(const bf16_t* t, int l31, int hf, int blk, int s2) {     // first-operand fragment: row l31, k in D-layout order
   const bf16_t* r = t + l31 * VTP + 32 * blk + 16 * s2 + 4 * hf;
   const uint2 lo = *(const uint2*)r, hi = *(const uint2*)(r + 8);
@@ -798,7 +824,8 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
   float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
   float* biast = biasl + WN * BLP + 16;                     // [49][52] (+16): bias[key][query]
   bf16_t* tbase = (bf16_t*)(biast + WN * BLP + 16);         // per wave: K^T, Q^T, dO^T [32][68] each
-  float* mzbase = (float*)(tbase + 4 * 3 * HD * VTP);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
+  bf16_t* nbase = tbase + 4 * 3 * HD * VTP;                 // per wave: K, Q, V, dO natural [64][40] each
+  float* mzbase = (float*)(nbase + 4 * 4 * 64 * NTP);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
   const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
   for (int e = tid; e < WN * WN; e += 256) {
@@ -810,7 +837,14 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
   bf16_t* kt = tbase + wave * 3 * HD * VTP;
   bf16_t* qt = kt + HD * VTP;
   bf16_t* dot = qt + HD * VTP;
+  bf16_t* nk = nbase + wave * 4 * 64 * NTP;
+  bf16_t* nq = nk + 64 * NTP;
+  bf16_t* nv = nq + 64 * NTP;
+  bf16_t* ng = nv + 64 * NTP;
   float* mz = mzbase + wave * 256;
+  // token rows / columns 49..63 are never written afterwards: zero them once (their probabilities are 0, LDS garbage could be NaN)
+  for (int e = lane; e < 3 * HD * (64 - WN); e += 64) { const int tI = e / (HD * (64 - WN)), r = e % (HD * (64 - WN)); kt[tI * HD * VTP + (r / (64 - WN)) * VTP + WN + r % (64 - WN)] = 0; }
+  for (int e = lane; e < 4 * (64 - WN) * NTP; e += 64) { const int tI = e / ((64 - WN) * NTP), r = e % ((64 - WN) * NTP); nk[tI * 64 * NTP + WN * NTP + r] = 0; }
   const float scale = rsqrtf((float)HD);
   f32x16_t dsum[2][2];
 #pragma unroll
@@ -824,45 +858,32 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
     const int wi = (chunk * wpw + t) * 4 + wave;
     if (wi >= nwin) break;
     const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
-    // natural-layout fragments (token rows, 8 consecutive d per lane)
-    uint4 kf[2][2], qf[2][2], vf[2][2], gf[2][2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int n = 32 * rb + l31, dofs = 16 * s2 + 8 * hf;
-        qf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 0, n, dofs);
-        kf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 1, n, dofs);
-        vf[rb][s2] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 2, n, dofs);
-        uint4 gv = make_uint4(0, 0, 0, 0);
-        if (n < WN) { int pix, reg; win_token(g, wy, wx, n, pix, reg); if (pix >= 0) gv = *(const uint4*)(dout + ((size_t)b * g.H * g.W + pix) * g.Cp + head * HD + dofs); }
-        gf[rb][s2] = gv;                                      // outputs of pad queries are cropped: zero gradient
-      }
-    lds_transposed(g, qkv, g.P3, 1 * g.C + head * HD, qkv_bias, 1 * g.C + head * HD, b, wy, wx, lane, kt);
-    lds_transposed(g, qkv, g.P3, 0 * g.C + head * HD, qkv_bias, 0 * g.C + head * HD, b, wy, wx, lane, qt);
-    lds_transposed(g, dout, g.Cp, head * HD, qkv_bias, -1, b, wy, wx, lane, dot);
+    lds_fill(g, qkv, g.P3, 1 * g.C + head * HD, qkv_bias, 1 * g.C + head * HD, b, wy, wx, lane, nk, kt);
+    lds_fill(g, qkv, g.P3, 0 * g.C + head * HD, qkv_bias, 0 * g.C + head * HD, b, wy, wx, lane, nq, qt);
+    lds_fill(g, qkv, g.P3, 2 * g.C + head * HD, qkv_bias, 2 * g.C + head * HD, b, wy, wx, lane, nv, nullptr);
+    lds_fill(g, dout, g.Cp, head * HD, qkv_bias, -1, b, wy, wx, lane, ng, dot);       // dO of pad queries is zero: their outputs are cropped
     unsigned pk[8];
     win_pack_regions(g, wy, wx, lane, pk);
-    // ---------------- T-layout
-    f32x16_t st[2][2], dp[2][2];
+    // natural-layout fragments (token row n, 8 consecutive d per lane) from LDS
+    auto frag = [&](int which, int n, int s2) { return *(const uint4*)((which == 0 ? nq : (which == 1 ? nk : nv)) + n * NTP + 16 * s2 + 8 * hf); };
+    auto gfrag = [&](int n, int s2) { return *(const uint4*)(ng + n * NTP + 16 * s2 + 8 * hf); };
+    // ---------------- T-layout, one 32-query block at a time (registers: 2 x 2 accumulators instead of 2 x 4)
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[ib][jb][r] = 0.f; dp[ib][jb][r] = 0.f; }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x16_t st[2], dp[2];
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-          st[ib][jb] = mfma16(kf[ib][s2], qf[jb][s2], st[ib][jb]);
-          dp[ib][jb] = mfma16(vf[ib][s2], gf[jb][s2], dp[ib][jb]);
-        }
-    // softmax with the row max / sum kept for the N-layout
+        for (int r = 0; r < 16; ++r) { st[ib][r] = 0.f; dp[ib][r] = 0.f; }
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 qv = frag(0, 32 * jb + l31, s2), gv = gfrag(32 * jb + l31, s2);
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          st[ib] = mfma16(frag(1, 32 * ib + l31, s2), qv, st[ib]);
+          dp[ib] = mfma16(frag(2, 32 * ib + l31, s2), gv, dp[ib]);
+        }
+      }
       const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
       const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
       float mx = -INFINITY;
@@ -875,10 +896,10 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
           const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float sc = st[ib][jb][4 * m + e] * scale + bb[e];
+            float sc = st[ib][4 * m + e] * scale + bb[e];
             if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
             sc = (i0 + e) < WN ? sc : -INFINITY;
-            st[ib][jb][4 * m + e] = sc;
+            st[ib][4 * m + e] = sc;
             mx = fmaxf(mx, sc);
           }
         }
@@ -887,69 +908,62 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const float e = __expf(st[ib][jb][r] - mx); st[ib][jb][r] = e; z += e; }
+        for (int r = 0; r < 16; ++r) { const float e = __expf(st[ib][r] - mx); st[ib][r] = e; z += e; }
       z += __shfl_xor(z, 32, 64);
       const float inv = 1.f / z;
       float rs = 0.f;
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st[ib][jb][r] *= inv; rs = fmaf(st[ib][jb][r], dp[ib][jb][r], rs); }
+        for (int r = 0; r < 16; ++r) { st[ib][r] *= inv; rs = fmaf(st[ib][r], dp[ib][r], rs); }
       rs += __shfl_xor(rs, 32, 64);
       if (hf == 0) { mz[4 * j + 0] = mx; mz[4 * j + 1] = inv; mz[4 * j + 2] = rs; }
       // dS^T in place of dP^T; pad / nonexistent queries have dO = 0 -> dP = 0, rs = 0 -> dS = 0
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dp[ib][jb][r] = st[ib][jb][r] * (dp[ib][jb][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][jb][r] : 0.f; }
-    }
-    // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
-    {
-      f32x16_t oq[2];
+        for (int r = 0; r < 16; ++r) { dp[ib][r] = st[ib][r] * (dp[ib][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][r] : 0.f; }
+      // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
+      f32x16_t oq;
 #pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oq[jb][r] = 0.f;
+      for (int r = 0; r < 16; ++r) oq[r] = 0.f;
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const uint4 a = lds_tfrag(kt, l31, hf, ib, s2);
-#pragma unroll
-          for (int jb = 0; jb < 2; ++jb) oq[jb] = mfma16(a, regs_frag(dp[ib][jb], s2), oq[jb]);
-        }
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb) {
-        const int j = 32 * jb + l31;
-        if (j >= WN) continue;
+        for (int s2 = 0; s2 < 2; ++s2) oq = mfma16(lds_tfrag(kt, l31, hf, ib, s2), regs_frag(dp[ib], s2), oq);
+      if (j < WN) {
         int pix, reg;
         win_token(g, wy, wx, j, pix, reg);
-        if (pix < 0) continue;
-        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3;
-        store_dT(dst + head * HD, oq[jb], hf, scale);
-        if (head == 0 && g.P3 > 3 * g.C && hf == 0)
-          for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
-      }
-    }
-    // ---------------- N-layout (lane = key)
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[ib][jb][r] = 0.f; dp[ib][jb][r] = 0.f; }
-    // here the FIRST index of st / dp is the query block (registers), the second the key block (lanes)
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-          st[jb][ib] = mfma16(qf[jb][s2], kf[ib][s2], st[jb][ib]);
-          dp[jb][ib] = mfma16(gf[jb][s2], vf[ib][s2], dp[jb][ib]);
+        if (pix >= 0) {
+          bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3;
+          store_dT(dst + head * HD, oq, hf, scale);
+          if (head == 0 && g.P3 > 3 * g.C && hf == 0)
+            for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
         }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- N-layout (lane = key), one 32-key block at a time
+    float padk[16], padv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
+    bool anypad = false;
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
+      f32x16_t st[2], dp[2];                              // index = query block (registers); lanes = keys 32*ib + l31
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[jb][r] = 0.f; dp[jb][r] = 0.f; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 kv = frag(1, 32 * ib + l31, s2), vv = frag(2, 32 * ib + l31, s2);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          st[jb] = mfma16(frag(0, 32 * jb + l31, s2), kv, st[jb]);
+          dp[jb] = mfma16(gfrag(32 * jb + l31, s2), vv, dp[jb]);
+        }
+      }
       const int i = 32 * ib + l31, ic = i < WN ? i : WN - 1;
       const unsigned regk = (pk[ic >> 3] >> (4 * (ic & 7))) & 15u;
 #pragma unroll
@@ -962,50 +976,37 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = j0 + e;
-            float sc = st[jb][ib][4 * m + e] * scale + bb[e];
+            float sc = st[jb][4 * m + e] * scale + bb[e];
             if (g.shift > 0) { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; if (rq != regk) sc += -100.f; }
-            const float4 mzv = *(const float4*)(mz + 4 * (j < 64 ? j : 63));
+            const float4 mzv = *(const float4*)(mz + 4 * j);
             const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
-            st[jb][ib][4 * m + e] = pr;                                            // P[query][key]
-            dp[jb][ib][4 * m + e] = pr * (dp[jb][ib][4 * m + e] - mzv.z);          // dS[query][key]
+            st[jb][4 * m + e] = pr;                                            // P[query][key]
+            dp[jb][4 * m + e] = pr * (dp[jb][4 * m + e] - mzv.z);              // dS[query][key]
           }
         }
-    }
-    // dK^T[d][key] = sum_query Q^T[d][query] dS[query][key];  dV^T[d][key] = sum_query dO^T[d][query] P[query][key]
-    f32x16_t ok[2], ov[2];
+      // dK^T[d][key] = sum_query Q^T[d][query] dS[query][key];  dV^T[d][key] = sum_query dO^T[d][query] P[query][key]
+      f32x16_t ok, ov;
 #pragma unroll
-    for (int ib = 0; ib < 2; ++ib)
+      for (int r = 0; r < 16; ++r) { ok[r] = 0.f; ov[r] = 0.f; }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { ok[ib][r] = 0.f; ov[ib][r] = 0.f; }
+      for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 aq = lds_tfrag(qt, l31, hf, jb, s2), ag = lds_tfrag(dot, l31, hf, jb, s2);
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-          ok[ib] = mfma16(aq, regs_frag(dp[jb][ib], s2), ok[ib]);
-          ov[ib] = mfma16(ag, regs_frag(st[jb][ib], s2), ov[ib]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          ok = mfma16(lds_tfrag(qt, l31, hf, jb, s2), regs_frag(dp[jb], s2), ok);
+          ov = mfma16(lds_tfrag(dot, l31, hf, jb, s2), regs_frag(st[jb], s2), ov);
         }
-      }
-    float padk[16], padv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
-    bool anypad = false;
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      const int i = 32 * ib + l31;
       int pix = -2, reg;
       if (i < WN) win_token(g, wy, wx, i, pix, reg);
       if (pix >= 0) {
         bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3 + head * HD;
-        store_dT(dst + 1 * g.C, ok[ib], hf, scale);
-        store_dT(dst + 2 * g.C, ov[ib], hf, 1.f);
+        store_dT(dst + 1 * g.C, ok, hf, scale);
+        store_dT(dst + 2 * g.C, ov, hf, 1.f);
       } else if (pix == -1) {
         anypad = true;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { padk[r] += ok[ib][r] * scale; padv[r] += ov[ib][r]; }
+        for (int r = 0; r < 16; ++r) { padk[r] += ok[r] * scale; padv[r] += ov[r]; }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
     if (__any(anypad)) {
@@ -1020,6 +1021,8 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
         for (int l = 0; l < 32; ++l) { tk += sk[(h2 * 32 + l) * 17 + r]; tv += sv[(h2 * 32 + l) * 17 + r]; }
         padp[d] = 0.f; padp[HD + d] = tk; padp[2 * HD + d] = tv;
       }
+      // the scratch overwrote token columns 49..63 of Q^T / dO^T, which must read as zero for the next window
+      for (int e = lane; e < 2 * HD * (64 - WN); e += 64) { const int tI = e / (HD * (64 - WN)), r = e % (HD * (64 - WN)); qt[tI * HD * VTP + (r / (64 - WN)) * VTP + WN + r % (64 - WN)] = 0; }
     } else {
       for (int e = lane; e < 96; e += 64) padp[e] = 0.f;
     }
@@ -1372,9 +1375,8 @@ extern "C" void sl_debug_attn_valu(int v);
 static int g_attn_valu_override = -1;
 extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
 static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && !(g_attn_valu_override >= 0 ? g_attn_valu_override : attn_valu()); }
-// The MFMA backward is correct (tests) but not yet faster than the VALU one: 256 VGPR + 256 AGPR and 104 spilled registers put one wave on a
-// SIMD (hipcc -Rpass-analysis=kernel-resource-usage); until its two score layouts are processed block by block it is opt-in.
-static int attn_bwd_mfma_env() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_MFMA"); v = (e && e[0] == '1') ? 1 : 0; } return v; }
+// MFMA backward: default for bf16 (1.57 ms per Swin-T step against 2.06 ms for the VALU kernel); SEGLAND_ATTN_BWD_MFMA=0 selects the VALU one.
+static int attn_bwd_mfma_env() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_MFMA"); v = (e && e[0] == '0') ? 0 : 1; } return v; }
 static bool use_attn_bwd_mfma(int dtype) {
   if (dtype != SL_BF16) return false;
   if (g_attn_valu_override >= 0) return g_attn_valu_override == 0;       // test hook: 0 = MFMA everywhere, 1 = VALU everywhere
@@ -1429,7 +1431,7 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
   const int nwin = g.B * g.nWy * g.nWx;
   if (use_attn_bwd_mfma(d->dtype)) {
     const int wpw = win_wpw(g), chunks = cdiv(nwin, 4 * wpw);
-    const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
+    const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 4 * 64 * NTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     hipLaunchKernelGGL(window_attention_bwd_mfma_kernel, dim3(chunks * g.heads), dim3(256), lds, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
