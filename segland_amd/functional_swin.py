@@ -18,7 +18,7 @@ from .ops_swin import pad_to
 
 # ------------------------------------------------------------------------------------------------ prepared (padded) weights
 class _Lin:
-    __slots__ = ('wf', 'wb', 'bias', 'spec', 'N', 'K', 'Np', 'Kp', 'k')
+    __slots__ = ('wf', 'wb', 'bias', 'spec', 'N', 'K', 'Np', 'Kp', 'k', 'stage')
 
 
 def _padded(t, shape, fill=0.0):
@@ -29,28 +29,109 @@ def _padded(t, shape, fill=0.0):
     return out
 
 
+class _Plan:
+    """Every GEMM weight of a Swin-POP model prepared in ONE kernel launch per optimizer step (the ResNet path's functional._PrepPlan for this
+    model family): lin_prep registers a weight the first time it sees it; refresh(), called at the top of a forward, re-pads the padded ones into
+    their persistent fp32 staging buffers and rebuilds all GEMM layouts with sl_weight_prep_batched."""
+
+    def __init__(self):
+        self.items, self.table, self.total, self.sig = {}, None, 0, None
+
+    def register(self, weight, bias, dtype, Kp, Np, k, col_map, L, stage):
+        self.items[(id(weight), Kp, Np, dtype)] = (weight, bias, dtype, Kp, Np, k, col_map, L, stage)
+        self.sig = None
+
+    def refresh(self):
+        import struct
+        if not self.items:
+            return
+        stale = [it for it in self.items.values() if getattr(it[0], '_sl_lin', {}).get((it[3], it[4], it[2]), (None,))[0] != _lin_key(it[0], it[1], it[2])]
+        if not stale:
+            return
+        if len(stale) * 2 < len(self.items):             # a few trainable weights over a frozen model (ft_pop): individual launches are cheaper
+            return
+        sig = tuple((id(it[0]), it[0].data_ptr(), it[3], it[4], it[2]) for it in self.items.values())
+        if sig != self.sig:
+            rec, start = b'', 0
+            for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
+                src = stage if stage is not None else w.detach()
+                assert Np % 64 == 0 and Kp % 32 == 0 and k * k <= 9
+                rec += struct.pack('<QQQiiiiq', src.data_ptr(), L.wf.data_ptr(), L.wb.data_ptr(), Np, Kp, k * k, ops.dt(dtype), start)
+                start += Np * Kp // 2048
+            self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(next(iter(self.items.values()))[0].device)
+            self.total, self.sig = start, sig
+        for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
+            if stage is not None:                         # zero pad is persistent; only the real block is rewritten
+                w4 = w.detach().reshape(w.shape[0], w.shape[1], k, k)
+                if cmap is not None:
+                    stage[:w.shape[0]].index_copy_(1, cmap, w4)
+                else:
+                    stage[:w.shape[0], :w.shape[1]].copy_(w4)
+            if L.bias is not None and b is not None and L.bias.data_ptr() != b.data_ptr():
+                L.bias[:b.shape[0]].copy_(b.detach())
+        ops.weight_prep_batched(self.table, len(self.items), self.total)
+        for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
+            w._sl_lin[(Kp, Np, dtype)] = (_lin_key(w, b, dtype), L)
+
+
+CURRENT_PLAN = [None]        # the model whose forward is running registers its weights here (GFSS_Model._features); None: per-weight launches
+
+
+def model_plan(model):
+    plan = model.__dict__.get('_sl_swin_plan')
+    if plan is None:
+        plan = model.__dict__['_sl_swin_plan'] = _Plan()
+    return plan
+
+
+def _lin_key(weight, bias, dtype):
+    return (_wver(weight), _wver(bias) if bias is not None else None, weight.data_ptr())
+
+
 def lin_prep(weight, bias, dtype, Kp=None, Np=None, k=1, col_map=None):
     """GEMM-layout copies of an nn.Linear weight [N,K] (or conv weight [N,K,k,k]) zero-padded to [Np,Kp], cached on the Parameter until it changes.
-    col_map (optional): (index tensor, Kp) scattering the K real input columns into a wider padded input (concat of padded maps)."""
+    col_map (optional): index tensor scattering the K real input columns into a wider padded input (concat of padded maps)."""
     N, K = weight.shape[0], weight.shape[1]
     Kp = pad_to(K) if Kp is None else Kp
     Np = pad_to(N) if Np is None else Np
-    key = (_wver(weight), _wver(bias) if bias is not None else None, dtype, weight.data_ptr(), Kp, Np)
-    ent = getattr(weight, '_sl_lin', None)
+    key = _lin_key(weight, bias, dtype)
+    cache = getattr(weight, '_sl_lin', None)
+    if cache is None:
+        cache = {}
+        weight._sl_lin = cache
+    ent = cache.get((Kp, Np, dtype))
     if ent is None or ent[0] != key:
         w4 = weight.detach().reshape(N, K, k, k) if weight.dim() == 2 else weight.detach()
-        if col_map is not None:
-            wp = torch.zeros((Np, Kp, k, k), dtype=torch.float32, device=weight.device)
-            wp[:N].index_copy_(1, col_map, w4.float())
+        padded = (Np, Kp) != (N, K) or col_map is not None
+        if ent is not None:
+            L, stage = ent[1], ent[1].stage
         else:
-            wp = _padded(w4.float(), (Np, Kp, k, k))
-        L = _Lin()
-        L.wf, L.wb = ops.weight_prep(wp.contiguous(), dtype)
-        L.bias = None if bias is None else _padded(bias, (Np,)).contiguous()
-        L.spec = ConvSpec(Kp, Np, k, 1, k // 2, 1)
-        L.N, L.K, L.Np, L.Kp, L.k = N, K, Np, Kp, k
-        ent = (key, L)
-        weight._sl_lin = ent
+            L, stage = _Lin(), None
+            if padded:
+                stage = torch.zeros((Np, Kp, k, k), dtype=torch.float32, device=weight.device)
+            L.wf = torch.empty((Np, k, k, Kp), dtype=dtype, device=weight.device)
+            L.wb = torch.empty((Kp, k, k, Np), dtype=dtype, device=weight.device)
+            L.bias = None if bias is None else (torch.zeros(Np, dtype=torch.float32, device=weight.device) if Np != N else None)
+            L.spec = ConvSpec(Kp, Np, k, 1, k // 2, 1)
+            L.N, L.K, L.Np, L.Kp, L.k, L.stage = N, K, Np, Kp, k, stage
+        if stage is not None:
+            if col_map is not None:
+                stage[:N].index_copy_(1, col_map, w4.float())
+            else:
+                stage[:N, :K].copy_(w4)
+        src = stage if stage is not None else w4.float().contiguous()
+        import ctypes as C
+        from . import _lib
+        _lib.check(_lib.lib().sl_weight_prep(ops.dt(dtype), ops._p(src), Np, Kp, k, k, ops._p(L.wf), ops._p(L.wb), ops._s()), 'weight_prep')
+        if bias is not None:
+            if Np != N:
+                L.bias[:N].copy_(bias.detach())
+            else:
+                L.bias = bias.detach()
+        if ent is None and CURRENT_PLAN[0] is not None and weight.dtype == torch.float32 and weight.is_contiguous() and weight.is_leaf:
+            CURRENT_PLAN[0].register(weight, bias, dtype, Kp, Np, k, col_map, L, stage)
+        cache[(Kp, Np, dtype)] = (key, L)
+        ent = cache[(Kp, Np, dtype)]
     return ent[1]
 
 
@@ -244,11 +325,28 @@ class LayerNormFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------------ decoder pieces
 def _bn_padded(bn, P):
-    """BatchNorm parameter / buffer vectors padded to the channel pitch (pad channels: gamma 1, beta 0 -> they stay exactly zero)."""
+    """BatchNorm parameter / statistic vectors at the channel pitch (pad channels: gamma 1, beta 0 -> they stay exactly zero).  The running statistics
+    LIVE in the padded buffers: bn.running_mean / running_var are re-pointed to views of them, so the finalize kernel updates the module's buffers in
+    place (state_dict, load_state_dict and .to() see ordinary [C] tensors; a .to() breaks the alias, which is re-established here).  gamma / beta are
+    copied once per optimizer step."""
     Cn = bn.num_features
     if P == Cn:
         return bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var
-    return (_padded(bn.weight, (P,), 1.0), _padded(bn.bias, (P,), 0.0), _padded(bn.running_mean, (P,), 0.0), _padded(bn.running_var, (P,), 1.0))
+    ent = bn.__dict__.get('_sl_pad')
+    dev = bn.weight.device
+    if ent is None or ent['P'] != P or ent['rm'].device != dev or bn.running_mean.data_ptr() != ent['rm'].data_ptr() or bn.running_var.data_ptr() != ent['rv'].data_ptr():
+        rm = torch.zeros(P, dtype=torch.float32, device=dev); rv = torch.ones(P, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            rm[:Cn].copy_(bn.running_mean); rv[:Cn].copy_(bn.running_var)
+        bn.running_mean, bn.running_var = rm[:Cn], rv[:Cn]
+        ent = bn.__dict__['_sl_pad'] = {'P': P, 'rm': rm, 'rv': rv, 'gw': torch.ones(P, dtype=torch.float32, device=dev),
+                                        'gb': torch.zeros(P, dtype=torch.float32, device=dev), 'key': None}
+    key = (_wver(bn.weight), _wver(bn.bias), bn.weight.data_ptr())
+    if ent['key'] != key:
+        with torch.no_grad():
+            ent['gw'][:Cn].copy_(bn.weight); ent['gb'][:Cn].copy_(bn.bias)
+        ent['key'] = key
+    return ent['gw'], ent['gb'], ent['rm'], ent['rv']
 
 
 def _bn_forward(bn, c, part, conv_bias, P):
@@ -261,10 +359,8 @@ def _bn_forward(bn, c, part, conv_bias, P):
         if count <= 1:
             raise ValueError('Expected more than 1 value per channel when training, got %d' % count)
         mean, invstd, scale, shift = ops.bn_finalize_train(part, count, gw.contiguous(), gb.contiguous(), rm, rv, bn.momentum, bn.eps)
-        with torch.no_grad():
-            if P != Cn:
-                bn.running_mean.copy_(rm[:Cn]); bn.running_var.copy_(rv[:Cn])
-            if conv_bias is not None:
+        if conv_bias is not None:
+            with torch.no_grad():
                 bn.running_mean.add_(conv_bias.detach(), alpha=bn.momentum)
         _nbt_pending.append(bn.num_batches_tracked)
         bn.__dict__['_sl_rs_epoch'] = bn.__dict__.get('_sl_rs_epoch', 0) + 1
@@ -300,7 +396,7 @@ class ConvBnReluFn(torch.autograd.Function):
         L = lin_prep(w, None, x.dtype, Kp=x.shape[-1], k=conv.kernel_size[0])
         need_w = ctx.needs_input_grad[2]
         Cn = bn.num_features
-        gw = _padded(gamma, (L.Np,), 1.0).contiguous()
+        gw = _bn_padded(bn, L.Np)[0]
         dc, _, dgam, dbet = ops.bn_bwd(dy.contiguous(), None, c, mean, invstd, gw, train=bn.training, mask=bits)
         dx, dw, _ = lin_bwd(x, dc, L, need_dx=ctx.needs_input_grad[0], need_w=need_w)
         dbias = ops.colsum_rows(dc)[:Cn].contiguous() if need_w else None
@@ -350,7 +446,11 @@ class PspSwinFn(torch.autograd.Function):
         Cs = psp.stages[0][1].out_channels
         Ps = pad_to(Cs)
         pooled = ops.ppm_pool_fwd(x, sizes)                                                   # [rows, Cf] float
-        wst = torch.stack([_padded(st[1].weight.view(Cs, Cf), (Ps, Cf)) for st in psp.stages]).contiguous()
+        wkey = tuple((_wver(st[1].weight), st[1].weight.data_ptr()) for st in psp.stages)
+        went = psp.__dict__.get('_sl_wst')
+        if went is None or went[0] != wkey:
+            went = psp.__dict__['_sl_wst'] = (wkey, torch.stack([_padded(st[1].weight.view(Cs, Cf), (Ps, Cf)) for st in psp.stages]).contiguous())
+        wst = went[1]
         call, part = ops.ppm_rows_gemm(pooled, wst, B, sizes, want_stats=any(st[2].training for st in psp.stages))
         stage_act = torch.empty_like(call)
         priors = torch.empty((B, h, w, nl * Ps), dtype=x.dtype, device=x.device)
@@ -395,7 +495,7 @@ class PspSwinFn(torch.autograd.Function):
             dy = osw.scale_add(dy, drop, None, per_channel=True, Cn=bnb.num_features)
         cmap = _psp_colmap(Cs, Ps, nl, Cf, x.device)
         L = lin_prep(bt[0].weight, None, x.dtype, Kp=nl * Ps + Cf, col_map=cmap)
-        gw = _padded(bnb.weight, (L.Np,), 1.0).contiguous()
+        gw = _bn_padded(bnb, L.Np)[0]
         dcb, _, dgb, dbb = ops.bn_bwd(dy, None, cb, mb, ib, gw, train=bnb.training, mask=bits)
         dcat, dwb, _ = lin_bwd(priors, dcb, L, need_w=need_w, col_map=cmap, x2=x)
         if need_w:
@@ -406,7 +506,7 @@ class PspSwinFn(torch.autograd.Function):
         for k, (s, st) in enumerate(zip(sizes, psp.stages)):
             n = B * s * s
             osw.bilinear_bwd(dcat, (s, s), True, out=dstage[off:off + n].view(B, s, s, Ps), Cn=Ps, dy_off=k * Ps)
-            gwk = _padded(st[2].weight, (Ps,), 1.0).contiguous()
+            gwk = _bn_padded(st[2], Ps)[0]
             _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], gwk, train=st[2].training, out=dc_all[off:off + n])
             dws = None
             if need_w:

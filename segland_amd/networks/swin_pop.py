@@ -135,7 +135,14 @@ class GFSS_Model(pspnet_pop.GFSS_Model):
     def _features(self, img):
         if not img.is_cuda:
             raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
-        feat = self.decoder(self.backbone(img))
+        from .. import functional_swin as fs
+        plan = fs.model_plan(self)
+        plan.refresh()                      # every GEMM weight whose parameter changed since the last step: one batched launch
+        fs.CURRENT_PLAN[0] = plan
+        try:
+            feat = self.decoder(self.backbone(img))
+        finally:
+            fs.CURRENT_PLAN[0] = None
         flush_num_batches_tracked()
         return feat
 
