@@ -132,7 +132,9 @@ class GFSS_Model(pspnet_pop.GFSS_Model):
             for p in self.decoder.parameters():
                 p.requires_grad = False
 
-    def _features(self, img):
+    def _features_eager(self, img):
+        """Backbone + decoder as an eager kernel sequence.  pspnet_pop.GFSS_Model._features (inherited) replays it from a HIP graph when everything
+        in it is frozen and in eval mode (ft_pop training, no-grad evaluation): ~600 launches of a few microseconds each are launch-bound otherwise."""
         if not img.is_cuda:
             raise RuntimeError('segland_amd.GFSS_Model runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
         from .. import functional_swin as fs

@@ -416,3 +416,22 @@ def test_swin_pop_through_the_drivers(hip, tmp_path):
     res = eval_base.main(['--model', 'swin_pop', '--backbone', 'swin-t', '--dataset', 'synthetic', '--base-size', '128,128', '--restore-from', str(tmp_path / 'novel.pth'),
                           '--save-path', str(tmp_path / 'out'), '--random-seed', '123'], ft=True)
     assert 123 in res and os.path.exists(str(tmp_path / 'out' / 'cmatrix_123.npy'))
+
+
+def test_swin_ft_feature_graph(hip):
+    """ft_pop mode on Swin replays the frozen backbone + decoder from a HIP graph (pspnet_pop.GFSS_Model._features_graphed, inherited): equal to the
+    eager kernel sequence for two inputs, dropped when a frozen weight changes."""
+    m = _swin_model(torch.float32, is_ft=True, criterion=False)
+    m.init_cls_n()
+    m.train_mode()
+    img = fm.formula_image(2, 96, 128, 'swgraph/img').to(DEV)
+    img2 = fm.formula_image(2, 96, 128, 'swgraph/img2').to(DEV)
+    with torch.no_grad():
+        for x in (img, img2, img):
+            assert torch.equal(m._features(x), m._features_eager(x))
+        assert m.__dict__['_sl_graph'][1] is not None, 'graph capture did not happen'
+        g0 = m.__dict__['_sl_graph'][1]
+        m.backbone.layers[2].blocks[1].mlp.fc1.weight.mul_(0.5)
+        f = m._features(img)
+        assert m.__dict__['_sl_graph'][1] is not g0
+        assert torch.equal(f, m._features_eager(img))
