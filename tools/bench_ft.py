@@ -6,15 +6,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from segland_amd.ft_pop import ft_iteration
 from segland_amd.loss.criterion import OrthLoss
-from segland_amd.networks.pspnet_pop import GFSS_Model
+from segland_amd import networks
 from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
 
 p = argparse.ArgumentParser(); p.add_argument('--steps', type=int, default=30); p.add_argument('--warmup', type=int, default=5)
 p.add_argument('--dtype', default='f32', choices=['f32', 'bf16']); p.add_argument('--pairs', type=int, default=1)
+p.add_argument('--model', default='pspnet_pop', choices=['pspnet_pop', 'swin_pop']); p.add_argument('--backbone', default=None)
 a = p.parse_args()
 dt = torch.float32 if a.dtype == 'f32' else torch.bfloat16
 torch.manual_seed(0)
-m = GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=dt).cuda()
+kw = dict(dilated=True, os=8) if a.model == 'pspnet_pop' else {}
+m = getattr(networks, a.model).GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone=a.backbone or ('resnet50' if a.model == 'pspnet_pop' else 'swin-t'),
+                                          pretrained_model=None, compute_dtype=dt, **kw).cuda()
 m.init_cls_n()
 opt = torch.optim.SGD(get_parameters(m, lr=1e-3, freeze_backbone=True), lr=1e-3, momentum=0.9, weight_decay=5e-4)
 B = a.pairs
