@@ -16,6 +16,7 @@ The JSON line also carries
                  fp32) on this host's cores -- rank 0, N = 1 only.  Reported, not a target.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -168,7 +169,8 @@ def main():
     torch.manual_seed(0)
     GFSS_Model = getattr(networks, a.model).GFSS_Model
     kw = dict(dilated=True, os=8) if a.model == 'pspnet_pop' else {}
-    model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, compute_dtype=dtype, **kw).to(dev).train()
+    with contextlib.redirect_stdout(sys.stderr):            # the factory prints 'Backbone:<name>' like the reference's; stdout carries the JSON line only
+        model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=a.backbone, pretrained_model=None, compute_dtype=dtype, **kw).to(dev).train()
     opt = make_optimizer(model, torch_optimizer=a.torch_optimizer)
     net = model
     grad_div = 1
