@@ -49,6 +49,8 @@ def parse():
     p.add_argument('--cpu-budget', type=float, default=40.0, help='seconds of CPU work allowed for the cpu_baseline sample')
     p.add_argument('--torch-optimizer', action='store_true', help='torch.optim.AdamW(fused=True) instead of segland_amd.optim.AdamW')
     p.add_argument('--single-step', action='store_true', help='one AdamW step per iteration (the reference does two, train_base.py:262-264)')
+    p.add_argument('--no-step-graph', action='store_true', help='time kernel-by-kernel steps only (default on one GPU: the timed steps replay the step as ONE HIP graph, '
+                   'segland_amd/graph_step.py, like train_base does; a second, eager region then carries the per-launch events of the roofline)')
     p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
     return p.parse_args()
 
@@ -200,23 +202,47 @@ def main():
     single = {k: v for k, v in table.items() if 'wgrad' not in k}     # families that are exactly one kernel per launch
     dominant = max(single.values(), key=lambda e: e['ms_total']) if single else None
 
-    # ---- timed region (only the dominant kernel's launches carry event pairs)
-    if dominant is not None:
-        ops.PROFILER.start(only=dominant['family'])
-    if use_ddp:
-        dist.barrier()
-    torch.cuda.synchronize()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for k in range(a.steps):
-        img, mask = batches[k % len(batches)]
-        train_step(net, opt, img, mask, params, double, grad_div)
-        marks[k + 1].record()                          # per-step GPU time without a host synchronisation (median below)
-    torch.cuda.synchronize()
-    if use_ddp:
-        dist.barrier()
-    dt_s = time.perf_counter() - t0
+    # ---- the product's default on one GPU: the whole step replayed as ONE HIP graph (train_base does the same).  A graph replay cannot carry
+    # per-launch events, so the K timed steps that give `value` are replays and a SECOND region of K kernel-by-kernel steps right after it
+    # carries the event pairs of the roofline kernel (same kernels, same shapes, same process).
+    from segland_amd import graph_step
+    graphed = None
+    if not a.no_step_graph and not use_ddp and graph_step.eligible(net, opt, dev):
+        fn = lambda m_, o_, s_, im_, mk_, double_step=True: (train_step(m_, o_, im_, mk_, params, double_step, grad_div), None)      # noqa: E731
+        graphed = graph_step.GraphedTrainStep(fn, net, opt, None, double_step=double, warmup=0)
+        for k in range(3):                                 # capture + two untimed replays
+            graphed(*batches[k % len(batches)])
+        if graphed.graph is None:
+            graphed = None
+
+    def timed_region(step_fn):
+        if use_ddp:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for k in range(a.steps):
+            img, mask = batches[k % len(batches)]
+            step_fn(img, mask)
+            marks[k + 1].record()                          # per-step GPU time without a host synchronisation (median below)
+        torch.cuda.synchronize()
+        if use_ddp:
+            dist.barrier()
+        return time.perf_counter() - t0, marks
+
+    eager_fn = lambda img, mask: train_step(net, opt, img, mask, params, double, grad_div)      # noqa: E731
+    eager_ms = None
+    if graphed is not None:
+        dt_s, marks = timed_region(lambda img, mask: graphed(img, mask))
+        if dominant is not None:
+            ops.PROFILER.start(only=dominant['family'])
+        dt_e, _ = timed_region(eager_fn)
+        eager_ms = 1e3 * dt_e / a.steps
+    else:
+        if dominant is not None:
+            ops.PROFILER.start(only=dominant['family'])     # only the dominant kernel's launches carry event pairs
+        dt_s, marks = timed_region(eager_fn)
     live = ops.PROFILER.stop()
     if use_ddp:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
@@ -244,7 +270,11 @@ def main():
                                    '(fwd+loss+bwd+clip+AdamW x%d), %d x MI355X' % (a.backbone, a.dtype, a.batch, a.size, a.size, 2 if double else 1, world),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
+            'step_issue': ('one HIP graph replay per step (segland_amd/graph_step.py, the train_base default on one GPU)' if graphed is not None
+                           else 'kernel by kernel from Python'),
         }
+        if eager_ms is not None:
+            out['ms_per_step_kernel_by_kernel'] = round(eager_ms, 3)      # the second timed region (the one the roofline events come from)
         per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
         out['ms_per_step_median'] = round(per[len(per) // 2], 3)
         out['value_at_median'] = round(a.batch * world / (per[len(per) // 2] * 1e-3), 1)
@@ -275,7 +305,8 @@ def main():
                                'traffic': traffic, 'traffic_source': tsrc, 'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
-                               'note': 'all launches of this kernel in the timed steps (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
+                               'note': 'all launches of this kernel in ' + ('the %d kernel-by-kernel steps timed right after the graph-replayed region' % a.steps if graphed is not None else 'the timed steps')
+                                       + ' (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone, a.model)
         print(json.dumps(out), flush=True)

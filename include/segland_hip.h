@@ -285,13 +285,18 @@ int sl_nchw_f32_to_nhwc(int dtype, const float* src, void* dst, int B, int H, in
 /* ---- optimizer ------------------------------------------------------------------------------------------------------------
  * torch.optim.AdamW (train_base.py:197-204; stepped twice per iteration, :262-264) over n parameter tensors in ONE launch.
  * table_dev: device array of n 64-byte records { float* p; const float* g; float* m; float* v; long long numel; float lr, wd;
- * long long start; long long pad; } with `start` the running count of 4096-element chunks (ceil(numel/4096)) of the preceding records
+ * long long start; int group; int pad; } with `start` the running count of 4096-element chunks (ceil(numel/4096)) of the preceding records
  * and total_chunks their grand total.  bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for this step, the
  * `_next` pair for step t+1 (used when repeat == 2: two consecutive steps on the same gradient in one pass).  grad_scale: optional
  * device scalar multiplied into every gradient (the clip_grad_norm_ coefficient). */
 int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
                    float bias_correction1, float bias_correction2_sqrt, float bias_correction1_next, float bias_correction2_sqrt_next,
                    int repeat, const float* grad_scale, sl_stream_t stream);
+/* The same step for a captured HIP graph (segland_amd/graph_step.py): every step-dependent scalar lives in device memory.
+ * hyper_dev = { bias_correction1, bias_correction2_sqrt, bias_correction1_next, bias_correction2_sqrt_next, then (lr, weight_decay) per
+ * parameter group }; a record's `group` selects its pair and the record's own lr / wd are ignored. */
+int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
+                       const float* hyper_dev, int repeat, const float* grad_scale, sl_stream_t stream);
 
 /* ---- Swin-POP path ---------------------------------------------------------------------------
  * Token maps are NHWC images [B][H][W][pitch] with C real channels and a ZERO channel pad up to `pitch` (a multiple of 64 so that the

@@ -7,8 +7,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------ finalize
 // Column sums of the [rows][2][C] partial buffers: a block owns 64 channels, 16 row-lanes stride over the rows (8 loads in
 // flight each), then a fixed-order 16-way LDS tree -- bit-stable, and ~100x less latency than one serial thread per channel.
-constexpr int FIN_CH = 64, FIN_RL = 16;
-
+template <int FIN_CH, int FIN_RL>
 __device__ __forceinline__ void colsum2(const float* __restrict__ part, int rows, int C, int c, int rl, double& s, double& q,
                                         double (*red)[FIN_RL][FIN_CH]) {
   double a0 = 0.0, a1 = 0.0;
@@ -36,6 +35,7 @@ __device__ __forceinline__ void colsum2(const float* __restrict__ part, int rows
   }
 }
 
+template <int FIN_CH, int FIN_RL>
 __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_finalize_train_kernel(const float* __restrict__ part, int rows, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* rmean, float* rvar, float momentum, float eps,
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_finalize_train_kernel(cons
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, rl = threadIdx.x / FIN_CH;
   double s, q;
-  colsum2(part, rows, C, c, rl, s, q, red);
+  colsum2<FIN_CH, FIN_RL>(part, rows, C, c, rl, s, q, red);
   if (rl != 0 || c >= C) return;
   const double mu = s / count;
   double var = q / count - mu * mu;
@@ -80,23 +80,26 @@ template <typename T, bool FIXEDC>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                   const T* __restrict__ res, int relu, T* __restrict__ y, uint8_t* __restrict__ mask_out, unsigned nvec, unsigned nvc) {
   constexpr int V = Vec16<T>::N;
-  const unsigned stride = gridDim.x * 256u;
   float sc[V], sh[V];
   if (FIXEDC) {
     const unsigned c = (threadIdx.x % nvc) * V;
 #pragma unroll
     for (int k = 0; k < V; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; }
   }
-  for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < nvec; i0 += 4 * stride) {
+  // a block-iteration owns 1024 consecutive vectors (16 KiB per operand).  Walking the tensor from its end (the bytes the producing conv
+  // wrote last) was measured for all three BN passes: no difference, the Infinity Cache does not retain these streams
+  const unsigned nchunk = (nvec + 1023u) >> 10;
+  for (unsigned ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const unsigned i0 = (ch << 10) + threadIdx.x;
     uint4 xv[4], rv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const unsigned i = i0 + u * stride;
+      const unsigned i = i0 + u * 256u;
       if (i < nvec) { xv[u] = ((const uint4*)x)[i]; if (res) rv[u] = ((const uint4*)res)[i]; }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const unsigned i = i0 + u * stride;
+      const unsigned i = i0 + u * 256u;
       if (i >= nvec) break;
       if (!FIXEDC) {
         const unsigned c = (i % nvc) * V;
@@ -126,36 +129,43 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            float* __restrict__ part, long long rows, int C, long long rows_per_blk) {
+                                                            float* __restrict__ part, long long rows, int C) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2 * 256 * V];
+  const unsigned lb = blockIdx.x;
   const int nvec = C / V;
   const int tpr = nvec < 256 ? nvec : 256;      // threads per row
   const int rpb = 256 / tpr;                    // rows handled in parallel
   const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
-  const long long r_begin = blockIdx.x * rows_per_blk;
-  long long r_end = r_begin + rows_per_blk; if (r_end > rows) r_end = rows;
+  // block b owns the row groups b, b + nblk, b + 2 nblk, ...: the chip reads ONE moving window of the tensor, like the streaming passes
+  // (measured 4.2 vs 4.0 TB/s for a contiguous row range per block; 2 or 4 rows in flight per thread were SLOWER: 3.9 / 3.2 TB/s)
+  const long long r_begin = (long long)lb * rpb, r_end = rows, rstep = (long long)gridDim.x * rpb;
   for (int vc = tc; vc < nvec; vc += tpr) {
     float s1[V], s2[V], mu[V], is[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = mean[vc * V + k]; is[k] = invstd[vc * V + k]; }
     if (tr < rpb) {
-      for (long long r = r_begin + tr; r < r_end; r += rpb) {
-        const size_t o = (size_t)r * nvec + vc;
+      auto acc = [&](const uint4& gq, const uint4& xq, const uint4& yq, unsigned mb) {
         float g[V], xv[V], yv[V];
-        unpack16<T>(((const uint4*)dy)[o], g);
-        unpack16<T>(((const uint4*)x)[o], xv);
+        unpack16<T>(gq, g);
+        unpack16<T>(xq, xv);
         if (mask) {
-          const unsigned b = mask[o];
 #pragma unroll
-          for (int k = 0; k < V; ++k) g[k] = (b >> k) & 1u ? g[k] : 0.f;
+          for (int k = 0; k < V; ++k) g[k] = (mb >> k) & 1u ? g[k] : 0.f;
         } else if (y) {
-          unpack16<T>(((const uint4*)y)[o], yv);
+          unpack16<T>(yq, yv);
 #pragma unroll
           for (int k = 0; k < V; ++k) g[k] = yv[k] > 0.f ? g[k] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) { s1[k] += g[k]; s2[k] += g[k] * ((xv[k] - mu[k]) * is[k]); }
+      };
+      long long r = r_begin + tr;
+      for (; r < r_end; r += rstep) {
+        const size_t o = (size_t)r * nvec + vc;
+        uint4 yq = make_uint4(0, 0, 0, 0);
+        if (!mask && y) yq = ((const uint4*)y)[o];
+        acc(((const uint4*)dy)[o], ((const uint4*)x)[o], yq, mask ? mask[o] : 0u);
       }
     }
     // reduce over the rpb row-lanes that share this channel vector
@@ -168,20 +178,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       for (int k = 0; k < V; ++k) {
         float a = 0.f, b = 0.f;
         for (int j = 0; j < rpb; ++j) { a += red[((j * tpr + tc) * V + k) * 2 + 0]; b += red[((j * tpr + tc) * V + k) * 2 + 1]; }
-        part[((size_t)blockIdx.x * 2 + 0) * C + vc * V + k] = a;
-        part[((size_t)blockIdx.x * 2 + 1) * C + vc * V + k] = b;
+        part[((size_t)lb * 2 + 0) * C + vc * V + k] = a;
+        part[((size_t)lb * 2 + 1) * C + vc * V + k] = b;
       }
     }
   }
 }
 
+template <int FIN_CH, int FIN_RL>
 __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count, const float* gamma,
                                        const float* mean, const float* invstd, int train, float* dgamma, float* dbeta,
                                        float* cA, float* cB, float* cC) {
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, rl = threadIdx.x / FIN_CH;
   double s1, s2;
-  colsum2(part, nblk, C, c, rl, s1, s2, red);
+  colsum2<FIN_CH, FIN_RL>(part, nblk, C, c, rl, s1, s2, red);
   if (rl != 0 || c >= C) return;
   if (dgamma) dgamma[c] = (float)s2;
   if (dbeta) dbeta[c] = (float)s1;
@@ -200,23 +211,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                     const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
                                     const float* __restrict__ mean, T* __restrict__ dx, T* __restrict__ dres, unsigned nvec, unsigned nvc) {
   constexpr int V = Vec16<T>::N;
-  const unsigned stride = gridDim.x * 256u;
   float a_[V], b_[V], c_[V], cc[V];      // dx = a*g + b*(x - c) + cc
   if (FIXEDC) {
     const unsigned c = (threadIdx.x % nvc) * V;
 #pragma unroll
     for (int k = 0; k < V; ++k) { a_[k] = cA[c + k]; b_[k] = cB[c + k]; c_[k] = mean[c + k]; cc[k] = cC[c + k]; }
   }
-  for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; i0 < nvec; i0 += 2 * stride) {
+  const unsigned nchunk = (nvec + 511u) >> 9;          // 512 consecutive vectors per block-iteration
+  for (unsigned ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const unsigned i0 = (ch << 9) + threadIdx.x;
     uint4 gv[2], xv[2], yv[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const unsigned i = i0 + u * stride;
+      const unsigned i = i0 + u * 256u;
       if (i < nvec) { gv[u] = ((const uint4*)dy)[i]; xv[u] = ((const uint4*)x)[i]; if (y && !mask) yv[u] = ((const uint4*)y)[i]; }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const unsigned i = i0 + u * stride;
+      const unsigned i = i0 + u * 256u;
       if (i >= nvec) break;
       if (!FIXEDC) {
         const unsigned c = (i % nvc) * V;
@@ -243,6 +255,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// block shape of the two finalize kernels: 0 = 64 channels x 16 row lanes, 1 = 32 x 32 (default: -0.26 ms per R50 step), 2 = 16 x 64
+static int fin_shape() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_BN_FIN"); v = e ? atoi(e) : 1; } return v; }
+
 inline int ew_blocks(long long nvec) { long long b = (nvec + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 inline int reduce_blocks(long long rows) { long long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
@@ -253,8 +268,10 @@ extern "C" int sl_bn_finalize_train(const float* stat_partial, int stat_rows, in
                                     float* mean, float* invstd, float* scale, float* shift, sl_stream_t stream) {
   SL_REQUIRE(stat_partial && mean && invstd && scale && shift && C > 0 && stat_rows > 0 && count > 0, "bn_finalize_train: bad args");
   SL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, (hipStream_t)stream, stat_partial, stat_rows, C,
-                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+#define SL_FIN_TRAIN(CH, RL) hipLaunchKernelGGL((bn_finalize_train_kernel<CH, RL>), dim3(cdiv(C, CH)), dim3(CH * RL), 0, (hipStream_t)stream, stat_partial, stat_rows, C, \
+                     (double)count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift)
+  switch (fin_shape()) { case 1: SL_FIN_TRAIN(32, 32); break; case 2: SL_FIN_TRAIN(16, 64); break; default: SL_FIN_TRAIN(64, 16); }
+#undef SL_FIN_TRAIN
   SL_LAUNCH_CHECK("bn_finalize_train_kernel");
   return 0;
 }
@@ -298,12 +315,11 @@ extern "C" int sl_bn_bwd_reduce(int dtype, const void* dy, const void* y, const 
                                 const float* invstd, float* partial, long long rows, int C, sl_stream_t stream) {
   SL_REQUIRE(dy && x && mean && invstd && partial && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce: bad args");
   const int nblk = reduce_blocks(rows);
-  const long long rpb = (rows + nblk - 1) / nblk;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SL_BF16)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, relu_mask, (const bf16_t*)x, mean, invstd, partial, rows, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)y, relu_mask, (const bf16_t*)x, mean, invstd, partial, rows, C);
   else if (dtype == SL_F32)
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)y, relu_mask, (const float*)x, mean, invstd, partial, rows, C, rpb);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)y, relu_mask, (const float*)x, mean, invstd, partial, rows, C);
   else SL_REQUIRE(false, "bn_bwd_reduce: bad dtype");
   SL_LAUNCH_CHECK("bn_bwd_reduce_kernel");
   return 0;
@@ -313,8 +329,10 @@ extern "C" int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long lo
                                   const float* mean, const float* invstd, int train, float* dgamma, float* dbeta,
                                   float* cA, float* cB, float* cC, sl_stream_t stream) {
   SL_REQUIRE(partial && invstd && cA && cB && cC && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_RL), 0, (hipStream_t)stream, partial, nblk, C, (double)count,
-                     gamma, mean, invstd, train, dgamma, dbeta, cA, cB, cC);
+#define SL_FIN_BWD(CH, RL) hipLaunchKernelGGL((bn_bwd_finalize_kernel<CH, RL>), dim3(cdiv(C, CH)), dim3(CH * RL), 0, (hipStream_t)stream, partial, nblk, C, (double)count, \
+                     gamma, mean, invstd, train, dgamma, dbeta, cA, cB, cC)
+  switch (fin_shape()) { case 1: SL_FIN_BWD(32, 32); break; case 2: SL_FIN_BWD(16, 64); break; default: SL_FIN_BWD(64, 16); }
+#undef SL_FIN_BWD
   SL_LAUNCH_CHECK("bn_bwd_finalize_kernel");
   return 0;
 }

@@ -7,17 +7,20 @@
 
 namespace {
 
-struct AdamEntry { float* p; const float* g; float* m; float* v; long long numel; float lr, wd; long long start; long long pad_; };
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long numel; float lr, wd; long long start; int group; int pad_; };
 static_assert(sizeof(AdamEntry) == 64, "table layout is part of the ABI");
 constexpr int AD_CHUNK = 4096;        // elements per block
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamEntry* __restrict__ tab, int n, long long total_chunks, float b1, float b2, float eps,
-                                                          float bc1_0, float rs2_0, float bc1_1, float rs2_1, int repeat, const float* __restrict__ gscale) {
+                                                          float bc1_0, float rs2_0, float bc1_1, float rs2_1, int repeat, const float* __restrict__ gscale,
+                                                          const float* __restrict__ hyp) {
   const float gs = gscale ? gscale[0] : 1.f;
+  if (hyp) { bc1_0 = hyp[0]; rs2_0 = hyp[1]; bc1_1 = hyp[2]; rs2_1 = hyp[3]; }      // step-dependent scalars from device memory (graph replay)
   for (long long chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
     int lo = 0, hi = n - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= chunk) lo = mid; else hi = mid - 1; }
-    const AdamEntry t = tab[lo];
+    AdamEntry t = tab[lo];
+    if (hyp) { t.lr = hyp[4 + 2 * t.group]; t.wd = hyp[5 + 2 * t.group]; }
     const long long base = (chunk - t.start) * AD_CHUNK;
     const float decay = 1.f - t.lr * t.wd;
     for (int k = threadIdx.x * 4; k < AD_CHUNK; k += 1024) {
@@ -64,7 +67,20 @@ extern "C" int sl_adamw_multi(const void* table_dev, int n, long long total_chun
   SL_REQUIRE(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f, "adamw_multi: bias corrections must be positive (step >= 1)");
   const int blocks = (int)(total_chunks < 8192 ? total_chunks : 8192);
   hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table_dev, n, total_chunks, beta1, beta2, eps,
-                     bias_correction1, bias_correction2_sqrt, bias_correction1_next, bias_correction2_sqrt_next, repeat, grad_scale);
+                     bias_correction1, bias_correction2_sqrt, bias_correction1_next, bias_correction2_sqrt_next, repeat, grad_scale, (const float*)nullptr);
+  SL_LAUNCH_CHECK("adamw_multi_kernel");
+  return 0;
+}
+
+// The same step with every step-dependent scalar in DEVICE memory, so that the launch can sit in a captured HIP graph and be replayed:
+// hyper_dev = { bias_correction1, bias_correction2_sqrt, the pair for the next step, then (lr, weight_decay) per parameter group };
+// record field `group` (the int after `start`) selects the pair, the records' own lr / wd are ignored.
+extern "C" int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
+                                  const float* hyper_dev, int repeat, const float* grad_scale, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && hyper_dev && n > 0 && total_chunks > 0 && (repeat == 1 || repeat == 2), "adamw_multi_dev: bad args");
+  const int blocks = (int)(total_chunks < 8192 ? total_chunks : 8192);
+  hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table_dev, n, total_chunks, beta1, beta2, eps,
+                     1.f, 1.f, 1.f, 1.f, repeat, grad_scale, hyper_dev);
   SL_LAUNCH_CHECK("adamw_multi_kernel");
   return 0;
 }

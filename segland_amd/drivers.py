@@ -45,6 +45,8 @@ _COMMON = [
     ('--test-batch-size', dict(type=int, default=1, help='Number of images sent to the network in one validation step.')),
     ('--filter-novel', dict(action='store_true', default=False, help='filter images containing novel classes during training.')),
     ('--freeze-backbone', dict(action='store_true', default=False, help='freeze the backbone during training.')),
+    ('--no-step-graph', dict(action='store_true', default=False, help='issue every kernel of the training step from Python instead of replaying '
+                                 'the step as one captured HIP graph (segland_amd/graph_step.py; single-GPU AdamW runs only).')),
     ('--allow-random-init', dict(action='store_true', default=False, help='continue with random weights when --restore-from does not exist '
                                                                            '(the reference fails in torch.load; so does this build without the flag).')),
     ('--fp16', dict(action='store_true', default=False, help='mixed precision: bf16 MFMA with fp32 accumulate on MI355X '

@@ -269,9 +269,32 @@ class SwinBlockFn(torch.autograd.Function):
         dtable = None
         if need_w:
             dbq = dbq + dpad                           # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
-            idx = blk.attn.relative_position_index.view(-1)
-            dtable = torch.zeros_like(table).index_add_(0, idx, drel.permute(1, 2, 0).reshape(-1, heads))
+            gidx, gmask = _rel_gather(blk.attn, table.shape[0])
+            # table row t collects the (query, key) pairs with relative offset t.  A fixed-order gather + sum instead of index_add_ (atomics,
+            # last-bit differences from run to run): the step stays bit-reproducible like the rest of the path
+            dtable = (drel.reshape(heads, -1)[:, gidx] * gmask).sum(-1).t().contiguous()
         return (dx, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
+
+
+def _rel_gather(attn, rows):
+    """([rows, m] flat (query, key) pair indices per relative-position table row, [rows, m] 0/1 validity), m = the largest pair count."""
+    ent = attn.__dict__.get('_sl_relgather')
+    if ent is None or ent[0].device != attn.relative_position_index.device:
+        idx = attn.relative_position_index.view(-1).cpu()
+        order = torch.argsort(idx, stable=True)
+        counts = torch.bincount(idx, minlength=rows)
+        m = int(counts.max())
+        gidx = torch.zeros((rows, m), dtype=torch.int64)
+        gmask = torch.zeros((rows, m), dtype=torch.float32)
+        start = 0
+        for t in range(rows):
+            c = int(counts[t])
+            gidx[t, :c] = order[start:start + c]
+            gmask[t, :c] = 1.0
+            start += c
+        dev = attn.relative_position_index.device
+        ent = attn.__dict__['_sl_relgather'] = (gidx.to(dev), gmask.to(dev))
+    return ent
 
 
 def block_params(blk):

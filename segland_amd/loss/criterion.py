@@ -13,11 +13,17 @@ class OrthLoss(nn.Module):
             raise ValueError('segland_amd OrthLoss implements reduction="mean" (what the reference uses)')
         self.ignore_index = ignore_index
         self.w = 10.0
+        self._triu = {}
 
     def get_orth_loss(self, proto_sim, is_ft=False):
         # mean |.| over the strict upper triangle, also of a rectangular [K1,K2] matrix (criterion.py:37-43)
-        sel = torch.triu(torch.ones_like(proto_sim), diagonal=1) == 1
-        return torch.abs(proto_sim[sel]).mean()
+        # the reference selects with a boolean mask (a host synchronisation: the element count comes back); the same elements in the same
+        # row-major order through constant indices keep the step free of read-backs (HIP-graph capture, graph_step.py) and the sum bit-identical
+        key = (tuple(proto_sim.shape), proto_sim.device)
+        idx = self._triu.get(key)
+        if idx is None:
+            idx = self._triu[key] = torch.triu_indices(proto_sim.shape[0], proto_sim.shape[1], offset=1).to(proto_sim.device)
+        return torch.abs(proto_sim[idx[0], idx[1]]).mean()
 
     def seg_loss(self, preds, target):
         return UpsampleCEFn.apply(preds.float(), target.contiguous(), self.ignore_index)

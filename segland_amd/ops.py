@@ -620,6 +620,10 @@ def adamw_multi(table, n, total_chunks, b1, b2, eps, bc1, rs2, bc1n, rs2n, repea
     check(_lib.lib().sl_adamw_multi(_p(table), n, int(total_chunks), b1, b2, eps, bc1, rs2, bc1n, rs2n, int(repeat), _p(grad_scale), _s()), 'adamw_multi')
 
 
+def adamw_multi_dev(table, n, total_chunks, b1, b2, eps, hyper, repeat, grad_scale=None):
+    check(_lib.lib().sl_adamw_multi_dev(_p(table), n, int(total_chunks), b1, b2, eps, _p(hyper), int(repeat), _p(grad_scale), _s()), 'adamw_multi_dev')
+
+
 def confusion_matrix(pred_u8, target, K, ignore_index):
     """[K][K] int64 counts, rows = ground truth, columns = prediction, pixels with target == ignore_index dropped."""
     cm = torch.zeros((K, K), dtype=torch.int64, device=target.device)

@@ -21,6 +21,8 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}             # launch slot -> (record bytes, device table); parameters are launched grouped by their step count
         self.repeat_next = 1          # drivers: set to 2 to fold the reference's second step() into the next one
+        self._cap = None              # HIP-graph capture: launch slot -> persistent {pinned table, device table, device hyper-parameters}
+        self._graph_plan = []         # [(slot, parameters, repeat)] of the captured step(), replayed by graph_prepare()
 
     @torch.no_grad()
     def step(self, closure=None, repeat=None, grad_scale=None):
@@ -34,8 +36,11 @@ class AdamW(torch.optim.Optimizer):
                 loss = closure()
         repeat = self.repeat_next if repeat is None else repeat
         self.repeat_next = 1
-        groups, hyper, dev = {}, None, None          # step count -> [record bytearray, n, chunk start]
-        for group in self.param_groups:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing and self._cap is None:
+            raise RuntimeError('segland_amd.optim.AdamW: call capture_begin() before capturing step() into a graph (segland_amd.graph_step does)')
+        groups, hyper, dev = {}, None, None          # step count -> [record bytearray, n, chunk start, parameters]
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group['betas']
             hp = (b1, b2, group['eps'])
             if hyper is not None and hp != hyper:
@@ -53,16 +58,27 @@ class AdamW(torch.optim.Optimizer):
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 t = int(st['step']) + 1
-                st['step'] += repeat
-                g = groups.setdefault(t, [bytearray(), 0, 0])
-                g[0] += struct.pack('<QQQQqffqq', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
-                                    p.numel(), group['lr'], group['weight_decay'], g[2], 0)
+                if not capturing:                   # a captured step does not execute: graph_prepare() counts the replays
+                    st['step'] += repeat
+                g = groups.setdefault(t, [bytearray(), 0, 0, []])
+                g[0] += struct.pack('<QQQQqffqii', p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(),
+                                    p.numel(), group['lr'], group['weight_decay'], g[2], gi, 0)
                 g[2] += (p.numel() + 4095) // 4096
                 g[1] += 1
+                g[3].append(p)
         if not groups:
             return loss
         b1, b2, eps = hyper
-        for slot, (step_t, (rec, n, total)) in enumerate(sorted(groups.items())):
+        for slot, (step_t, (rec, n, total, plist)) in enumerate(sorted(groups.items())):
+            if capturing:
+                cap = self._cap.get(slot)
+                if cap is None or len(rec) > cap['pinned'].numel():
+                    raise RuntimeError('segland_amd.optim.AdamW: the captured step touches more parameters / step counts than capture_begin() saw')
+                cap['pinned'][:len(rec)] = torch.frombuffer(rec, dtype=torch.uint8)        # host write now; the H2D copy below is a graph node
+                cap['dev'].copy_(cap['pinned'], non_blocking=True)
+                ops.adamw_multi_dev(cap['dev'], n, total, b1, b2, eps, cap['hyp'], repeat, grad_scale=grad_scale)
+                self._graph_plan.append((slot, plist, repeat))
+                continue
             ent = self._tables.get(slot)
             if ent is None or ent[0] != rec:      # the caching allocator hands back the same gradient addresses step after step: usually no upload
                 # pinned staging + asynchronous copy: a pageable upload would synchronise the host with the GPU once per step
@@ -70,6 +86,39 @@ class AdamW(torch.optim.Optimizer):
             bc = [(1.0 - b1 ** (step_t + r), math.sqrt(1.0 - b2 ** (step_t + r))) for r in (0, 1)]
             ops.adamw_multi(ent[1], n, total, b1, b2, eps, bc[0][0], bc[0][1], bc[1][0], bc[1][1], repeat, grad_scale=grad_scale)
         return loss
+
+
+    # ---- whole-step HIP graphs (segland_amd/graph_step.py) ---------------------------------------------------------------------------
+    def capture_begin(self):
+        """Before capturing a step(): allocates what a captured launch needs to stay valid across replays -- per launch slot a pinned host
+        table + its device copy (gradient addresses are only known inside the capture) and the device vector of step-dependent scalars."""
+        dev, counts, n = None, set(), 0
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.requires_grad and p.is_cuda:
+                    dev = p.device
+                    n += 1
+                    st = self.state.get(p)
+                    counts.add(int(st['step']) if st else 0)
+        if dev is None:
+            raise RuntimeError('segland_amd.optim.AdamW.capture_begin: no GPU parameters')
+        self._cap, self._graph_plan = {}, []
+        for slot in range(max(1, len(counts))):
+            self._cap[slot] = dict(pinned=torch.zeros(64 * n, dtype=torch.uint8).pin_memory(), dev=torch.zeros(64 * n, dtype=torch.uint8, device=dev),
+                                   hyp=torch.zeros(4 + 2 * len(self.param_groups), dtype=torch.float32, device=dev))
+
+    def graph_prepare(self):
+        """Before every replay of a graph that holds a captured step(): advances the step counts like step() would and uploads this step's
+        bias corrections and the groups' current lr / weight_decay (stream-ordered, from a fresh pinned buffer: the host may run ahead)."""
+        for slot, plist, repeat in self._graph_plan:
+            t = int(self.state[plist[0]]['step']) + 1
+            for p in plist:
+                self.state[p]['step'] += repeat
+            b1, b2 = self.param_groups[0]['betas']
+            vals = [1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 1.0 - b1 ** (t + 1), math.sqrt(1.0 - b2 ** (t + 1))]
+            for group in self.param_groups:
+                vals += [group['lr'], group['weight_decay']]
+            self._cap[slot]['hyp'].copy_(torch.tensor(vals, dtype=torch.float32).pin_memory(), non_blocking=True)
 
 
 def clip_coefficient(parameters, max_norm, grad_div=1):

@@ -13,6 +13,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
+from . import graph_step
 from .drivers import adjust_learning_rate_poly, batch_to_device, build_parser, load_training_state, save_training_state, checkpoint_or_none, compute_dtype, miou, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
@@ -72,6 +73,11 @@ def main(argv=None):
         if engine.is_main:
             os.makedirs(args.snapshot_dir, exist_ok=True)
 
+        step = train_iteration
+        if not args.no_step_graph and graph_step.eligible(model, optimizer, engine.device):
+            graphed = graph_step.GraphedTrainStep(train_iteration, model, optimizer, loss_scaler, double_step=not args.single_step)
+            step = lambda m, o, s, img, mask, double_step: graphed(img, mask)      # noqa: E731  (one HIP graph launch per step)
+
         best, best_epoch = 0.0, 0
         if engine.continue_state_object:                                # -c / --continue FILE (engine.py:62-65 parses it; the reference never uses it)
             args.start_epoch, best, best_epoch = load_training_state(model, optimizer, engine.continue_state_object)
@@ -96,7 +102,7 @@ def main(argv=None):
             for i, batch in enumerate(train_loader):
                 it += 1
                 img, mask = batch_to_device(batch, trainset, engine.device)
-                loss_dict, grad_norm = train_iteration(model, optimizer, loss_scaler, img, mask, double_step=not args.single_step)
+                loss_dict, grad_norm = step(model, optimizer, loss_scaler, img, mask, double_step=not args.single_step)
                 if i % args.print_frequency == 0:
                     vals = engine.reduce_loss_dict(loss_dict)
                     if engine.is_main:

@@ -1,0 +1,105 @@
+"""The training step replayed as ONE HIP graph (segland_amd/graph_step.py) against the same step issued kernel by kernel: identical
+losses, gradient norms, parameters, AdamW moments and step counts -- with a different batch every step (static-input copies), a learning
+rate changed between replays (device-side hyper-parameters), an eager step of another shape in between, and evaluation afterwards (stale
+weight copies).  PSPNet-POP in fp32 and bf16, Swin-POP with fixed DropPath / Dropout2d scales."""
+import copy
+
+import pytest
+import torch
+
+from oracle import formula as fm
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _pspnet(dtype):
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=dtype)
+    fm.load_formula_weights(m)
+    return m.to(DEV).train()
+
+
+def _swin(dtype):
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.swin_pop import GFSS_Model
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='swin-t', pretrained_model=None, compute_dtype=dtype)
+    fm.load_formula_weights(m)
+    m = m.to(DEV).train()
+    # fixed stochastic-depth / Dropout2d scales: the graph's Philox draws differ from an eager run's, the comparison must not
+    m.backbone.drop_path_hook = lambda index, B, p: torch.full((B,), 1.0, device=DEV)
+    m.decoder.dropout2d_hook = lambda B, Cn, p: torch.full((B, Cn), 1.0, device=DEV)
+    return m
+
+
+def _batches(n, B, H, W):
+    out = []
+    for k in range(n):
+        img = fm.formula_image(B, H, W, 'gs/img%d' % k).to(DEV)
+        mask = fm.formula_mask(B, H, W, 8, 'gs/mask%d' % k, block=16, ignore_rows=4).to(DEV)
+        out.append((img, mask))
+    return out
+
+
+def _run(model, batches, graphed, lr_change_at, odd=None):
+    from segland_amd import graph_step
+    from segland_amd.optim import AdamW
+    from segland_amd.train_base import train_iteration
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    opt = AdamW(get_parameters(model, lr=1e-4), lr=1e-4, weight_decay=1e-4)
+    scaler = NativeScalerWithGradNormCount()
+    step = graph_step.GraphedTrainStep(train_iteration, model, opt, scaler, double_step=True, warmup=2) if graphed else None
+    log = []
+    for k, (img, mask) in enumerate(batches):
+        if k == lr_change_at:
+            for i, g in enumerate(opt.param_groups):
+                g['lr'] = 3e-5 * (1 + i)
+        if odd is not None and k == odd[0]:                      # a batch of another shape: runs eagerly, the graph survives it
+            d, gn = (step(*odd[1]) if graphed else train_iteration(model, opt, scaler, *odd[1], double_step=True))
+            log.append((float(d['total_loss'].detach()), float(gn)))
+        d, gn = (step(img, mask) if graphed else train_iteration(model, opt, scaler, img, mask, double_step=True))
+        log.append((float(d['total_loss'].detach()), float(gn)))
+    model.eval()
+    with torch.no_grad():
+        logits = model(batches[0][0]).float().cpu()
+    return log, {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, opt, logits, step
+
+
+@pytest.mark.parametrize('family,dtype', [('pspnet', torch.float32), ('pspnet', torch.bfloat16), ('swin', torch.float32), ('swin', torch.bfloat16)])
+def test_graphed_step_equals_eager(hip, family, dtype):
+    build = _pspnet if family == 'pspnet' else _swin
+    H, W = (96, 128) if family == 'pspnet' else (128, 160)
+    batches = _batches(6, 2, H, W)
+    odd = (4, _batches(1, 3, H, W)[0])
+    ref = build(dtype)
+    got = copy.deepcopy(ref)
+    if family == 'swin':
+        got.backbone.drop_path_hook, got.decoder.dropout2d_hook = ref.backbone.drop_path_hook, ref.decoder.dropout2d_hook
+    log_r, sd_r, opt_r, logits_r, _ = _run(ref, batches, False, 3, odd)
+    log_g, sd_g, opt_g, logits_g, step = _run(got, batches, True, 3, odd)
+    assert step.graph is not None and step.replays >= 4, 'the step was never replayed from a graph'
+    print('losses / grad norms eager vs graph:', log_r, log_g)
+    assert log_r == log_g                                         # same kernels in the same order on the same data: bit-identical
+    for k in sd_r:
+        assert torch.equal(sd_r[k], sd_g[k]), k
+    assert torch.equal(logits_r, logits_g)
+    for (pr, sr), (pg, sg) in zip(opt_r.state.items(), opt_g.state.items()):
+        assert float(sr['step']) == float(sg['step']) and torch.equal(sr['exp_avg'], sg['exp_avg']) and torch.equal(sr['exp_avg_sq'], sg['exp_avg_sq'])
+
+
+def test_graphed_step_draws_fresh_stochastic_depth(hip):
+    """DropPath / Dropout2d inside the graph draw new masks on every replay (torch's graph-safe Philox offsets): two replays on the SAME
+    batch with the learning rate at 0 give different losses in train mode."""
+    from segland_amd import graph_step
+    from segland_amd.optim import AdamW
+    from segland_amd.train_base import train_iteration
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    m = _swin(torch.float32)
+    m.backbone.drop_path_hook = m.decoder.dropout2d_hook = None
+    opt = AdamW(get_parameters(m, lr=0.0), lr=0.0, weight_decay=0.0)
+    step = graph_step.GraphedTrainStep(train_iteration, m, opt, NativeScalerWithGradNormCount(), warmup=2)
+    img, mask = _batches(1, 2, 128, 160)[0]
+    losses = [float(step(img, mask)[0]['total_loss']) for _ in range(5)]
+    print(losses)
+    assert step.replays >= 3 and len(set(losses[2:])) > 1
