@@ -11,6 +11,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
+from . import graph_step
 from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
@@ -22,6 +23,26 @@ def ft_iteration(model, optimizer, loss_scaler, batch, device):
     img, mask, img_b, mask_b = (t.to(device, non_blocking=True) for t in batch[:4])
     loss_dict = model(img, mask, img_b, mask_b.contiguous())
     grad_norm = loss_scaler(loss_dict['total_loss'], optimizer, clip_grad=5.0, parameters=model.parameters())
+    optimizer.zero_grad()
+    return loss_dict, grad_norm
+
+
+def ft_graph_body(model, clip_grad=5.0):
+    """forward + backward + clip_grad_norm_ of ft_iteration as a function of the four batch tensors, for graph_step.GraphedStep (the SGD
+    step stays outside the graph: torch.optim.SGD bakes the learning rate, which changes every iteration here, into its launches)."""
+    def body(img, mask, img_b, mask_b):
+        loss_dict = model(img, mask, img_b, mask_b)
+        loss_dict['total_loss'].backward()
+        params = [p for p in model.parameters() if p.grad is not None]
+        return loss_dict, torch.nn.utils.clip_grad_norm_(params, clip_grad)
+    return body
+
+
+def ft_iteration_graphed(graphed, optimizer, batch, device):
+    """ft_iteration with the model part replayed from one HIP graph."""
+    img, mask, img_b, mask_b = (t.to(device, non_blocking=True) for t in batch[:4])
+    loss_dict, grad_norm = graphed(img, mask, img_b, mask_b.contiguous())
+    optimizer.step()
     optimizer.zero_grad()
     return loss_dict, grad_norm
 
@@ -59,6 +80,9 @@ def main(argv=None):
             optimizer.zero_grad()
             model = engine.data_parallel(seg_model)
             loss_scaler = my_utils.NativeScalerWithGradNormCount()
+            graphed = None
+            if not args.no_step_graph and graph_step.eligible(model, optimizer, engine.device, need_adamw=False):
+                graphed = graph_step.GraphedStep(ft_graph_body(model), model)
             if engine.is_main:
                 os.makedirs(args.snapshot_dir, exist_ok=True)
             it, max_it = args.start_epoch * len(train_loader), args.num_epoch * len(train_loader)
@@ -72,7 +96,10 @@ def main(argv=None):
                     it += 1
                     if not args.fix_lr:
                         lr = adjust_learning_rate_poly(optimizer, args.learning_rate, it - 1, max_it, args.power, split)   # per ITERATION here
-                    loss_dict, grad_norm = ft_iteration(model, optimizer, loss_scaler, batch, engine.device)
+                    if graphed is not None:
+                        loss_dict, grad_norm = ft_iteration_graphed(graphed, optimizer, batch, engine.device)
+                    else:
+                        loss_dict, grad_norm = ft_iteration(model, optimizer, loss_scaler, batch, engine.device)
                     if i % args.print_frequency == 0:
                         vals = engine.reduce_loss_dict(loss_dict)
                         if engine.is_main:

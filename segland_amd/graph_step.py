@@ -13,58 +13,66 @@ import os
 import torch
 
 
-def eligible(model, optimizer, device):
+def eligible(model, optimizer, device, need_adamw=True):
     from .optim import AdamW
     return (os.environ.get('SEGLAND_STEP_GRAPH', '1') != '0' and torch.cuda.is_available() and torch.device(device).type == 'cuda'
-            and isinstance(optimizer, AdamW) and not isinstance(model, torch.nn.parallel.DistributedDataParallel))
+            and (isinstance(optimizer, AdamW) or not need_adamw) and not isinstance(model, torch.nn.parallel.DistributedDataParallel))
 
 
-class GraphedTrainStep:
-    """Callable with the signature and results of train_base.train_iteration(model, optimizer, loss_scaler, img, mask).
-    The first `warmup` calls per input shape run eagerly (lazy allocations, optimizer state); the next one is captured; later calls copy
-    the batch into the graph's static inputs and replay.  The returned loss dict / gradient norm are the graph's static outputs: read
-    them (`.item()`, `float()`) before the next call."""
+def _detached(out):
+    """Losses handed to the caller without their autograd graph: a loss the caller keeps would keep this step's graph -- and its
+    AccumulateGrad nodes, bound to THIS stream -- alive into a capture on another stream (autograd then synchronises the two streams,
+    which a capture cannot contain)."""
+    if isinstance(out, dict):
+        return {k: _detached(v) for k, v in out.items()}
+    if isinstance(out, (tuple, list)):
+        return type(out)(_detached(v) for v in out)
+    return out.detach() if torch.is_tensor(out) else out
 
-    def __init__(self, step_fn, model, optimizer, loss_scaler, double_step=True, warmup=3):
-        self.step_fn, self.model, self.optimizer, self.loss_scaler = step_fn, model, optimizer, loss_scaler
-        self.double_step, self.warmup = double_step, warmup
+
+class GraphedStep:
+    """`body(*tensors)` -- a function of GPU tensors that launches the kernels of a step and returns tensors -- captured once per input
+    signature and replayed.  The first `warmup` calls per signature run eagerly (lazy allocations, optimizer state, weight-preparation
+    tables); the next one is captured; later calls copy the arguments into the graph's static inputs and replay.  The returned tensors
+    are the graph's static outputs: read them (`.item()`, `float()`) before the next call.  `optimizer`: a segland_amd.optim.AdamW whose
+    step() is inside `body` (its step counts and hyper-parameters are advanced / uploaded before every replay) or None."""
+
+    def __init__(self, body, model, optimizer=None, warmup=3):
+        self.body, self.model, self.optimizer, self.warmup = body, model, optimizer, warmup
         self.seen, self.key, self.graph = {}, None, None
         self.static_in, self.static_out, self.static_grads = None, None, None
         self.replays, self.failures = 0, 0
 
-    def _state_key(self, img, mask):
+    def _state_key(self, tensors):
         trainable = sum(1 for p in self.model.parameters() if p.requires_grad)
         modes = sum(1 for m in self.model.modules() if m.training)
-        return (tuple(img.shape), img.dtype, tuple(mask.shape), mask.dtype, trainable, modes)
+        return tuple((tuple(t.shape), t.dtype) for t in tensors) + (trainable, modes)
 
-    def _eager(self, img, mask):
-        out = self.step_fn(self.model, self.optimizer, self.loss_scaler, img, mask, double_step=self.double_step)
-        # detached: a loss the caller keeps would keep this step's autograd graph -- and its AccumulateGrad nodes, bound to THIS stream --
-        # alive into the capture on another stream (autograd then synchronises the two streams, which a capture cannot contain)
-        d = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out[0].items()} if isinstance(out[0], dict) else out[0]
-        return (d,) + tuple(out[1:])
+    def _eager(self, tensors):
+        return _detached(self.body(*tensors))
 
-    def _capture(self, img, mask, key):
+    def _capture(self, tensors, key):
         self.graph = None                                   # drop an older graph (and its pool) first
-        self.static_in = (img.clone(), mask.clone())
-        self.optimizer.capture_begin()
+        self.static_in = tuple(t.clone() for t in tensors)
+        if self.optimizer is not None:
+            self.optimizer.capture_begin()
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
-            out = self._eager(*self.static_in)
+            out = self._eager(self.static_in)
         self.graph, self.key, self.static_out = g, key, out
         # the gradients the replays write: tensors of the graph's pool that the parameters keep pointing at
         self.static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
 
-    def __call__(self, img, mask):
-        key = self._state_key(img, mask)
+    def __call__(self, *tensors):
+        key = self._state_key(tensors)
         if key != self.key:
             n = self.seen.get(key, 0)
             if n < self.warmup:
                 self.seen[key] = n + 1
-                return self._eager(img, mask)
+                return self._eager(tensors)
             try:
-                self._capture(img, mask, key)
+                self._capture(tensors, key)
             except Exception as e:              # something on the path still needed the host (a lazy upload, a read-back): run it eagerly
                 self.graph, self.key = None, None
                 self.failures += 1
@@ -74,13 +82,22 @@ class GraphedTrainStep:
                                                           'one more eager step, then another attempt' if self.failures < 3 else 'staying eager')
                 if self.failures >= 3:
                     self.warmup = float('inf')
-                return self._eager(img, mask)
-        self.static_in[0].copy_(img, non_blocking=True)
-        self.static_in[1].copy_(mask, non_blocking=True)
-        for p, g in self.static_grads:                      # an eager step in between (odd last batch) re-pointed .grad
+                return self._eager(tensors)
+        for dst, src in zip(self.static_in, tensors):
+            dst.copy_(src, non_blocking=True)
+        for p, g in self.static_grads:                      # an eager step in between (odd last batch) or zero_grad() re-pointed .grad
             if p.grad is not g:
                 p.grad = g
-        self.optimizer.graph_prepare()
+        if self.optimizer is not None:
+            self.optimizer.graph_prepare()
         self.graph.replay()
         self.replays += 1
         return self.static_out
+
+
+class GraphedTrainStep(GraphedStep):
+    """Callable with the signature and results of train_base.train_iteration(model, optimizer, loss_scaler, img, mask): the whole loop body
+    (train_base.py:250-264) including clip + both AdamW steps in the graph."""
+
+    def __init__(self, step_fn, model, optimizer, loss_scaler, double_step=True, warmup=3):
+        super().__init__(lambda img, mask: step_fn(model, optimizer, loss_scaler, img, mask, double_step=double_step), model, optimizer, warmup)

@@ -103,3 +103,56 @@ def test_graphed_step_draws_fresh_stochastic_depth(hip):
     losses = [float(step(img, mask)[0]['total_loss']) for _ in range(5)]
     print(losses)
     assert step.replays >= 3 and len(set(losses[2:])) > 1
+
+
+@pytest.mark.parametrize('family', ['pspnet', 'swin'])
+def test_graphed_ft_step_equals_eager(hip, family):
+    """ft_pop loop body (ft_pop.py:243-256): forward_novel + forward_all on a (novel, base) pair with in-place pseudo-labels, backward and
+    clip_grad_norm_ replayed from a graph, torch SGD outside it with a learning rate that changes every iteration."""
+    from segland_amd import graph_step
+    from segland_amd.ft_pop import ft_graph_body, ft_iteration, ft_iteration_graphed
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    if family == 'pspnet':
+        from segland_amd.networks.pspnet_pop import GFSS_Model
+        kw, (H, W) = dict(backbone='resnet50', dilated=True, os=8), (96, 128)
+    else:
+        from segland_amd.networks.swin_pop import GFSS_Model
+        kw, (H, W) = dict(backbone='swin-t'), (128, 160)
+    ref = GFSS_Model(n_base=7, criterion=OrthLoss(255), pretrained_model=None, is_ft=True, n_novel=4, compute_dtype=torch.float32, **kw)
+    fm.load_formula_weights(ref)
+    ref = ref.to(DEV)
+    ref.init_cls_n()
+    got = copy.deepcopy(ref)
+    data = []
+    for k in range(6):
+        img = fm.formula_image(2, H, W, 'gf/img%d' % k).to(DEV)
+        img_b = fm.formula_image(2, H, W, 'gf/imgb%d' % k).to(DEV)
+        mask = (fm.formula_mask(2, H, W, 4, 'gf/mask%d' % k, block=16, ignore_rows=4) + 8)
+        mask[mask > 11] = 255
+        mask_b = fm.formula_mask(2, H, W, 8, 'gf/maskb%d' % k, block=16, ignore_rows=0)
+        data.append((img, mask.to(DEV), img_b, mask_b.to(DEV)))
+
+    def run(model, graphed):
+        model.train_mode()
+        opt = torch.optim.SGD(get_parameters(model, lr=1e-2, freeze_backbone=True), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+        opt.zero_grad()
+        sc = NativeScalerWithGradNormCount()
+        g = graph_step.GraphedStep(ft_graph_body(model), model, warmup=2) if graphed else None
+        log = []
+        for k, (img, mask, img_b, mask_b) in enumerate(data):
+            for grp in opt.param_groups:
+                grp['lr'] = 1e-2 * (1 - k / 10.0)
+            batch = (img, mask, img_b, mask_b.clone())
+            d, gn = ft_iteration_graphed(g, opt, batch, DEV) if graphed else ft_iteration(model, opt, sc, batch, DEV)
+            log.append((float(d['total_loss'].detach()), float(gn)))
+        return log, {n: p.detach().float().cpu() for n, p in model.named_parameters() if p.requires_grad}, g
+
+    log_r, par_r, _ = run(ref, False)
+    log_g, par_g, g = run(got, True)
+    print(log_r, log_g)
+    assert g.graph is not None and g.replays >= 3
+    assert log_r == log_g
+    assert par_r.keys() == par_g.keys() and len(par_r) > 0
+    for n in par_r:
+        assert torch.equal(par_r[n], par_g[n]), n
