@@ -69,6 +69,12 @@ int sl_conv2d_fwd(const SlConvDesc* d, const void* x, const void* x2, const void
 int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend,
                      const float* bias, int relu, void* y, float* stat_partial, sl_stream_t stream);
 
+/* nn.Linear (a 1x1 conv over an NHWC token map) with the elementwise tail of a Swin block in the epilogue (swintransformer.py:36,246-249):
+ *   y = row_scale[b] * (x w^T + bias) + residual     row_scale: NULL or float[B] (DropPath), residual: NULL or [B][Ho][Wo][Cout]
+ *   gelu_out (NULL or [B][Ho][Wo][Cout]) receives GELU(x w^T + bias) evaluated on the value y stores (Mlp fc1 + act). */
+int sl_linear_fwd(const SlConvDesc* d, const void* x, const void* w, const float* bias, const float* row_scale, const void* residual,
+                  void* y, void* gelu_out, sl_stream_t stream);
+
 /* Inference / frozen-BN form: y = act(conv(x|x2, w) * scale[c] + shift[c] (+ residual)) in ONE kernel -- eval-mode
  * BatchNorm (running statistics), the shortcut add and the ReLU of resnet.py:60-76 folded into the conv epilogue. */
 int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,

@@ -28,6 +28,8 @@ struct ConvGemmParams {
   const void* pre_addend;               // [M][N] added to the accumulators BEFORE statistics / bias (factorised PPM priors) or null
   const unsigned char* addend_mask;     // relu bits (1 byte per 16-byte vector) gating the addend, or null
   float* stat_partial;                  // [gridM][2][N] or null
+  const float* row_scale;               // [B] per-sample multiplier of (acc * scale + bias), applied before the addend (DropPath), or null
+  void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
   int gridM, gridN;
 };
@@ -427,7 +429,7 @@ template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
-  const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend;
+  const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2;
   if (full && !shaped && !p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
   else if (full && !shaped && !p.stat_partial) conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
   else conv_epilogue_generic<T, BM, BN, WM, WN, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
@@ -455,7 +457,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
     __syncthreads();
     // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
     // flight together instead of one load -> use -> store latency chain per row
-    const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src || p.pre_addend);
+    const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2);
     constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
     static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
     const int mrow0 = bm * BM + pass * ROWS + r0;
@@ -511,6 +513,18 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
           if (p.bias || p.scale) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) v[e] = v[e] * scl[e] + bias[e];
+          }
+          if (p.out2) {                                   // the activation sees what `out` stores (the rounded pre-activation)
+            float g[EPC];
+            unpack16<T>(pack16<T>(v), g);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = 0.5f * g[e] * (1.f + erff(g[e] * 0.70710678118654752440f));
+            st16((T*)p.out2 + (size_t)m * p.N + ncol, pack16<T>(g));
+          }
+          if (p.row_scale) {
+            const float rs = p.row_scale[m / (p.Hd * p.Wd)];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) v[e] *= rs;
           }
           if (p.addend) {
             float a[EPC];
@@ -1242,6 +1256,23 @@ extern "C" int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* 
   p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
   p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
   p.bias = bias; p.relu = relu; p.stat_partial = stat_partial; p.pre_addend = pre_addend;
+  p.M = d->B * d->Ho * d->Wo;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// nn.Linear as a 1x1 conv with the elementwise tail of a transformer block in the epilogue:
+//   y = row_scale[b] * (x w^T + bias) + residual          (attention proj / Mlp fc2 with DropPath, swintransformer.py:246-249)
+//   y = x w^T + bias,  gelu_out = GELU(y)                  (Mlp fc1 + act, swintransformer.py:36)
+extern "C" int sl_linear_fwd(const SlConvDesc* d, const void* x, const void* w, const float* bias, const float* row_scale, const void* residual,
+                             void* y, void* gelu_out, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(x && w && y, "linear fwd: null buffer");
+  SL_REQUIRE(d->C1 == d->Cin, "linear fwd: single input tensor");
+  ConvGemmParams p{};
+  p.src1 = x; p.src2 = nullptr; p.C1 = d->C1; p.C2 = 0; p.wt = w; p.out = y;
+  p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
+  p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
+  p.bias = bias; p.row_scale = row_scale; p.addend = residual; p.out2 = gelu_out;
   p.M = d->B * d->Ho * d->Wo;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

@@ -135,8 +135,12 @@ def lin_prep(weight, bias, dtype, Kp=None, Np=None, k=1, col_map=None):
     return ent[1]
 
 
-def lin_fwd(x, L, residual=None, x2=None):
-    """x [B,H,W,Kp] -> [B,H,W,Np] = x W^T + b (+ residual)."""
+def lin_fwd(x, L, residual=None, x2=None, row_scale=None, want_gelu=False):
+    """x [B,H,W,Kp] -> [B,H,W,Np] = row_scale[b] * (x W^T + b) + residual (row_scale: DropPath's per-sample factor);
+    want_gelu: (y, GELU(y)) from the same epilogue."""
+    if x2 is None:
+        return ops.linear_fwd(x, L.wf, L.spec, bias=L.bias, row_scale=row_scale, residual=residual, want_gelu=want_gelu)
+    assert row_scale is None and not want_gelu
     return ops.conv2d_fwd(x, L.wf, L.spec, bias=L.bias, pre_addend=residual, x2=x2)[0]
 
 
@@ -224,20 +228,14 @@ class SwinBlockFn(torch.autograd.Function):
         xn, st1 = osw.layernorm_fwd(x, n1w.detach(), n1b.detach(), Cn)
         qkv = lin_fwd(xn, Lq)
         att = osw.window_attention_fwd(qkv, qb.detach().contiguous(), rel, Cn, heads, shift, P)
-        if s1 is None:
-            x1 = lin_fwd(att, Lp, residual=x)
-        else:
-            x1 = osw.scale_add(lin_fwd(att, Lp), s1, x)
+        x1 = lin_fwd(att, Lp, residual=x, row_scale=s1)            # DropPath scale + shortcut in the GEMM epilogue
         xn2, st2 = osw.layernorm_fwd(x1, n2w.detach(), n2b.detach(), Cn)
-        h = lin_fwd(xn2, L1)
-        g = osw.gelu_fwd(h)
-        if s2 is None:
-            out = lin_fwd(g, L2, residual=x1)
-        else:
-            out = osw.scale_add(lin_fwd(g, L2), s2, x1)
+        h, g = lin_fwd(xn2, L1, want_gelu=True)                     # pre-activation (for the backward) and GELU from one epilogue
+        out = lin_fwd(g, L2, residual=x1, row_scale=s2)
         if any(ctx.needs_input_grad):
             ctx.blk = blk
-            ctx.save_for_backward(x, st1, xn, qkv, att, x1, st2, xn2, h, rel, s1, s2, *params)
+            # g ([B,H,W,4C], the largest tensor of the block) is kept rather than recomputed: 0.6 GB over a Swin-T at 8 tiles of 512x512
+            ctx.save_for_backward(x, st1, xn, qkv, att, x1, st2, xn2, h, g, rel, s1, s2, *params)
         return out
 
     @staticmethod
@@ -245,8 +243,8 @@ class SwinBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         blk = ctx.blk
         sv = ctx.saved_tensors
-        x, st1, xn, qkv, att, x1, st2, xn2, h, rel, s1, s2 = sv[:12]
-        n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = sv[12:]
+        x, st1, xn, qkv, att, x1, st2, xn2, h, g, rel, s1, s2 = sv[:13]
+        n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = sv[13:]
         Cn, heads, shift = blk.dim, blk.num_heads, blk.shift_size
         dtp, P = x.dtype, x.shape[-1]
         need_w = ctx.needs_input_grad[4]               # parameters of a block are frozen or trainable together
@@ -256,7 +254,6 @@ class SwinBlockFn(torch.autograd.Function):
         L2 = lin_prep(f2w, f2b, dtp, Np=P)
         dout = dout.contiguous()
         dz = dout if s2 is None else osw.scale_add(dout, s2)
-        g = osw.gelu_fwd(h)                            # recomputed: [B,H,W,4C] is the largest tensor of the block
         dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w)
         dh = osw.gelu_bwd(h, dg)
         dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w)

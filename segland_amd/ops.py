@@ -176,6 +176,19 @@ def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False, pr
     return y, part
 
 
+def linear_fwd(x, wf, spec, bias=None, row_scale=None, residual=None, want_gelu=False):
+    """nn.Linear over an NHWC token map with the block's elementwise tail in the GEMM epilogue:
+    y = row_scale[b] * (x w^T + bias) + residual; want_gelu: also returns GELU(y) (evaluated on the stored, rounded y)."""
+    B, H, W, _ = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, None)
+    y = torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    g = torch.empty_like(y) if want_gelu else None
+    tok = PROFILER.begin('conv_fwd', d)
+    check(_lib.lib().sl_linear_fwd(C.byref(d), _p(x), _p(wf), _p(bias), _p(row_scale), _p(residual), _p(y), _p(g), _s()), 'linear_fwd')
+    PROFILER.end(tok)
+    return (y, g) if want_gelu else y
+
+
 def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=True, out=None):
     """y = act(conv(x|x2) * scale + shift (+ residual)): eval-mode BN folded into the conv epilogue."""
     B, H, W, C1 = x.shape

@@ -435,3 +435,28 @@ def test_swin_ft_feature_graph(hip):
         f = m._features(img)
         assert m.__dict__['_sl_graph'][1] is not g0
         assert torch.equal(f, m._features_eager(img))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_linear_epilogue_rowscale_residual_gelu(hip, dtype):
+    """sl_linear_fwd: y = row_scale[b] * (x W^T + b) + residual (DropPath + shortcut, swintransformer.py:246-249) and the (pre-activation,
+    GELU) pair of Mlp fc1 (:36) from one GEMM epilogue, against torch on the same (rounded) operands."""
+    from segland_amd import ops
+    from segland_amd.functional_swin import lin_prep
+    B, H, W, K, N = 3, 9, 14, 128, 256
+    x = fm.sym('le/x', (B, H, W, K), 1.0).to(DEV)
+    w = torch.nn.Parameter(fm.sym('le/w', (N, K), 0.1).to(DEV))
+    b = torch.nn.Parameter(fm.sym('le/b', (N,), 0.5).to(DEV))
+    res = fm.sym('le/r', (B, H, W, N), 1.0).to(DEV)
+    rs = torch.tensor([0.0, 1.25, 1.0], device=DEV)
+    L = lin_prep(w, b, dtype)
+    xd, resd = x.to(dtype).contiguous(), res.to(dtype).contiguous()
+    y = ops.linear_fwd(xd, L.wf, L.spec, bias=L.bias, row_scale=rs, residual=resd)
+    h, g = ops.linear_fwd(xd, L.wf, L.spec, bias=L.bias, want_gelu=True)
+    wr = w.detach().to(dtype).float()
+    lin = xd.float() @ wr.t() + b.detach()
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert rel(y.float(), rs.view(B, 1, 1, 1) * lin + resd.float()) < tol
+    assert rel(h.float(), lin) < tol
+    assert torch.equal(g, F.gelu(h.float()).to(dtype)) or rel(g.float(), F.gelu(h.float())) < (1e-6 if dtype == torch.float32 else 4e-3)
+    assert float(y[0].float().sub(resd[0].float()).abs().max()) == 0.0          # a dropped sample is the shortcut exactly
