@@ -358,6 +358,52 @@ def test_hip_model_under_rccl_ddp(hip, sync):
         assert abs(a - b) <= 1e-5 * abs(b) + (1e-4 if sync == 'force' else 0) and abs(ga - gb) <= 1e-3 * gb
 
 
+@pytest.mark.timeout(900)
+def test_two_ranks_equal_one_full_batch(hip, tmp_path):
+    """a 2-rank data-parallel step on a split batch == the 1-process step on the full batch.  Two processes share the one
+    GPU of the box (gloo group: RCCL refuses two ranks per device); the product path is otherwise complete -- DDP with the sum-only hook and
+    gradients written into the bucket views, nn.SyncBatchNorm with global statistics (fp64 all-reduce of the partial sums, PPM level 1
+    with ONE value per channel per rank included), AdamW with 1 / world_size in its kernel.  One backward: loss, all gradients and the running
+    statistics agree to reduction-order tolerance; three train_base.py iterations on top stay together."""
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    child = os.path.join(ROOT, 'tests', 'ddp2_child.py')
+    outs = [str(tmp_path / 'two.pt'), str(tmp_path / 'one.pt')]
+    procs = [subprocess.Popen([sys.executable, child, str(r), port, outs[0]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]
+    logs = [p.communicate(timeout=800)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), 'rank failed:\n' + '\n----\n'.join(l[-3000:] for l in logs)
+    r = subprocess.run([sys.executable, child, '-1', port, outs[1]], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    two, one = torch.load(outs[0]), torch.load(outs[1])
+    # (1) one forward/backward: loss, every gradient and the updated running statistics, exact up to the order of the reductions
+    assert abs(two['loss0'] - one['loss0']) <= 2e-6 * abs(one['loss0']), (two['loss0'], one['loss0'])
+    assert two['grads0'].keys() == one['grads0'].keys() and len(one['grads0']) >= 170
+    num = sum(float(((two['grads0'][k] - g) ** 2).sum()) for k, g in one['grads0'].items())
+    den = sum(float((g ** 2).sum()) for g in one['grads0'].values())
+    worst_g, key_g = max((float((two['grads0'][k] - g).norm() / max(float(g.norm()), 1e-20)), k) for k, g in one['grads0'].items())
+    print('gradients after one backward: global relative L2 %.3e, worst tensor %.3e (%s)' % ((num / den) ** 0.5, worst_g, key_g))
+    # the train-mode BN chain of the formula-weight network amplifies a 1e-7 difference of the batch statistics ~1e3..1e4 x (DESIGN.md 5):
+    # measured 1e-3; a missing 1 / world_size, a per-rank count or a dropped rank would be O(1)
+    assert (num / den) ** 0.5 <= 5e-3 and worst_g <= 2e-2, (worst_g, key_g)
+    for k, b in one['stats0'].items():
+        assert float((two['stats0'][k] - b).abs().max()) <= 1e-3 * max(float(b.abs().max()), 1e-3), k
+    # (2) three train_base.py iterations on top (Adam's sign-like first steps amplify the last bits: sanity bounds only)
+    print('losses (total, grad norm)  2 ranks:', two['losses'], ' 1 process:', one['losses'])
+    for (a, ga), (b, gb) in zip(two['losses'], one['losses']):
+        assert abs(a - b) <= 3e-3 * abs(b) and abs(ga - gb) <= 0.1 * gb
+    worst, key = 0.0, ''
+    for k, b in one['sd'].items():
+        if k.endswith('num_batches_tracked'):
+            assert torch.equal(two['sd'][k], b)
+            continue
+        e = float((two['sd'][k] - b).abs().max() / max(float(b.abs().max()), 1e-12))
+        if e > worst:
+            worst, key = e, k
+    print('after three iterations: worst parameter / buffer difference %.3e (%s)' % (worst, key))
+    # (no bound on `worst`: lr * sign(g) steps on weights of magnitude ~lr make it O(1) for some tensors; the losses and logits bound the drift)
+    assert float((two['logits'] - one['logits']).abs().max() / one['logits'].abs().max()) <= 5e-2
+
+
 # --------------------------------------------------------------------------------------------- ADVICE regressions
 def test_eval_coefficients_follow_train_mode_statistics(hip):
     """ADVICE r1 (functional.py:182): BN with FROZEN affine parameters run in train mode (get_parameters(fix_bn=True), BN recalibration)
