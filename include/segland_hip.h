@@ -227,6 +227,16 @@ int sl_rowdot_bwd(int dtype, const void* h, const float* w, const float* dz, voi
                   int C, sl_stream_t stream);
 /* out[c] = sum_blk partial[blk][c] */
 int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream);
+/* the same for up to SL_COLSUM_MAX independent partial buffers in ONE launch (host struct, read during the call) */
+#define SL_COLSUM_MAX 12
+typedef struct SlColsumBatch {
+  int n;
+  const float* part[SL_COLSUM_MAX];
+  float* out[SL_COLSUM_MAX];
+  int nblk[SL_COLSUM_MAX];
+  int C[SL_COLSUM_MAX];
+} SlColsumBatch;
+int sl_colsum_finalize_multi(const SlColsumBatch* batch, sl_stream_t stream);
 /* SyncBatchNorm (train_base.py:175-176: nn.SyncBatchNorm under DDP): the per-channel totals of the statistic partials are kept in double
  * for the all-reduce over the process group (out[c] = sum_blk partial[blk][c], double), then handed to sl_bn_finalize_train /
  * sl_bn_bwd_finalize as TWO float partial rows hi_lo[0][i] + hi_lo[1][i] == totals[i] to 48 bits. */
@@ -359,6 +369,9 @@ int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qk
 /* backward (probabilities recomputed): dqkv like qkv; drel_partial [sl_window_attention_bwd_chunks()][heads][49*49] (sum the chunks);
  * pad_partial [sl_window_attention_windows()][heads][96]: q/k/v gradients that reach the qkv bias through the pad tokens (sum the windows) */
 int sl_window_attention_bwd_chunks(const SlWinDesc* d);
+/* d relative_position_bias_table [rows][heads] from d bias [heads][npair] (npair = 49*49): dtable[t][h] = sum_j dbias[h][pairs[t][j]] over the
+ * pairs[t][0..m) >= 0 (constant lists of the (query, key) pairs with relative offset t; swintransformer.py:128-131 backward, fixed order) */
+int sl_relpos_table_grad(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, sl_stream_t stream);
 int sl_window_attention_windows(const SlWinDesc* d);
 int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
                             float* drel_partial, float* pad_partial, sl_stream_t stream);

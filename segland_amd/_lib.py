@@ -34,6 +34,14 @@ class SlResizeDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('dtype', 'B', 'h', 'w', 'H', 'W', 'C', 'src_pitch', 'src_off', 'dst_pitch', 'dst_off', 'align_corners', 'accumulate', 'src_f32')]
 
 
+SL_COLSUM_MAX = 12
+
+
+class SlColsumBatch(C.Structure):
+    _fields_ = [('n', C.c_int), ('part', C.c_void_p * SL_COLSUM_MAX), ('out', C.c_void_p * SL_COLSUM_MAX), ('nblk', C.c_int * SL_COLSUM_MAX),
+                ('C', C.c_int * SL_COLSUM_MAX)]
+
+
 _CTYPE = {
     'int': C.c_int, 'long long': C.c_longlong, 'float': C.c_float, 'size_t': C.c_size_t, 'sl_stream_t': C.c_void_p,
 }

@@ -160,6 +160,37 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
   }
 }
 
+// The same for up to SL_COLSUM_MAX partial buffers in ONE launch (the bias / LayerNorm / attention-bias gradients of a transformer block
+// backward: eight 5 us launches otherwise).  The batch descriptor travels by value in the kernel arguments; entry i owns the blocks
+// [first[i], first[i+1]).
+struct ColsumBatchDev { int n; int first[SL_COLSUM_MAX + 1]; const float* part[SL_COLSUM_MAX]; float* out[SL_COLSUM_MAX]; int nblk[SL_COLSUM_MAX]; int C[SL_COLSUM_MAX]; };
+__global__ __launch_bounds__(1024) void colsum_finalize_multi_kernel(ColsumBatchDev b) {
+  __shared__ double red[16][64];
+  int e = 0;
+  while (e + 1 < b.n && (int)blockIdx.x >= b.first[e + 1]) ++e;
+  const float* __restrict__ part = b.part[e];
+  const int nblk = b.nblk[e], C = b.C[e];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = ((int)blockIdx.x - b.first[e]) * 64 + cl;
+  double s = 0.0;
+  if (c < C) {
+    int r = rl;
+    for (; r + 3 * 16 < nblk; r += 4 * 16) {
+      const float v0 = part[(size_t)r * C + c], v1 = part[(size_t)(r + 16) * C + c], v2 = part[(size_t)(r + 32) * C + c], v3 = part[(size_t)(r + 48) * C + c];
+      s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; r < nblk; r += 16) s += (double)part[(size_t)r * C + c];
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][cl];
+    b.out[e][c] = (float)t;
+  }
+}
+
 // SyncBatchNorm totals: the same column sum kept in double (all-reduced in double by the caller) ...
 __global__ __launch_bounds__(1024) void colsum_f64_kernel(const float* __restrict__ part, int nblk, int C, double* __restrict__ out) {
   __shared__ double red[16][64];
@@ -393,6 +424,22 @@ extern "C" int sl_colsum_finalize(const float* partial, int nblk, int C, float* 
   SL_REQUIRE(partial && out && nblk > 0 && C > 0, "colsum_finalize: bad args");
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, out);
   SL_LAUNCH_CHECK("colsum_finalize_kernel");
+  return 0;
+}
+
+extern "C" int sl_colsum_finalize_multi(const SlColsumBatch* batch, sl_stream_t stream) {
+  SL_REQUIRE(batch && batch->n > 0 && batch->n <= SL_COLSUM_MAX, "colsum_finalize_multi: 1..%d entries", SL_COLSUM_MAX);
+  ColsumBatchDev b{};
+  b.n = batch->n;
+  int blocks = 0;
+  for (int i = 0; i < batch->n; ++i) {
+    SL_REQUIRE(batch->part[i] && batch->out[i] && batch->nblk[i] > 0 && batch->C[i] > 0, "colsum_finalize_multi: bad entry %d", i);
+    b.first[i] = blocks; b.part[i] = batch->part[i]; b.out[i] = batch->out[i]; b.nblk[i] = batch->nblk[i]; b.C[i] = batch->C[i];
+    blocks += cdiv(batch->C[i], 64);
+  }
+  b.first[batch->n] = blocks;
+  hipLaunchKernelGGL(colsum_finalize_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, b);
+  SL_LAUNCH_CHECK("colsum_finalize_multi_kernel");
   return 0;
 }
 

@@ -1409,6 +1409,27 @@ static int win_wpb(const WinGeom& g) {
 }
 static int win_wpw(const WinGeom& g) { return (win_wpb(g) + 3) / 4; }         // MFMA path: 4 waves per block, each walks wpw windows
 
+// d relative_position_bias_table[t][h] = sum over the (query, key) pairs with relative offset t of d bias[h][pair] (swintransformer.py:128-131 backward):
+// fixed-order gather through the constant pair lists (pairs[t][j], -1 padded) -- the index_add_ of an autograd gather is atomic, this is bit-stable.
+__global__ void relpos_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ pairs, int rows, int m, int heads, int npair, float* __restrict__ dtable) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * heads) return;
+  const int t = i / heads, h = i - t * heads;
+  float s = 0.f;
+  for (int j = 0; j < m; ++j) {
+    const int pidx = pairs[t * m + j];
+    if (pidx >= 0) s += dbias[(size_t)h * npair + pidx];
+  }
+  dtable[i] = s;
+}
+
+extern "C" int sl_relpos_table_grad(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, sl_stream_t stream) {
+  SL_REQUIRE(dbias && pairs && dtable && rows > 0 && m > 0 && heads > 0 && npair > 0, "relpos_table_grad: bad args");
+  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(rows * heads, 256)), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable);
+  SL_LAUNCH_CHECK("relpos_table_grad_kernel");
+  return 0;
+}
+
 extern "C" int sl_window_attention_bwd_chunks(const SlWinDesc* d) {
   WinGeom g;
   if (check_geom(d, g)) return SL_EINVAL;

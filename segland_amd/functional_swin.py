@@ -144,8 +144,8 @@ def lin_fwd(x, L, residual=None, x2=None, row_scale=None, want_gelu=False):
     return ops.conv2d_fwd(x, L.wf, L.spec, bias=L.bias, pre_addend=residual, x2=x2)[0]
 
 
-def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None):
-    """(dx, dw in the parameter's shape, dbias) of lin_fwd."""
+def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=None):
+    """(dx, dw in the parameter's shape, dbias) of lin_fwd.  batch (ops.ColsumBatch): dbias is filled by batch.run()."""
     dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
     dw = db = None
     if need_w:
@@ -154,7 +154,8 @@ def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None):
         if L.k == 1:
             dw = dw.view(L.N, L.K) if dw.shape[1] == L.K else dw
         if L.bias is not None:
-            db = ops.colsum_rows(dy)[:L.N].contiguous()
+            db = ops.colsum_rows(dy, batch=batch)[:L.N]
+            db = db.contiguous() if batch is None else db
     return dx, dw, db
 
 
@@ -254,43 +255,42 @@ class SwinBlockFn(torch.autograd.Function):
         L2 = lin_prep(f2w, f2b, dtp, Np=P)
         dout = dout.contiguous()
         dz = dout if s2 is None else osw.scale_add(dout, s2)
-        dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w)
+        # the eight column sums of this backward (four bias gradients, two LayerNorm (dgamma, dbeta) pairs, the attention bias and the pad-token
+        # bias) are finalised by ONE launch at the end
+        batch = ops.ColsumBatch() if need_w else None
+        dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch)
         dh = osw.gelu_bwd(h, dg)
-        dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w)
-        dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w)
+        dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w, batch=batch)
+        dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch)
         dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)
-        datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w)
-        dqkv, drel, dpad = osw.window_attention_bwd(qkv, qb.detach().contiguous(), rel, datt, Cn, heads, shift)
-        dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w)
-        dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w)
+        datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w, batch=batch)
+        dqkv, drel, dpad = osw.window_attention_bwd(qkv, qb.detach().contiguous(), rel, datt, Cn, heads, shift, batch=batch)
+        dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w, batch=batch)
+        dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch)
         dtable = None
         if need_w:
-            dbq = dbq + dpad                           # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
-            gidx, gmask = _rel_gather(blk.attn, table.shape[0])
-            # table row t collects the (query, key) pairs with relative offset t.  A fixed-order gather + sum instead of index_add_ (atomics,
-            # last-bit differences from run to run): the step stays bit-reproducible like the rest of the path
-            dtable = (drel.reshape(heads, -1)[:, gidx] * gmask).sum(-1).t().contiguous()
+            batch.run()
+            dbq = (dbq.view(3, heads, 32) + dpad).view(3 * Cn)         # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
+            # table row t collects the (query, key) pairs with relative offset t: a fixed-order gather instead of index_add_ (atomics,
+            # last-bit differences from run to run) -- the step stays bit-reproducible like the rest of the path
+            dtable = osw.relpos_table_grad(drel.view(heads, -1), _rel_pairs(blk.attn, table.shape[0]), table.shape[0])
         return (dx, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
 
 
-def _rel_gather(attn, rows):
-    """([rows, m] flat (query, key) pair indices per relative-position table row, [rows, m] 0/1 validity), m = the largest pair count."""
-    ent = attn.__dict__.get('_sl_relgather')
-    if ent is None or ent[0].device != attn.relative_position_index.device:
+def _rel_pairs(attn, rows):
+    """[rows, m] int32: the flat (query, key) pair indices that read relative-position table row t, -1 padded (m = the largest pair count)."""
+    ent = attn.__dict__.get('_sl_relpairs')
+    if ent is None or ent.device != attn.relative_position_index.device:
         idx = attn.relative_position_index.view(-1).cpu()
         order = torch.argsort(idx, stable=True)
         counts = torch.bincount(idx, minlength=rows)
-        m = int(counts.max())
-        gidx = torch.zeros((rows, m), dtype=torch.int64)
-        gmask = torch.zeros((rows, m), dtype=torch.float32)
+        pairs = torch.full((rows, int(counts.max())), -1, dtype=torch.int32)
         start = 0
         for t in range(rows):
             c = int(counts[t])
-            gidx[t, :c] = order[start:start + c]
-            gmask[t, :c] = 1.0
+            pairs[t, :c] = order[start:start + c].to(torch.int32)
             start += c
-        dev = attn.relative_position_index.device
-        ent = attn.__dict__['_sl_relgather'] = (gidx.to(dev), gmask.to(dev))
+        ent = attn.__dict__['_sl_relpairs'] = pairs.to(attn.relative_position_index.device).contiguous()
     return ent
 
 

@@ -112,6 +112,21 @@ class SwinTransformer(nn.Module):
         keep = 1.0 - blk.drop_path_p
         return torch.floor(keep + torch.rand(B, device=device)) / keep          # timm DropPath, scale_by_keep
 
+    def _drop_scales(self, B, device):
+        """The two DropPath scales of every block (attention branch, MLP branch: `self.drop_path` is applied twice, swintransformer.py:246-249),
+        drawn for the whole network with ONE torch.rand instead of one per call (4 tiny launches each, 24 calls per Swin-T forward)."""
+        blocks = [blk for layer in self.layers for blk in layer.blocks]
+        if self.drop_path_hook is not None or not self.training or all(b.drop_path_p <= 0.0 for b in blocks):
+            out = []
+            for blk in blocks:
+                out += [self._drop_scale(blk, B, device), self._drop_scale(blk, B, device)]
+            return out
+        keep = self.__dict__.get('_sl_keep')
+        if keep is None or keep.device != device:
+            keep = self.__dict__['_sl_keep'] = torch.tensor([1.0 - b.drop_path_p for b in blocks for _ in (0, 1)], dtype=torch.float32, device=device).view(-1, 1)
+        s = torch.floor(keep + torch.rand(len(blocks) * 2, B, device=device)) / keep        # timm DropPath, scale_by_keep: 0 or 1 / keep per sample
+        return [None if blocks[k // 2].drop_path_p <= 0.0 else s[k] for k in range(2 * len(blocks))]
+
     def forward(self, img):
         if not img.is_cuda:
             raise RuntimeError('segland_amd SwinTransformer runs on the GPU only (no CPU fallback): move the model and inputs to cuda')
@@ -120,10 +135,11 @@ class SwinTransformer(nn.Module):
                                *((pe.norm.weight, pe.norm.bias) if pe.norm is not None else (None, None)))
         B = x.shape[0]
         outs = []
+        scales = self._drop_scales(B, x.device)
         for i, layer in enumerate(self.layers):
             Cn = self.filters[i]
             for blk in layer.blocks:
-                x = SwinBlockFn.apply(x, blk, self._drop_scale(blk, B, x.device), self._drop_scale(blk, B, x.device), *block_params(blk))
+                x = SwinBlockFn.apply(x, blk, scales[2 * blk.index], scales[2 * blk.index + 1], *block_params(blk))
             nm = getattr(self, 'norm%d' % i)
             outs.append(LayerNormFn.apply(x, Cn, nm.weight, nm.bias))
             if layer.downsample is not None:

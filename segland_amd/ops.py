@@ -306,7 +306,7 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
 _zeros_cache = {}
 
 
-def colsum_rows(t):
+def colsum_rows(t, batch=None):
     """Per-channel sum over all rows of an NHWC tensor (conv bias gradient) via the BN reduce kernel (S1 with no mask)."""
     Cn = t.shape[-1]
     rows = t.numel() // Cn
@@ -317,6 +317,8 @@ def colsum_rows(t):
     if z is None:
         z = _zeros_cache[(Cn, t.device)] = _f32((2, Cn), t.device, zero=True)          # read-only (mean 0, invstd 0): shared by every call
     check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
+    if batch is not None:
+        return batch.add(part)[0]                     # filled by batch.run()
     return colsum(part)[0].contiguous()
 
 
@@ -510,6 +512,30 @@ def colsum(part):
     out = _f32(tuple(part.shape[1:]), part.device)
     check(_lib.lib().sl_colsum_finalize(_p(part), nblk, Cn, _p(out), _s()), 'colsum_finalize')
     return out
+
+
+class ColsumBatch:
+    """Column sums of several partial buffers with ONE finalize launch: add(part [nblk, ...]) hands out the result tensor right away (shape
+    part.shape[1:]), run() fills all of them (sl_colsum_finalize_multi; SL_COLSUM_MAX entries per launch)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, part):
+        out = _f32(tuple(part.shape[1:]), part.device)
+        self.items.append((part, out))
+        return out
+
+    def run(self):
+        L = _lib.lib()
+        for i0 in range(0, len(self.items), _lib.SL_COLSUM_MAX):
+            chunk = self.items[i0:i0 + _lib.SL_COLSUM_MAX]
+            b = _lib.SlColsumBatch()
+            b.n = len(chunk)
+            for i, (part, out) in enumerate(chunk):
+                b.part[i], b.out[i], b.nblk[i], b.C[i] = part.data_ptr(), out.data_ptr(), part.shape[0], part[0].numel()
+            check(L.sl_colsum_finalize_multi(C.byref(b), _s()), 'colsum_finalize_multi')
+        self.items = []
 
 
 def allreduce_partials(part):

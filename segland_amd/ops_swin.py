@@ -48,7 +48,7 @@ def layernorm_fwd(x, gamma, beta, Cn, out_pitch=None, eps=1e-5, want_stats=True)
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, dx_pitch=None):
+def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, dx_pitch=None, batch=None):
     """(dx, dgamma, dbeta); dx gets `addend` added (the gradient that bypasses the norm through the residual connection)."""
     pdy, px = dy.shape[-1], x.shape[-1]
     pdx = px if dx_pitch is None else dx_pitch
@@ -59,7 +59,7 @@ def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, d
     check(L.sl_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(stats), _p(addend), _p(dx), _p(part), rows, Cn, pdy, px, pdx, _s()), 'layernorm_bwd')
     if not want_param_grads:
         return dx, None, None
-    tot = ops.colsum(part)
+    tot = batch.add(part) if batch is not None else ops.colsum(part)       # batch: filled by batch.run()
     return dx, tot[0], tot[1]
 
 
@@ -138,8 +138,17 @@ def window_attention_fwd(qkv, qkv_bias, rel_bias, Cn, heads, shift, out_pitch):
     return out
 
 
-def window_attention_bwd(qkv, qkv_bias, rel_bias, dout, Cn, heads, shift):
-    """(dqkv, d rel_bias [heads,49,49], d qkv_bias through the pad tokens [3C])."""
+def relpos_table_grad(dbias, pairs, rows):
+    """d relative_position_bias_table [rows, heads] from d bias [heads, 49*49] through the constant pair lists `pairs` [rows, m] (int32, -1 padded)."""
+    heads = dbias.shape[0]
+    out = _f32((rows, heads), dbias.device)
+    check(_lib.lib().sl_relpos_table_grad(_p(dbias), _p(pairs), rows, pairs.shape[1], heads, dbias[0].numel(), _p(out), _s()), 'relpos_table_grad')
+    return out
+
+
+def window_attention_bwd(qkv, qkv_bias, rel_bias, dout, Cn, heads, shift, batch=None):
+    """(dqkv, d rel_bias [heads,49,49], d qkv_bias through the pad tokens [3C] as a [3, heads, 32] view); batch: the two column sums are
+    filled by batch.run()."""
     B, H, W, P3 = qkv.shape
     d = win_desc(qkv.dtype, B, H, W, Cn, heads, P3, dout.shape[-1], shift)
     L = _lib.lib()
@@ -148,6 +157,8 @@ def window_attention_bwd(qkv, qkv_bias, rel_bias, dout, Cn, heads, shift):
     drel = _f32((nchunk, heads * 49 * 49), qkv.device)
     pad = _f32((nwin, heads * 96), qkv.device)
     check(L.sl_window_attention_bwd(C.byref(d), _p(qkv), _p(qkv_bias), _p(rel_bias), _p(dout), _p(dqkv), _p(drel), _p(pad), _s()), 'window_attention_bwd')
+    if batch is not None:
+        return dqkv, batch.add(drel).view(heads, 49, 49), batch.add(pad).view(heads, 3, 32).permute(1, 0, 2)
     drel_b = ops.colsum(drel).view(heads, 49, 49)
     dpad = ops.colsum(pad).view(heads, 3, 32).permute(1, 0, 2).reshape(3 * Cn)       # [q | k | v] x heads x 32, the qkv channel order
     return dqkv, drel_b, dpad
