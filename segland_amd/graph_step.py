@@ -13,6 +13,9 @@ import os
 import torch
 
 
+STATS = {'captures': 0, 'replays': 0, 'failures': 0}          # process-wide counters (tests / logs: did the drivers really replay?)
+
+
 def eligible(model, optimizer, device, need_adamw=True):
     from .optim import AdamW
     return (os.environ.get('SEGLAND_STEP_GRAPH', '1') != '0' and torch.cuda.is_available() and torch.device(device).type == 'cuda'
@@ -61,6 +64,7 @@ class GraphedStep:
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             out = self._eager(self.static_in)
         self.graph, self.key, self.static_out = g, key, out
+        STATS['captures'] += 1
         # the gradients the replays write: tensors of the graph's pool that the parameters keep pointing at
         self.static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
 
@@ -76,6 +80,7 @@ class GraphedStep:
             except Exception as e:              # something on the path still needed the host (a lazy upload, a read-back): run it eagerly
                 self.graph, self.key = None, None
                 self.failures += 1
+                STATS['failures'] += 1
                 torch.cuda.synchronize()
                 import logging
                 logging.getLogger('Segmentation').warning('graph_step: capture failed (%s: %s); %s', type(e).__name__, str(e).splitlines()[0] if str(e) else '',
@@ -92,6 +97,7 @@ class GraphedStep:
             self.optimizer.graph_prepare()
         self.graph.replay()
         self.replays += 1
+        STATS['replays'] += 1
         return self.static_out
 
 

@@ -156,3 +156,23 @@ def test_graphed_ft_step_equals_eager(hip, family):
     assert par_r.keys() == par_g.keys() and len(par_r) > 0
     for n in par_r:
         assert torch.equal(par_r[n], par_g[n]), n
+
+
+def test_train_base_replays_the_step_with_loader_workers(hip, tmp_path):
+    """train_base.py end to end with the drivers' defaults that matter here -- DataLoader workers and the pin-memory thread alive while the
+    step is captured (thread_local capture mode) -- must capture once and replay every later iteration; BatchNorm's num_batches_tracked,
+    advanced inside the graph, counts all of them."""
+    import glob
+    import os
+    from segland_amd import graph_step, train_base
+    before = dict(graph_step.STATS)
+    snap = str(tmp_path / 'snap')
+    train_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic', '--batch-size', '4', '--input-size', '128,128',
+                     '--base-size', '128,128', '--num-epoch', '2', '--learning-rate', '1e-4', '--print-frequency', '4', '--snapshot-dir', snap,
+                     '--num-workers', '2', '--restore-from', '/nonexistent', '--allow-random-init', '--fp16'])
+    d = {k: graph_step.STATS[k] - before[k] for k in before}
+    print(d)
+    assert d['captures'] == 1 and d['failures'] == 0 and d['replays'] == 32 - 3, d          # 2 epochs x 16 iterations, 3 eager warm-up steps
+    sd = torch.load(glob.glob(os.path.join(snap, 'epoch_2.pth'))[0], map_location='cpu')
+    assert int(sd['module.backbone.bn1.num_batches_tracked']) == 32
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
