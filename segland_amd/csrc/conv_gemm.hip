@@ -1330,29 +1330,43 @@ struct PrepEntry { const float* src; void* wf; void* wb; int O, I, KHW, dtype; l
 // element-wise version scattered 2-byte stores.
 constexpr int WP_O = 64, WP_I = 32;
 template <typename T>
-__device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long tile, unsigned char* smem) {
+__device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long tile, unsigned char* smem, int src_I = 0, int src_off = 0) {
+  if (src_I == 0) src_I = t.I;                             // source input-channel count / first channel (a channel slice of a wider weight)
+  constexpr int V = 16 / (int)sizeof(T);                   // elements per 16-byte store
   const int it_n = t.I / WP_I;
   const int o0 = (int)(tile / it_n) * WP_O, i0 = (int)(tile % it_n) * WP_I;
   const int KHW = t.KHW, row = WP_I * KHW;                 // contiguous source floats per output channel of the tile
   T* lds = (T*)smem;                                       // [WP_O][row (+pad)]
   const int pitch = row + 2;
-  for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
-    const int o = e / row, r = e - o * row;
-    lds[o * pitch + r] = from_f<T>(t.src[((size_t)(o0 + o) * t.I + i0) * KHW + r]);      // r = i*KHW + k
+  // source rows as float4 (row = 32 * KHW is a multiple of 4), converted on the way into the LDS
+  const int row4 = row >> 2;
+  for (int e = threadIdx.x; e < WP_O * row4; e += blockDim.x) {
+    const int o = e / row4, r = (e - o * row4) << 2;
+    const float4 v = *(const float4*)(t.src + ((size_t)(o0 + o) * src_I + src_off + i0) * KHW + r);      // r = i*KHW + k
+    T* d = lds + o * pitch + r;
+    d[0] = from_f<T>(v.x); d[1] = from_f<T>(v.y); d[2] = from_f<T>(v.z); d[3] = from_f<T>(v.w);
   }
   __syncthreads();
-  if (t.wf) {
+  if (t.wf) {                                              // wf[o][k][i0 .. i0+31]: 16-byte stores of V consecutive input channels
     T* wf = (T*)t.wf;
-    for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
-      const int i = e % WP_I, ok = e / WP_I, k = ok % KHW, o = ok / KHW;
-      wf[((size_t)(o0 + o) * KHW + k) * t.I + i0 + i] = lds[o * pitch + i * KHW + k];
+    constexpr int CH = WP_I / V;
+    for (int e = threadIdx.x; e < WP_O * KHW * CH; e += blockDim.x) {
+      const int c = e % CH, ok = e / CH, k = ok % KHW, o = ok / KHW;
+      T tmp[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) tmp[j] = lds[o * pitch + (c * V + j) * KHW + k];
+      *(uint4*)(wf + ((size_t)(o0 + o) * KHW + k) * t.I + i0 + c * V) = *(const uint4*)tmp;
     }
   }
-  if (t.wb) {
+  if (t.wb) {                                              // wb[i][k][o0 .. o0+63]: 16-byte stores of V consecutive output channels
     T* wb = (T*)t.wb;
-    for (int e = threadIdx.x; e < WP_O * row; e += blockDim.x) {
-      const int o = e % WP_O, ik = e / WP_O, k = ik % KHW, i = ik / KHW;
-      wb[((size_t)(i0 + i) * KHW + k) * t.O + o0 + o] = lds[o * pitch + i * KHW + k];
+    constexpr int CH = WP_O / V;
+    for (int e = threadIdx.x; e < WP_I * KHW * CH; e += blockDim.x) {
+      const int c = e % CH, ik = e / CH, k = ik % KHW, i = ik / KHW;
+      T tmp[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) tmp[j] = lds[(c * V + j) * pitch + i * KHW + k];
+      *(uint4*)(wb + ((size_t)(i0 + i) * KHW + k) * t.O + o0 + c * V) = *(const uint4*)tmp;
     }
   }
   __syncthreads();
@@ -1400,9 +1414,29 @@ __global__ void weight_prep_slice_kernel(const float* __restrict__ w, int Cout, 
 }  // namespace
 
 // GEMM layouts of the input-channel slice [ci_off, ci_off + ci_cnt) of an OIHW weight with CinTot input channels
+namespace {
+__global__ __launch_bounds__(256) void weight_prep_slice_tiles_kernel(PrepEntry t, int CinTot, int ci_off, long long total_tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wp_smem[];
+  for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+    if (t.dtype == SL_BF16) weight_prep_tile<bf16_t>(t, tile, wp_smem, CinTot, ci_off);
+    else                    weight_prep_tile<float>(t, tile, wp_smem, CinTot, ci_off);
+  }
+}
+}  // namespace
+
 extern "C" int sl_weight_prep_slice(int dtype, const float* w_oihw, int Cout, int CinTot, int ci_off, int ci_cnt, int KH, int KW,
                                     void* w_fwd, void* w_bwd, sl_stream_t stream) {
   SL_REQUIRE(w_oihw && (w_fwd || w_bwd) && ci_off >= 0 && ci_cnt > 0 && ci_off + ci_cnt <= CinTot, "weight_prep_slice: bad args");
+  if ((dtype == SL_BF16 || dtype == SL_F32) && Cout % WP_O == 0 && ci_cnt % WP_I == 0 && ci_off % 4 == 0 && KH * KW <= 9) {      // tiled, 16-byte stores
+    PrepEntry t{w_oihw, w_fwd, w_bwd, Cout, ci_cnt, KH * KW, dtype, 0};
+    const long long tiles = (long long)(Cout / WP_O) * (ci_cnt / WP_I);
+    const size_t lds = (size_t)WP_O * (WP_I * 9 + 2) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)weight_prep_slice_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(weight_prep_slice_tiles_kernel, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), lds, (hipStream_t)stream, t, CinTot, ci_off, tiles);
+    SL_LAUNCH_CHECK("weight_prep_slice_tiles_kernel");
+    return 0;
+  }
   const long long n = (long long)Cout * ci_cnt * KH * KW;
   const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
   if (dtype == SL_BF16) hipLaunchKernelGGL(weight_prep_slice_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, CinTot, ci_off, ci_cnt, KH * KW, (bf16_t*)w_fwd, (bf16_t*)w_bwd);
