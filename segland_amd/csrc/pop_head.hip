@@ -21,13 +21,13 @@ template <int LPR> __device__ __forceinline__ float across_groups(float v) {  //
   return v;
 }
 
-template <typename T, int NV, int LPR>   // NV 16-byte vectors per lane, LPR lanes per row
+template <typename T, int NV, int LPR, int KM>   // NV 16-byte vectors per lane, LPR lanes per row, KM >= Kt prototypes (unrolled)
 __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ S, int Kt,
                                                                 float* __restrict__ proj, T* __restrict__ bg, long long R, int C) {
   constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* Sl = sm;                       // [Kt][C]
-  for (int e = threadIdx.x; e < Kt * C; e += 256) Sl[e] = S[e];
+  float* Sl = sm;                       // [KM][C], rows >= Kt are zero
+  for (int e = threadIdx.x; e < KM * C; e += 256) Sl[e] = e < Kt * C ? S[e] : 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   for (long long rb = (blockIdx.x * 4LL + wave) * RPW; rb < R; rb += gridDim.x * 4LL * RPW) {
@@ -41,20 +41,32 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
 #pragma unroll
         for (int e = 0; e < V; ++e) q[j * V + e] = 0.f;
     }
+    // all projections first (they use q, not the running residual): KM independent shuffle reductions in flight instead of a chain of Kt x log2(LPR)
+    float d[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) a = fmaf(q[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], a);
+      d[k] = a;
+    }
+#pragma unroll
+    for (int ofs = LPR / 2; ofs > 0; ofs >>= 1)
+#pragma unroll
+      for (int k = 0; k < KM; ++k) d[k] += __shfl_xor(d[k], ofs, 64);
 #pragma unroll
     for (int e = 0; e < NV * V; ++e) o[e] = q[e];
-    for (int k = 0; k < Kt; ++k) {
-      float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < NV; ++j)
+    for (int k = 0; k < KM; ++k) {                        // same order of the subtractions as before (k ascending)
+      if (k < Kt) {
+        if (sub == 0 && live) proj[(size_t)r * Kt + k] = d[k];
 #pragma unroll
-        for (int e = 0; e < V; ++e) d = fmaf(q[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], d);
-      d = group_sum<LPR>(d);
-      if (sub == 0 && live) proj[(size_t)r * Kt + k] = d;
+        for (int j = 0; j < NV; ++j)
 #pragma unroll
-      for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < V; ++e) o[j * V + e] -= d * Sl[k * C + (j * LPR + sub) * V + e];
+          for (int e = 0; e < V; ++e) o[j * V + e] -= d[k] * Sl[k * C + (j * LPR + sub) * V + e];
+      }
     }
     if (live) {
 #pragma unroll
@@ -375,7 +387,8 @@ extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S
   const size_t lds = (size_t)KMAXP * C * sizeof(float);
   if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
         using T = decltype(t);
-        hipLaunchKernelGGL((pop_decompose_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value>), dim3(blocks), dim3(256), lds, st, (const T*)feats, S, Kt, proj, (T*)bg, R, C);
+        if (Kt <= 8) hipLaunchKernelGGL((pop_decompose_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value, 8>), dim3(blocks), dim3(256), lds, st, (const T*)feats, S, Kt, proj, (T*)bg, R, C);
+        else hipLaunchKernelGGL((pop_decompose_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value, 16>), dim3(blocks), dim3(256), lds, st, (const T*)feats, S, Kt, proj, (T*)bg, R, C);
         return 0; })) return e;
   SL_LAUNCH_CHECK("pop_decompose_fwd_kernel");
   return 0;
