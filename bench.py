@@ -274,7 +274,9 @@ def main():
                            else 'kernel by kernel from Python'),
         }
         if eager_ms is not None:
-            out['ms_per_step_kernel_by_kernel'] = round(eager_ms, 3)      # the second timed region (the one the roofline events come from)
+            # the second timed region (the one the roofline events come from): kernel-by-kernel steps WITH event pairs around the roofline kernel, run
+            # right after the replays (fresh gradient buffers, allocator re-warm) -- not the kernel-by-kernel throughput, which `--no-step-graph` measures
+            out['roofline_region_ms_per_step'] = round(eager_ms, 3)
         per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
         out['ms_per_step_median'] = round(per[len(per) // 2], 3)
         out['value_at_median'] = round(a.batch * world / (per[len(per) // 2] * 1e-3), 1)
