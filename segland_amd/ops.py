@@ -31,7 +31,14 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _s():
+    """The current HIP stream of the current device as the C ABI's stream handle.  torch.cuda.current_stream() builds a Stream object (and
+    resolves the device through three Python layers): 9 us per launch, ~15 % of the host time of a step; the raw getter is one C call."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -217,7 +224,7 @@ _ws_cache = {}
 
 def workspace(nbytes, dev):
     """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream)."""
-    key = (dev, torch.cuda.current_stream().cuda_stream)
+    key = (dev, _s().value)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
