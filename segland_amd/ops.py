@@ -28,18 +28,19 @@ def _p(t):
         raise RuntimeError('segland_amd: tensor is not on the GPU; the HIP path has no CPU fallback')
     if not t.is_contiguous():
         raise RuntimeError('segland_amd: non-contiguous tensor passed to a kernel')
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()                  # a plain int: every pointer parameter is declared c_void_p (_lib.declared_functions), ctypes converts
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
 def _s():
     """The current HIP stream of the current device as the C ABI's stream handle.  torch.cuda.current_stream() builds a Stream object (and
     resolves the device through three Python layers): 9 us per launch, ~15 % of the host time of a step; the raw getter is one C call."""
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def _f32(n, dev, zero=False):
@@ -224,7 +225,7 @@ _ws_cache = {}
 
 def workspace(nbytes, dev):
     """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream)."""
-    key = (dev, _s().value)
+    key = (dev, _s())
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)

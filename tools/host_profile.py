@@ -11,6 +11,7 @@ opt = bench.make_optimizer(m); params = [p for p in m.parameters() if p.requires
 img, mask = bench.synthetic_batch(B, 256, 'cuda')
 for _ in range(4): bench.train_step(m, opt, img, mask, params, True)
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): bench.train_step(m, opt, img, mask, params, True)
 torch.cuda.synchronize(); pr.disable()
