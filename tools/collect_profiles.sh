@@ -10,6 +10,7 @@ python bench.py --no-cpu-baseline --no-step-graph --profile-table $O/r2_conv_sha
 python bench.py --backbone resnet101 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' > $O/r2_bench_r101.json
 python bench.py --model swin_pop 2>/dev/null | grep '^{"metric"' > $O/r2_bench_swin.json
 for a in "--dtype bf16" "--dtype bf16 --model swin_pop" "--dtype bf16 --pairs 8" "--dtype bf16 --no-step-graph"; do python tools/bench_ft.py $a 2>/dev/null | grep '^{'; done > $O/r2_bench_ft.txt
+bash tools/ddp_overhead.sh 50 > $O/r2_ddp_overhead.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_r50 -o b -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 cp $(find /tmp/prof_r50 -name '*kernel_stats.csv' | head -1) $O/r2_rocprofv3_kernel_stats.csv
