@@ -49,8 +49,8 @@ def parse():
     p.add_argument('--cpu-budget', type=float, default=40.0, help='seconds of CPU work allowed for the cpu_baseline sample')
     p.add_argument('--torch-optimizer', action='store_true', help='torch.optim.AdamW(fused=True) instead of segland_amd.optim.AdamW')
     p.add_argument('--single-step', action='store_true', help='one AdamW step per iteration (the reference does two, train_base.py:262-264)')
-    p.add_argument('--no-step-graph', action='store_true', help='time kernel-by-kernel steps only (default on one GPU: the timed steps replay the step as ONE HIP graph, '
-                   'segland_amd/graph_step.py, like train_base does; a second, eager region then carries the per-launch events of the roofline)')
+    p.add_argument('--no-step-graph', action='store_true', help='issue the timed steps kernel by kernel (default on one GPU: they replay the step as ONE HIP graph, segland_amd/graph_step.py, '
+                   'like train_base does).  Either way a second region of instrumented kernel-by-kernel steps carries the roofline events')
     p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
     return p.parse_args()
 
@@ -232,17 +232,16 @@ def main():
         return time.perf_counter() - t0, marks
 
     eager_fn = lambda img, mask: train_step(net, opt, img, mask, params, double, grad_div)      # noqa: E731
+    # Region 1 -- the K timed steps of `value`: uninstrumented (graph replays on one GPU; kernel by kernel under DDP).
+    # Region 2 -- K more steps issued kernel by kernel with HIP-event pairs around every launch of the roofline kernel (each pair costs two
+    # ~5.7 us queue markers: 0.3 ms per R50 step, more next to DDP's RCCL stream, so they stay out of the number the driver compares).
+    dt_s, marks = timed_region((lambda img, mask: graphed(img, mask)) if graphed is not None else eager_fn)
     eager_ms = None
-    if graphed is not None:
-        dt_s, marks = timed_region(lambda img, mask: graphed(img, mask))
+    if os.environ.get('SEGLAND_BENCH_NOEVENTS') != '1':
         if dominant is not None:
             ops.PROFILER.start(only=dominant['family'])
         dt_e, _ = timed_region(eager_fn)
         eager_ms = 1e3 * dt_e / a.steps
-    else:
-        if dominant is not None and os.environ.get('SEGLAND_BENCH_NOEVENTS') != '1':       # (A/B knob: what the event pairs themselves cost)
-            ops.PROFILER.start(only=dominant['family'])     # only the dominant kernel's launches carry event pairs
-        dt_s, marks = timed_region(eager_fn)
     live = ops.PROFILER.stop()
     if use_ddp:
         t = torch.tensor([dt_s], device=dev, dtype=torch.float64)
@@ -271,11 +270,10 @@ def main():
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
             'step_issue': ('one HIP graph replay per step (segland_amd/graph_step.py, the train_base default on one GPU)' if graphed is not None
-                           else 'kernel by kernel from Python'),
+                           else 'kernel by kernel from Python' + (' under DistributedDataParallel / RCCL' if use_ddp else '')),
         }
         if eager_ms is not None:
-            # the second timed region (the one the roofline events come from): kernel-by-kernel steps WITH event pairs around the roofline kernel, run
-            # right after the replays (fresh gradient buffers, allocator re-warm) -- not the kernel-by-kernel throughput, which `--no-step-graph` measures
+            # the second region (the one the roofline events come from): kernel-by-kernel steps WITH event pairs around the roofline kernel
             out['roofline_region_ms_per_step'] = round(eager_ms, 3)
         per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(a.steps))
         out['ms_per_step_median'] = round(per[len(per) // 2], 3)
@@ -307,7 +305,7 @@ def main():
                                'traffic': traffic, 'traffic_source': tsrc, 'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
-                               'note': 'all launches of this kernel in ' + ('the %d kernel-by-kernel steps timed right after the graph-replayed region' % a.steps if graphed is not None else 'the timed steps')
+                               'note': 'all launches of this kernel in the %d instrumented kernel-by-kernel steps run right after the %d timed ones' % (a.steps, a.steps)
                                        + ' (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone, a.model)

@@ -1,0 +1,28 @@
+import os, sys, time
+sys.path.insert(0, '/root/repo')
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29544', RANK='0', WORLD_SIZE='1')
+import torch, torch.distributed as dist
+import bench
+from segland_amd.loss.criterion import OrthLoss
+from segland_amd.networks.pspnet_pop import GFSS_Model
+mode = sys.argv[1]; B = int(sys.argv[2])
+torch.cuda.set_device(0)
+if mode != 'plain': dist.init_process_group('nccl', init_method='env://')
+torch.manual_seed(0); dev = torch.device('cuda', 0)
+model = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8).to(dev).train()
+opt = bench.make_optimizer(model)
+net, gd = model, 1
+if mode != 'plain':
+    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True, bucket_cap_mb=64)
+    if mode == 'inplace':
+        from segland_amd.engine import enable_inplace_bucket_gradients
+        enable_inplace_bucket_gradients(net)
+params = [p for p in model.parameters() if p.requires_grad]
+img, mask = bench.synthetic_batch(B, 512, dev)
+for _ in range(5): bench.train_step(net, opt, img, mask, params, True, gd)
+torch.cuda.synchronize()
+K = 10; t0 = time.perf_counter()
+for _ in range(K): bench.train_step(net, opt, img, mask, params, True, gd)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print('%s batch %d: enqueue %.2f ms/step, complete %.2f ms/step' % (mode, B, 1e3 * (t1 - t0) / K, 1e3 * (t2 - t0) / K))
+if mode != 'plain': dist.destroy_process_group()
