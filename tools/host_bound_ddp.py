@@ -18,11 +18,15 @@ if mode != 'plain':
         from segland_amd.engine import enable_inplace_bucket_gradients
         enable_inplace_bucket_gradients(net)
 params = [p for p in model.parameters() if p.requires_grad]
-img, mask = bench.synthetic_batch(B, 512, dev)
-for _ in range(5): bench.train_step(net, opt, img, mask, params, True, gd)
+variant = sys.argv[3] if len(sys.argv) > 3 else ''
+batches = [bench.synthetic_batch(B, 512, dev, seed=k) for k in range(4 if 'b' in variant else 1)]
+for i in range(10): bench.train_step(net, opt, *batches[i % len(batches)], params, True, gd)
 torch.cuda.synchronize()
-K = 10; t0 = time.perf_counter()
-for _ in range(K): bench.train_step(net, opt, img, mask, params, True, gd)
+K = 50; marks = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+t0 = time.perf_counter()
+for i in range(K):
+    bench.train_step(net, opt, *batches[i % len(batches)], params, True, gd)
+    if 'e' in variant: marks[i + 1].record()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print('%s batch %d: enqueue %.2f ms/step, complete %.2f ms/step' % (mode, B, 1e3 * (t1 - t0) / K, 1e3 * (t2 - t0) / K))
+print(variant, '%s batch %d: enqueue %.2f ms/step, complete %.2f ms/step' % (mode, B, 1e3 * (t1 - t0) / K, 1e3 * (t2 - t0) / K))
 if mode != 'plain': dist.destroy_process_group()
