@@ -145,8 +145,9 @@ int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const uint8_t* rel
 /* ------------------------------------------------------------------------------------------------ stem
  * resnet.py:86-90,124-125: conv 7x7 s2 p3 3->64 on the NCHW float image, BN, ReLU, maxpool 3x3 s2 p1. */
 int sl_stem_conv_stat_rows(int B, int H, int W);
+size_t sl_stem_conv_fwd_workspace(int dtype);                                 /* bytes of caller-provided scratch (bf16: the weights in MFMA fragment order) */
 int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w_oihw, void* y, float* stat_partial, int B, int H,
-                     int W, sl_stream_t stream);                              /* y: [B][H/2][W/2][64] */
+                     int W, void* workspace, sl_stream_t stream);             /* y: [B][H/2][W/2][64] */
 /* pooled: [B][Hc/2][Wc/2][64]; argmax (nullable): uint8 window position ky*3+kx of the FIRST maximum in ATen's
  * scan order, same shape as pooled (needed by the backward). */
 int sl_stem_bn_relu_pool_fwd(int dtype, const void* c0, const float* scale, const float* shift, void* pooled,

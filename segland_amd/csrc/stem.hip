@@ -89,6 +89,135 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 forward on the matrix cores: the 16x16-pixel output tile of a block is a [256 pixels] x [160 = 147 taps, zero padded] x [64 channels]
+// GEMM whose pixel operand is gathered from the bf16 image patch in the LDS (im2col is never materialised).  Operand roles as in the conv
+// kernels: first MFMA operand = weight rows (-> accumulator registers), second = pixel rows (-> lanes).  A wave owns 64 pixels x 64 channels
+// (4 accumulators).  The math is 40 MFMAs per wave; what decides the time is the glue around them, so: the weight fragments come ready-made
+// from a 20 KiB table (stem_weight_frag_kernel, one tiny launch per step) straight into registers, the patch is loaded without a division
+// in the loop, the im2col offsets of a k-step are compile-time constants selected by the lane half, and the BN statistic partials are
+// column sums over the staged (rounded) tile, like the conv kernels' epilogue.
+constexpr int MP = 38;                 // patch row pitch (bf16 elements)
+constexpr int KSTEPS = 10;             // 160 = 147 taps zero padded
+
+// wfrag[(nb*10 + ks)*64 + lane] = W[nb*32 + (lane & 31)][ks*16 + (lane >> 5)*8 .. +8] as bf16 (taps >= 147 zero)
+__global__ void stem_weight_frag_kernel(const float* __restrict__ w, uint4* __restrict__ wfrag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * KSTEPS * 64) return;
+  const int lane = t & 63, ks = (t >> 6) % KSTEPS, nb = (t >> 6) / KSTEPS;
+  const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  unsigned short v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = k0 + e < NTAP ? from_f<bf16_t>(w[n * NTAP + k0 + e]) : (unsigned short)0;
+  wfrag[t] = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16));
+}
+
+__host__ __device__ constexpr int stem_tap_off(int k) { return k < NTAP ? ((k / 49) * PS + (k % 49) / 7) * MP + (k % 7) : 0; }
+
+template <int KS>
+__device__ __forceinline__ void stem_kstep(const bf16_t* __restrict__ patch, const int (&pbase)[2], int fh, const uint4* __restrict__ wfrag, int lane, f32x16_t (&acc)[2][2]) {
+  const uint4 w0 = wfrag[(0 * KSTEPS + KS) * 64 + lane], w1 = wfrag[(1 * KSTEPS + KS) * 64 + lane];
+  int off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) off[e] = fh ? stem_tap_off(KS * 16 + 8 + e) : stem_tap_off(KS * 16 + e);      // two immediates and a select
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    unsigned v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = patch[pbase[rb] + off[e]];
+    // taps >= 147 read patch[pbase + 0] (a finite bf16) against a ZERO weight: no masking needed
+    const uint4 a = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, a), acc[rb][0], 0, 0, 0);
+    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, a), acc[rb][1], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_conv_fwd_mfma_kernel(const float* __restrict__ img, const uint4* __restrict__ wfrag,
+                                                                 bf16_t* __restrict__ y, float* __restrict__ part, int B, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* patch = (bf16_t*)smem;                           // [3][PS][MP]
+  bf16_t* outt = (bf16_t*)smem;                            // [256][64 + 8]: takes the patch's place after the main loop
+  float* red = (float*)(smem + 256 * 72 * sizeof(bf16_t)); // [4][2][64]
+  const int Ho = H / 2, Wo = W / 2;
+  const int tx = cdiv(Wo, TS), ty = cdiv(Ho, TS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int blk = blockIdx.x;
+  const int bx = blk % tx; blk /= tx;
+  const int by = blk % ty; const int b = blk / ty;
+  {                                                        // 3 x 37 patch rows, two threads per row (19 + 18 elements), no division in the loop
+    const int rr = tid >> 1, half = tid & 1;
+    if (rr < 3 * PS) {
+      const int c = rr / PS, r = rr - c * PS;
+      const int iy = 2 * by * TS - 3 + r, ix0 = 2 * bx * TS - 3;
+      const bool rowok = (unsigned)iy < (unsigned)H;
+      const float* src = img + ((size_t)(b * 3 + c) * H + (rowok ? iy : 0)) * W;
+      bf16_t* dst = patch + rr * MP;
+      const int q0 = half * 19, q1 = half ? PS : 19;
+      for (int q = q0; q < q1; ++q) {
+        const int ix = ix0 + q;
+        dst[q] = from_f<bf16_t>(rowok && (unsigned)ix < (unsigned)W ? src[ix] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  const int l31 = lane & 31, fh = lane >> 5;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.f;
+  int pbase[2];                                            // pixel of this lane in row block rb: p = wave*64 + rb*32 + l31 -> (py, px) of the tile
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int pidx = wave * 64 + rb * 32 + l31;
+    pbase[rb] = (2 * (pidx >> 4)) * MP + 2 * (pidx & 15);
+  }
+  stem_kstep<0>(patch, pbase, fh, wfrag, lane, acc); stem_kstep<1>(patch, pbase, fh, wfrag, lane, acc);
+  stem_kstep<2>(patch, pbase, fh, wfrag, lane, acc); stem_kstep<3>(patch, pbase, fh, wfrag, lane, acc);
+  stem_kstep<4>(patch, pbase, fh, wfrag, lane, acc); stem_kstep<5>(patch, pbase, fh, wfrag, lane, acc);
+  stem_kstep<6>(patch, pbase, fh, wfrag, lane, acc); stem_kstep<7>(patch, pbase, fh, wfrag, lane, acc);
+  stem_kstep<8>(patch, pbase, fh, wfrag, lane, acc); stem_kstep<9>(patch, pbase, fh, wfrag, lane, acc);
+  __syncthreads();                                         // the patch is dead: the staging tile takes its place
+  // D layout: lane = pixel (l31), register r = channel (r&3) + 8*(r>>2) + 4*fh of the 32-channel block
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int pidx = wave * 64 + rb * 32 + l31;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 pk;
+        pk.x = (unsigned)from_f<bf16_t>(acc[rb][nb][4 * q + 0]) | ((unsigned)from_f<bf16_t>(acc[rb][nb][4 * q + 1]) << 16);
+        pk.y = (unsigned)from_f<bf16_t>(acc[rb][nb][4 * q + 2]) | ((unsigned)from_f<bf16_t>(acc[rb][nb][4 * q + 3]) << 16);
+        *(uint2*)(outt + pidx * 72 + nb * 32 + 8 * q + 4 * fh) = pk;
+      }
+  }
+  __syncthreads();
+  for (int e = tid; e < 256 * 8; e += 256) {               // 8 x 16-byte chunks per pixel row
+    const int pidx = e >> 3, ch8 = e & 7;
+    const int oy = by * TS + (pidx >> 4), ox = bx * TS + (pidx & 15);
+    if (oy < Ho && ox < Wo) *(uint4*)(y + ((size_t)(b * Ho + oy) * Wo + ox) * 64 + ch8 * 8) = *(const uint4*)(outt + pidx * 72 + ch8 * 8);
+  }
+  if (part) {                                              // column sums of the stored (rounded) tile: thread = (channel, quarter of the pixels)
+    const int ch = tid & 63, qtr = tid >> 6;
+    float a = 0.f, c = 0.f;
+    for (int pp = 0; pp < 64; ++pp) {
+      const int pidx = qtr * 64 + pp;
+      const int oy = by * TS + (pidx >> 4), ox = bx * TS + (pidx & 15);
+      if (oy < Ho && ox < Wo) { const float v = to_f<bf16_t>(outt[pidx * 72 + ch]); a += v; c += v * v; }
+    }
+    red[(qtr * 2 + 0) * 64 + ch] = a; red[(qtr * 2 + 1) * 64 + ch] = c;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6;
+      part[((size_t)blockIdx.x * 2 + which) * 64 + ch] = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch] + red[(2 * 2 + which) * 64 + ch] + red[(3 * 2 + which) * 64 + ch];
+    }
+  }
+}
+
 // pooled = maxpool3x3s2p1(relu(c0*scale+shift)); idx = first-max window position ky*3+kx (ATen scan order)
 template <typename T>
 __global__ void stem_bn_relu_pool_fwd_kernel(const T* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
@@ -269,11 +398,23 @@ inline int stem_wgrad_blocks(int ntiles) { return ntiles < 512 ? ntiles : 512; }
 
 extern "C" int sl_stem_conv_stat_rows(int B, int H, int W) { return stem_tiles(B, H, W); }
 
+extern "C" size_t sl_stem_conv_fwd_workspace(int dtype) { return dtype == SL_BF16 ? 2 * KSTEPS * 64 * sizeof(uint4) : 0; }
+
 extern "C" int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w_oihw, void* y, float* stat_partial, int B,
-                                int H, int W, sl_stream_t stream) {
+                                int H, int W, void* workspace, sl_stream_t stream) {
   SL_REQUIRE(img_nchw && w_oihw && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_conv_fwd: bad args");
   const size_t lds = (NTAP * 64 + 3 * PS * PS) * sizeof(float);
   dim3 grid(stem_tiles(B, H, W));
+  static const bool valu = getenv("SEGLAND_STEM_VALU") != nullptr;              // A/B: the fp32-arithmetic VALU kernel also for bf16 outputs
+  if (dtype == SL_BF16 && !valu) {
+    SL_REQUIRE(workspace && ((size_t)workspace & 15) == 0, "stem_conv_fwd: bf16 needs the 16-byte aligned workspace of sl_stem_conv_fwd_workspace()");
+    uint4* wfrag = (uint4*)workspace;                                           // the weights in MFMA fragment order, rebuilt on every call (20 KiB)
+    hipLaunchKernelGGL(stem_weight_frag_kernel, dim3(cdiv(2 * KSTEPS * 64, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, wfrag);
+    const size_t l2 = 256 * 72 * sizeof(bf16_t) + 4 * 2 * 64 * sizeof(float);   // staging tile + statistic scratch (the patch, 8.4 KB, lives in the tile's place first)
+    hipLaunchKernelGGL(stem_conv_fwd_mfma_kernel, grid, dim3(256), l2, (hipStream_t)stream, img_nchw, (const uint4*)wfrag, (bf16_t*)y, stat_partial, B, H, W);
+    SL_LAUNCH_CHECK("stem_conv_fwd_mfma_kernel");
+    return 0;
+  }
   if (dtype == SL_BF16) hipLaunchKernelGGL(stem_conv_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (bf16_t*)y, stat_partial, B, H, W);
   else if (dtype == SL_F32) hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (float*)y, stat_partial, B, H, W);
   else SL_REQUIRE(false, "stem_conv_fwd: bad dtype");

@@ -336,7 +336,9 @@ def stem_conv_fwd(img, w, dtype, want_stats):
     L = _lib.lib()
     y = torch.empty((B, H // 2, W // 2, 64), dtype=dtype, device=img.device)
     part = _f32((L.sl_stem_conv_stat_rows(B, H, W), 2, 64), img.device) if want_stats else None
-    check(L.sl_stem_conv_fwd(_DT[dtype], _p(img), _p(w), _p(y), _p(part), B, H, W, _s()), 'stem_conv_fwd')
+    need = L.sl_stem_conv_fwd_workspace(_DT[dtype])
+    ws = torch.empty(need, dtype=torch.uint8, device=img.device) if need else None
+    check(L.sl_stem_conv_fwd(_DT[dtype], _p(img), _p(w), _p(y), _p(part), B, H, W, _p(ws), _s()), 'stem_conv_fwd')
     return y, part
 
 

@@ -205,8 +205,9 @@ def test_stem(hip, dtype):
     c0, part = ops.stem_conv_fwd(img.to(DEV), w.detach().to(DEV), dtype, True)
     assert_close(nchw(c0), c_ref, dtype, 'stem conv')
     s = part.sum(0).cpu()
-    assert_close(s[0], c_ref.detach().sum((0, 2, 3)), torch.float32, 'stem stat sum', scale=float(c_ref.abs().sum((0, 2, 3)).max()))
-    assert_close(s[1], (c_ref.detach() ** 2).sum((0, 2, 3)), torch.float32, 'stem stat sq')
+    # bf16: the MFMA kernel rounds image and weights to bf16 (like every other conv of the path), the statistics are those of ITS accumulators
+    assert_close(s[0], c_ref.detach().sum((0, 2, 3)), dtype, 'stem stat sum', scale=float(c_ref.abs().sum((0, 2, 3)).max()))
+    assert_close(s[1], (c_ref.detach() ** 2).sum((0, 2, 3)), dtype, 'stem stat sq')
     # BN(eval-style affine) + ReLU + maxpool and its backward, on the kernel's own (rounded) conv output
     scale = (0.8 + 0.4 * fm.uniform01('stem/sc', 64)).float(); shift = fm.sym('stem/sh', (64,), 0.3)
     cr = nchw(c0).requires_grad_(True)
