@@ -356,12 +356,104 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int nblk) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= 64 * NTAP) return;
-  float s = 0.f;
-  for (int k = 0; k < nblk; ++k) s += ws[(size_t)k * 64 * NTAP + e];
-  dw[e] = s;
+// bf16 weight gradient on the matrix cores: dw[n][k] = sum over pixels of dc0[p][n] * patch(p, k).  The reduction index is the pixel, so both
+// MFMA operands are gathered K-major from the LDS: first operand = dc0^T (rows = output channels -> registers), second = the im2col view of the
+// bf16 image patch (rows = taps -> lanes), 8 consecutive pixels of one tile row per lane.  A wave reduces its 64 pixels of every tile the
+// persistent block walks into ten 32x32 accumulators (64 channels x 160 taps); the four waves are summed through the LDS at the end and the
+// block writes one [64][147] partial (the existing fixed-order reduce kernel adds the blocks).
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ img, const bf16_t* __restrict__ dc0, float* __restrict__ ws,
+                                                              int B, int H, int W, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* patch = (bf16_t*)smem;                           // [3][PS][MP]                       8 436 B
+  bf16_t* dct = patch + 3 * PS * MP + 6;                   // [256][64 + 8] (16-byte aligned)  36 864 B
+  float* red = (float*)smem;                               // [4][16][64] floats, after the tile loop
+  const int Ho = H / 2, Wo = W / 2;
+  const int tx = cdiv(Wo, TS), ty = cdiv(Ho, TS);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, fh = lane >> 5;
+  f32x16_t acc[2][5];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][kb][r] = 0.f;
+  int toff[5];                                             // patch offset of this lane's tap in tap block kb (taps >= 147: any valid address)
+#pragma unroll
+  for (int kb = 0; kb < 5; ++kb) {
+    const int k = kb * 32 + l31;
+    const int c = k / 49, r = k - c * 49, ky = r / 7, kx = r - ky * 7;
+    toff[kb] = k < NTAP ? (c * PS + ky) * MP + kx : 0;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int blk = tile;
+    const int bx = blk % tx; blk /= tx;
+    const int by = blk % ty; const int b = blk / ty;
+    {
+      const int rr = tid >> 1, half = tid & 1;
+      if (rr < 3 * PS) {
+        const int c = rr / PS, r = rr - c * PS;
+        const int iy = 2 * by * TS - 3 + r, ix0 = 2 * bx * TS - 3;
+        const bool rowok = (unsigned)iy < (unsigned)H;
+        const float* src = img + ((size_t)(b * 3 + c) * H + (rowok ? iy : 0)) * W;
+        bf16_t* dst = patch + rr * MP;
+        const int q0 = half * 19, q1 = half ? PS : 19;
+        for (int q = q0; q < q1; ++q) {
+          const int ix = ix0 + q;
+          dst[q] = from_f<bf16_t>(rowok && (unsigned)ix < (unsigned)W ? src[ix] : 0.f);
+        }
+      }
+    }
+    for (int e = tid; e < 256 * 8; e += 256) {             // the dc0 tile, zero outside the map
+      const int pidx = e >> 3, ch8 = e & 7;
+      const int oy = by * TS + (pidx >> 4), ox = bx * TS + (pidx & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oy < Ho && ox < Wo) v = *(const uint4*)(dc0 + ((size_t)(b * Ho + oy) * Wo + ox) * 64 + ch8 * 8);
+      *(uint4*)(dct + pidx * 72 + ch8 * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      // pixels p = wave*64 + ks*16 + fh*8 + e: tile row py = wave*4 + ks, columns px = fh*8 + e
+      const int prow = wave * 64 + ks * 16 + fh * 8;
+      uint4 fa[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        unsigned v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = dct[(prow + e) * 72 + nb * 32 + l31];
+        fa[nb] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+      }
+      const int pb = (2 * (wave * 4 + ks)) * MP + 2 * (fh * 8);
+#pragma unroll
+      for (int kb = 0; kb < 5; ++kb) {
+        unsigned v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = patch[pb + toff[kb] + 2 * e];
+        const uint4 fb = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa[nb]), __builtin_bit_cast(bf16x8_t, fb), acc[nb][kb], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // D layout: lane l31 = tap of the block, register r = channel (r&3) + 8*(r>>2) + 4*fh of the block.  Sum the four waves, one accumulator at a time.
+  float* out = ws + (size_t)blockIdx.x * 64 * NTAP;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[nb][kb][r];
+      __syncthreads();
+      for (int e = tid; e < 16 * 64; e += 256) {
+        const int r = e >> 6, ln = e & 63;
+        const float t = red[(0 * 16 + r) * 64 + ln] + red[(1 * 16 + r) * 64 + ln] + red[(2 * 16 + r) * 64 + ln] + red[(3 * 16 + r) * 64 + ln];
+        const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), k = kb * 32 + (ln & 31);
+        if (k < NTAP) out[n * NTAP + k] = t;
+      }
+      __syncthreads();
+    }
 }
 
 // im2col of the stem's receptive fields: col[m][t], t = c*49 + ky*7 + kx (OIHW tap order), padded to 192 columns with
@@ -457,13 +549,16 @@ extern "C" int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const v
   if (workspace_bytes < (size_t)nblk * 64 * NTAP * sizeof(float)) { sl_set_error("stem_conv_bwd_weight: workspace too small"); return SL_EWORKSPACE; }
   const size_t lds = (256 * 64 + 3 * PS * PS) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
+  static const bool valu = getenv("SEGLAND_STEM_VALU") != nullptr;
+  if (dtype == SL_BF16 && !valu) {
+    const size_t l2 = (size_t)(3 * PS * MP + 6) * sizeof(bf16_t) + 256 * 72 * sizeof(bf16_t);
+    hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nblk), dim3(256), l2, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, ntiles);
+    SL_LAUNCH_CHECK("stem_wgrad_mfma_kernel");
+  } else if (dtype == SL_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
   else if (dtype == SL_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), lds, st, img_nchw, (const float*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
   else SL_REQUIRE(false, "stem_conv_bwd_weight: bad dtype");
   SL_LAUNCH_CHECK("stem_wgrad_kernel");
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(64 * NTAP, 256)), dim3(256), 0, st, (const float*)workspace, dw_oihw, nblk);
-  SL_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
-  return 0;
+  return sl_colsum_finalize((const float*)workspace, nblk, 64 * NTAP, dw_oihw, stream);       // fixed-order sum of the block partials (64 x 16 lanes per block of columns)
 }
 
 extern "C" int sl_stem_im2col(int dtype, const float* img_nchw, void* col, int B, int H, int W, sl_stream_t stream) {

@@ -358,7 +358,15 @@ def stem_pool_relu_bwd(dpooled, idx, c0, scale, shift):
 
 
 def stem_conv_bwd_weight(img, dc0):
-    """7x7 stem weight gradient as im2col + the MFMA wgrad kernel (19.7 GFLOP at B=16: a few hundred microseconds)."""
+    """7x7 stem weight gradient.  bf16: one MFMA kernel that gathers the im2col view from the image patch in the LDS (+ the fixed-order block
+    reduce); fp32: im2col + the exact-fp32 MFMA wgrad kernel."""
+    if dc0.dtype == torch.bfloat16:
+        return stem_conv_bwd_weight_direct(img, dc0)
+    return stem_conv_bwd_weight_im2col(img, dc0)
+
+
+def stem_conv_bwd_weight_im2col(img, dc0):
+    """im2col (materialised, [M,192]) + the conv wgrad kernel."""
     B, _, H, W = img.shape
     M = B * (H // 2) * (W // 2)
     col = torch.empty((1, 1, M, 192), dtype=dc0.dtype, device=img.device)

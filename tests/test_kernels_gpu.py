@@ -223,10 +223,11 @@ def test_stem(hip, dtype):
     assert_close(nchw(g0), g_ref, dtype, 'pool+relu bwd')
     gc = rnd(fm.sym('stem/gc', tuple(c_ref.shape), 1.0), dtype)
     c_ref.backward(gc)
-    dw = ops.stem_conv_bwd_weight(img.to(DEV), nhwc(gc, dtype))
+    dw = ops.stem_conv_bwd_weight_im2col(img.to(DEV), nhwc(gc, dtype))
     assert_close(dw, w.grad, dtype, 'stem wgrad (im2col + MFMA)')
-    dw2 = ops.stem_conv_bwd_weight_direct(img.to(DEV), nhwc(gc, dtype))
+    dw2 = ops.stem_conv_bwd_weight_direct(img.to(DEV), nhwc(gc, dtype))          # bf16: the fused MFMA kernel; fp32: the VALU kernel
     assert_close(dw2, w.grad, dtype, 'stem wgrad (direct)')
+    assert torch.equal(ops.stem_conv_bwd_weight(img.to(DEV), nhwc(gc, dtype)), dw2 if dtype == torch.bfloat16 else dw)
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
