@@ -1330,8 +1330,11 @@ struct PrepEntry { const float* src; void* wf; void* wb; int O, I, KHW, dtype; l
 // element-wise version scattered 2-byte stores.
 constexpr int WP_O = 64, WP_I = 32;
 template <typename T>
-__device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long tile, unsigned char* smem, int src_I = 0, int src_off = 0) {
+__device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long tile, unsigned char* smem, int src_I = 0, int src_off = 0,
+                                                 long long f_so = 0, long long f_sk = 0, long long b_si = 0, long long b_sk = 0) {
   if (src_I == 0) src_I = t.I;                             // source input-channel count / first channel (a channel slice of a wider weight)
+  // element strides of the two outputs: wf[o*f_so + k*f_sk + i], wb[i*b_si + k*b_sk + o]  (defaults: [O][KHW][I] and [I][KHW][O])
+  if (f_so == 0) { f_so = (long long)t.KHW * t.I; f_sk = t.I; b_si = (long long)t.KHW * t.O; b_sk = t.O; }
   constexpr int V = 16 / (int)sizeof(T);                   // elements per 16-byte store
   const int it_n = t.I / WP_I;
   const int o0 = (int)(tile / it_n) * WP_O, i0 = (int)(tile % it_n) * WP_I;
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long t
       T tmp[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) tmp[j] = lds[o * pitch + (c * V + j) * KHW + k];
-      *(uint4*)(wf + ((size_t)(o0 + o) * KHW + k) * t.I + i0 + c * V) = *(const uint4*)tmp;
+      *(uint4*)(wf + (size_t)(o0 + o) * f_so + (size_t)k * f_sk + i0 + c * V) = *(const uint4*)tmp;
     }
   }
   if (t.wb) {                                              // wb[i][k][o0 .. o0+63]: 16-byte stores of V consecutive output channels
@@ -1366,7 +1369,7 @@ __device__ __forceinline__ void weight_prep_tile(const PrepEntry& t, long long t
       T tmp[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) tmp[j] = lds[(c * V + j) * pitch + i * KHW + k];
-      *(uint4*)(wb + ((size_t)(i0 + i) * KHW + k) * t.O + o0 + c * V) = *(const uint4*)tmp;
+      *(uint4*)(wb + (size_t)(i0 + i) * b_si + (size_t)k * b_sk + o0 + c * V) = *(const uint4*)tmp;
     }
   }
   __syncthreads();
@@ -1412,6 +1415,30 @@ __global__ void weight_prep_slice_kernel(const float* __restrict__ w, int Cout, 
   }
 }
 }  // namespace
+
+// Factorised PPM priors (ppm.hip): per pyramid level l the slice [l*Cs, (l+1)*Cs) of W_oihw [N][Ctot][3][3] as wq_f [l][tap*N + n][Cs] and
+// wq_b [l][c][tap*N + n] (fp32): the same 64 x 32 tiles with the tap-major output strides.
+namespace {
+__global__ __launch_bounds__(256) void ppm_wq_prep_tiles_kernel(const float* __restrict__ w, int N, int Ctot, int Cs, float* __restrict__ wq_f, float* __restrict__ wq_b, long long tiles_per_level) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char wp_smem[];
+  const int l = blockIdx.y;
+  PrepEntry t{w, wq_f + (size_t)l * 9 * N * Cs, wq_b + (size_t)l * Cs * 9 * N, N, Cs, 9, SL_F32, 0};
+  for (long long tile = blockIdx.x; tile < tiles_per_level; tile += gridDim.x)
+    weight_prep_tile<float>(t, tile, wp_smem, Ctot, l * Cs, Cs, (long long)N * Cs, 9LL * N, N);
+}
+}  // namespace
+
+extern "C" int sl_ppm_wq_prep(const float* w_oihw, int N, int Ctot, int Cs, int nlevels, float* wq_f, float* wq_b, sl_stream_t stream) {
+  SL_REQUIRE(w_oihw && wq_f && wq_b && N > 0 && Cs > 0 && nlevels >= 1 && nlevels * Cs <= Ctot, "ppm_wq_prep: bad args");
+  SL_REQUIRE(N % WP_O == 0 && Cs % WP_I == 0, "ppm_wq_prep: N %% 64 == 0 and Cs %% 32 == 0");
+  const long long tiles = (long long)(N / WP_O) * (Cs / WP_I);
+  const size_t lds = (size_t)WP_O * (WP_I * 9 + 2) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)ppm_wq_prep_tiles_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(ppm_wq_prep_tiles_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024), nlevels), dim3(256), lds, (hipStream_t)stream, w_oihw, N, Ctot, Cs, wq_f, wq_b, tiles);
+  SL_LAUNCH_CHECK("ppm_wq_prep_tiles_kernel");
+  return 0;
+}
 
 // GEMM layouts of the input-channel slice [ci_off, ci_off + ci_cnt) of an OIHW weight with CinTot input channels
 namespace {

@@ -493,14 +493,15 @@ extern "C" int sl_pop_combine_bwd(const float* dpreds, const float* proj, const 
   return 0;
 }
 
-extern "C" int sl_pop_decompose_bwd_rows(long long R) { return row_blocks(R, 512); }
+static int dec_bwd_cap() { return 1024; }     // measured 180 / 160 / 161 us for 512 / 1024 / 2048 blocks at 65 536 rows
+extern "C" int sl_pop_decompose_bwd_rows(long long R) { return row_blocks(R, dec_bwd_cap()); }
 
 extern "C" int sl_pop_decompose_bwd(int dtype, const void* dg, const void* feats, const float* S, const float* proj,
                                     const float* dproj, int Kt, void* dq, float* dS_partial, long long R, int C,
                                     sl_stream_t stream) {
   SL_REQUIRE(dg && feats && S && proj && dproj && dq && dS_partial && R > 0 && Kt >= 1 && Kt <= KMAXP, "pop_decompose_bwd: bad args");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = row_blocks(R, 512);
+  const int nblk = row_blocks(R, dec_bwd_cap());
   const long long rpb = (R + nblk - 1) / nblk;
   if (Kt <= 8) {
     const size_t lds = 8 * (size_t)C * sizeof(float);

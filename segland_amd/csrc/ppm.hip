@@ -261,18 +261,7 @@ __global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __rest
 // u_tap = [pixel shifted by the tap is inside the map] * (bilinear weight of the shifted pixel on cell (i,j)), which is
 // separable in y and x.  Exact by linearity; removes 77 of the 154.6 GFLOP/tile of this conv (and of its dgrad / wgrad).
 
-// weight re-layout: W_oihw [N][Ctot][3][3] -> per level  wq_f [9N][Cs] (1x1 forward layout) and wq_b [Cs][9N] (dgrad layout)
-__global__ void ppm_wq_prep_kernel(const float* __restrict__ w, int N, int Ctot, int Cs, int nl, float* __restrict__ wq_f, float* __restrict__ wq_b) {
-  const long long total = (long long)nl * 9 * N * Cs;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % Cs); long long r = e / Cs;
-    const int n = (int)(r % N); r /= N;
-    const int tap = (int)(r % 9); const int l = (int)(r / 9);
-    const float v = w[((size_t)n * Ctot + l * Cs + c) * 9 + tap];
-    wq_f[((size_t)l * 9 * N + tap * N + n) * Cs + c] = v;
-    wq_b[((size_t)l * Cs + c) * 9 * N + tap * N + n] = v;
-  }
-}
+// weight re-layout W_oihw [N][Ctot][3][3] -> per level wq_f [9N][Cs] (1x1 forward layout) and wq_b [Cs][9N] (dgrad layout): sl_ppm_wq_prep in conv_gemm.hip
 
 // dwq [l][(tap,n)][c] -> dw_oihw[n][l*Cs + c][tap]
 __global__ void ppm_dwq_scatter_kernel(const float* __restrict__ dwq, int N, int Ctot, int Cs, int nl, float* __restrict__ dw) {
@@ -497,13 +486,6 @@ extern "C" int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat,
 }
 
 // ---- factorised prior path (see the comment block above ppm_wq_prep_kernel)
-extern "C" int sl_ppm_wq_prep(const float* w_oihw, int N, int Ctot, int Cs, int nlevels, float* wq_f, float* wq_b, sl_stream_t stream) {
-  SL_REQUIRE(w_oihw && wq_f && wq_b && N > 0 && Cs > 0 && nlevels >= 1 && nlevels * Cs <= Ctot, "ppm_wq_prep: bad args");
-  hipLaunchKernelGGL(ppm_wq_prep_kernel, dim3(gs_blocks((long long)nlevels * 9 * N * Cs)), dim3(256), 0, (hipStream_t)stream, w_oihw, N, Ctot, Cs, nlevels, wq_f, wq_b);
-  SL_LAUNCH_CHECK("ppm_wq_prep_kernel");
-  return 0;
-}
-
 extern "C" int sl_ppm_dwq_scatter(const float* dwq, int N, int Ctot, int Cs, int nlevels, float* dw_oihw, sl_stream_t stream) {
   SL_REQUIRE(dwq && dw_oihw && N > 0 && Cs > 0 && nlevels >= 1 && nlevels * Cs <= Ctot, "ppm_dwq_scatter: bad args");
   hipLaunchKernelGGL(ppm_dwq_scatter_kernel, dim3(gs_blocks((long long)nlevels * 9 * N * Cs)), dim3(256), 0, (hipStream_t)stream, dwq, N, Ctot, Cs, nlevels, dw_oihw);
