@@ -136,6 +136,116 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(UpGeom g, const fl
   }
 }
 
+// Tiled form of the same gradient: a block owns CT x CT low-resolution cells and evaluates the softmax of every pixel of their joint
+// footprint ONCE (the per-cell gather above evaluates each pixel for each of the ~4 cells it touches, from global memory), then applies the
+// separable bilinear weights in two LDS passes:  H1[Y][j][k] = sum_X wx(X, j) G[Y][X][k],  dlg[i][j][k] = sum_Y wy(Y, i) H1[Y][j][k].
+// Sums run in a fixed order (deterministic); they are associated differently from the gather kernel (last-bit differences).
+constexpr int CT = 4;
+struct UpTile { int NYmax, NXmax; };
+__global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, UpTile ut, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
+                                                                    const float* __restrict__ loss_cnt, const float* __restrict__ gscale,
+                                                                    int ignore, float* __restrict__ dlg) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int K = g.K;
+  float* lgt = sm;                                   // [(CT+2)^2][K] logits of the cells around the tile (clamped at the map border)
+  float* wy0 = lgt + (CT + 2) * (CT + 2) * K;        // per footprint row: weight on cell y0, weight on y1 ; y0 as int
+  float* wx0 = wy0 + 3 * ut.NYmax;
+  float* wxj = wx0 + 3 * ut.NXmax;                   // [NX][CT] weight of footprint column X on cell j0 + jr
+  float* wyi = wxj + CT * ut.NXmax;                  // [NY][CT]
+  float* H1 = wyi + CT * ut.NYmax;                   // [NY][CT][K]
+  float* G = H1 + ut.NYmax * CT * K;                 // [NY][NX][K]
+  const int tid = threadIdx.x;
+  const int tw = cdiv(g.w, CT), th = cdiv(g.h, CT);
+  int blk = blockIdx.x;
+  const int tj = blk % tw; blk /= tw;
+  const int ti = blk % th; const int b = blk / th;
+  const int i0 = ti * CT, j0 = tj * CT;
+  const int i1 = min(i0 + CT, g.h) - 1, j1 = min(j0 + CT, g.w) - 1;          // last cell of the tile
+  const int Ylo = g.sy > 0.f ? max(0, (int)floorf((float)(i0 - 1) / g.sy)) : 0;
+  const int Yhi = g.sy > 0.f ? min(g.H - 1, (int)ceilf((float)(i1 + 1) / g.sy)) : g.H - 1;
+  const int Xlo = g.sx > 0.f ? max(0, (int)floorf((float)(j0 - 1) / g.sx)) : 0;
+  const int Xhi = g.sx > 0.f ? min(g.W - 1, (int)ceilf((float)(j1 + 1) / g.sx)) : g.W - 1;
+  const int NY = Yhi - Ylo + 1, NX = Xhi - Xlo + 1;
+  const float* lb = lg + (size_t)b * K * g.h * g.w;
+  for (int e = tid; e < (CT + 2) * (CT + 2) * K; e += 256) {
+    const int k = e % K, c = e / K, cy = c / (CT + 2), cx = c - cy * (CT + 2);
+    const int yy = min(max(i0 - 1 + cy, 0), g.h - 1), xx = min(max(j0 - 1 + cx, 0), g.w - 1);
+    lgt[e] = lb[((size_t)k * g.h + yy) * g.w + xx];
+  }
+  for (int e = tid; e < NY; e += 256) {
+    int y0, y1; float ly; src_index_ac1(Ylo + e, g.h, g.sy, y0, y1, ly);
+    wy0[3 * e] = __int_as_float(y0); wy0[3 * e + 1] = __int_as_float(y1); wy0[3 * e + 2] = ly;
+#pragma unroll
+    for (int r = 0; r < CT; ++r) wyi[e * CT + r] = (y0 == i0 + r ? 1.f - ly : 0.f) + (y1 == i0 + r ? ly : 0.f);
+  }
+  for (int e = tid; e < NX; e += 256) {
+    int x0, x1; float lx; src_index_ac1(Xlo + e, g.w, g.sx, x0, x1, lx);
+    wx0[3 * e] = __int_as_float(x0); wx0[3 * e + 1] = __int_as_float(x1); wx0[3 * e + 2] = lx;
+#pragma unroll
+    for (int r = 0; r < CT; ++r) wxj[e * CT + r] = (x0 == j0 + r ? 1.f - lx : 0.f) + (x1 == j0 + r ? lx : 0.f);
+  }
+  __syncthreads();
+  // ---- pass 1: softmax - onehot of every footprint pixel, once
+  for (int pix = tid; pix < NY * NX; pix += 256) {
+    const int yr = pix / NX, xr = pix - yr * NX;
+    float* out = G + (size_t)pix * K;
+    const long long t = tgt[((size_t)b * g.H + Ylo + yr) * g.W + Xlo + xr];
+    if (t == ignore || t < 0 || t >= K) {
+      for (int k = 0; k < K; ++k) out[k] = 0.f;
+      continue;
+    }
+    const int y0 = __float_as_int(wy0[3 * yr]), y1 = __float_as_int(wy0[3 * yr + 1]); const float ly = wy0[3 * yr + 2];
+    const int x0 = __float_as_int(wx0[3 * xr]), x1 = __float_as_int(wx0[3 * xr + 1]); const float lx = wx0[3 * xr + 2];
+    const float wya = 1.f - ly, wxa = 1.f - lx;
+    // a footprint pixel at the rim may interpolate from a cell outside the (CT+2)^2 neighbourhood; it then has zero weight on every cell of
+    // this tile, so any finite value will do: clamp the index
+    const int ry0 = min(max(y0 - i0 + 1, 0), CT + 1), ry1 = min(max(y1 - i0 + 1, 0), CT + 1);
+    const int rx0 = min(max(x0 - j0 + 1, 0), CT + 1), rx1 = min(max(x1 - j0 + 1, 0), CT + 1);
+    const float* q00 = lgt + (ry0 * (CT + 2) + rx0) * K;
+    const float* q01 = lgt + (ry0 * (CT + 2) + rx1) * K;
+    const float* q10 = lgt + (ry1 * (CT + 2) + rx0) * K;
+    const float* q11 = lgt + (ry1 * (CT + 2) + rx1) * K;
+    float v[KMAXC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) {
+      if (k < K) { v[k] = wya * (wxa * q00[k] + lx * q01[k]) + ly * (wxa * q10[k] + lx * q11[k]); m = fmaxf(m, v[k]); }
+      else v[k] = -INFINITY;
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) { v[k] = k < K ? __expf(v[k] - m) : 0.f; ssum += v[k]; }      // hardware exp2-based: 2 ulp, the gradient's tolerance is 1e-3
+    const float inv = 1.f / ssum;
+#pragma unroll
+    for (int k = 0; k < KMAXC; ++k) if (k < K) out[k] = v[k] * inv - (k == (int)t ? 1.f : 0.f);
+  }
+  __syncthreads();
+  // ---- pass 2a: along X
+  for (int e = tid; e < NY * CT * K; e += 256) {
+    const int k = e % K, r = e / K, jr = r % CT, yr = r / CT;
+    const int j = j0 + jr;
+    float acc = 0.f;
+    if (j <= j1) {
+      const int xa = (g.sx > 0.f ? max(Xlo, (int)floorf((float)(j - 1) / g.sx)) : Xlo) - Xlo, xb = (g.sx > 0.f ? min(Xhi, (int)ceilf((float)(j + 1) / g.sx)) : Xhi) - Xlo;
+      const float* grow = G + (size_t)yr * NX * K + k;
+      for (int xr = xa; xr <= xb; ++xr) acc += wxj[xr * CT + jr] * grow[xr * K];
+    }
+    H1[e] = acc;
+  }
+  __syncthreads();
+  // ---- pass 2b: along Y, scale, store
+  const float f = gscale[0] / loss_cnt[1];
+  for (int e = tid; e < CT * CT * K; e += 256) {
+    const int k = e % K, c = e / K, ir = c / CT, jr = c - ir * CT;
+    const int i = i0 + ir, j = j0 + jr;
+    if (i > i1 || j > j1) continue;
+    const int ya = g.sy > 0.f ? max(Ylo, (int)floorf((float)(i - 1) / g.sy)) : Ylo, yb = g.sy > 0.f ? min(Yhi, (int)ceilf((float)(i + 1) / g.sy)) : Yhi;
+    float acc = 0.f;
+    for (int yr = ya - Ylo; yr <= yb - Ylo; ++yr) acc += wyi[yr * CT + ir] * H1[(yr * CT + jr) * K + k];
+    dlg[(((size_t)b * K + k) * g.h + i) * g.w + j] = acc * f;
+  }
+}
+
 template <bool PSEUDO>
 __global__ void upsample_argmax_kernel(UpGeom g, const float* __restrict__ lg, uint8_t* __restrict__ labels, int64_t* __restrict__ mask,
                                        int n_base) {
@@ -292,6 +402,21 @@ extern "C" int sl_upsample_ce_bwd(const float* logits, const int64_t* target, co
   SL_REQUIRE(logits && target && loss_and_count && gscale && dlogits && K >= 1 && K <= KMAXC, "upsample_ce_bwd: bad args");
   const UpGeom g = make_up(B, K, h, w, H, W);
   const long long cells = (long long)B * h * w;
+  // tiled kernel when the joint footprint of a CT x CT cell tile fits the LDS (always for an upsampling factor <= ~12 at K <= 16)
+  static const bool gather_only = getenv("SEGLAND_CE_BWD_GATHER") != nullptr;
+  if (!gather_only && g.sy > 0.f && g.sx > 0.f) {
+    UpTile ut;
+    ut.NYmax = (int)ceilf((float)(CT + 1) / g.sy) + 3; if (ut.NYmax > H) ut.NYmax = H;
+    ut.NXmax = (int)ceilf((float)(CT + 1) / g.sx) + 3; if (ut.NXmax > W) ut.NXmax = W;
+    const size_t lds = ((size_t)(CT + 2) * (CT + 2) * K + (3 + CT) * (ut.NYmax + ut.NXmax) + (size_t)ut.NYmax * CT * K + (size_t)ut.NYmax * ut.NXmax * K) * sizeof(float);
+    if (lds <= 150 * 1024) {
+      static size_t attr = 0;
+      if (lds > attr) { (void)hipFuncSetAttribute((const void*)upsample_ce_bwd_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = 150 * 1024; }
+      hipLaunchKernelGGL(upsample_ce_bwd_tiled_kernel, dim3((unsigned)(B * cdiv(h, CT) * cdiv(w, CT))), dim3(256), lds, (hipStream_t)stream, g, ut, logits, target, loss_and_count, gscale, ignore_index, dlogits);
+      SL_LAUNCH_CHECK("upsample_ce_bwd_tiled_kernel");
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(upsample_ce_bwd_kernel, dim3((unsigned)((cells * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, logits, target, loss_and_count, gscale, ignore_index, dlogits);
   SL_LAUNCH_CHECK("upsample_ce_bwd_kernel");
   return 0;

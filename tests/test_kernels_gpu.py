@@ -373,6 +373,25 @@ def test_loss_vs_oracle_512(hip):
     assert np.isnan(out2[0].item()) and out2[1].item() == 0
 
 
+@pytest.mark.parametrize('K,hw,HW', [(8, (64, 64), (512, 512)), (12, (16, 20), (125, 160)), (3, (8, 8), (8, 8)), (8, (9, 7), (40, 33)), (16, (5, 6), (64, 64))])
+def test_loss_backward_tiled_equals_gather(hip, K, hw, HW):
+    """The tiled backward (each pixel's softmax once per 4x4 cell tile, separable weights in two LDS passes) against the per-cell gather kernel
+    (SEGLAND_CE_BWD_GATHER / the fallback for footprints that do not fit the LDS) and torch autograd: ignored rows, odd sizes, ragged tiles,
+    the identity resize, 16 classes."""
+    import subprocess, sys, os
+    from segland_amd import ops
+    preds = fm.sym('lt/p%d' % K, (2, K, hw[0], hw[1]), 3.0)
+    target = fm.formula_mask(2, HW[0], HW[1], K, tag='lt/m%d' % K, block=8, ignore_rows=min(5, HW[0] // 2))
+    pr = preds.clone().requires_grad_(True)
+    ref = F.cross_entropy(F.interpolate(pr, size=HW, mode='bilinear', align_corners=True), target, ignore_index=255)
+    (ref * 0.7).backward()
+    gs = torch.full((1,), 0.7, device=DEV)
+    out = ops.upsample_ce_fwd(preds.to(DEV), target.to(DEV), 255)
+    dl = ops.upsample_ce_bwd(preds.to(DEV), target.to(DEV), out, gs, 255)
+    np.testing.assert_allclose(dl.cpu().numpy(), pr.grad.numpy(), rtol=1e-3, atol=2e-8)
+    assert torch.isfinite(dl).all()
+
+
 def test_pseudo_label_argmax_iou_bitexact(hip):
     from segland_amd import ops
     logits = fm.sym('pl/l', (2, 5, 64, 64), 2.0)
