@@ -17,6 +17,11 @@ if mode != 'plain':
     if mode == 'inplace':
         from segland_amd.engine import enable_inplace_bucket_gradients
         enable_inplace_bucket_gradients(net)
+    if mode == 'builtin':        # C++ all-reduce hook (averages), bucket views cached like the in-place mode
+        from segland_amd import engine as _e
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        net._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
+        register_optimizer_step_pre_hook(_e._cache_bucket_views)
 params = [p for p in model.parameters() if p.requires_grad]
 variant = sys.argv[3] if len(sys.argv) > 3 else ''
 batches = [bench.synthetic_batch(B, 512, dev, seed=k) for k in range(4 if 'b' in variant else 1)]
