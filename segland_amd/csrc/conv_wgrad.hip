@@ -492,6 +492,109 @@ __global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels, 3x3, stride 1, dilation 1 (layer1.conv2 at 128 x 128: the layers the review named at 116-157 TFLOP/s).  The generic kernels
+// give every tap its own blocks, which re-read dy and x nine times through the LDS (the launch is LDS-fill bound, and the pixel-pair trick that
+// makes 64 channels fit the 128-wide tiles discards half of its MFMAs).  Here a block owns 16 x 16-pixel tiles: the dy tile and the x patch WITH
+// its one-pixel halo go to the LDS once, and all nine taps read their shifted pixel rows from that patch (ds_read_b64_tr_b16, the reduction index
+// is the pixel).  Wave w accumulates taps {w, w+4, w+8}; persistent blocks; one [64][9][64] slab per block, summed by the fixed-order
+// column-sum kernel and turned into OIHW by the slab-reduce kernel (a slab written directly in OIHW order was 4-byte stores 36 B apart: 3x slower).  Row pitch 192 B: four pixel rows x 64 B tile the 64 banks (conflict-free transpose reads).
+constexpr int C3_T = 16;                       // tile edge
+constexpr int C3_PITCH = 192;                  // bytes per pixel row in the LDS (128 B of channels + 64 B pad)
+constexpr int C3_PW = C3_T + 2;                // patch edge
+__global__ __launch_bounds__(256) void conv_wgrad_c64k3_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ ws,
+                                                               int B, int H, int W, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* lx = smem;                                  // [18*18][192 B]
+  unsigned char* ld = smem + C3_PW * C3_PW * C3_PITCH;       // [256][192 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = cdiv(W, C3_T), ty = cdiv(H, C3_T);
+  f32x16_t acc[3][2][2];                                     // [tap slot][n block][c block]
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][i][j][r] = 0.f;
+  // transpose-read geometry (see conv_wgrad_kernel): 16-lane group g supplies rows 8(g>>1) + (l>>2) (+4 for the second read), columns 16(g&1) + 4(l&3)
+  const int g = lane >> 4, l = lane & 15;
+  const int rsub = 8 * (g >> 1) + (l >> 2), cofs = (16 * (g & 1) + 4 * (l & 3)) * 2;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int blk = tile;
+    const int bx = blk % tx; blk /= tx;
+    const int by = blk % ty; const int b = blk / ty;
+    const int y0 = by * C3_T, x0 = bx * C3_T;
+    for (int e = tid; e < C3_PW * C3_PW * 8; e += 256) {     // x patch with halo, zero outside the map: 8 x 16-byte chunks per pixel
+      const int ch8 = e & 7, pp = e >> 3, py = pp / C3_PW, px = pp - py * C3_PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *(const uint4*)(x + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
+      *(uint4*)(lx + pp * C3_PITCH + ch8 * 16) = v;
+    }
+    for (int e = tid; e < 256 * 8; e += 256) {               // dy tile, zero outside the map
+      const int ch8 = e & 7, pp = e >> 3;
+      const int iy = y0 + (pp >> 4), ix = x0 + (pp & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (iy < H && ix < W) v = *(const uint4*)(dy + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
+      *(uint4*)(ld + pp * C3_PITCH + ch8 * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int ks = 0; ks < 16; ++ks) {                        // k-step = one tile row of 16 pixels
+      uint4 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* a0 = ld + (ks * 16 + rsub) * C3_PITCH + i * 64 + cofs;
+        const uint2 lo = lds_tr16_b64(a0), hi = lds_tr16_b64(a0 + 4 * C3_PITCH);
+        af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int tap = wave + 4 * t;
+        if (tap < 9) {                                        // wave-uniform
+          const int ky = tap / 3, kx = tap - 3 * ky;
+          const unsigned char* rowb = lx + ((ks + ky) * C3_PW + kx + rsub) * C3_PITCH + cofs;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint2 lo = lds_tr16_b64(rowb + j * 64), hi = lds_tr16_b64(rowb + j * 64 + 4 * C3_PITCH);
+            const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc[t][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf), acc[t][i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // D layout: lane & 31 = input channel of the block (second operand row), register r = output channel (r&3) + 8(r>>2) + 4(lane>>5)
+  float* out = ws + (size_t)blockIdx.x * 64 * 64 * 9;
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < 9) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf, c = j * 32 + frow;
+            out[((size_t)n * 9 + tap) * 64 + c] = acc[t][i][j][r];       // slab layout [n][tap][c]: the lanes of a store are 32 consecutive c
+          }
+    }
+  }
+}
+inline bool c64k3_eligible(const SlConvDesc* d, int dw_cin_total, int dw_ci_off) {
+  static const bool off = getenv("SEGLAND_WGRAD_C64K3") && getenv("SEGLAND_WGRAD_C64K3")[0] == '0';
+  return !off && d->dtype == SL_BF16 && d->Cin == 64 && d->Cout == 64 && d->C1 == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 &&
+         dw_cin_total == 64 && dw_ci_off == 0 && (long long)d->B * d->H * d->W >= 65536;
+}
+inline int c64k3_blocks(const SlConvDesc* d) { const int t = d->B * cdiv(d->H, C3_T) * cdiv(d->W, C3_T); return t < 256 ? t : 256; }
+
 int g_use_tr = -1;
 int use_tr() {
   if (g_use_tr < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); g_use_tr = (e && e[0] == '0') ? 0 : 1; }
@@ -611,7 +714,9 @@ extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 
 extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 32) return 0;
-  return plan(d).ws_bytes;
+  size_t need = plan(d).ws_bytes;
+  if (c64k3_eligible(d, 64, 0)) { const size_t n2 = (size_t)(c64k3_blocks(d) + 1) * 64 * 64 * 9 * sizeof(float); if (n2 > need) need = n2; }
+  return need;
 }
 
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
@@ -633,6 +738,21 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
   SL_REQUIRE(d->Cout % 64 == 0 && d->C1 % 64 == 0 && c2 % 64 == 0, "conv bwd_weight: channels must be multiples of 64 (Cout %d, C1 %d, C2 %d)", d->Cout, d->C1, c2);
   (void)bke;
   SL_REQUIRE(c2 == 0 || x2, "conv bwd_weight: x2 missing");
+  if (c64k3_eligible(d, dw_cin_total, dw_ci_off) && use_tr()) {
+    const int nblk = c64k3_blocks(d), ntiles = d->B * cdiv(d->H, C3_T) * cdiv(d->W, C3_T);
+    const size_t need = (size_t)(nblk + 1) * 64 * 64 * 9 * sizeof(float);         // nblk slabs + their sum
+    if (workspace_bytes < need) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
+    const size_t lds = (size_t)(C3_PW * C3_PW + 256) * C3_PITCH;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_c64k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    hipLaunchKernelGGL(conv_wgrad_c64k3_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, d->B, d->H, d->W, ntiles);
+    SL_LAUNCH_CHECK("conv_wgrad_c64k3_kernel");
+    float* sum = (float*)workspace + (size_t)nblk * 64 * 64 * 9;
+    if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, stream)) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
+    SL_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return 0;
+  }
   const WgradPlan pl = plan(d);
   if (workspace_bytes < pl.ws_bytes) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, pl.ws_bytes); return SL_EWORKSPACE; }
   WgradParams p{};

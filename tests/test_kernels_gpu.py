@@ -124,6 +124,26 @@ def test_conv_fwd_dgrad_wgrad(hip, dtype, case):
         assert torch.equal(dw0, dw), 'transpose-read and scalar fragment paths must agree bit for bit'
 
 
+@pytest.mark.parametrize('B,H,W', [(4, 128, 128), (5, 120, 136)])
+def test_wgrad_c64_k3_patch_kernel(hip, B, H, W):
+    """layer1.conv2 (64 -> 64, 3x3) at map sizes that take the patch kernel (>= 65 536 pixels): dy tile + x patch with halo in the LDS once,
+    nine taps from shifted transpose reads; full and ragged 16 x 16 tiles, against torch and against the generic (per-tap) kernel on a
+    sub-batch below the threshold."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    x = rnd(fm.sym('c64/x%d' % H, (B, 64, H, W), 1.0), dtype)
+    w = rnd(fm.sym('c64/w', (64, 64, 3, 3), (3.0 / 576) ** 0.5), dtype).requires_grad_(True)
+    gy = rnd(fm.sym('c64/gy%d' % H, (B, 64, H, W), 1.0), dtype)
+    F.conv2d(x, w, None, 1, 1, 1).backward(gy)
+    spec = ops.ConvSpec(64, 64, 3, 1, 1, 1)
+    dw = ops.conv2d_bwd_weight(nhwc(x, dtype), nhwc(gy, dtype), spec)
+    assert_close(dw, w.grad, dtype, 'wgrad 64->64 3x3 (patch kernel)')
+    # the same layer on two images only (32 768 pixels): generic kernel; sum of per-image-pair gradients must agree with the full batch
+    if B == 4:
+        parts = [ops.conv2d_bwd_weight(nhwc(x[i:i + 2], dtype), nhwc(gy[i:i + 2], dtype), spec) for i in (0, 2)]
+        assert_close(parts[0] + parts[1], dw, dtype, 'patch kernel vs generic kernel')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('C1,C2,Cout', [(128, 64, 64), (256, 256, 256)])
 def test_conv_concat_bias_relu_addend_mask(hip, dtype, C1, C2, Cout):
