@@ -521,26 +521,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_c64k3_kernel(const bf16_t* __r
   // transpose-read geometry (see conv_wgrad_kernel): 16-lane group g supplies rows 8(g>>1) + (l>>2) (+4 for the second read), columns 16(g&1) + 4(l&3)
   const int g = lane >> 4, l = lane & 15;
   const int rsub = 8 * (g >> 1) + (l >> 2), cofs = (16 * (g & 1) + 4 * (l & 3)) * 2;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // the tile's 4 640 16-byte chunks (x patch with halo: 324 pixels, dy: 256 pixels, 8 chunks each) travel global -> registers -> LDS; the loads of
+  // the NEXT tile are issued before the MFMA loop of the current one and land while it runs
+  constexpr int NCH = (C3_PW * C3_PW + 256) * 8, CPT = (NCH + 255) / 256;        // 19 chunks per thread
+  uint4 stage[CPT];
+  auto fetch = [&](int tile) {
     int blk = tile;
     const int bx = blk % tx; blk /= tx;
     const int by = blk % ty; const int b = blk / ty;
     const int y0 = by * C3_T, x0 = bx * C3_T;
-    for (int e = tid; e < C3_PW * C3_PW * 8; e += 256) {     // x patch with halo, zero outside the map: 8 x 16-byte chunks per pixel
-      const int ch8 = e & 7, pp = e >> 3, py = pp / C3_PW, px = pp - py * C3_PW;
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int e = tid + u * 256;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *(const uint4*)(x + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
-      *(uint4*)(lx + pp * C3_PITCH + ch8 * 16) = v;
+      if (e < C3_PW * C3_PW * 8) {
+        const int ch8 = e & 7, pp = e >> 3, py = pp / C3_PW, px = pp - py * C3_PW;
+        const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *(const uint4*)(x + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
+      } else if (e < NCH) {
+        const int e2 = e - C3_PW * C3_PW * 8, ch8 = e2 & 7, pp = e2 >> 3;
+        const int iy = y0 + (pp >> 4), ix = x0 + (pp & 15);
+        if (iy < H && ix < W) v = *(const uint4*)(dy + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
+      }
+      stage[u] = v;
     }
-    for (int e = tid; e < 256 * 8; e += 256) {               // dy tile, zero outside the map
-      const int ch8 = e & 7, pp = e >> 3;
-      const int iy = y0 + (pp >> 4), ix = x0 + (pp & 15);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (iy < H && ix < W) v = *(const uint4*)(dy + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
-      *(uint4*)(ld + pp * C3_PITCH + ch8 * 16) = v;
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int e = tid + u * 256;
+      if (e < C3_PW * C3_PW * 8) *(uint4*)(lx + (e >> 3) * C3_PITCH + (e & 7) * 16) = stage[u];
+      else if (e < NCH) { const int e2 = e - C3_PW * C3_PW * 8; *(uint4*)(ld + (e2 >> 3) * C3_PITCH + (e2 & 7) * 16) = stage[u]; }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 2
     for (int ks = 0; ks < 16; ++ks) {                        // k-step = one tile row of 16 pixels
       uint4 af[2];
