@@ -1121,6 +1121,157 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels, 3x3, stride 1, dilation 1 (layer1.conv2 at 128 x 128), forward and data gradient.  The tile kernels above fetch the pixel
+// operand once per tap: with only 64 output channels per 64 input channels that makes the launch LDS-fill bound at a third of what the MFMAs
+// could do.  Here a persistent block owns 16 x 16-pixel tiles: the input patch WITH its halo goes to the LDS once (324 pixels for 256 outputs)
+// and the nine taps are nine shifted 16-byte reads per fragment; the whole weight tensor (64 x 576) sits in the LDS in MFMA fragment order; the
+// next tile's patch is loaded into registers while the current one is multiplied.  Same result layout, same BN statistic partials (one row per
+// TILE: sl_conv2d_stat_rows knows) as the generic path.  mode 1 (data gradient) = the same kernel on the transposed weights with the taps flipped.
+constexpr int C64_T = 16, C64_PW = C64_T + 2, C64_PITCH = 144;        // 128 B of channels + 16 B pad: conflict-free 16-byte fragment reads
+constexpr int C64_WFRAG = 2 * 36 * 64 * 16;                           // weights in fragment order, bytes
+constexpr int C64_LDS = C64_WFRAG + C64_PW * C64_PW * C64_PITCH + 4 * 2 * 64 * (int)sizeof(float);
+__global__ __launch_bounds__(256) void conv_c64k3_kernel(ConvGemmParams p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* wl = (uint4*)smem;                                           // [nb][ks][lane]
+  unsigned char* patch = smem + C64_WFRAG;                            // [18*18][144 B]; the output tile [256][144 B] takes its place after the MFMA loop
+  float* red = (float*)(patch + C64_PW * C64_PW * C64_PITCH);         // [4][2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, fh = lane >> 5;
+  const int H = p.Hs, W = p.Ws;
+  const int tx = cdiv(W, C64_T), ty = cdiv(H, C64_T);
+  const bf16_t* src = (const bf16_t*)p.src1;
+  for (int e = tid; e < 2 * 36 * 64; e += 256) {                      // wt [64][9][64] -> fragments: rows nb*32 + l31, tap ks/4, channels (ks%4)*16 + fh*8 .. +8
+    const int ln = e & 63, ks = (e >> 6) % 36, nb = (e >> 6) / 36;
+    wl[e] = *(const uint4*)((const bf16_t*)p.wt + ((size_t)(nb * 32 + (ln & 31)) * 9 + (ks >> 2)) * 64 + (ks & 3) * 16 + (ln >> 5) * 8);
+  }
+  constexpr int NCH = C64_PW * C64_PW * 8, CPT = (NCH + 255) / 256;   // 11 chunks of 16 B per thread
+  uint4 stage[CPT];
+  auto fetch = [&](int tile) {
+    int blk = tile;
+    const int bx = blk % tx; blk /= tx;
+    const int by = blk % ty; const int b = blk / ty;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int e = tid + u * 256;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (e < NCH) {
+        const int ch8 = e & 7, pp = e >> 3, py = pp / C64_PW, px = pp - py * C64_PW;
+        const int iy = by * C64_T - 1 + py, ix = bx * C64_T - 1 + px;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = *(const uint4*)(src + ((size_t)(b * H + iy) * W + ix) * 64 + ch8 * 8);
+      }
+      stage[u] = v;
+    }
+  };
+  int pbase[2];                                                       // patch byte offset of this lane's pixel in row block rb (tap (0,0))
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const int pidx = wave * 64 + rb * 32 + l31;
+    pbase[rb] = ((pidx >> 4) * C64_PW + (pidx & 15)) * C64_PITCH + fh * 16;
+  }
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int blk = tile;
+    const int bx = blk % tx; blk /= tx;
+    const int by = blk % ty; const int b = blk / ty;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      const int e = tid + u * 256;
+      if (e < NCH) *(uint4*)(patch + (e >> 3) * C64_PITCH + (e & 7) * 16) = stage[u];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.f;
+#pragma unroll 4
+    for (int ks = 0; ks < 36; ++ks) {
+      int tap = ks >> 2;
+      if (p.mode) tap = 8 - tap;                                      // data gradient: the correlation with the flipped window
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int toff = (ky * C64_PW + kx) * C64_PITCH + (ks & 3) * 32;
+      const uint4 w0 = wl[(0 * 36 + ks) * 64 + lane], w1 = wl[(1 * 36 + ks) * 64 + lane];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const uint4 a = *(const uint4*)(patch + pbase[rb] + toff);
+        acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w0), __builtin_bit_cast(bf16x8_t, a), acc[rb][0], 0, 0, 0);
+        acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1), __builtin_bit_cast(bf16x8_t, a), acc[rb][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                                  // the patch is dead: stage the tile (lane = pixel, register r = channel (r&3) + 8(r>>2) + 4fh)
+    unsigned char* outt = patch;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int pidx = wave * 64 + rb * 32 + l31;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint2 pk;
+          pk.x = (unsigned)f2bf(acc[rb][nb][4 * q + 0]) | ((unsigned)f2bf(acc[rb][nb][4 * q + 1]) << 16);
+          pk.y = (unsigned)f2bf(acc[rb][nb][4 * q + 2]) | ((unsigned)f2bf(acc[rb][nb][4 * q + 3]) << 16);
+          *(uint2*)(outt + pidx * C64_PITCH + (nb * 32 + 8 * q + 4 * fh) * 2) = pk;
+        }
+    }
+    __syncthreads();
+    bf16_t* out = (bf16_t*)p.out;
+    float sa[8], sq[8];                                               // this thread's 8 channels (tid & 7) over its 8 pixels: column sums of the stored (rounded) tile
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sa[c] = 0.f; sq[c] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = tid + u * 256;
+      const int pidx = e >> 3, ch8 = e & 7;
+      const int oy = by * C64_T + (pidx >> 4), ox = bx * C64_T + (pidx & 15);
+      if (oy < H && ox < W) {
+        const uint4 v = *(const uint4*)(outt + pidx * C64_PITCH + ch8 * 16);
+        st16(out + ((size_t)(b * H + oy) * W + ox) * 64 + ch8 * 8, v);
+        if (p.stat_partial) {
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float lo = __uint_as_float(wv[c] << 16), hi = __uint_as_float(wv[c] & 0xffff0000u);
+            sa[2 * c] += lo; sq[2 * c] += lo * lo; sa[2 * c + 1] += hi; sq[2 * c + 1] += hi * hi;
+          }
+        }
+      }
+    }
+    if (p.stat_partial) {                                             // lanes 8 apart share the channel octet: three xor steps, then the four waves through the LDS
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) { sa[c] += __shfl_xor(sa[c], o); sq[c] += __shfl_xor(sq[c], o); }
+      if (lane < 8) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { red[(wave * 2 + 0) * 64 + lane * 8 + c] = sa[c]; red[(wave * 2 + 1) * 64 + lane * 8 + c] = sq[c]; }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int which = tid >> 6, ch = tid & 63;
+        p.stat_partial[((size_t)tile * 2 + which) * 64 + ch] = red[(0 * 2 + which) * 64 + ch] + red[(1 * 2 + which) * 64 + ch] + red[(2 * 2 + which) * 64 + ch] + red[(3 * 2 + which) * 64 + ch];
+      }
+    }
+    __syncthreads();                                                  // the next iteration overwrites the tile with its patch
+  }
+}
+
+static bool c64k3_shape(int dtype, int KH, int KW, int stride, int pad, int dil, int Cin, int C1, int Cout, long long M) {
+  static const bool off = getenv("SEGLAND_CONV_C64K3") && getenv("SEGLAND_CONV_C64K3")[0] == '0';
+  return !off && dtype == SL_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && Cin == 64 && C1 == 64 && Cout == 64 && M >= 65536;
+}
+
+int launch_c64k3(ConvGemmParams& p, hipStream_t st) {
+  const int ntiles = p.B * cdiv(p.Hs, C64_T) * cdiv(p.Ws, C64_T);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_c64k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS); attr_set = true; }
+  hipLaunchKernelGGL(conv_c64k3_kernel, dim3(ntiles < 256 ? ntiles : 256), dim3(256), C64_LDS, st, p, ntiles);
+  SL_LAUNCH_CHECK("conv_c64k3_kernel");
+  return 0;
+}
+
 int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3: glds 256-row 8-wave tiles, 4: 64-byte-row ring, 5 (default): half-tile slots with 128-byte rows where N % 256 == 0
 static int conv_variant() {
   if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '5') ? e[0] - '0' : 5; }
@@ -1167,6 +1318,11 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   }
   // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
   const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
+  if constexpr (sizeof(T) == 2) {
+    if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
+        !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2))
+      return launch_c64k3(p, st);
+  }
   if constexpr (sizeof(T) == 2) {
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
     if (big && v >= 5 && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
@@ -1234,6 +1390,7 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;
+  if (c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return d->B * cdiv(d->H, C64_T) * cdiv(d->W, C64_T);    // one row per 16 x 16 tile
   return cdiv(M, block_rows(M, d->KH * d->KW * d->Cin));
 }
 

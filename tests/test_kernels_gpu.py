@@ -144,6 +144,38 @@ def test_wgrad_c64_k3_patch_kernel(hip, B, H, W):
         assert_close(parts[0] + parts[1], dw, dtype, 'patch kernel vs generic kernel')
 
 
+@pytest.mark.parametrize('B,H,W', [(4, 128, 128), (5, 120, 136)])
+def test_conv_c64_k3_patch_kernel(hip, B, H, W):
+    """layer1.conv2 (64 -> 64, 3x3) forward and data gradient at map sizes that take the patch kernel (>= 65 536 pixels): input patch with
+    halo in the LDS once, nine taps from shifted fragment reads; full and ragged 16 x 16 tiles; result, BN statistic partials (one row per
+    tile) and data gradient against torch, and against the generic per-tap kernel (SEGLAND_CONV_C64K3 off is not switchable at run time, so
+    the generic kernel runs on a sub-batch below the threshold)."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    x = rnd(fm.sym('c64f/x%d' % H, (B, 64, H, W), 1.0), dtype).requires_grad_(True)
+    w = rnd(fm.sym('c64f/w', (64, 64, 3, 3), (3.0 / 576) ** 0.5), dtype)
+    gy = rnd(fm.sym('c64f/gy%d' % H, (B, 64, H, W), 1.0), dtype)
+    y_ref = F.conv2d(x, w, None, 1, 1, 1)
+    y_ref.backward(gy)
+    spec = ops.ConvSpec(64, 64, 3, 1, 1, 1)
+    wf, wb = ops.weight_prep(w.to(DEV), dtype)
+    xg, gyg = nhwc(x.detach(), dtype), nhwc(gy, dtype)
+    y, part = ops.conv2d_fwd(xg, wf, spec, want_stats=True)
+    assert part.shape[0] == B * ((H + 15) // 16) * ((W + 15) // 16)
+    assert_close(nchw(y), y_ref, dtype, 'fwd 64->64 3x3 (patch kernel)')
+    s = part.sum(0).cpu()
+    assert_close(s[0], y_ref.detach().sum((0, 2, 3)), dtype, 'stat sum', scale=float(y_ref.abs().sum((0, 2, 3)).max()))
+    assert_close(s[1], (y_ref.detach() ** 2).sum((0, 2, 3)), dtype, 'stat sq')
+    dx = ops.conv2d_bwd_data(gyg, wb, spec, (H, W))
+    assert_close(nchw(dx), x.grad, dtype, 'dgrad 64->64 3x3 (patch kernel)')
+    # same accumulation order per output element in both kernels (tap-major, 16 channels per MFMA): the rounded results agree bit for bit
+    y2 = torch.cat([ops.conv2d_fwd(xg[i:i + 2].contiguous(), wf, spec, want_stats=False)[0] for i in range(0, B - 1, 2)])
+    dx2 = torch.cat([ops.conv2d_bwd_data(gyg[i:i + 2].contiguous(), wb, spec, (H, W)) for i in range(0, B - 1, 2)])
+    n = y2.shape[0]
+    assert_close(y2.float(), y[:n].float(), dtype, 'patch kernel vs generic kernel (fwd)')
+    assert_close(dx2.float(), dx[:n].float(), dtype, 'patch kernel vs generic kernel (dgrad)')
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('C1,C2,Cout', [(128, 64, 64), (256, 256, 256)])
 def test_conv_concat_bias_relu_addend_mask(hip, dtype, C1, C2, Cout):
