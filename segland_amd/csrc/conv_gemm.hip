@@ -1272,6 +1272,252 @@ int launch_c64k3(ConvGemmParams& p, hipStream_t st) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short-K 1x1 convs (64 / 128 / 256 input channels, stride 1, >= 65 536 pixels): out[M][N] = A[M][K] x W[N][K]^T is bound by the HBM traffic of
+// `out` (and of the residual addend in the data gradient), not by the MFMAs: the tile kernels above spend a round per 256 x 256 tile on
+// load -> 1..4 K-tiles -> store with nothing overlapping the store.  Here the PIXEL operand is stationary: a block owns 256 rows, each of its
+// 8 waves keeps its 32 rows x K in registers as MFMA fragments (read once, straight from global memory) and walks over N in steps of 64
+// columns; only the weight rows of a step (64 x K, from the L2) go through a two-slot LDS ring (LDS-DMA, rows XOR-swizzled for the fragment
+// reads).  Per step a wave: issues its share of the next step's weight rows and this step's addend loads, runs 2 x K/16 MFMAs, stages its
+// 32 x 64 result through its own LDS patch (row-major, rounded), waits for everything it has in flight (the stores of the PREVIOUS step have
+// had a whole step to drain), adds / gates / stores 16 bytes per lane in full 128-byte lines, and meets the other waves at a barrier.
+// BN statistic partials (one row per 256-row block, like the tile kernels) come from the rounded values in the store loop.
+// SKEW: the two waves of a SIMD (w, w + 4) run HALF A STEP APART: while waves 0-3 multiply step s (matrix pipe), waves 4-7 add / gate / store
+// step s - 1 (VALU + memory), and vice versa -- two barriers per step; waves 0-3 issue all the LDS-DMA.
+template <int KS> struct SkGeom {
+  static constexpr int RB = KS * 32;                                   // operand row bytes (K bf16)
+  static constexpr int BSTEP = 64 * RB;                                // weight rows of one step
+  static constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;     // 32 rows x (128 B + pad) per wave
+  static constexpr int OFF_STG = 2 * BSTEP, OFF_RED = OFF_STG + 8 * STG_WAVE;
+  static constexpr int LDS = OFF_RED + 2 * 8 * 2 * 64 * (int)sizeof(float);      // red[parity][wave][sum, sq][64 columns]
+};
+template <int KS> __device__ __forceinline__ int sk_swz(int row) { return KS == 16 ? (row & 31) : (KS == 8 ? (row & 15) : ((row >> 1) & 7)); }
+// sums over the lanes 8, 16 and 32 apart (the lanes of a wave that share lane & 7), without the LDS: one rotation inside the 16-lane rows, then the
+// row swaps of gfx950 (permlane16_swap: odd rows of the first operand <-> even rows of the second; permlane32_swap: upper half <-> lower half)
+__device__ __forceinline__ float sk_sum_8_16_32(float v) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));       // row_ror:8
+  u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+template <int KS, int MODE, bool SKEW>       // MODE 1: store (+ statistics), 2: + (bit-gated) addend
+__global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(ConvGemmParams p) {
+  using G = SkGeom<KS>;
+  using T = bf16_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                                           // SKEW: 0 leads, 1 is half a step behind
+  const int l31 = lane & 31, fh = lane >> 5;
+  const int bm = blockIdx.x;
+  const int NS = p.N / 64;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // weight rows of a step: 2 KS wave-instructions of 1 KiB shared by the issuing waves; the swizzle is applied to the SOURCE chunk (the LDS side of LDS-DMA is lane-linear)
+  constexpr int NWI = SKEW ? 4 : 8, NI = 2 * KS / NWI, LPR = 2 * KS, RPI = 64 / LPR;
+  const int iw = SKEW ? (wave & 3) : wave;
+  const bool issuer = !SKEW || grp == 0;
+  const unsigned char* bsrc[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (iw * NI + j) * RPI + lane / LPR, pos = lane % LPR;
+    bsrc[j] = (const unsigned char*)p.wt + (size_t)row * G::RB + ((pos ^ sk_swz<KS>(row)) << 4);
+  }
+  auto issueB = [&](int s, int buf) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) glds16_asm(bsrc[j] + (size_t)s * G::BSTEP, lds_base + buf * G::BSTEP + (iw * NI + j) * 1024);
+  };
+  if (issuer) issueB(0, 0);
+  uint4 a[KS];
+  {
+    const unsigned char* arow = (const unsigned char*)p.src1 + ((size_t)bm * 256 + wave * 32 + l31) * G::RB + fh * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = *(const uint4*)(arow + ks * 32);
+  }
+  int foff[KS];
+  {
+    const int x = sk_swz<KS>(l31);                                     // rows l31 and 32 + l31 of the step share the swizzle (all three patterns have period <= 32)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) foff[ks] = l31 * G::RB + (((2 * ks + fh) ^ x) << 4);
+  }
+  unsigned char* stg = smem + G::OFF_STG + wave * G::STG_WAVE;
+  float* red = (float*)(smem + G::OFF_RED);
+  const int srow = lane >> 3, sch = lane & 7;                          // store phase: row it * 8 + srow, 16-byte chunk sch of the wave's 32 x 64 patch (a full 128-byte line per row)
+  const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
+  uint4 addv[4];
+  // the gate bytes of the block's 256 rows (N / 8 per row, contiguous over the rows) are copied to the LDS once: read step by step from global memory, each step would
+  // pull 8 useful bytes out of every row's line, and 256 lines per step do not survive in the 32 KiB L1 next to the addend stream (measured: 58 -> 73 us on 1024 -> 256)
+  const int mpitch = p.N / 8 + 16;
+  unsigned char* msk = smem + G::OFF_RED;
+  if (MODE == 2 && p.addend_mask) {
+    const int cpr = p.N / 128;                                         // 16-byte chunks per row
+    const unsigned char* src = p.addend_mask + (size_t)bm * 256 * (p.N / 8);
+    for (int e = tid; e < 256 * cpr; e += 512) {
+      const int row = e / cpr, c = e - row * cpr;
+      *(uint4*)(msk + row * mpitch + c * 16) = *(const uint4*)(src + (size_t)e * 16);
+    }
+  }
+
+  auto multiply = [&](int s) {
+    const int cur = s & 1;
+    if (issuer && s + 1 < NS) issueB(s + 1, cur ^ 1);
+    if constexpr (MODE == 2) {
+      const int ncol = s * 64 + sch * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
+    }
+    f32x16_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned char* bb = smem + cur * G::BSTEP;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const uint4 b0 = *(const uint4*)(bb + foff[ks]), b1 = *(const uint4*)(bb + 32 * G::RB + foff[ks]);
+      Mma<T>::run(b0, a[ks], acc[0]);
+      Mma<T>::run(b1, a[ks], acc[1]);
+    }
+    // D layout: lane = pixel (l31), register r = column (r & 3) + 8 (r >> 2) + 4 fh of column half j
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 v;
+        v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[j][4 * q + 0], acc[j][4 * q + 1]}, bf16x2_t));
+        v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[j][4 * q + 2], acc[j][4 * q + 3]}, bf16x2_t));
+        *(uint2*)(stg + l31 * G::STG_PITCH + 64 * j + 16 * q + 8 * fh) = v;
+      }
+  };
+
+  auto store = [&](int s) {
+    const int cur = s & 1;
+    const int ncol = s * 64 + sch * 8;
+    wait_vmcnt<0>();                                                   // the next step's weight rows, this step's addend, the previous step's stores
+    float sa[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint4 raw = *(const uint4*)(stg + (it * 8 + srow) * G::STG_PITCH + sch * 16);
+      T* o = (T*)p.out + (orow + it * 8) * p.N + ncol;
+      if constexpr (MODE == 1) {
+        st16(o, raw);
+        if (p.stat_partial) {
+          const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float lo = __uint_as_float(w[c] << 16), hi = __uint_as_float(w[c] & 0xffff0000u);
+            sa[2 * c] += lo; sq[2 * c] += lo * lo; sa[2 * c + 1] += hi; sq[2 * c + 1] += hi * hi;
+          }
+        }
+      } else {
+        uint4 ad = addv[it];
+        if (p.addend_mask) {
+          const unsigned b = msk[(wave * 32 + it * 8 + srow) * mpitch + s * 8 + sch];
+          ad.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
+          ad.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
+          ad.z &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
+          ad.w &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
+        }
+        const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w}, aw[4] = {ad.x, ad.y, ad.z, ad.w};
+        unsigned ow[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x2_t v = (f32x2_t){__uint_as_float(rw[c] << 16) + __uint_as_float(aw[c] << 16), __uint_as_float(rw[c] & 0xffff0000u) + __uint_as_float(aw[c] & 0xffff0000u)};
+          ow[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        }
+        st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
+      }
+    }
+    if (MODE == 1 && p.stat_partial) {                                 // lanes 8 apart share the column octet
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sa[e] = sk_sum_8_16_32(sa[e]); sq[e] = sk_sum_8_16_32(sq[e]); }
+      if (lane < 8) {
+        float* r0 = red + ((cur * 8 + wave) * 2) * 64 + sch * 8;
+        *(float4*)(r0) = make_float4(sa[0], sa[1], sa[2], sa[3]); *(float4*)(r0 + 4) = make_float4(sa[4], sa[5], sa[6], sa[7]);
+        *(float4*)(r0 + 64) = make_float4(sq[0], sq[1], sq[2], sq[3]); *(float4*)(r0 + 68) = make_float4(sq[4], sq[5], sq[6], sq[7]);
+      }
+    }
+  };
+  auto finalize = [&](int s, int t0) {                                 // 128 threads from t0 on, after the barrier behind the last store phase of step s
+    if (MODE == 1 && p.stat_partial && tid >= t0 && tid < t0 + 128) {
+      const int which = ((tid - t0) >> 6) & 1, col = tid & 63;
+      const float* r0 = red + ((s & 1) * 16 + which) * 64 + col;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += r0[k * 128];
+      p.stat_partial[((size_t)bm * 2 + which) * p.N + s * 64 + col] = t;
+    }
+  };
+
+  // raw barriers: __syncthreads() would also wait for the stores in flight.  LDS writes (statistic partials; the staging patch is wave-private) are drained explicitly.
+  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  wait_vmcnt<0>();
+  bar();
+  if constexpr (!SKEW) {
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      multiply(s);
+      store(s);
+      bar();
+      finalize(s, 0);
+    }
+  } else if (grp == 0) {
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      multiply(s);
+      bar();
+      store(s);
+      bar();
+    }
+    bar();
+  } else {
+    bar();
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      multiply(s);
+      bar();
+      store(s);
+      bar();
+      finalize(s, 256);
+    }
+  }
+}
+
+static int sk_min_n() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_CONV_SK_MINN"); v = e ? atoi(e) : 64; } return v; }
+static bool sk_shape(int dtype, int KH, int KW, int stride, int pad, int Cin, int C1, int N, long long M) {
+  static const bool off = getenv("SEGLAND_CONV_SK") && getenv("SEGLAND_CONV_SK")[0] == '0';
+  return !off && dtype == SL_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && C1 == Cin && (Cin == 64 || Cin == 128 || Cin == 256) &&
+         N % 64 == 0 && N >= sk_min_n() && M >= 65536 && M % 256 == 0;
+}
+
+template <int KS, int MODE, bool SKEW>
+int launch_sk_t(ConvGemmParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_sk_kernel<KS, MODE, SKEW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  const int lds = MODE == 2 && p.addend_mask ? SkGeom<KS>::OFF_RED + 256 * (p.N / 8 + 16) : SkGeom<KS>::LDS;      // statistic partials or the block's gate bytes behind the staging patches
+  hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, MODE, SKEW>), dim3(p.M / 256), dim3(512), lds, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_sk_kernel");
+  return 0;
+}
+template <int MODE, bool SKEW>
+int launch_sk_k(ConvGemmParams& p, hipStream_t st) {
+  return p.C1 == 256 ? launch_sk_t<16, MODE, SKEW>(p, st) : (p.C1 == 128 ? launch_sk_t<8, MODE, SKEW>(p, st) : launch_sk_t<4, MODE, SKEW>(p, st));
+}
+int launch_sk(ConvGemmParams& p, hipStream_t st) {
+  // measured (tools/sk_time.sh): half-a-step-apart wave groups pay where the store phase carries the statistics (256 -> 1024 forward: 53 -> 49 us) and cost where it is pure
+  // memory traffic (data gradient 1024 -> 256: 41 -> 47 us, with addend 58 -> 67 us).  bit 0: statistics, bit 1: plain store, bit 2: addend
+  static const int skew = getenv("SEGLAND_CONV_SK_SKEW") ? atoi(getenv("SEGLAND_CONV_SK_SKEW")) : 1;
+  p.gridM = p.M / 256; p.gridN = 1;
+  if (p.addend) return (skew & 4) ? launch_sk_k<2, true>(p, st) : launch_sk_k<2, false>(p, st);
+  return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);
+}
+
 int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3: glds 256-row 8-wave tiles, 4: 64-byte-row ring, 5 (default): half-tile slots with 128-byte rows where N % 256 == 0
 static int conv_variant() {
   if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '5') ? e[0] - '0' : 5; }
@@ -1322,6 +1568,12 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2))
       return launch_c64k3(p, st);
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (v >= 5 && sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
+        !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask) &&
+        (!p.addend_mask || (p.N % 128 == 0 && p.N <= 1024)))
+      return launch_sk(p, st);
   }
   if constexpr (sizeof(T) == 2) {
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
@@ -1380,6 +1632,9 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
   if (v == 1) return 1000000 + 128000 + (n128 ? 128 : 64);
   const bool big = block_rows(M, ktot) == 256;
+  if (v >= 2 && d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
+  // the short-K kernel serves the unshaped epilogues (training-mode convs: raw result + statistics, or + addend); folded eval-mode convs of these shapes stay on the tile kernels
+  if (v >= 5 && sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
   if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
   if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
   if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));

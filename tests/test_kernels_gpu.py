@@ -176,6 +176,51 @@ def test_conv_c64_k3_patch_kernel(hip, B, H, W):
     assert_close(dx2.float(), dx[:n].float(), dtype, 'patch kernel vs generic kernel (dgrad)')
 
 
+@pytest.mark.parametrize('K,N', [(64, 256), (128, 512), (256, 1024), (256, 512)])
+def test_conv_short_k_stationary_kernel(hip, K, N):
+    """1x1 convs with 64 / 128 / 256 input channels at >= 65 536 pixels run on the pixel-stationary kernel (conv_gemm_sk_kernel): forward with
+    BN statistic partials (one row per 256 pixels), plain data gradient, data gradient + addend and + bit-gated addend, against an fp32 matmul
+    of the same bf16-rounded operands and bit for bit against the tile kernels (SEGLAND_CONV_SK_MINN is read once, so the tile kernels run a
+    32 768-pixel half of the same problem, below the kernel's threshold)."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    B, H, W = 4, 128, 128
+    g = torch.Generator(device='cpu').manual_seed(K * 7 + N)
+    x = torch.randn(B, H, W, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, 1, 1, generator=g) * (3.0 / K) ** 0.5).to(dtype).float().to(DEV)
+    spec = ops.ConvSpec(K, N, 1, 1, 0, 1)
+    wf, wb = ops.weight_prep(w, dtype)
+    # forward: x [M, K] x w [N, K]^T
+    y, part = ops.conv2d_fwd(x, wf, spec, want_stats=True)
+    y_ref = x.float().reshape(-1, K) @ w.reshape(N, K).t()
+    assert part.shape[0] == B * H * W // 256
+    assert_close(y.reshape(-1, N), y_ref, dtype, 'fwd')
+    yr = y.float().reshape(-1, N)
+    s = part.sum(0)
+    assert_close(s[0], yr.sum(0), torch.float32, 'stat sum (of the rounded result)', scale=float(yr.abs().sum(0).max()), factor=10)
+    assert_close(s[1], (yr * yr).sum(0), torch.float32, 'stat sq', factor=10)
+    y_half, _ = ops.conv2d_fwd(x[:2].contiguous(), wf, spec, want_stats=True)
+    assert torch.equal(y_half, y[:2]), 'stationary kernel vs tile kernel (fwd) must agree bit for bit'
+    # data gradient of a conv N -> K... the same GEMM shape is reached with the roles swapped: conv K_in = N_ch -> K, dy has K channels
+    spec_b = ops.ConvSpec(N, K, 1, 1, 0, 1)                      # conv N -> K; its data gradient maps dy [M, K] to dx [M, N]
+    wv = (torch.randn(K, N, 1, 1, generator=g) * (3.0 / K) ** 0.5).to(dtype).float().to(DEV)
+    _, wvb = ops.weight_prep(wv, dtype)
+    dy = torch.randn(B, H, W, K, generator=g).to(dtype).to(DEV)
+    dx_ref = dy.float().reshape(-1, K) @ wv.reshape(K, N)
+    dx = ops.conv2d_bwd_data(dy, wvb, spec_b, (H, W))
+    assert_close(dx.reshape(-1, N), dx_ref, dtype, 'dgrad')
+    add = torch.randn(B, H, W, N, generator=g).to(dtype).to(DEV)
+    dx = ops.conv2d_bwd_data(dy, wvb, spec_b, (H, W), addend=add)
+    assert_close(dx.reshape(-1, N), dx_ref + add.float().reshape(-1, N), dtype, 'dgrad + addend')
+    gate = torch.randn(B, H, W, N, generator=g).to(dtype).to(DEV)
+    one = torch.ones(N, device=DEV)
+    _, bits = ops.bn_act(gate, one, torch.zeros_like(one), relu=True, want_mask=True)
+    dxg = ops.conv2d_bwd_data(dy, wvb, spec_b, (H, W), addend=add, addend_mask=bits)
+    assert_close(dxg.reshape(-1, N), dx_ref + (add.float() * (gate.float() > 0)).reshape(-1, N), dtype, 'dgrad + bit-gated addend')
+    dxg_half = ops.conv2d_bwd_data(dy[:2].contiguous(), wvb, spec_b, (H, W), addend=add[:2].contiguous(), addend_mask=bits[:bits.numel() // 2].contiguous())
+    assert torch.equal(dxg_half, dxg[:2]), 'stationary kernel vs tile kernel (dgrad + gated addend) must agree bit for bit'
+
+
 @pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('C1,C2,Cout', [(128, 64, 64), (256, 256, 256)])
 def test_conv_concat_bias_relu_addend_mask(hip, dtype, C1, C2, Cout):
