@@ -252,7 +252,8 @@ def main():
         with open(a.profile_table, 'w') as f:
             f.write('# one instrumented step, %s %s batch %d: conv launches by kernel and shape (HIP events on the launch stream)\n' % (a.backbone, a.dtype, a.batch))
             for fam in sorted(table.values(), key=lambda e: -e['ms_total']):
-                f.write('== %-58s calls %4d  %8.3f ms  %9.1f GFLOP  %7.1f TFLOP/s\n' % (fam['family'], fam['calls'], fam['ms_total'], fam['gflop'], fam['gflop'] / max(fam['ms_total'], 1e-9)))
+                f.write('== %-58s calls %4d  %8.3f ms  %9.1f GFLOP  %7.1f TFLOP/s  %6.2f TB/s\n' % (fam['family'], fam['calls'], fam['ms_total'], fam['gflop'], fam['gflop'] / max(fam['ms_total'], 1e-9),
+                                                                                                      fam.get('gbytes', 0.0) / max(fam['ms_total'], 1e-9)))
                 for shape, (n, ms, gf) in sorted(fam['shapes'].items(), key=lambda kv: -kv[1][1]):
                     f.write('   %-50s %4d %9.3f ms %9.1f GFLOP %8.1f TFLOP/s\n' % (shape, n, ms, gf, gf / max(ms, 1e-9)))
             f.write('# total conv time %.2f ms, total conv GFLOP %.1f\n' % (sum(e['ms_total'] for e in table.values()), sum(e['gflop'] for e in table.values())))
@@ -285,6 +286,10 @@ def main():
         fams = {}
         for k_, e in table.items():
             fams[k_] = {'tflops': round(e['gflop'] / max(e['ms_total'], 1e-9), 1), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls']}
+            if e.get('gbytes'):
+                # algorithmic operand + result bytes (activations in and out, weights once, residual addend + gate bits): the HBM-bound families
+                # (conv_gemm_sk_kernel: K <= 256 1x1 convs; conv_c64k3_kernel) are judged on this figure against the 8 TB/s peak, the MFMA-bound ones on tflops
+                fams[k_]['gb_per_s'] = round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0)
         for k_, e in table_bytes.items():
             fams[k_] = {'gb_per_s': round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls'], 'gbytes_per_step': round(e['gbytes'], 3)}
         out['families'] = fams               # one instrumented (un-timed) step: MFMA families in TFLOP/s, BatchNorm passes in algorithmic GB/s vs the 8 TB/s HBM peak

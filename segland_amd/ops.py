@@ -53,7 +53,7 @@ class _Profiler:
     Off by default.  Launches are attributed to the kernel they are dispatched to (`family`, the name rocprofv3 shows);
     `only` restricts timing to one family so the timed region carries just those event pairs."""
 
-    FAMILY = {5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
+    FAMILY = {7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
         self.on, self.only, self.rec, self.rec_bytes = False, None, {}, {}
@@ -77,14 +77,17 @@ class _Profiler:
         e0.record()
         return fam, kind, e0, e1, d
 
-    def end(self, tok):
+    def end(self, tok, extra_bytes=0):
+        """extra_bytes: operand bytes of the launch beyond input + output activations (the residual addend and its gate bits in a data gradient)."""
         if tok is None:
             return
         fam, kind, e0, e1, d = tok
         e1.record()
         gflop = 2.0 * d.B * d.Ho * d.Wo * d.Cout * d.Cin * d.KH * d.KW / 1e9
+        es = 2 if d.dtype == SL_BF16 else 4
+        gbytes = ((d.B * d.H * d.W * d.Cin + d.B * d.Ho * d.Wo * d.Cout + d.Cout * d.Cin * d.KH * d.KW) * es + extra_bytes) / 1e9
         shape = '%s B%d %dx%d %d->%d k%d s%d d%d' % (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
-        self.rec.setdefault(fam, []).append((e0, e1, gflop, shape))
+        self.rec.setdefault(fam, []).append((e0, e1, gflop, shape, gbytes))
 
     def begin_bytes(self, family, nbytes):
         """HBM-bound kernel families (BatchNorm passes): algorithmic bytes instead of FLOPs; only in the instrumented (un-timed) step."""
@@ -115,10 +118,10 @@ class _Profiler:
         torch.cuda.synchronize()
         out = {}
         for fam, evs in self.rec.items():
-            ent = out[fam] = {'family': fam, 'calls': 0, 'ms_total': 0.0, 'gflop': 0.0, 'shapes': {}}
-            for e0, e1, gflop, shape in evs:
+            ent = out[fam] = {'family': fam, 'calls': 0, 'ms_total': 0.0, 'gflop': 0.0, 'gbytes': 0.0, 'shapes': {}}
+            for e0, e1, gflop, shape, gbytes in evs:
                 ms = e0.elapsed_time(e1)
-                ent['calls'] += 1; ent['ms_total'] += ms; ent['gflop'] += gflop
+                ent['calls'] += 1; ent['ms_total'] += ms; ent['gflop'] += gflop; ent['gbytes'] += gbytes
                 sh = ent['shapes'].setdefault(shape, [0, 0.0, 0.0])
                 sh[0] += 1; sh[1] += ms; sh[2] += gflop
         self.rec = {}
@@ -216,7 +219,8 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
     assert dx.numel() == B * H * W * spec.cin and dx.dtype == dy.dtype
     tok = PROFILER.begin('conv_dgrad', d)
     check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(addend_mask), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
-    PROFILER.end(tok)
+    if tok is not None:
+        PROFILER.end(tok, sum(t.numel() * t.element_size() for t in (addend, addend_mask, mask_src) if t is not None))
     return dx
 
 

@@ -23,6 +23,7 @@ python3 $R/tools/prof_summary.py /tmp/prof_sw2 7 $O/r2_swin_kernel_stats.txt "be
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o b -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph > /dev/null 2>&1
 cd $R && python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_p8_kernel' 'conv_gemm_p8_kernel<bf16, 256, 256>' > /dev/null 2>&1; cp profiles/r2_traffic.json $O/r2_traffic.json 2>/dev/null
+python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_sk_kernel' 'conv_gemm_sk_kernel<bf16, 256, 64>' $O/r2_traffic_sk.json > /dev/null 2>&1      # the HBM-bound family: compare with gbytes / launches of the bench line's `families`
 ls -la $O
 head -c 400 $O/r2_bench_default.json; echo
 cat $O/r2_bench_ft.txt
