@@ -32,6 +32,8 @@ struct ConvGemmParams {
   void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
   int gridM, gridN;
+  int flags;                            // p8: bit 0 = counted first wait (SEGLAND_P8_COUNTED, default on)
+  unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
 
 template <typename T> struct Mma;
@@ -249,33 +251,41 @@ __device__ __forceinline__ void st16(T* dst, const uint4& v) {
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)dst);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// Barrier for LDS hand-offs inside the epilogues.  __syncthreads() carries a workgroup release fence: with global stores in flight it becomes
+// s_waitcnt vmcnt(0) + s_barrier, i.e. every pass (and the end of the tile) would wait for its stores to be acknowledged by the L2.  The hand-offs
+// here are LDS only (staged tile <-> store loop <-> statistic partials), so only the LDS counter is drained.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 struct EpiGeom {
   static constexpr int PITCH = BN * (int)sizeof(T) + 16;
   static constexpr int TILE_BYTES = BM * PITCH;
-  static constexpr int NPASS = TILE_BYTES > 150 * 1024 ? 2 : 1;
+  // SPLIT (conv_gemm_p8_kernel): always two passes of BM / 2 rows = the two operand halves, 66 KiB of staging: the persistent kernel keeps the next tile's first K-tile
+  // (four 16 KiB slots) in flight across the epilogue
+  static constexpr int NPASS = (SPLIT || TILE_BYTES > 150 * 1024) ? 2 : 1;
   static constexpr int MAIN_BYTES = 2 * (BM + BN) * 128;
   static constexpr int LDS_BYTES = (TILE_BYTES / NPASS) > MAIN_BYTES ? (TILE_BYTES / NPASS) : MAIN_BYTES;
-  static_assert(WM % NPASS == 0, "passes split whole wave rows");
+  static_assert(SPLIT || WM % NPASS == 0, "passes split whole wave rows");
 };
 
 // accumulators of the wave rows belonging to `pass` -> LDS staging tile (rounded to T), in the row-major layout the store phase reads
 // SPLIT: the half-tile kernel's wave layout (wave rows/columns interleaved over the two operand halves, see conv_gemm_p8_kernel).
 template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int pass, int wm, int wn, int lane, unsigned char* smem) {
-  using G = EpiGeom<T, BM, BN, WM, WN>;
+  using G = EpiGeom<T, BM, BN, WM, WN, SPLIT>;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(!SPLIT || (G::NPASS == 1 && TM == 4 && TN == 2), "split layout: one pass, 4x2 accumulator blocks per wave");
+  static_assert(!SPLIT || (G::NPASS == 2 && TM == 4 && TN == 2), "split layout: two passes (operand halves), 4x2 accumulator blocks per wave");
   const int fhalf = lane >> 5;
-  if (wm / (WM / G::NPASS) != pass) return;
-  const int lrow = (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
+  if constexpr (!SPLIT) { if (wm / (WM / G::NPASS) != pass) return; }
+  const int lrow = SPLIT ? 0 : (wm % (WM / G::NPASS)) * (BM / WM) + (lane & 31);
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int row = SPLIT ? (i >> 1) * (BM / 2) + wm * (BM / 4) + (i & 1) * 32 + (lane & 31) : lrow + i * 32;
+        if (SPLIT && (i >> 1) != pass) continue;                       // pass h = accumulator blocks of operand half h: every wave stages in both passes
+        const int row = SPLIT ? wm * (BM / 4) + (i & 1) * 32 + (lane & 31) : lrow + i * 32;
         const int col = SPLIT ? j * (BN / 2) + wn * (BN / 8) + 8 * q + 4 * fhalf : wn * (BN / WN) + j * 32 + 8 * q + 4 * fhalf;
         unsigned char* dst = smem + row * G::PITCH + col * (int)sizeof(T);
         if constexpr (sizeof(T) == 2) {
@@ -297,13 +307,13 @@ __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN /
 template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                    int lane, int tid, unsigned char* smem) {
-  using G = EpiGeom<T, BM, BN, WM, WN>;
+  using G = EpiGeom<T, BM, BN, WM, WN, SPLIT>;
   constexpr int EPC = 16 / sizeof(T);
   constexpr int NT = 64 * WM * WN;
   constexpr int CPR = BN / EPC;
   constexpr int RS = NT / CPR;
   constexpr int ROWS = BM / G::NPASS;
-  constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+  constexpr int NIT = ROWS / RS, CH = SPLIT ? 4 : (NIT < 8 ? NIT : 8);     // SPLIT: half of the accumulators and the next tile's row map are live across the first pass
   typedef __attribute__((ext_vector_type(2))) float f2_t;
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
@@ -323,7 +333,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
     epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
-    __syncthreads();
+    lds_barrier();
     const size_t goff = ((size_t)(bm * BM + pass * ROWS + r0) * p.N + ncol) * sizeof(T);
     unsigned char* o = (unsigned char*)p.out + goff;
     const unsigned char* l = smem + r0 * G::PITCH + cc * 16;
@@ -388,7 +398,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if constexpr (MODE == 1) {
     if (p.stat_partial) {
@@ -409,7 +419,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
           red[(wave * 2 + 1) * BN + cc * EPC + e] = fq[e];
         }
       }
-      __syncthreads();
+      lds_barrier();
       for (int e = tid; e < 2 * BN; e += NT) {
         const int which = e / BN, col = e % BN;
         float t = 0.f;
@@ -426,19 +436,31 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
                                                       int lane, int tid, unsigned char* smem);
 
 template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
-__device__ __forceinline__ void conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+__device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
   const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2;
-  if (full && !shaped && !p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-  else if (full && !shaped && !p.stat_partial) conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-  else conv_epilogue_generic<T, BM, BN, WM, WN, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  // Returns the number of vector-memory instructions the wave issued (loads + stores; every path below issues the same count in every wave), or -1 when that is
+  // not a compile-time fact of the path: the persistent half-tile kernel uses it to wait for loads that are OLDER than these instructions without waiting for them.
+  if (full && !shaped && !p.addend) {
+    if constexpr (SPLIT) asm volatile("; EPI_BEGIN mode1");
+    conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    if constexpr (SPLIT) asm volatile("; EPI_END mode1");
+    return SPLIT ? 16 + (p.stat_partial ? 1 : 0) : -1;                  // 2 passes x 8 row sweeps, + the statistic partial
+  } else if (full && !shaped && !p.stat_partial) {
+    if constexpr (SPLIT) asm volatile("; EPI_BEGIN mode2");
+    conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    if constexpr (SPLIT) asm volatile("; EPI_END mode2");
+    return SPLIT ? (p.addend_mask ? 48 : 32) : -1;                      // per sweep: addend load (+ gate byte) + store
+  }
+  conv_epilogue_generic<T, BM, BN, WM, WN, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  return -1;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool SPLIT>
 __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                       int lane, int tid, unsigned char* smem) {
-  using G = EpiGeom<T, BM, BN, WM, WN>;
+  using G = EpiGeom<T, BM, BN, WM, WN, SPLIT>;
   constexpr int EPC = 16 / sizeof(T);
   constexpr int NT = 64 * WM * WN;
   constexpr int CPR = BN / EPC;              // 16-byte chunks per tile row
@@ -454,11 +476,11 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
     epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
-    __syncthreads();
+    lds_barrier();
     // the residual / mask operands are fetched CH rows at a time BEFORE they are consumed: 16-byte loads of CH rows are in
     // flight together instead of one load -> use -> store latency chain per row
     const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2);
-    constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+    constexpr int NIT = ROWS / RS, CH = SPLIT ? 2 : (NIT < 8 ? NIT : 8);
     static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
     const int mrow0 = bm * BM + pass * ROWS + r0;
 #pragma unroll 1
@@ -551,7 +573,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (p.stat_partial) {
     // lanes l and l + CPR*k of a wave own the same chunk column
@@ -569,7 +591,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
         red[(wave * 2 + 1) * BN + cc * EPC + e] = ssq[e];
       }
     }
-    __syncthreads();
+    lds_barrier();
     for (int e = tid; e < 2 * BN; e += NT) {
       const int which = e / BN, col = e % BN;
       float t = 0.f;
@@ -955,7 +977,21 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
 // Wave (wm, wn) of the 2 x 4 grid owns rows {h*128 + wm*64 ..+63} and columns {h*128 + wn*32 ..+31} of both halves h.
 constexpr int P8_SLOT = 128 * 128;
 constexpr int P8_RING = 10 * P8_SLOT;         // A0 x3, A1 x2, B1 x2, B0 x3 = the whole 160 KiB
-constexpr int P8_LDS = EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES > P8_RING ? EpiGeom<bf16_t, 256, 256, 2, 4>::TILE_BYTES : P8_RING;
+constexpr int P8_LDS = P8_RING;
+static_assert(EpiGeom<bf16_t, 256, 256, 2, 4, true>::TILE_BYTES / 2 <= 6 * P8_SLOT, "the half-tile staging area must fit below the four slots of a prefetched K-tile");
+
+// PERSISTENT: the grid is min(tiles, 256) blocks (one per CU, 160 KiB of LDS each) and a block walks over tiles b, b + grid, ...  tools/p8_trace.py (s_memtime per
+// block) showed where a one-tile block spends its time on the short-K layers: 512 -> 2048 forward 15 % prologue (address set-up + the HBM latency of the first K-tile)
+// / 61 % main loop / 24 % epilogue, 2048 -> 512 data gradient with gated addend 15 / 46 / 40, 1024 -> 2048 10 / 75 / 15, 3x3 512 -> 512 6 / 90 / 4, plus ~800 ticks
+// between two blocks on a CU.  Here the NEXT tile's set-up and first K-tile (LDS-DMA into four slots) are issued right after the main loop, so that latency runs
+// under the epilogue; the epilogue stages the tile in two half-tile passes in the six slots the prefetch leaves free.  Physical slot order (16 KiB each):
+//   0,1 = A0 of K-tiles 1,2 (mod 3)   2 = A1 odd   3 = B1 odd   4,5 = B0 of K-tiles 1,2   | 6 = A0 of K-tile 0   7 = A1 even   8 = B1 even   9 = B0 of K-tile 0
+// vmcnt is in order over loads AND stores: the first wait of the next tile (all but the 8 LDS-DMA of its second K-tile) also covers the epilogue's stores, which by
+// then have had the set-up of the second K-tile to drain.
+__device__ __forceinline__ int p8_slot_a0(int j) { return (j == 0 ? 6 : j - 1) * P8_SLOT; }
+__device__ __forceinline__ int p8_slot_a1(int par) { return (par ? 2 : 7) * P8_SLOT; }
+__device__ __forceinline__ int p8_slot_b1(int par) { return (par ? 3 : 8) * P8_SLOT; }
+__device__ __forceinline__ int p8_slot_b0(int j) { return (j == 0 ? 9 : j + 3) * P8_SLOT; }
 
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   using T = bf16_t;
@@ -964,12 +1000,9 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int bid = blockIdx.x;
-  {
-    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int bm = bid / p.gridN, bn = bid % p.gridN;
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (p.trace) tr0 = __builtin_amdgcn_s_memtime();
+  const int ntiles = p.gridM * p.gridN;
   const int taps = p.KH * p.KW;
   const int CT = p.C1 + p.C2;
   const int nk = taps * (CT / 64);
@@ -982,36 +1015,40 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   const size_t wpitch = (size_t)taps * CT * sizeof(T);
 #pragma unroll
   for (int j = 0; j < 2; ++j) rsw[j] = (lpos ^ (((j * 8 + lr) >> 1) & 7)) * 16;
+  auto tile_of = [&](int t, int& bm, int& bn) {                        // XCD-aware order: the tiles a CU group of one XCD works on concurrently share their A rows
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = t & 7, idx = t >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bm = bid / p.gridN; bn = bid % p.gridN;
+  };
+  auto setup = [&](int bm, int bn) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = h * 128 + wave * 16 + j * 8 + lr;
-      const int m = bm * BM + row;
-      rbase[h][j] = 0; vmask[h][j] = 0;
-      if (m < p.M) {
-        const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
-        const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
-        const int ry = p.mode == 0 ? yd * p.stride - p.pad : yd + p.pad;
-        const int rx = p.mode == 0 ? xd * p.stride - p.pad : xd + p.pad;
-        rbase[h][j] = (b * p.Hs + ry) * p.Ws + rx;
-        unsigned mk = 0;
-        for (int t = 0; t < taps; ++t) {
-          const int ky = t / p.KW, kx = t - ky * p.KW;
-          const int ys = ry + sgn * ky * p.dil, xs = rx + sgn * kx * p.dil;
-          if ((unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws) mk |= 1u << t;
+      for (int j = 0; j < 2; ++j) {
+        const int row = h * 128 + wave * 16 + j * 8 + lr;
+        const int m = bm * BM + row;
+        rbase[h][j] = 0; vmask[h][j] = 0;
+        if (m < p.M) {
+          const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
+          const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
+          const int ry = p.mode == 0 ? yd * p.stride - p.pad : yd + p.pad;
+          const int rx = p.mode == 0 ? xd * p.stride - p.pad : xd + p.pad;
+          rbase[h][j] = (b * p.Hs + ry) * p.Ws + rx;
+          unsigned mk = 0;
+          for (int t = 0; t < taps; ++t) {
+            const int ky = t / p.KW, kx = t - ky * p.KW;
+            const int ys = ry + sgn * ky * p.dil, xs = rx + sgn * kx * p.dil;
+            if ((unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws) mk |= 1u << t;
+          }
+          vmask[h][j] = mk;
         }
-        vmask[h][j] = mk;
+        wptr[h][j] = (const unsigned char*)p.wt + (size_t)(bn * BN + row) * wpitch + rsw[j];
       }
-      wptr[h][j] = (const unsigned char*)p.wt + (size_t)(bn * BN + row) * wpitch + rsw[j];
-    }
+  };
   const unsigned char* zsrc = g_zero_page + lpos * 16;
   const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  // slot map: A0 -> 0,1,2 (K-tile mod 3)   A1 -> 3,4 (parity)   B1 -> 5,6 (parity)   B0 -> 7,8,9 (K-tile mod 3).  The two halves that
-  // are read early AND late in a K-tile (B0: phases 0 and 3; A0: fragments of the NEXT K-tile are fetched in phase 3) get a third slot,
-  // which takes their re-issue off the barrier chain: two barriers per K-tile.
-  auto issueA = [&](int h, int tap, int ct, int slot) {
-    const unsigned dst = lds_base + slot * P8_SLOT + wave * 2048;
+  auto issueA = [&](int h, int tap, int ct, int slot_off) {
+    const unsigned dst = lds_base + slot_off + wave * 2048;
     const int c0 = ct * 64;
     const unsigned char* base; unsigned pitchb;
     if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
@@ -1025,13 +1062,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       glds16_asm(ok ? src : zsrc, dst + j * 1024);
     }
   };
-  auto issueB = [&](int h, int tap, int ct, int slot) {
-    const unsigned dst = lds_base + slot * P8_SLOT + wave * 2048;
+  auto issueB = [&](int h, int tap, int ct, int slot_off) {
+    const unsigned dst = lds_base + slot_off + wave * 2048;
     const size_t koff = ((size_t)tap * CT + ct * 64) * sizeof(T);
 #pragma unroll
     for (int j = 0; j < 2; ++j) glds16_asm(wptr[h][j] + koff, dst + j * 1024);
   };
   auto adv = [&](int& tap, int& ct) { if (++tap == taps) { tap = 0; ++ct; } };
+  auto issue_first = [&]() { issueB(0, 0, 0, p8_slot_b0(0)); issueA(0, 0, 0, p8_slot_a0(0)); issueA(1, 0, 0, p8_slot_a1(0)); issueB(1, 0, 0, p8_slot_b1(0)); };
 
   // ---- fragment side: lane (l31, fh) reads row base + l31, 16-byte chunk 2*ks + fh (swizzled) of a slot
   const int l31 = lane & 31, fh = lane >> 5;
@@ -1040,83 +1078,117 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + fh) ^ ((l31 >> 1) & 7)) << 4);
   const unsigned char* fa = smem + wm * (64 * 128);
   const unsigned char* fb = smem + wn * (32 * 128);
-  auto ldA = [&](int slot, int i2, int ks) { return *(const uint4*)(fa + slot * P8_SLOT + i2 * 4096 + foff[ks]); };
-  auto ldB = [&](int slot, int ks) { return *(const uint4*)(fb + slot * P8_SLOT + foff[ks]); };
+  auto ldA = [&](int slot_off, int i2, int ks) { return *(const uint4*)(fa + slot_off + i2 * 4096 + foff[ks]); };
+  auto ldB = [&](int slot_off, int ks) { return *(const uint4*)(fb + slot_off + foff[ks]); };
 
-  f32x16_t acc[4][2];                         // [half*2 + 32-row block][column half]
+  int bm, bn;
+  tile_of(blockIdx.x, bm, bn);
+  setup(bm, bn);
+  issue_first();
+  int younger = 0;                               // vector-memory instructions issued after the current K-tile 0 was requested (see the first wait)
+  const bool counted = p.flags & 1;
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    f32x16_t acc[4][2];                         // [half*2 + 32-row block][column half]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- prologue.  Global issue order is K-tile by K-tile: B0(s), A0(s), A1(s), B1(s); the loop continues it with
-  // B0(i+2) in P0(i), A0(i+2) in P1(i), A1(i+2) and B1(i+2) in P3(i).
-  int tap2 = 0, ct2 = 0;                      // K-tile i+2 (after the prologue)
-  issueB(0, 0, 0, 7); issueA(0, 0, 0, 0); issueA(1, 0, 0, 3); issueB(1, 0, 0, 5);
-  adv(tap2, ct2);
-  if (nk > 1) { issueB(0, tap2, ct2, 8); issueA(0, tap2, ct2, 1); issueA(1, tap2, ct2, 4); issueB(1, tap2, ct2, 6); wait_vmcnt<8>(); } else wait_vmcnt<0>();
-  adv(tap2, ct2);
-  __builtin_amdgcn_s_barrier();
-  uint4 a[4][2], b[4], b0k[4], b1k[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, ks); a[ks][1] = ldA(0, 1, ks); }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) b[q] = ldB(7, q);
-
-  int s3 = 0;                                 // i mod 3
-  for (int i = 0; i < nk; ++i) {
-    const int par = i & 1;
-    const int s3n = s3 == 2 ? 0 : s3 + 1, s3nn = s3 == 0 ? 2 : s3 - 1;                                   // (i+1) % 3, (i+2) % 3
-    const int b0cur = 7 + s3, b0nxt = 7 + s3n, b0nn = 7 + s3nn;                                         // B0 slots of K-tiles i, i+1, i+2
-    const bool more2 = i + 2 < nk;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int ph = q >> 2, ks = q & 3;
-      const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
-      // the two waves of a SIMD (w, w + 4) run the same phase; their address/issue sections are placed two k-steps apart so that
-      // one wave's MFMAs cover the other's VALU + LDS-DMA issue (same per-wave issue order, so the vmcnt arithmetic is unchanged)
-      if ((ks == 0 || ks == 2) && more2 && (ks == 2) == (wm == 1)) {
-        if (ph == 0) issueB(0, tap2, ct2, b0nn);
-        if (ph == 1) issueA(0, tap2, ct2, s3nn);
-        if (ph == 3) { issueA(1, tap2, ct2, 3 + par); issueB(1, tap2, ct2, 5 + par); }
-      }
-      {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
-        const int q3 = q + 3;
-        if (q3 < 8) { const int p3 = q3 >> 2; b[q3 & 3] = ldB(p3 == 1 ? 5 + par : b0cur, q3 & 3); }
-        else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P2 / P3 re-use the B1 / B0 fragments of P1 / P0 from registers
-      }
-      if (ph == 0) b0k[ks] = b[q & 3];
-      if (ph == 1) b1k[ks] = b[q & 3];
-      const uint4 bq = ph == 3 ? b0k[ks] : (ph == 2 ? b1k[ks] : b[q & 3]);
-      Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
-      Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
-      if (ph == 1) { a[ks][0] = ldA(3 + par, 0, ks); a[ks][1] = ldA(3 + par, 1, ks); }   // A1 of this K-tile
-      if (ph == 3) { a[ks][0] = ldA(s3n, 0, ks); a[ks][1] = ldA(s3n, 1, ks); }           // A0 of the next K-tile
-      if (ks == 3) {
-        // end of P2: B0(i+1), A0(i+1) must have landed (read in P3); end of P3: A1(i+1), B1(i+1) (read from P0(i+1) on)
-        if (ph == 2) { if (more2) wait_vmcnt<8>(); else if (i + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
-        if (ph == 3) { if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
-        if (ph >= 2) __builtin_amdgcn_s_barrier();
-      }
-    }
+    // ---- prologue.  Global issue order is K-tile by K-tile: B0(s), A0(s), A1(s), B1(s) (K-tile 0 is already in flight); the loop continues it with
+    // B0(i+2) in P0(i), A0(i+2) in P1(i), A1(i+2) and B1(i+2) in P3(i).
+    int tap2 = 0, ct2 = 0;                      // K-tile i+2 (after the prologue)
     adv(tap2, ct2);
-    s3 = s3 == 2 ? 0 : s3 + 1;
+    if (nk > 1) {
+      issueB(0, tap2, ct2, p8_slot_b0(1)); issueA(0, tap2, ct2, p8_slot_a0(1)); issueA(1, tap2, ct2, p8_slot_a1(1)); issueB(1, tap2, ct2, p8_slot_b1(1));
+      // K-tile 0 must have landed.  Younger than its loads: the 8 LDS-DMA just issued and the `younger` loads / stores of the previous tile's epilogue, which need not be waited for
+      switch (younger) { case 16: wait_vmcnt<24>(); break; case 17: wait_vmcnt<25>(); break; case 32: wait_vmcnt<40>(); break; case 48: wait_vmcnt<56>(); break; default: wait_vmcnt<8>(); }
+    } else wait_vmcnt<0>();
+    adv(tap2, ct2);
+    __builtin_amdgcn_s_barrier();
+    if (p.trace && tile == (int)blockIdx.x) tr1 = __builtin_amdgcn_s_memtime();
+    uint4 a[4][2], b[4], b0k[4], b1k[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(p8_slot_a0(0), 0, ks); a[ks][1] = ldA(p8_slot_a0(0), 1, ks); }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) b[q] = ldB(p8_slot_b0(0), q);
+
+    int s3 = 0;                                 // i mod 3
+    for (int i = 0; i < nk; ++i) {
+      const int par = i & 1;
+      const int s3n = s3 == 2 ? 0 : s3 + 1, s3nn = s3 == 0 ? 2 : s3 - 1;                                   // (i+1) % 3, (i+2) % 3
+      const int b0cur = p8_slot_b0(s3), b0nxt = p8_slot_b0(s3n), b0nn = p8_slot_b0(s3nn);                 // B0 slots of K-tiles i, i+1, i+2
+      const int a1cur = p8_slot_a1(par), b1cur = p8_slot_b1(par), a0nxt = p8_slot_a0(s3n), a0nn = p8_slot_a0(s3nn);
+      const bool more2 = i + 2 < nk;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ph = q >> 2, ks = q & 3;
+        const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
+        // the two waves of a SIMD (w, w + 4) run the same phase; their address/issue sections are placed two k-steps apart so that
+        // one wave's MFMAs cover the other's VALU + LDS-DMA issue (same per-wave issue order, so the vmcnt arithmetic is unchanged)
+        if ((ks == 0 || ks == 2) && more2 && (ks == 2) == (wm == 1)) {
+          if (ph == 0) issueB(0, tap2, ct2, b0nn);
+          if (ph == 1) issueA(0, tap2, ct2, a0nn);
+          if (ph == 3) { issueA(1, tap2, ct2, a1cur); issueB(1, tap2, ct2, b1cur); }
+        }
+        {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
+          const int q3 = q + 3;
+          if (q3 < 8) { const int p3 = q3 >> 2; b[q3 & 3] = ldB(p3 == 1 ? b1cur : b0cur, q3 & 3); }
+          else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P2 / P3 re-use the B1 / B0 fragments of P1 / P0 from registers
+        }
+        if (ph == 0) b0k[ks] = b[q & 3];
+        if (ph == 1) b1k[ks] = b[q & 3];
+        const uint4 bq = ph == 3 ? b0k[ks] : (ph == 2 ? b1k[ks] : b[q & 3]);
+        Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
+        Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
+        if (ph == 1) { a[ks][0] = ldA(a1cur, 0, ks); a[ks][1] = ldA(a1cur, 1, ks); }   // A1 of this K-tile
+        if (ph == 3) { a[ks][0] = ldA(a0nxt, 0, ks); a[ks][1] = ldA(a0nxt, 1, ks); }   // A0 of the next K-tile
+        if (ks == 3) {
+          // end of P2: B0(i+1), A0(i+1) must have landed (read in P3); end of P3: A1(i+1), B1(i+1) (read from P0(i+1) on)
+          if (ph == 2) { if (more2) wait_vmcnt<8>(); else if (i + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
+          if (ph == 3) { if (more2) wait_vmcnt<8>(); else wait_vmcnt<0>(); }
+          if (ph >= 2) __builtin_amdgcn_s_barrier();
+        }
+      }
+      adv(tap2, ct2);
+      s3 = s3 == 2 ? 0 : s3 + 1;
+    }
+    if (p.trace && tile == (int)blockIdx.x) tr2 = __builtin_amdgcn_s_memtime();
+    lds_barrier();
+    // every slot is idle: the next tile's row map, weight rows and first K-tile go out now and land under the epilogue (slots 6-9; the staging passes use 0-5)
+    const int cbm = bm, cbn = bn;
+    if (tile + (int)gridDim.x < ntiles) {
+      tile_of(tile + gridDim.x, bm, bn);
+      setup(bm, bn);
+      issue_first();
+    }
+    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
+    if (!counted) younger = 0;
+    lds_barrier();                              // statistic partials are read from the staging area: the next tile's second K-tile goes to slots inside it
   }
-  __syncthreads();
-  conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  if (p.trace && tid == 0) {
+    unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime(); t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));      // HW_ID, XCC_ID
+  }
 }
 
+unsigned long long* g_p8_trace = nullptr;
 int launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, 256);
   p.gridN = p.N / 256;
+  p.trace = g_p8_trace;
+  static const bool counted = !(getenv("SEGLAND_P8_COUNTED") && getenv("SEGLAND_P8_COUNTED")[0] == '0');
+  p.flags = counted ? 1 : 0;
+  static const bool persist = !(getenv("SEGLAND_P8_PERSIST") && getenv("SEGLAND_P8_PERSIST")[0] == '0');
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_gemm_p8_kernel, dim3(p.gridM * p.gridN), dim3(512), P8_LDS, st, p);
+  const int ntiles = p.gridM * p.gridN;
+  hipLaunchKernelGGL(conv_gemm_p8_kernel, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;
 }
@@ -1620,6 +1692,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
+extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
 // Which kernel a shape runs on: 1000000*variant + 1000*BM + BN  (variant 4 = ring, 2 = two-stage glds, 1 = register staged).
 // mode 0: forward, 1: data gradient.  Used by bench.py to attribute HIP-event timings to rocprof kernel names.
