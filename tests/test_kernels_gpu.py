@@ -176,7 +176,7 @@ def test_conv_c64_k3_patch_kernel(hip, B, H, W):
     assert_close(dx2.float(), dx[:n].float(), dtype, 'patch kernel vs generic kernel (dgrad)')
 
 
-@pytest.mark.parametrize('K,N', [(64, 256), (128, 512), (256, 1024), (256, 512)])
+@pytest.mark.parametrize('K,N', [(64, 256), (128, 512), (256, 1024), (256, 512), (256, 64), (128, 128), (64, 64)])
 def test_conv_short_k_stationary_kernel(hip, K, N):
     """1x1 convs with 64 / 128 / 256 input channels at >= 65 536 pixels run on the pixel-stationary kernel (conv_gemm_sk_kernel): forward with
     BN statistic partials (one row per 256 pixels), plain data gradient, data gradient + addend and + bit-gated addend, against an fp32 matmul
