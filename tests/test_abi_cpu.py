@@ -58,3 +58,32 @@ def test_more_argument_validation_without_launch(lib):
     assert lib.sl_ppm_rows_gemm_stat_rows(C.byref(p4)) == 4                                                     # ceil(2*s*s/128) per level
     assert lib.sl_confusion_matrix(dummy, dummy, 100, 65, 255, dummy, None) == -1                               # K > 64
     assert lib.sl_upsample_ce_fwd is not None and lib.sl_weight_prep_batched(None, 1, 1, None) == -1
+
+
+def test_kernel_dispatch_and_statistic_rows_by_shape(lib):
+    """Which kernel a conv shape runs on (sl_conv2d_tile_config: 1000000 x family + 1000 x rows + columns, what bench.py attributes its HIP-event
+    timings with) and the granularity of the BN statistic partials it writes -- host logic, no launch.  Family 5 = half-tile kernel
+    (conv_gemm_p8_kernel), 6 = pixel-stationary short-K kernel, 7 = 64 -> 64 3x3 patch kernel."""
+    bf = _lib.SL_BF16
+
+    def desc(B, H, W, cin, cout, k, pad=0, dil=1, dtype=bf):
+        return _lib.SlConvDesc(dtype, B, H, W, cin, cout, k, k, 1, pad, dil, H, W, cin)
+    # layer3 conv3 (256 -> 1024) forward and layer3 conv1 (1024 -> 256) data gradient: K = 256 at 65 536 pixels -> stationary kernel, one partial row per 256 pixels
+    d = desc(16, 64, 64, 256, 1024, 1)
+    assert lib.sl_conv2d_tile_config(C.byref(d), 0) == 6256064 and lib.sl_conv2d_stat_rows(C.byref(d)) == 256
+    assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 1024, 256, 1)), 1) == 6256064
+    # the same layers the other way round reduce over 1024 channels: half-tile kernel
+    assert lib.sl_conv2d_tile_config(C.byref(d), 1) == 5256256
+    assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 1024, 256, 1)), 0) == 5256256
+    # below 65 536 pixels, in fp32, or with a 3x3 window the stationary kernel does not apply
+    assert lib.sl_conv2d_tile_config(C.byref(desc(8, 64, 64, 256, 1024, 1)), 0) == 5256256
+    assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 256, 1024, 1, dtype=_lib.SL_F32)), 0) // 1000000 == 4
+    assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 256, 256, 3, pad=2, dil=2)), 0) == 5256256
+    # layer1.conv2: 64 -> 64 3x3 at 128 x 128 -> patch kernel, one partial row per 16 x 16-pixel tile; a ragged map rounds the tile grid up
+    d = desc(16, 128, 128, 64, 64, 3, pad=1)
+    assert lib.sl_conv2d_tile_config(C.byref(d), 0) == 7016016 and lib.sl_conv2d_tile_config(C.byref(d), 1) == 7016016
+    assert lib.sl_conv2d_stat_rows(C.byref(d)) == 16 * 8 * 8
+    assert lib.sl_conv2d_stat_rows(C.byref(desc(5, 120, 136, 64, 64, 3, pad=1))) == 5 * 8 * 9
+    # a small map of the same layer stays on the tile kernels (128-row blocks below 24 576 pixels)
+    d = desc(2, 64, 64, 64, 64, 3, pad=1)
+    assert lib.sl_conv2d_tile_config(C.byref(d), 0) // 1000000 == 2 and lib.sl_conv2d_stat_rows(C.byref(d)) == 2 * 64 * 64 // 128
