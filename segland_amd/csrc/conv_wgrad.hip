@@ -610,6 +610,129 @@ inline bool c64k3_eligible(const SlConvDesc* d, int dw_cin_total, int dw_ci_off)
 }
 inline int c64k3_blocks(const SlConvDesc* d) { const int t = d->B * cdiv(d->H, C3_T) * cdiv(d->W, C3_T); return t < 256 ? t : 256; }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 1x1 layers with a 64-channel side at >= 65 536 pixels (layer1: 64 -> 256, 256 -> 64, 64 -> 64 at 128 x 128): dw [Cout][Cin] is at most 16 K numbers and the
+// launch is bound by reading x and dy ONCE (168 MB for 64 <-> 256; 34 us at 5 TB/s).  The pixel-pair path above reaches 2.3 TB/s (half of its MFMAs and of its LDS
+// traffic are discarded).  Here a persistent block walks over 128-pixel tiles: both tiles go global -> registers -> LDS (the next tile's loads are in flight during
+// the MFMA loop), fragments by ds_read_b64_tr_b16 (the reduction index is the pixel), the whole [Cout][Cin] result stays in the accumulators of the block's four
+// waves (64 x 64 each; 64 -> 64: the four waves split the pixels instead), ONE slab per block (per wave for 64 -> 64), summed in a fixed order by
+// wgrad_reduce_flat_kernel.  D layout: lane & 31 = input channel, register = output channel: the lanes of a slab store are 32 consecutive input channels.
+constexpr int CP_T = 128;                                                // pixels per tile (two tiles in flight per block: 2 x 20 or 2 x 8 register chunks per thread)
+template <int CA, int CB>                                                // CA = Cout (dy channels), CB = Cin (x channels)
+__global__ __launch_bounds__(256) void conv_wgrad_c64p_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ ws, int ntiles) {
+  constexpr int PA = CA * 2 + 64, PB = CB * 2 + 64;                       // LDS row pitches: 64 B of pad keep four pixel rows on distinct 64-byte bank groups (192 and 576 B)
+  constexpr int CHA = CA / 8, CHB = CB / 8;                               // 16-byte chunks per pixel row
+  constexpr int NCH = CP_T * (CHA + CHB), CPT = NCH / 256;                // chunks per tile / per thread (8 or 20)
+  constexpr bool KSPLIT = CA == 64 && CB == 64;
+  constexpr int CPT_A = CP_T * CHA / 256;                                 // the first CPT_A chunks of a thread are dy, the rest x
+  static_assert(NCH % 256 == 0 && (CP_T * CHA) % 256 == 0, "tile chunks divide over the block, operand by operand");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* la = smem;                                               // dy tile [128][PA]
+  unsigned char* lb = smem + CP_T * PA;                                   // x tile  [128][PB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ia = CA == 256 ? wave : 0, jb = CB == 256 ? wave : 0;         // this wave's 64-channel block of the wide side
+  f32x16_t acc[2][2];                                                     // [output-channel 32-block][input-channel 32-block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int g = lane >> 4, l = lane & 15;
+  const int rsub = 8 * (g >> 1) + (l >> 2), cofs = (16 * (g & 1) + 4 * (l & 3)) * 2;      // transpose-read geometry, see conv_wgrad_c64k3_kernel
+  // TWO tiles in flight: a tile's loads are issued two tiles ahead of its use (global -> registers), so a block keeps 2 x (CA + CB) x 256 B outstanding while it
+  // multiplies -- with one tile ahead the short MFMA loop left most of the memory latency exposed (76 us against 50 us for the pixel-pair path).
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;      // NOT HIP's uint4: arrays of that struct stayed in scratch memory here (ScratchSize 656 B/lane)
+  u32x4_t st0[CPT], st1[CPT];
+  // (every fetch is UNCONDITIONAL -- past the end it re-reads the last tile: with loads under a branch the compiler can no longer count them and falls back to
+  // vmcnt(0) in front of every LDS write, which also waits for the tile that was just requested.  The two register stages are named, not passed by reference:
+  // an array handed to a lambda as a parameter lands in scratch memory.)
+  auto fetch0 = [&](int t_) {
+    const size_t m0 = (size_t)(t_ < ntiles ? t_ : ntiles - 1) * CP_T;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      if (u < CPT_A) { const int e = tid + u * 256; st0[u] = *(const u32x4_t*)(dy + (m0 + e / CHA) * CA + (e % CHA) * 8); }          // compile-time split: no per-thread branch
+      else { const int e2 = tid + (u - CPT_A) * 256; st0[u] = *(const u32x4_t*)(x + (m0 + e2 / CHB) * CB + (e2 % CHB) * 8); }
+    }
+  };
+  auto fetch1 = [&](int t_) {
+    const size_t m0 = (size_t)(t_ < ntiles ? t_ : ntiles - 1) * CP_T;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+      if (u < CPT_A) { const int e = tid + u * 256; st1[u] = *(const u32x4_t*)(dy + (m0 + e / CHA) * CA + (e % CHA) * 8); }          // compile-time split: no per-thread branch
+      else { const int e2 = tid + (u - CPT_A) * 256; st1[u] = *(const u32x4_t*)(x + (m0 + e2 / CHB) * CB + (e2 % CHB) * 8); }
+    }
+  };
+  auto multiply = [&]() {
+    constexpr int KS0 = CP_T / 16 / (KSPLIT ? 4 : 1);                    // k-steps of 16 pixels per wave
+#pragma unroll
+    for (int k = 0; k < KS0; ++k) {
+      const int ks = KSPLIT ? wave * KS0 + k : k;
+      uint4 af[2], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* a0 = la + (ks * 16 + rsub) * PA + ia * 128 + i * 64 + cofs;
+        const uint2 lo = lds_tr16_b64(a0), hi = lds_tr16_b64(a0 + 4 * PA);
+        af[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const unsigned char* b0 = lb + (ks * 16 + rsub) * PB + jb * 128 + j * 64 + cofs;
+        const uint2 lo = lds_tr16_b64(b0), hi = lds_tr16_b64(b0 + 4 * PB);
+        bfr[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+  };
+  // a step: the stage holds the tile; after the hand-off to the LDS it is refilled with the tile two grid strides ahead
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  fetch0(tile);
+  fetch1(tile + G);
+  for (; tile + G < ntiles; tile += 2 * G) {
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {
+      if (u < CPT_A) { const int e = tid + u * 256; *(u32x4_t*)(la + (e / CHA) * PA + (e % CHA) * 16) = st0[u]; }
+      else { const int e2 = tid + (u - CPT_A) * 256; *(u32x4_t*)(lb + (e2 / CHB) * PB + (e2 % CHB) * 16) = st0[u]; }
+    }
+    __syncthreads(); fetch0(tile + 2 * G); multiply(); __syncthreads();
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {
+      if (u < CPT_A) { const int e = tid + u * 256; *(u32x4_t*)(la + (e / CHA) * PA + (e % CHA) * 16) = st1[u]; }
+      else { const int e2 = tid + (u - CPT_A) * 256; *(u32x4_t*)(lb + (e2 / CHB) * PB + (e2 % CHB) * 16) = st1[u]; }
+    }
+    __syncthreads(); fetch1(tile + 3 * G); multiply(); __syncthreads();
+  }
+  if (tile < ntiles) {                                                    // odd number of tiles for this block
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {
+      if (u < CPT_A) { const int e = tid + u * 256; *(u32x4_t*)(la + (e / CHA) * PA + (e % CHA) * 16) = st0[u]; }
+      else { const int e2 = tid + (u - CPT_A) * 256; *(u32x4_t*)(lb + (e2 / CHB) * PB + (e2 % CHB) * 16) = st0[u]; }
+    }
+    __syncthreads(); multiply(); __syncthreads();
+  }
+  float* out = ws + (size_t)(KSPLIT ? blockIdx.x * 4 + wave : blockIdx.x) * CA * CB;
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = ia * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf, c = jb * 64 + j * 32 + frow;
+        out[(size_t)n * CB + c] = acc[i][j][r];
+      }
+}
+inline bool c64p_eligible(const SlConvDesc* d) {
+  static const bool off = getenv("SEGLAND_WGRAD_C64P") && getenv("SEGLAND_WGRAD_C64P")[0] == '0';
+  const long long M = (long long)d->B * d->H * d->W;
+  const bool shape = (d->Cout == 256 && d->Cin == 64) || (d->Cout == 64 && d->Cin == 256) || (d->Cout == 64 && d->Cin == 64);
+  return !off && d->dtype == SL_BF16 && shape && d->C1 == d->Cin && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && M >= 65536 && M % CP_T == 0;
+}
+inline int c64p_blocks(const SlConvDesc* d) { const long long t = (long long)d->B * d->H * d->W / CP_T; return t < 256 ? (int)t : 256; }
+inline int c64p_slabs(const SlConvDesc* d) { return c64p_blocks(d) * ((d->Cout == 64 && d->Cin == 64) ? 4 : 1); }
+
 int g_use_tr = -1;
 int use_tr() {
   if (g_use_tr < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); g_use_tr = (e && e[0] == '0') ? 0 : 1; }
@@ -731,6 +854,7 @@ extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 32) return 0;
   size_t need = plan(d).ws_bytes;
   if (c64k3_eligible(d, 64, 0)) { const size_t n2 = (size_t)(c64k3_blocks(d) + 1) * 64 * 64 * 9 * sizeof(float); if (n2 > need) need = n2; }
+  if (c64p_eligible(d)) { const size_t n2 = (size_t)(c64p_slabs(d) + 1) * d->Cout * d->Cin * sizeof(float); if (n2 > need) need = n2; }
   return need;
 }
 
@@ -766,6 +890,25 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
     if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, stream)) return e;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return 0;
+  }
+  if (c64p_eligible(d) && use_tr()) {
+    const int nblk = c64p_blocks(d), nslab = c64p_slabs(d), ntiles = (int)((long long)d->B * d->H * d->W / CP_T);
+    const size_t need = (size_t)(nslab + 1) * d->Cout * d->Cin * sizeof(float);       // the slabs + their sum
+    if (workspace_bytes < need) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
+    const size_t lds = (size_t)CP_T * (2 * (d->Cout + d->Cin) + 128);
+    hipStream_t st = (hipStream_t)stream;
+#define SL_C64P(CA, CB) do { static bool attr_set = false; \
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_c64p_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+      hipLaunchKernelGGL((conv_wgrad_c64p_kernel<CA, CB>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, ntiles); } while (0)
+    if (d->Cout == 256) SL_C64P(256, 64); else if (d->Cin == 256) SL_C64P(64, 256); else SL_C64P(64, 64);
+#undef SL_C64P
+    SL_LAUNCH_CHECK("conv_wgrad_c64p_kernel");
+    const long long total = (long long)d->Cout * d->Cin;
+    float* sum = (float*)workspace + (size_t)nslab * total;
+    if (int e = sl_colsum_finalize((const float*)workspace, nslab, (int)total, sum, stream)) return e;          // fixed-order column sums over the slabs (one block per 64 numbers)
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off);
+    SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
     return 0;
   }
   const WgradPlan pl = plan(d);

@@ -144,6 +144,29 @@ def test_wgrad_c64_k3_patch_kernel(hip, B, H, W):
         assert_close(parts[0] + parts[1], dw, dtype, 'patch kernel vs generic kernel')
 
 
+@pytest.mark.parametrize('Cin,Cout', [(64, 256), (256, 64), (64, 64)])
+def test_wgrad_c64_pointwise_kernel(hip, Cin, Cout):
+    """1x1 layers with a 64-channel side at >= 65 536 pixels (layer1 conv1 / conv3 / downsample) take conv_wgrad_c64p_kernel: 128-pixel tiles, the whole
+    [Cout][Cin] gradient in the accumulators of a block, one slab per block; against an fp32 matmul of the same bf16 operands, against the generic
+    kernel on a half batch (below the threshold), into a wider gradient tensor at a channel offset, and run to run (fixed summation order)."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    B, H, W = 4, 128, 128
+    g = torch.Generator(device='cpu').manual_seed(Cin * 3 + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dtype).to(DEV)
+    dy = torch.randn(B, H, W, Cout, generator=g).to(dtype).to(DEV)
+    spec = ops.ConvSpec(Cin, Cout, 1, 1, 0, 1)
+    ref = (dy.float().reshape(-1, Cout).t() @ x.float().reshape(-1, Cin)).reshape(Cout, Cin, 1, 1)
+    dw = ops.conv2d_bwd_weight(x, dy, spec)
+    assert_close(dw, ref, dtype, 'wgrad %d->%d 1x1 (pointwise 64-channel kernel)' % (Cin, Cout))
+    assert torch.equal(dw, ops.conv2d_bwd_weight(x, dy, spec)), 'run-to-run bit stability'
+    halves = [ops.conv2d_bwd_weight(x[i:i + 2].contiguous(), dy[i:i + 2].contiguous(), spec) for i in (0, 2)]
+    assert_close(halves[0] + halves[1], dw, dtype, 'pointwise kernel vs generic kernel')
+    wide = torch.zeros(Cout, Cin + 64, 1, 1, device=DEV)
+    ops.conv2d_bwd_weight(x, dy, spec, out=wide, out_ci_off=64)
+    assert torch.equal(wide[:, 64:], dw) and float(wide[:, :64].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('B,H,W', [(4, 128, 128), (5, 120, 136)])
 def test_conv_c64_k3_patch_kernel(hip, B, H, W):
     """layer1.conv2 (64 -> 64, 3x3) forward and data gradient at map sizes that take the patch kernel (>= 65 536 pixels): input patch with
