@@ -622,7 +622,7 @@ template <int CA, int CB>                                                // CA =
 __global__ __launch_bounds__(256) void conv_wgrad_c64p_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ ws, int ntiles) {
   constexpr int PA = CA * 2 + 64, PB = CB * 2 + 64;                       // LDS row pitches: 64 B of pad keep four pixel rows on distinct 64-byte bank groups (192 and 576 B)
   constexpr int CHA = CA / 8, CHB = CB / 8;                               // 16-byte chunks per pixel row
-  constexpr int NCH = CP_T * (CHA + CHB), CPT = NCH / 256;                // chunks per tile / per thread (8 or 20)
+  constexpr int NCH = CP_T * (CHA + CHB), CPT = NCH / 256;                // chunks per tile / per thread (8, 16 or 20)
   constexpr bool KSPLIT = CA == 64 && CB == 64;
   constexpr int CPT_A = CP_T * CHA / 256;                                 // the first CPT_A chunks of a thread are dy, the rest x
   static_assert(NCH % 256 == 0 && (CP_T * CHA) % 256 == 0, "tile chunks divide over the block, operand by operand");
@@ -630,7 +630,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_c64p_kernel(const bf16_t* __re
   unsigned char* la = smem;                                               // dy tile [128][PA]
   unsigned char* lb = smem + CP_T * PA;                                   // x tile  [128][PB]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ia = CA == 256 ? wave : 0, jb = CB == 256 ? wave : 0;         // this wave's 64-channel block of the wide side
+  constexpr int NB64 = CB / 64;
+  static_assert((CA / 64) * NB64 == 4 || (CA == 64 && CB == 64), "four 64 x 64 blocks, one per wave");
+  const int ia = KSPLIT ? 0 : wave / NB64, jb = KSPLIT ? 0 : wave % NB64;  // this wave's 64 x 64 block of the gradient (256 x 64, 64 x 256 or 128 x 128)
   f32x16_t acc[2][2];                                                     // [output-channel 32-block][input-channel 32-block]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c64p_kernel(const bf16_t* __re
 inline bool c64p_eligible(const SlConvDesc* d) {
   static const bool off = getenv("SEGLAND_WGRAD_C64P") && getenv("SEGLAND_WGRAD_C64P")[0] == '0';
   const long long M = (long long)d->B * d->H * d->W;
-  const bool shape = (d->Cout == 256 && d->Cin == 64) || (d->Cout == 64 && d->Cin == 256) || (d->Cout == 64 && d->Cin == 64);
+  const bool shape = (d->Cout == 256 && d->Cin == 64) || (d->Cout == 64 && d->Cin == 256) || (d->Cout == 64 && d->Cin == 64) || (d->Cout == 128 && d->Cin == 128);
   return !off && d->dtype == SL_BF16 && shape && d->C1 == d->Cin && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && M >= 65536 && M % CP_T == 0;
 }
 inline int c64p_blocks(const SlConvDesc* d) { const long long t = (long long)d->B * d->H * d->W / CP_T; return t < 256 ? (int)t : 256; }
@@ -901,7 +903,7 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
 #define SL_C64P(CA, CB) do { static bool attr_set = false; \
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad_c64p_kernel<CA, CB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
       hipLaunchKernelGGL((conv_wgrad_c64p_kernel<CA, CB>), dim3(nblk), dim3(256), lds, st, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, ntiles); } while (0)
-    if (d->Cout == 256) SL_C64P(256, 64); else if (d->Cin == 256) SL_C64P(64, 256); else SL_C64P(64, 64);
+    if (d->Cout == 256) SL_C64P(256, 64); else if (d->Cin == 256) SL_C64P(64, 256); else if (d->Cout == 128) SL_C64P(128, 128); else SL_C64P(64, 64);
 #undef SL_C64P
     SL_LAUNCH_CHECK("conv_wgrad_c64p_kernel");
     const long long total = (long long)d->Cout * d->Cin;

@@ -144,7 +144,7 @@ def test_wgrad_c64_k3_patch_kernel(hip, B, H, W):
         assert_close(parts[0] + parts[1], dw, dtype, 'patch kernel vs generic kernel')
 
 
-@pytest.mark.parametrize('Cin,Cout', [(64, 256), (256, 64), (64, 64)])
+@pytest.mark.parametrize('Cin,Cout', [(64, 256), (256, 64), (64, 64), (128, 128)])
 def test_wgrad_c64_pointwise_kernel(hip, Cin, Cout):
     """1x1 layers with a 64-channel side at >= 65 536 pixels (layer1 conv1 / conv3 / downsample) take conv_wgrad_c64p_kernel: 128-pixel tiles, the whole
     [Cout][Cin] gradient in the accumulators of a block, one slab per block; against an fp32 matmul of the same bf16 operands, against the generic
