@@ -1109,17 +1109,18 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
     adv(tap2, ct2);
     __builtin_amdgcn_s_barrier();
     if (p.trace && tile == (int)blockIdx.x) tr1 = __builtin_amdgcn_s_memtime();
-    uint4 a[4][2], b[4], b0k[4], b1k[4];
+    // B fragments live in two register sets that are loaded IN PLACE four k-steps before their first use: b0k (B0 half: used in P0 and P3, reloaded for the next K-tile
+    // right after its P3 use) and b1k (B1 half: loaded in P0, used in P1 and P2).  (An earlier form streamed them through a 4-deep ring and copied them into keep registers:
+    // 32 v_mov per K-tile next to 32 MFMAs.)
+    uint4 a[4][2], b0k[4], b1k[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(p8_slot_a0(0), 0, ks); a[ks][1] = ldA(p8_slot_a0(0), 1, ks); }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) b[q] = ldB(p8_slot_b0(0), q);
+    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(p8_slot_a0(0), 0, ks); a[ks][1] = ldA(p8_slot_a0(0), 1, ks); b0k[ks] = ldB(p8_slot_b0(0), ks); }
 
     int s3 = 0;                                 // i mod 3
     for (int i = 0; i < nk; ++i) {
       const int par = i & 1;
       const int s3n = s3 == 2 ? 0 : s3 + 1, s3nn = s3 == 0 ? 2 : s3 - 1;                                   // (i+1) % 3, (i+2) % 3
-      const int b0cur = p8_slot_b0(s3), b0nxt = p8_slot_b0(s3n), b0nn = p8_slot_b0(s3nn);                 // B0 slots of K-tiles i, i+1, i+2
+      const int b0nxt = p8_slot_b0(s3n), b0nn = p8_slot_b0(s3nn);                                         // B0 slots of K-tiles i+1, i+2
       const int a1cur = p8_slot_a1(par), b1cur = p8_slot_b1(par), a0nxt = p8_slot_a0(s3n), a0nn = p8_slot_a0(s3nn);
       const bool more2 = i + 2 < nk;
 #pragma unroll
@@ -1133,18 +1134,12 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
           if (ph == 1) issueA(0, tap2, ct2, a0nn);
           if (ph == 3) { issueA(1, tap2, ct2, a1cur); issueB(1, tap2, ct2, b1cur); }
         }
-        {                                        // B fragment three k-steps ahead (wraps into the next K-tile's B0)
-          const int q3 = q + 3;
-          if (q3 < 8) { const int p3 = q3 >> 2; b[q3 & 3] = ldB(p3 == 1 ? b1cur : b0cur, q3 & 3); }
-          else if (q3 >= 16) b[q3 & 3] = ldB(b0nxt, q3 - 16);      // P2 / P3 re-use the B1 / B0 fragments of P1 / P0 from registers
-        }
-        if (ph == 0) b0k[ks] = b[q & 3];
-        if (ph == 1) b1k[ks] = b[q & 3];
-        const uint4 bq = ph == 3 ? b0k[ks] : (ph == 2 ? b1k[ks] : b[q & 3]);
+        if (ph == 0) b1k[ks] = ldB(b1cur, ks);                                           // B1 of this K-tile, used from P1 on
+        const uint4 bq = (ph == 0 || ph == 3) ? b0k[ks] : b1k[ks];
         Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
         Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
         if (ph == 1) { a[ks][0] = ldA(a1cur, 0, ks); a[ks][1] = ldA(a1cur, 1, ks); }   // A1 of this K-tile
-        if (ph == 3) { a[ks][0] = ldA(a0nxt, 0, ks); a[ks][1] = ldA(a0nxt, 1, ks); }   // A0 of the next K-tile
+        if (ph == 3) { a[ks][0] = ldA(a0nxt, 0, ks); a[ks][1] = ldA(a0nxt, 1, ks); b0k[ks] = ldB(b0nxt, ks); }   // A0 and B0 of the next K-tile
         if (ks == 3) {
           // end of P2: B0(i+1), A0(i+1) must have landed (read in P3); end of P3: A1(i+1), B1(i+1) (read from P0(i+1) on)
           if (ph == 2) { if (more2) wait_vmcnt<8>(); else if (i + 1 < nk) wait_vmcnt<4>(); else wait_vmcnt<0>(); }
