@@ -32,6 +32,7 @@ struct ConvGemmParams {
   void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
   int gridM, gridN;
+  int tile16;                           // patch kernel: row block bm is a 16 x 16-pixel tile (b, y0 / 16, x0 / 16), its 256 rows are 16 segments of 16 pixels
   int flags;                            // p8: bit 0 = counted first wait (SEGLAND_P8_COUNTED, default on)
   unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
@@ -317,7 +318,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   typedef __attribute__((ext_vector_type(2))) float f2_t;
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
-  const size_t rstep = (size_t)RS * p.N * sizeof(T);
+  const size_t rstep = (p.tile16 ? (size_t)p.Wd : (size_t)RS) * p.N * sizeof(T);          // tile16: a sweep of RS = 16 rows is one 16-pixel segment, the next sweep is the next image row
   f2_t ssum[EPC / 2], ssq[EPC / 2];
 #pragma unroll
   for (int e = 0; e < EPC / 2; ++e) { ssum[e] = (f2_t){0.f, 0.f}; ssq[e] = (f2_t){0.f, 0.f}; }
@@ -334,7 +335,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   for (int pass = 0; pass < G::NPASS; ++pass) {
     epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
     lds_barrier();
-    const size_t goff = ((size_t)(bm * BM + pass * ROWS + r0) * p.N + ncol) * sizeof(T);
+    size_t grow = (size_t)(bm * BM + pass * ROWS + r0);
+    if (p.tile16) {
+      static_assert(!SPLIT || RS == 16, "tile16 row map: one sweep = one 16-pixel segment");
+      const int tx = p.Wd >> 4, ty = p.Hd >> 4;
+      const int bx = bm % tx, by = (bm / tx) % ty, b = bm / (tx * ty);
+      grow = ((size_t)b * p.Hd + by * 16 + pass * (ROWS / 16)) * p.Wd + bx * 16 + r0;
+    }
+    const size_t goff = (grow * p.N + ncol) * sizeof(T);
     unsigned char* o = (unsigned char*)p.out + goff;
     const unsigned char* l = smem + r0 * G::PITCH + cc * 16;
     if constexpr (MODE == 1) {
@@ -1189,6 +1197,152 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3, stride 1 layers of the dilated trunk (pad = dilation, N % 256 == 0, H and W multiples of 16): the half-tile kernel above fetches the pixel operand once per TAP --
+// nine shifted copies of nearly the same rows -- and its main loop is co-limited by the LDS fill rate.  Here a block owns a 16 x 16-pixel output tile:
+// per 64-channel chunk the input patch WITH its dilation halo ((16 + 2d)^2 pixels x 128 B: 41 / 50 / 72 KiB for d = 1 / 2 / 4) goes to the LDS once and the nine taps read
+// their fragments from shifted patch rows; only the weight rows (two 16 KiB halves per tap) stream through a two-K-tile ring.  Same wave grid, accumulator layout, phases
+// (A0,B0) (A0,B1) (A1,B1) (A1,B0) and epilogues as the half-tile kernel (A0 / A1 = image rows 0-7 / 8-15 of the tile); one barrier per tap.
+constexpr int P9_PATCH = 576 * 128;                                     // largest patch (d = 4)
+constexpr int P9_LDS = P9_PATCH + 4 * P8_SLOT;                          // + B0 / B1 of two K-tiles = 136 KiB
+__global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bm = bid / p.gridN, bn = bid % p.gridN;
+  const int d = p.dil, PW = 16 + 2 * d, PP = PW * PW;
+  const int CT = p.C1, nchunk = CT / 64;
+  const int tx = p.Ws >> 4, ty = p.Hs >> 4;
+  const int bx = bm % tx, by = (bm / tx) % ty, bb = bm / (tx * ty);
+  const int y0 = by * 16 - d, x0 = bx * 16 - d;                          // image position of patch pixel (0, 0)
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  const int lr = lane >> 3, lpos = lane & 7;
+  const unsigned char* zsrc = g_zero_page + lpos * 16;
+
+  // ---- patch fill: wave-instruction g = j * 8 + wave covers patch rows g * 8 .. + 7 (lane -> row lr, 16-byte position lpos; the swizzle is applied to the source piece)
+  constexpr int NPI = 9;                                                  // instructions per wave: 9 x 8 waves x 8 rows = 576 rows (rows >= PP are skipped)
+  const unsigned char* psrc[NPI];
+#pragma unroll
+  for (int j = 0; j < NPI; ++j) {
+    const int pr = (j * 8 + wave) * 8 + lr;
+    const int py = pr / PW, px = pr - py * PW;
+    const int iy = y0 + py, ix = x0 + px;
+    const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((pr >> 1) & 7)) << 4) : nullptr;
+  }
+  auto issue_patch = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NPI; ++j) {
+      if ((j * 8 + wave) * 8 < PP)                                        // wave-uniform
+        glds16_asm(psrc[j] ? psrc[j] + (size_t)chunk * 128 : zsrc, lds_base + (j * 8 + wave) * 1024);
+    }
+  };
+  // ---- weight rows: half h, rows h*128 + wave*16 + j*8 + lr of the block's 256 output channels; K-tile (tap, chunk) at byte offset (tap * CT + chunk * 64) * 2
+  const size_t wpitch = (size_t)9 * CT * sizeof(T);
+  int rsw[2];
+  const unsigned char* wptr[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rsw[j] = (lpos ^ (((j * 8 + lr) >> 1) & 7)) * 16;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wptr[h][j] = (const unsigned char*)p.wt + (size_t)(bn * BN + h * 128 + wave * 16 + j * 8 + lr) * wpitch + rsw[j];
+  auto issueB = [&](int tap, int chunk, int par) {
+    const size_t koff = ((size_t)tap * CT + chunk * 64) * sizeof(T);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned dst = lds_base + P9_PATCH + (par * 2 + h) * P8_SLOT + wave * 2048;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) glds16_asm(wptr[h][j] + koff, dst + j * 1024);
+    }
+  };
+  // ---- fragments.  B: as in the half-tile kernel.  A: lane (l31, fh) of row block (h, i2) is tile pixel (ty, tx) = (h*8 + wm*4 + i2*2 + (l31 >> 4), l31 & 15) -> patch row
+  // (ty + ky d) PW + tx + kx d, 16-byte piece (2 ks + fh) ^ ((row >> 1) & 7)
+  const int l31 = lane & 31, fh = lane >> 5;
+  int foff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + fh) ^ ((l31 >> 1) & 7)) << 4);
+  const unsigned char* fb = smem + P9_PATCH + wn * (32 * 128);
+  auto ldB = [&](int slot_off, int ks) { return *(const uint4*)(fb + slot_off + foff[ks]); };
+  int prow[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) prow[h][i2] = (h * 8 + wm * 4 + i2 * 2 + (l31 >> 4)) * PW + (l31 & 15);
+  auto ldA = [&](int h, int i2, int toff, int ks) {
+    const int pr = prow[h][i2] + toff;
+    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
+  };
+
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue_patch(0);
+  issueB(0, 0, 0);
+  int par = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    for (int tap = 0; tap < 9; ++tap) {
+      wait_vmcnt<0>();                                                    // this K-tile's weight rows (and, at tap 0, the chunk's patch)
+      __builtin_amdgcn_s_barrier();
+      // next K-tile's weight rows into the other slot pair (every wave is past its reads of it: the barrier above)
+      if (tap < 8) issueB(tap + 1, chunk, par ^ 1);
+      else if (chunk + 1 < nchunk) issueB(0, chunk + 1, par ^ 1);
+      const int t2 = p.mode ? 8 - tap : tap;                              // data gradient: the correlation with the flipped window
+      const int toff = ((t2 / 3) * PW + (t2 % 3)) * d;
+      const int b0s = (par * 2 + 0) * P8_SLOT, b1s = (par * 2 + 1) * P8_SLOT;
+      uint4 a[4][2], b0k[4], b1k[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toff, ks); a[ks][1] = ldA(0, 1, toff, ks); b0k[ks] = ldB(b0s, ks); }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int ph = q >> 2, ks = q & 3;
+        const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
+        if (ph == 0) b1k[ks] = ldB(b1s, ks);
+        const uint4 bq = (ph == 0 || ph == 3) ? b0k[ks] : b1k[ks];
+        Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
+        Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
+        if (ph == 1) { a[ks][0] = ldA(1, 0, toff, ks); a[ks][1] = ldA(1, 1, toff, ks); }   // rows 8-15 of the tile
+      }
+      par ^= 1;
+    }
+    if (chunk + 1 < nchunk) {
+      __builtin_amdgcn_s_barrier();                                       // every wave is past its last read of the patch
+      issue_patch(chunk + 1);
+    }
+  }
+  lds_barrier();
+  conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
+int g_conv_p9 = -1;      // SEGLAND_CONV_P9 / sl_debug_conv_p9
+static bool p9_shape(const ConvGemmParams& p) {
+  if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
+  return g_conv_p9 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
+         p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && (long long)p.M >= 65536 &&
+         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && !(p.addend && p.stat_partial);
+}
+int launch_p9(ConvGemmParams& p, hipStream_t st) {
+  p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P9_LDS); attr_set = true; }
+  hipLaunchKernelGGL(conv_gemm_p9_kernel, dim3(p.gridM * p.gridN), dim3(512), P9_LDS, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_p9_kernel");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 64 -> 64 channels, 3x3, stride 1, dilation 1 (layer1.conv2 at 128 x 128), forward and data gradient.  The tile kernels above fetch the pixel
 // operand once per tap: with only 64 output channels per 64 input channels that makes the launch LDS-fill bound at a third of what the MFMAs
 // could do.  Here a persistent block owns 16 x 16-pixel tiles: the input patch WITH its halo goes to the LDS once (324 pixels for 256 outputs)
@@ -1643,6 +1797,9 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
       return launch_sk(p, st);
   }
   if constexpr (sizeof(T) == 2) {
+    if (v >= 5 && p9_shape(p)) return launch_p9(p, st);
+  }
+  if constexpr (sizeof(T) == 2) {
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
     if (big && v >= 5 && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
   }
@@ -1687,6 +1844,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
+extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = v ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
 // Which kernel a shape runs on: 1000000*variant + 1000*BM + BN  (variant 4 = ring, 2 = two-stage glds, 1 = register staged).
@@ -1703,6 +1861,8 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   if (v >= 2 && d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
   // the short-K kernel serves the unshaped epilogues (training-mode convs: raw result + statistics, or + addend); folded eval-mode convs of these shapes stay on the tile kernels
   if (v >= 5 && sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
+  if (v >= 5 && d->dtype == SL_BF16 && n256 && (g_conv_p9 != 0) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
+      d->C1 == d->Cin && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 && d->H % 16 == 0 && d->W % 16 == 0 && M >= 65536) return 8256256;      // conv_gemm_p9_kernel (unshaped epilogues)
   if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
   if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
   if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));

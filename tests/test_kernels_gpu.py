@@ -199,6 +199,44 @@ def test_conv_c64_k3_patch_kernel(hip, B, H, W):
     assert_close(dx2.float(), dx[:n].float(), dtype, 'patch kernel vs generic kernel (dgrad)')
 
 
+@pytest.mark.parametrize('C_,N,dil', [(256, 256, 2), (128, 512, 4), (128, 256, 1)])
+def test_conv_3x3_patch_kernel(hip, C_, N, dil):
+    """3x3 stride-1 layers (pad = dilation) on the patch kernel (conv_gemm_p9_kernel: 16 x 16-pixel output tiles, the input patch with its dilation halo in the
+    LDS once per 64-channel chunk, nine taps from shifted fragment reads): forward + statistics, data gradient, data gradient + bit-gated addend must equal the
+    half-tile kernel bit for bit (same K order: chunk-major, taps inside), and agree with torch on a corner crop (zero padding) and an interior crop."""
+    from segland_amd import ops
+    dtype = torch.bfloat16
+    B, H, W = 16, 64, 64
+    g = torch.Generator(device='cpu').manual_seed(C_ + N + dil)
+    x = torch.randn(B, H, W, C_, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, C_, 3, 3, generator=g) * (3.0 / (9 * C_)) ** 0.5).to(dtype).float().to(DEV)
+    spec = ops.ConvSpec(C_, N, 3, 1, dil, dil)
+    wf, wb = ops.weight_prep(w, dtype)
+    dy = torch.randn(B, H, W, N, generator=g).to(dtype).to(DEV)
+    add = torch.randn(B, H, W, C_, generator=g).to(dtype).to(DEV)
+    bits = torch.randint(0, 256, (add.numel() // 8,), dtype=torch.uint8, device=DEV)
+    out = {}
+    try:
+        for on in (0, 1):
+            hip.sl_debug_conv_p9(on)
+            y, part = ops.conv2d_fwd(x, wf, spec, want_stats=True)
+            dx = ops.conv2d_bwd_data(dy, wb, spec, (H, W)) if N % 256 == 0 and C_ % 256 == 0 else None
+            dxa = ops.conv2d_bwd_data(dy, wb, spec, (H, W), addend=add, addend_mask=bits) if dx is not None else None
+            out[on] = (y, part, dx, dxa)
+    finally:
+        hip.sl_debug_conv_p9(1)
+    assert torch.equal(out[0][0], out[1][0]), 'forward: patch kernel vs half-tile kernel'
+    assert_close(out[1][1].sum(0), out[0][1].sum(0), torch.float32, 'statistics', factor=10)
+    if out[0][2] is not None:
+        assert torch.equal(out[0][2], out[1][2]), 'data gradient'
+        assert torch.equal(out[0][3], out[1][3]), 'data gradient + gated addend'
+    # against torch on two crops of image 3 (top-left corner incl. zero padding; interior)
+    xi = x[3].float().permute(2, 0, 1)[None]
+    ref = F.conv2d(xi, w, None, 1, dil, dil)[0].permute(1, 2, 0)
+    assert_close(out[1][0][3, :20, :20], ref[:20, :20], dtype, 'corner crop')
+    assert_close(out[1][0][3, 24:44, 40:64], ref[24:44, 40:64], dtype, 'interior / right-edge crop')
+
+
 @pytest.mark.parametrize('K,N', [(64, 256), (128, 512), (256, 1024), (256, 512), (256, 64), (128, 128), (64, 64)])
 def test_conv_short_k_stationary_kernel(hip, K, N):
     """1x1 convs with 64 / 128 / 256 input channels at >= 65 536 pixels run on the pixel-stationary kernel (conv_gemm_sk_kernel): forward with
