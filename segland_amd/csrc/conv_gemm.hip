@@ -1289,38 +1289,64 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // K-tile k = (chunk, tap), weight slot pair k & 1.  One barrier per K-tile, at the end of P2: by then every wave has read both halves of slot pair k & 1 (B0(k) in P3 of
+  // K-tile k - 1, B1(k) in P0), so B(k + 2) is issued into it right there and has a whole K-tile to land; B(k + 1) is waited for at the same point and P3 already loads the next
+  // K-tile's first fragments (B0 from the other slot pair, the first eight image rows of the patch at the next tap's offset), so no K-tile starts with an empty pipeline.
+  const int NK = 9 * nchunk;
+  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((t2 / 3) * PW + (t2 % 3)) * d; };      // data gradient: the correlation with the flipped window
   issue_patch(0);
   issueB(0, 0, 0);
-  int par = 0;
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    for (int tap = 0; tap < 9; ++tap) {
-      wait_vmcnt<0>();                                                    // this K-tile's weight rows (and, at tap 0, the chunk's patch)
-      __builtin_amdgcn_s_barrier();
-      // next K-tile's weight rows into the other slot pair (every wave is past its reads of it: the barrier above)
-      if (tap < 8) issueB(tap + 1, chunk, par ^ 1);
-      else if (chunk + 1 < nchunk) issueB(0, chunk + 1, par ^ 1);
-      const int t2 = p.mode ? 8 - tap : tap;                              // data gradient: the correlation with the flipped window
-      const int toff = ((t2 / 3) * PW + (t2 % 3)) * d;
-      const int b0s = (par * 2 + 0) * P8_SLOT, b1s = (par * 2 + 1) * P8_SLOT;
-      uint4 a[4][2], b0k[4], b1k[4];
+  issueB(1, 0, 1);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  uint4 a[4][2], b0k[4], b1k[4];
+  {
+    const int toff = toff_of(0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toff, ks); a[ks][1] = ldA(0, 1, toff, ks); b0k[ks] = ldB(b0s, ks); }
+    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toff, ks); a[ks][1] = ldA(0, 1, toff, ks); b0k[ks] = ldB(0, ks); }
+  }
+  int tap = 0, chunk = 0;
+#pragma unroll 1
+  for (int k = 0; k < NK; ++k) {
+    const int par = k & 1;
+    const int b1s = (par * 2 + 1) * P8_SLOT, b0n = ((par ^ 1) * 2 + 0) * P8_SLOT;
+    const int toff = toff_of(tap);
+    const bool last_tap = tap == 8;
+    const int toffn = toff_of(last_tap ? 0 : tap + 1);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int ph = q >> 2, ks = q & 3;
-        const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
-        if (ph == 0) b1k[ks] = ldB(b1s, ks);
-        const uint4 bq = (ph == 0 || ph == 3) ? b0k[ks] : b1k[ks];
-        Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
-        Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
-        if (ph == 1) { a[ks][0] = ldA(1, 0, toff, ks); a[ks][1] = ldA(1, 1, toff, ks); }   // rows 8-15 of the tile
+    for (int q = 0; q < 16; ++q) {
+      const int ph = q >> 2, ks = q & 3;
+      const int ih = ph >> 1, jh = (ph == 1 || ph == 2) ? 1 : 0;
+      if (ph == 0) b1k[ks] = ldB(b1s, ks);
+      const uint4 bq = (ph == 0 || ph == 3) ? b0k[ks] : b1k[ks];
+      Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
+      Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
+      if (ph == 1) { a[ks][0] = ldA(1, 0, toff, ks); a[ks][1] = ldA(1, 1, toff, ks); }   // image rows 8-15 of the tile
+      if (ph == 2 && ks == 3) {
+        wait_vmcnt<0>();                                                  // B(k + 1)
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < NK) {
+          int t2 = tap + 2, c2 = chunk;
+          if (t2 >= 9) { t2 -= 9; ++c2; }
+          issueB(t2, c2, par);
+        }
       }
-      par ^= 1;
+      if (ph == 3) {
+        b0k[ks] = ldB(b0n, ks);                                           // B0 of the next K-tile
+        if (!last_tap) { a[ks][0] = ldA(0, 0, toffn, ks); a[ks][1] = ldA(0, 1, toffn, ks); }
+      }
     }
-    if (chunk + 1 < nchunk) {
-      __builtin_amdgcn_s_barrier();                                       // every wave is past its last read of the patch
-      issue_patch(chunk + 1);
-    }
+    if (last_tap) {
+      tap = 0; ++chunk;
+      if (chunk < nchunk) {
+        __builtin_amdgcn_s_barrier();                                     // every wave is past its last read of the patch
+        issue_patch(chunk);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toffn, ks); a[ks][1] = ldA(0, 1, toffn, ks); }
+      }
+    } else ++tap;
   }
   lds_barrier();
   conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
