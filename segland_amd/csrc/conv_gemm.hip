@@ -490,14 +490,19 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
     const bool plain = !(p.bias || p.scale || p.addend || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2);
     constexpr int NIT = ROWS / RS, CH = SPLIT ? 2 : (NIT < 8 ? NIT : 8);
     static_assert(ROWS % RS == 0 && NIT % CH == 0, "store-phase chunking");
-    const int mrow0 = bm * BM + pass * ROWS + r0;
+    int mrow0 = bm * BM + pass * ROWS + r0, mstep = RS;                 // global row of the thread's first sweep, rows between sweeps
+    if (p.tile16) {                                                     // 16 x 16-pixel tile: a sweep of RS = 16 rows is one 16-pixel segment, the next sweep is the next image row
+      const int tx = p.Wd >> 4, ty = p.Hd >> 4;
+      const int bx = bm % tx, by = (bm / tx) % ty, b = bm / (tx * ty);
+      mrow0 = (b * p.Hd + by * 16 + pass * (ROWS / 16)) * p.Wd + bx * 16 + r0; mstep = p.Wd;
+    }
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += CH) {
       uint4 addv[CH], mskv[CH], prev[CH];
       if (p.pre_addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * RS;
+          const int m = mrow0 + (it0 + u) * mstep;
           if (m < p.M) prev[u] = *(const uint4*)((const T*)p.pre_addend + (size_t)m * p.N + ncol);
         }
       }
@@ -505,13 +510,13 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
       if (p.addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * RS;
+          const int m = mrow0 + (it0 + u) * mstep;
           if (m < p.M) addv[u] = *(const uint4*)((const T*)p.addend + (size_t)m * p.N + ncol);
         }
         if (p.addend_mask) {                    // the gate bytes ride in the same batch (one exposed latency, not one per row)
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int m = mrow0 + (it0 + u) * RS;
+            const int m = mrow0 + (it0 + u) * mstep;
             if (m < p.M) abit[u] = p.addend_mask[((size_t)m * p.N + ncol) / EPC];
           }
         }
@@ -519,14 +524,14 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
       if (p.mask_src) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * RS;
+          const int m = mrow0 + (it0 + u) * mstep;
           if (m < p.M) mskv[u] = *(const uint4*)((const T*)p.mask_src + (size_t)m * p.N + ncol);
         }
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int row = r0 + (it0 + u) * RS;
-        const int m = mrow0 + (it0 + u) * RS;
+        const int m = mrow0 + (it0 + u) * mstep;
         if (m < p.M) {
           float v[EPC];
           const uint4 raw = *(const uint4*)(smem + row * G::PITCH + cc * 16);
@@ -1357,7 +1362,7 @@ static bool p9_shape(const ConvGemmParams& p) {
   if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
   return g_conv_p9 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
          p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && (long long)p.M >= 65536 &&
-         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && !(p.addend && p.stat_partial);
+         !(p.out2 || p.row_scale);                                       // every epilogue with the tile16 row map (fast: store / statistics / gated addend; generic: bias, folded BN, ReLU, pre-addend)
 }
 int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;

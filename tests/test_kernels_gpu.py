@@ -215,6 +215,7 @@ def test_conv_3x3_patch_kernel(hip, C_, N, dil):
     dy = torch.randn(B, H, W, N, generator=g).to(dtype).to(DEV)
     add = torch.randn(B, H, W, C_, generator=g).to(dtype).to(DEV)
     bits = torch.randint(0, 256, (add.numel() // 8,), dtype=torch.uint8, device=DEV)
+    bias_v = torch.randn(N, generator=g).to(DEV); scale_v = (torch.rand(N, generator=g) + 0.5).to(DEV)
     out = {}
     try:
         for on in (0, 1):
@@ -222,7 +223,12 @@ def test_conv_3x3_patch_kernel(hip, C_, N, dil):
             y, part = ops.conv2d_fwd(x, wf, spec, want_stats=True)
             dx = ops.conv2d_bwd_data(dy, wb, spec, (H, W)) if N % 256 == 0 and C_ % 256 == 0 else None
             dxa = ops.conv2d_bwd_data(dy, wb, spec, (H, W), addend=add, addend_mask=bits) if dx is not None else None
-            out[on] = (y, part, dx, dxa)
+            # shaped epilogues (generic store phase with the tile row map): pre-addend + statistics (factorised PPM conv), bias + ReLU, folded BN + residual + ReLU
+            pre = dy
+            yp, pp = ops.conv2d_fwd(x, wf, spec, pre_addend=pre, want_stats=True)
+            yb, _ = ops.conv2d_fwd(x, wf, spec, bias=bias_v, relu=True)
+            ya = ops.conv2d_affine_fwd(x, wf, spec, scale_v, bias_v, residual=dy, relu=True)
+            out[on] = (y, part, dx, dxa, yp, pp, yb, ya)
     finally:
         hip.sl_debug_conv_p9(1)
     assert torch.equal(out[0][0], out[1][0]), 'forward: patch kernel vs half-tile kernel'
@@ -230,6 +236,10 @@ def test_conv_3x3_patch_kernel(hip, C_, N, dil):
     if out[0][2] is not None:
         assert torch.equal(out[0][2], out[1][2]), 'data gradient'
         assert torch.equal(out[0][3], out[1][3]), 'data gradient + gated addend'
+    assert torch.equal(out[0][4], out[1][4]), 'forward + pre-addend'
+    assert_close(out[1][5].sum(0), out[0][5].sum(0), torch.float32, 'statistics with pre-addend', factor=10)
+    assert torch.equal(out[0][6], out[1][6]), 'forward + bias + ReLU'
+    assert torch.equal(out[0][7], out[1][7]), 'folded BN + residual + ReLU'
     # against torch on two crops of image 3 (top-left corner incl. zero padding; interior)
     xi = x[3].float().permute(2, 0, 1)[None]
     ref = F.conv2d(xi, w, None, 1, dil, dil)[0].permute(1, 2, 0)

@@ -22,7 +22,8 @@ rocprofv3 --kernel-trace -d /tmp/prof_sw2 -- python3 $R/bench.py --model swin_po
 python3 $R/tools/prof_summary.py /tmp/prof_sw2 7 $O/r2_swin_kernel_stats.txt "bench.py --model swin_pop --steps 5 --warmup 2 --no-step-graph (Swin-T bf16 B=8): rocprofv3 --kernel-trace, all 7 steps" > /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_fetch -o b -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc_write -o b -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph > /dev/null 2>&1
-cd $R && python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_p8_kernel' 'conv_gemm_p8_kernel<bf16, 256, 256>' > /dev/null 2>&1; cp profiles/r2_traffic.json $O/r2_traffic.json 2>/dev/null
+cd $R && python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_p9_kernel' 'conv_gemm_p9_kernel<bf16, 256, 256>' > /dev/null 2>&1; cp profiles/r2_traffic.json $O/r2_traffic.json 2>/dev/null      # the roofline kernel of the bench line
+python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_p8_kernel' 'conv_gemm_p8_kernel<bf16, 256, 256>' $O/r2_traffic_p8.json > /dev/null 2>&1
 python tools/collect_traffic.py /tmp/pmc_fetch /tmp/pmc_write 'conv_gemm_sk_kernel' 'conv_gemm_sk_kernel<bf16, 256, 64>' $O/r2_traffic_sk.json > /dev/null 2>&1      # the HBM-bound family: compare with gbytes / launches of the bench line's `families`
 ls -la $O
 head -c 400 $O/r2_bench_default.json; echo
