@@ -1209,6 +1209,8 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
 // (A0,B0) (A0,B1) (A1,B1) (A1,B0) and epilogues as the half-tile kernel (A0 / A1 = image rows 0-7 / 8-15 of the tile); one barrier per tap.
 constexpr int P9_PATCH = 576 * 128;                                     // largest patch (d = 4)
 constexpr int P9_LDS = P9_PATCH + 4 * P8_SLOT;                          // + B0 / B1 of two K-tiles = 136 KiB
+constexpr int P9_PATCH1 = 42 * 1024;                                    // d = 1: 324 rows -> two patch buffers (the next chunk's patch lands under the current chunk's taps)
+constexpr int P9_LDS1 = 2 * P9_PATCH1 + 4 * P8_SLOT;                    // 148 KiB
 __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
@@ -1242,11 +1244,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
     psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((pr >> 1) & 7)) << 4) : nullptr;
   }
+  const bool dbuf = d == 1 && !(p.flags & 8);                             // two patch buffers fit (flags bit 3: SEGLAND_P9_DBUF=0, A/B)
+  const int boff = dbuf ? 2 * P9_PATCH1 : P9_PATCH;                       // weight ring behind the patch area
   auto issue_patch = [&](int chunk) {
+    const unsigned dst = lds_base + (dbuf && (chunk & 1) ? P9_PATCH1 : 0);
 #pragma unroll
     for (int j = 0; j < NPI; ++j) {
       if ((j * 8 + wave) * 8 < PP)                                        // wave-uniform
-        glds16_asm(psrc[j] ? psrc[j] + (size_t)chunk * 128 : zsrc, lds_base + (j * 8 + wave) * 1024);
+        glds16_asm(psrc[j] ? psrc[j] + (size_t)chunk * 128 : zsrc, dst + (j * 8 + wave) * 1024);
     }
   };
   // ---- weight rows: half h, rows h*128 + wave*16 + j*8 + lr of the block's 256 output channels; K-tile (tap, chunk) at byte offset (tap * CT + chunk * 64) * 2
@@ -1263,7 +1268,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const size_t koff = ((size_t)tap * CT + chunk * 64) * sizeof(T);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const unsigned dst = lds_base + P9_PATCH + (par * 2 + h) * P8_SLOT + wave * 2048;
+      const unsigned dst = lds_base + boff + (par * 2 + h) * P8_SLOT + wave * 2048;
 #pragma unroll
       for (int j = 0; j < 2; ++j) glds16_asm(wptr[h][j] + koff, dst + j * 1024);
     }
@@ -1274,16 +1279,16 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   int foff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) foff[ks] = l31 * 128 + (((2 * ks + fh) ^ ((l31 >> 1) & 7)) << 4);
-  const unsigned char* fb = smem + P9_PATCH + wn * (32 * 128);
+  const unsigned char* fb = smem + boff + wn * (32 * 128);
   auto ldB = [&](int slot_off, int ks) { return *(const uint4*)(fb + slot_off + foff[ks]); };
   int prow[2][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) prow[h][i2] = (h * 8 + wm * 4 + i2 * 2 + (l31 >> 4)) * PW + (l31 & 15);
-  auto ldA = [&](int h, int i2, int toff, int ks) {
+  auto ldA = [&](int h, int i2, int toff, int ks, int pbase = 0) {
     const int pr = prow[h][i2] + toff;
-    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
+    return *(const uint4*)(smem + pbase + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
   };
 
   f32x16_t acc[4][2];
@@ -1318,6 +1323,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const int toff = toff_of(tap);
     const bool last_tap = tap == 8;
     const int toffn = toff_of(last_tap ? 0 : tap + 1);
+    const int pb = dbuf && (chunk & 1) ? P9_PATCH1 : 0, pbn = dbuf && last_tap ? (pb ? 0 : P9_PATCH1) : pb;      // patch buffer of this / of the next K-tile
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int ph = q >> 2, ks = q & 3;
@@ -1326,10 +1332,11 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
       const uint4 bq = (ph == 0 || ph == 3) ? b0k[ks] : b1k[ks];
       Mma<T>::run(bq, a[ks][0], acc[ih * 2 + 0][jh]);
       Mma<T>::run(bq, a[ks][1], acc[ih * 2 + 1][jh]);
-      if (ph == 1) { a[ks][0] = ldA(1, 0, toff, ks); a[ks][1] = ldA(1, 1, toff, ks); }   // image rows 8-15 of the tile
+      if (ph == 1) { a[ks][0] = ldA(1, 0, toff, ks, pb); a[ks][1] = ldA(1, 1, toff, ks, pb); }   // image rows 8-15 of the tile
       if (ph == 2 && ks == 3) {
-        wait_vmcnt<0>();                                                  // B(k + 1)
+        wait_vmcnt<0>();                                                  // B(k + 1) (and, with two patch buffers, the next chunk's patch once it has been requested)
         __builtin_amdgcn_s_barrier();
+        if (dbuf && tap == 0 && chunk + 1 < nchunk) issue_patch(chunk + 1);      // the other buffer: every wave is past the previous chunk
         if (k + 2 < NK) {
           int t2 = tap + 2, c2 = chunk;
           if (t2 >= 9) { t2 -= 9; ++c2; }
@@ -1338,12 +1345,12 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
       }
       if (ph == 3) {
         b0k[ks] = ldB(b0n, ks);                                           // B0 of the next K-tile
-        if (!last_tap) { a[ks][0] = ldA(0, 0, toffn, ks); a[ks][1] = ldA(0, 1, toffn, ks); }
+        if (!last_tap || dbuf) { a[ks][0] = ldA(0, 0, toffn, ks, pbn); a[ks][1] = ldA(0, 1, toffn, ks, pbn); }
       }
     }
     if (last_tap) {
       tap = 0; ++chunk;
-      if (chunk < nchunk) {
+      if (chunk < nchunk && !dbuf) {
         __builtin_amdgcn_s_barrier();                                     // every wave is past its last read of the patch
         issue_patch(chunk);
         wait_vmcnt<0>();
@@ -1366,9 +1373,11 @@ static bool p9_shape(const ConvGemmParams& p) {
 }
 int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
+  static const bool nodbuf = getenv("SEGLAND_P9_DBUF") && getenv("SEGLAND_P9_DBUF")[0] == '0';
+  if (nodbuf) p.flags |= 8;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P9_LDS); attr_set = true; }
-  hipLaunchKernelGGL(conv_gemm_p9_kernel, dim3(p.gridM * p.gridN), dim3(512), P9_LDS, st, p);
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS)); attr_set = true; }
+  hipLaunchKernelGGL(conv_gemm_p9_kernel, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p9_kernel");
   return 0;
 }

@@ -199,7 +199,7 @@ def test_conv_c64_k3_patch_kernel(hip, B, H, W):
     assert_close(dx2.float(), dx[:n].float(), dtype, 'patch kernel vs generic kernel (dgrad)')
 
 
-@pytest.mark.parametrize('C_,N,dil', [(256, 256, 2), (128, 512, 4), (128, 256, 1)])
+@pytest.mark.parametrize('C_,N,dil', [(256, 256, 2), (128, 512, 4), (128, 256, 1), (256, 256, 1)])
 def test_conv_3x3_patch_kernel(hip, C_, N, dil):
     """3x3 stride-1 layers (pad = dilation) on the patch kernel (conv_gemm_p9_kernel: 16 x 16-pixel output tiles, the input patch with its dilation halo in the
     LDS once per 64-channel chunk, nine taps from shifted fragment reads): forward + statistics, data gradient, data gradient + bit-gated addend must equal the
