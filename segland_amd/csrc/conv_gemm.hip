@@ -1223,7 +1223,11 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int bm = bid / p.gridN, bn = bid % p.gridN;
+  // block order: column tiles in groups of two, row tiles inside a group -- with many column tiles (PPM data gradient: 8 x 2.4 MB of weight rows) an XCD's contiguous share of
+  // the blocks then covers ONE group, whose weights stay in its L2, instead of streaming all 18.9 MB once per round of its 32 CUs
+  const int GN = p.gridN > 2 && p.gridN % 2 == 0 && !(p.flags & 16) ? 2 : p.gridN;
+  const int grp = bid / (p.gridM * GN), rem = bid - grp * (p.gridM * GN);
+  const int bm = rem / GN, bn = grp * GN + rem % GN;
   const int d = p.dil, PW = 16 + 2 * d, PP = PW * PW;
   const int CT = p.C1, nchunk = CT / 64;
   const int tx = p.Ws >> 4, ty = p.Hs >> 4;
@@ -1375,6 +1379,8 @@ int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
   static const bool nodbuf = getenv("SEGLAND_P9_DBUF") && getenv("SEGLAND_P9_DBUF")[0] == '0';
   if (nodbuf) p.flags |= 8;
+  static const bool nogroup = getenv("SEGLAND_P9_NGROUP") && getenv("SEGLAND_P9_NGROUP")[0] == '0';
+  if (nogroup) p.flags |= 16;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS)); attr_set = true; }
   hipLaunchKernelGGL(conv_gemm_p9_kernel, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
