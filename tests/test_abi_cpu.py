@@ -78,11 +78,12 @@ def test_kernel_dispatch_and_statistic_rows_by_shape(lib):
     # below 65 536 pixels, in fp32, or with a 3x3 window the stationary kernel does not apply
     assert lib.sl_conv2d_tile_config(C.byref(desc(8, 64, 64, 256, 1024, 1)), 0) == 5256256
     assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 256, 1024, 1, dtype=_lib.SL_F32)), 0) // 1000000 == 4
-    # 3x3 stride-1 layers of the dilated trunk at >= 65 536 pixels, map a multiple of 16: patch kernel (family 8); a ragged map or a small batch: half-tile kernel
+    # 3x3 stride-1 layers of the dilated trunk at >= 32 768 pixels, map a multiple of 16: patch kernel (family 8); a ragged map or a small batch: the tile kernels
     assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 256, 256, 3, pad=2, dil=2)), 0) == 8256256
     assert lib.sl_conv2d_tile_config(C.byref(desc(16, 64, 64, 512, 512, 3, pad=4, dil=4)), 1) == 8256256
     assert lib.sl_conv2d_tile_config(C.byref(desc(18, 60, 64, 256, 256, 3, pad=2, dil=2)), 0) == 5256256
-    assert lib.sl_conv2d_tile_config(C.byref(desc(8, 64, 64, 256, 256, 3, pad=2, dil=2)), 0) == 5256256
+    assert lib.sl_conv2d_tile_config(C.byref(desc(8, 64, 64, 256, 256, 3, pad=2, dil=2)), 0) == 8256256          # 32 768 pixels: still the patch kernel
+    assert lib.sl_conv2d_tile_config(C.byref(desc(4, 64, 64, 256, 256, 3, pad=2, dil=2)), 0) // 1000000 != 8
     # layer1.conv2: 64 -> 64 3x3 at 128 x 128 -> patch kernel, one partial row per 16 x 16-pixel tile; a ragged map rounds the tile grid up
     d = desc(16, 128, 128, 64, 64, 3, pad=1)
     assert lib.sl_conv2d_tile_config(C.byref(d), 0) == 7016016 and lib.sl_conv2d_tile_config(C.byref(d), 1) == 7016016
