@@ -319,6 +319,11 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
   const size_t rstep = (p.tile16 ? (size_t)p.Wd : (size_t)RS) * p.N * sizeof(T);          // tile16: a sweep of RS = 16 rows is one 16-pixel segment, the next sweep is the next image row
+  // byte offset of sweep `it` from the thread's first row.  tile16 with RS == 8 (the four-wave patch kernel: 256 threads): two sweeps per 16-pixel segment
+  auto soff = [&](int it) -> size_t {
+    if constexpr (RS == 8) { if (p.tile16) return (size_t)(it >> 1) * rstep + (size_t)(it & 1) * (8 * p.N * sizeof(T)); }
+    return (size_t)it * rstep;
+  };
   f2_t ssum[EPC / 2], ssq[EPC / 2];
 #pragma unroll
   for (int e = 0; e < EPC / 2; ++e) { ssum[e] = (f2_t){0.f, 0.f}; ssq[e] = (f2_t){0.f, 0.f}; }
@@ -337,7 +342,6 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
     lds_barrier();
     size_t grow = (size_t)(bm * BM + pass * ROWS + r0);
     if (p.tile16) {
-      static_assert(!SPLIT || RS == 16, "tile16 row map: one sweep = one 16-pixel segment");
       const int tx = p.Wd >> 4, ty = p.Hd >> 4;
       const int bx = bm % tx, by = (bm / tx) % ty, b = bm / (tx * ty);
       grow = ((size_t)b * p.Hd + by * 16 + pass * (ROWS / 16)) * p.Wd + bx * 16 + r0;
@@ -350,7 +354,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
 #pragma unroll 4
         for (int it = 0; it < NIT; ++it) {
           const uint4 raw = *(const uint4*)(l + it * (RS * G::PITCH));
-          st16(o, raw); o += rstep;
+          st16(o + soff(it), raw);
           f2_t v[EPC / 2];
           unpack2(raw, v);
 #pragma unroll
@@ -358,20 +362,19 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
         }
       } else {
 #pragma unroll 8
-        for (int it = 0; it < NIT; ++it) { st16(o, *(const uint4*)(l + it * (RS * G::PITCH))); o += rstep; }
+        for (int it = 0; it < NIT; ++it) st16(o + soff(it), *(const uint4*)(l + it * (RS * G::PITCH)));
       }
     } else {
       const unsigned char* ad = (const unsigned char*)p.addend + goff;
       const unsigned char* ab = p.addend_mask ? p.addend_mask + goff / 16 : nullptr;
-      const size_t bstep = rstep / 16;
 #pragma unroll 1
       for (int it0 = 0; it0 < NIT; it0 += CH) {
         uint4 addv[CH]; unsigned bits[CH];
 #pragma unroll
-        for (int u = 0; u < CH; ++u) addv[u] = *(const uint4*)(ad + (size_t)(it0 + u) * rstep);
+        for (int u = 0; u < CH; ++u) addv[u] = *(const uint4*)(ad + soff(it0 + u));
         if (ab) {
 #pragma unroll
-          for (int u = 0; u < CH; ++u) bits[u] = ab[(size_t)(it0 + u) * bstep];
+          for (int u = 0; u < CH; ++u) bits[u] = ab[soff(it0 + u) / 16];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -402,7 +405,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
           } else {
             r = make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
           }
-          st16(o, r); o += rstep;
+          st16(o + soff(it0 + u), r);
         }
       }
     }
@@ -496,13 +499,14 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
       const int bx = bm % tx, by = (bm / tx) % ty, b = bm / (tx * ty);
       mrow0 = (b * p.Hd + by * 16 + pass * (ROWS / 16)) * p.Wd + bx * 16 + r0; mstep = p.Wd;
     }
+    auto mrow = [&](int it) { if constexpr (RS == 8) { if (p.tile16) return mrow0 + (it >> 1) * mstep + (it & 1) * 8; } return mrow0 + it * mstep; };
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += CH) {
       uint4 addv[CH], mskv[CH], prev[CH];
       if (p.pre_addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * mstep;
+          const int m = mrow(it0 + u);
           if (m < p.M) prev[u] = *(const uint4*)((const T*)p.pre_addend + (size_t)m * p.N + ncol);
         }
       }
@@ -510,13 +514,13 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
       if (p.addend) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * mstep;
+          const int m = mrow(it0 + u);
           if (m < p.M) addv[u] = *(const uint4*)((const T*)p.addend + (size_t)m * p.N + ncol);
         }
         if (p.addend_mask) {                    // the gate bytes ride in the same batch (one exposed latency, not one per row)
 #pragma unroll
           for (int u = 0; u < CH; ++u) {
-            const int m = mrow0 + (it0 + u) * mstep;
+            const int m = mrow(it0 + u);
             if (m < p.M) abit[u] = p.addend_mask[((size_t)m * p.N + ncol) / EPC];
           }
         }
@@ -524,14 +528,14 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
       if (p.mask_src) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-          const int m = mrow0 + (it0 + u) * mstep;
+          const int m = mrow(it0 + u);
           if (m < p.M) mskv[u] = *(const uint4*)((const T*)p.mask_src + (size_t)m * p.N + ncol);
         }
       }
 #pragma unroll
       for (int u = 0; u < CH; ++u) {
         const int row = r0 + (it0 + u) * RS;
-        const int m = mrow0 + (it0 + u) * mstep;
+        const int m = mrow(it0 + u);
         if (m < p.M) {
           float v[EPC];
           const uint4 raw = *(const uint4*)(smem + row * G::PITCH + cc * 16);
@@ -1368,7 +1372,144 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
+// Four-wave form of the patch kernel (experimental, SEGLAND_CONV_P9W4=1): one wave per SIMD, 128 x 128 of the tile per wave (16 accumulator blocks = 256 registers), so an A
+// fragment serves four column blocks and a B fragment four row blocks: 32 fragment reads per 64 MFMAs instead of 24 per 32 -- a third fewer LDS reads, the co-limiter of
+// the eight-wave loop -- at the price of no second wave on the SIMD to cover stalls: the fragments of the next k-step are loaded while the current one multiplies.
+__global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int bid = blockIdx.x;
+  {
+    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int GN = p.gridN > 2 && p.gridN % 2 == 0 ? 2 : p.gridN;
+  const int grp = bid / (p.gridM * GN), rem = bid - grp * (p.gridM * GN);
+  const int bm = rem / GN, bn = grp * GN + rem % GN;
+  const int d = p.dil, PW = 16 + 2 * d, PP = PW * PW;
+  const int CT = p.C1, nchunk = CT / 64;
+  const int tx = p.Ws >> 4, ty = p.Hs >> 4;
+  const int bx = bm % tx, by = (bm / tx) % ty, bb = bm / (tx * ty);
+  const int y0 = by * 16 - d, x0 = bx * 16 - d;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  const int lr = lane >> 3, lpos = lane & 7;
+  const unsigned char* zsrc = g_zero_page + lpos * 16;
+  // patch fill: instruction g = j * 4 + wave covers patch rows g * 8 .. + 7
+  constexpr int NPI = 18;
+  const unsigned char* psrc[NPI];
+#pragma unroll
+  for (int j = 0; j < NPI; ++j) {
+    const int pr = (j * 4 + wave) * 8 + lr;
+    const int py = pr / PW, px = pr - py * PW;
+    const int iy = y0 + py, ix = x0 + px;
+    const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((pr >> 1) & 7)) << 4) : nullptr;
+  }
+  auto issue_patch = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NPI; ++j) {
+      if ((j * 4 + wave) * 8 < PP) glds16_asm(psrc[j] ? psrc[j] + (size_t)chunk * 128 : zsrc, lds_base + (j * 4 + wave) * 1024);
+    }
+  };
+  // weight rows of a K-tile: 256 rows x 128 B = 32 instructions, 8 per wave; row n = (j * 4 + wave) * 8 + lr at LDS offset n * 128
+  const size_t wpitch = (size_t)9 * CT * sizeof(T);
+  const unsigned char* wptr[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = (j * 4 + wave) * 8 + lr;
+    wptr[j] = (const unsigned char*)p.wt + (size_t)(bn * BN + n) * wpitch + ((lpos ^ ((n >> 1) & 7)) << 4);
+  }
+  auto issueB = [&](int tap, int chunk, int par) {
+    const size_t koff = ((size_t)tap * CT + chunk * 64) * sizeof(T);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16_asm(wptr[j] + koff, lds_base + P9_PATCH + par * (2 * P8_SLOT) + (j * 4 + wave) * 1024);
+  };
+  const int l31 = lane & 31, fh = lane >> 5;
+  int prow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) prow[i] = (wm * 8 + i * 2 + (l31 >> 4)) * PW + (l31 & 15);
+  auto ldA = [&](int i, int toff, int ks) {
+    const int pr = prow[i] + toff;
+    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
+  };
+  const unsigned char* fb = smem + P9_PATCH + (wn * 128 + l31) * 128;
+  const int bsw = (l31 >> 1) & 7;
+  auto ldB = [&](int par, int j, int ks) { return *(const uint4*)(fb + par * (2 * P8_SLOT) + j * 4096 + (((2 * ks + fh) ^ bsw) << 4)); };
+
+  f32x16_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int NK = 9 * nchunk;
+  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((t2 / 3) * PW + (t2 % 3)) * d; };
+  issue_patch(0);
+  issueB(0, 0, 0);
+  issueB(1, 0, 1);
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  uint4 fa[2][4], fbv[2][4];                                             // fragment sets of k-steps of alternating parity
+  {
+    const int toff = toff_of(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[0][i] = ldA(i, toff, 0); fbv[0][i] = ldB(0, i, 0); }
+  }
+  int tap = 0, chunk = 0;
+#pragma unroll 1
+  for (int k = 0; k < NK; ++k) {
+    const int par = k & 1;
+    const int toff = toff_of(tap);
+    const bool last_tap = tap == 8;
+    const int toffn = toff_of(last_tap ? 0 : tap + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[nxt][i] = ldA(i, toff, ks + 1); fbv[nxt][i] = ldB(par, i, ks + 1); }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fbv[nxt][i] = ldB(par ^ 1, i, 0); if (!last_tap) fa[nxt][i] = ldA(i, toffn, 0); }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Mma<T>::run(fbv[cur][j], fa[cur][i], acc[i][j]);
+      if (ks == 2) {
+        wait_vmcnt<0>();                                                  // B(k + 1)
+        __builtin_amdgcn_s_barrier();
+        if (k + 2 < NK) {
+          int t2 = tap + 2, c2 = chunk;
+          if (t2 >= 9) { t2 -= 9; ++c2; }
+          issueB(t2, c2, par);
+        }
+      }
+    }
+    if (last_tap) {
+      tap = 0; ++chunk;
+      if (chunk < nchunk) {
+        __builtin_amdgcn_s_barrier();
+        issue_patch(chunk);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = ldA(i, toffn, 0);
+      }
+    } else ++tap;
+  }
+  lds_barrier();
+  conv_epilogue_lds<T, BM, BN, 2, 2, false>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+}
+
 int g_conv_p9 = -1;      // SEGLAND_CONV_P9 / sl_debug_conv_p9
+int g_conv_p9w4 = -1;    // SEGLAND_CONV_P9W4 / sl_debug_conv_p9 bit 1: the four-wave form
 static bool p9_shape(const ConvGemmParams& p) {
   if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
   return g_conv_p9 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
@@ -1377,6 +1518,14 @@ static bool p9_shape(const ConvGemmParams& p) {
 }
 int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
+  if (g_conv_p9w4 < 0) g_conv_p9w4 = (getenv("SEGLAND_CONV_P9W4") && getenv("SEGLAND_CONV_P9W4")[0] == '1') ? 1 : 0;
+  if (g_conv_p9w4) {
+    static bool attr4 = false;
+    if (!attr4) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P9_LDS); attr4 = true; }
+    hipLaunchKernelGGL(conv_gemm_p9w4_kernel, dim3(p.gridM * p.gridN), dim3(256), P9_LDS, st, p);
+    SL_LAUNCH_CHECK("conv_gemm_p9w4_kernel");
+    return 0;
+  }
   static const bool nodbuf = getenv("SEGLAND_P9_DBUF") && getenv("SEGLAND_P9_DBUF")[0] == '0';
   if (nodbuf) p.flags |= 8;
   static const bool nogroup = getenv("SEGLAND_P9_NGROUP") && getenv("SEGLAND_P9_NGROUP")[0] == '0';
@@ -1890,7 +2039,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
-extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = v ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
+extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; g_conv_p9w4 = (v & 2) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off (bit 0), four-wave form (bit 1)
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
 // Which kernel a shape runs on: 1000000*variant + 1000*BM + BN  (variant 4 = ring, 2 = two-stage glds, 1 = register staged).

@@ -218,7 +218,7 @@ def test_conv_3x3_patch_kernel(hip, C_, N, dil):
     bias_v = torch.randn(N, generator=g).to(DEV); scale_v = (torch.rand(N, generator=g) + 0.5).to(DEV)
     out = {}
     try:
-        for on in (0, 1):
+        for on in (0, 1, 3):                       # half-tile kernel, patch kernel (eight waves), patch kernel (four waves: experimental form, SEGLAND_CONV_P9W4)
             hip.sl_debug_conv_p9(on)
             y, part = ops.conv2d_fwd(x, wf, spec, want_stats=True)
             dx = ops.conv2d_bwd_data(dy, wb, spec, (H, W)) if N % 256 == 0 and C_ % 256 == 0 else None
@@ -231,6 +231,9 @@ def test_conv_3x3_patch_kernel(hip, C_, N, dil):
             out[on] = (y, part, dx, dxa, yp, pp, yb, ya)
     finally:
         hip.sl_debug_conv_p9(1)
+    for k in range(8):
+        if out[1][k] is not None and k not in (1, 5):
+            assert torch.equal(out[1][k], out[3][k]), 'four-wave form vs eight-wave form, output %d' % k
     assert torch.equal(out[0][0], out[1][0]), 'forward: patch kernel vs half-tile kernel'
     assert_close(out[1][1].sum(0), out[0][1].sum(0), torch.float32, 'statistics', factor=10)
     if out[0][2] is not None:
