@@ -8,6 +8,7 @@ p = argparse.ArgumentParser()
 p.add_argument('--B', type=int, default=16); p.add_argument('--hw', type=int, default=64)
 p.add_argument('--cin', type=int, default=256); p.add_argument('--cout', type=int, default=1024)
 p.add_argument('--k', type=int, default=1); p.add_argument('--dil', type=int, default=1); p.add_argument('--iters', type=int, default=20)
+p.add_argument('--zeros', action='store_true', help='all-zero operands: the same instruction stream at lower switching power (DVFS check, MI355X_MICROARCH.md)')
 a = p.parse_args()
 dt = torch.bfloat16
 spec = ops.ConvSpec(a.cin, a.cout, a.k, 1, a.dil * (a.k // 2), a.dil)
@@ -17,6 +18,8 @@ wf, wb = ops.weight_prep(w, dt)
 dy = torch.randn(a.B, a.hw, a.hw, a.cout, device='cuda').to(dt)
 add = torch.randn(a.B, a.hw, a.hw, a.cin, device='cuda').to(dt)
 bits = torch.randint(0, 256, (add.numel() // 8,), dtype=torch.uint8, device='cuda')
+if a.zeros:
+    for t in (x, dy, add, wf, wb): t.zero_()
 def timeit(fn):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
