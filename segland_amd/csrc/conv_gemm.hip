@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const int py = pr / PW, px = pr - py * PW;
     const int iy = y0 + py, ix = x0 + px;
     const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((pr >> 1) & 7)) << 4) : nullptr;
+    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((px >> 1) & 7)) << 4) : nullptr;      // swizzle by the patch COLUMN (see ldA)
   }
   const bool dbuf = d == 1 && !(p.flags & 8);                             // two patch buffers fit (flags bit 3: SEGLAND_P9_DBUF=0, A/B)
   const int boff = dbuf ? 2 * P9_PATCH1 : P9_PATCH;                       // weight ring behind the patch area
@@ -1294,9 +1294,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2) prow[h][i2] = (h * 8 + wm * 4 + i2 * 2 + (l31 >> 4)) * PW + (l31 & 15);
+  // The XOR swizzle is a function of the patch COLUMN px, not of the LDS row: a ds_read_b128 is serviced in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... --
+  // with lane = (image row l31 >> 4, pixel l31 & 15) a group holds 16 DIFFERENT columns of two image rows, and since the patch width is even the row parity (address bit 7)
+  // is the column parity: (px & 1, (px >> 1) & 7) is distinct for 16 consecutive columns, whatever the tap shift.  (Swizzled by the LDS row, the second image row of a group
+  // landed on the first one's banks: SQ_LDS_BANK_CONFLICT = 40 % of the LDS cycles.)
   auto ldA = [&](int h, int i2, int toff, int ks, int pbase = 0) {
-    const int pr = prow[h][i2] + toff;
-    return *(const uint4*)(smem + pbase + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
+    const int pr = prow[h][i2] + (toff >> 8);                             // toff = ((ky PW + kx) d) << 8 | kx d
+    const int px = (l31 & 15) + (toff & 255);
+    return *(const uint4*)(smem + pbase + pr * 128 + (((2 * ks + fh) ^ ((px >> 1) & 7)) << 4));
   };
 
   f32x16_t acc[4][2];
@@ -1311,7 +1316,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   // K-tile k - 1, B1(k) in P0), so B(k + 2) is issued into it right there and has a whole K-tile to land; B(k + 1) is waited for at the same point and P3 already loads the next
   // K-tile's first fragments (B0 from the other slot pair, the first eight image rows of the patch at the next tap's offset), so no K-tile starts with an empty pipeline.
   const int NK = 9 * nchunk;
-  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((t2 / 3) * PW + (t2 % 3)) * d; };      // data gradient: the correlation with the flipped window
+  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((((t2 / 3) * PW + (t2 % 3)) * d) << 8) | ((t2 % 3) * d); };      // patch row offset << 8 | column offset      // data gradient: the correlation with the flipped window
   issue_patch(0);
   issueB(0, 0, 0);
   issueB(1, 0, 1);
@@ -1407,7 +1412,7 @@ __global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
     const int py = pr / PW, px = pr - py * PW;
     const int iy = y0 + py, ix = x0 + px;
     const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((pr >> 1) & 7)) << 4) : nullptr;
+    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((px >> 1) & 7)) << 4) : nullptr;      // swizzle by the patch COLUMN (see ldA)
   }
   auto issue_patch = [&](int chunk) {
 #pragma unroll
@@ -1433,8 +1438,9 @@ __global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) prow[i] = (wm * 8 + i * 2 + (l31 >> 4)) * PW + (l31 & 15);
   auto ldA = [&](int i, int toff, int ks) {
-    const int pr = prow[i] + toff;
-    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((pr >> 1) & 7)) << 4));
+    const int pr = prow[i] + (toff >> 8);                                 // toff = ((ky PW + kx) d) << 8 | kx d
+    const int px = (l31 & 15) + (toff & 255);
+    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((px >> 1) & 7)) << 4));
   };
   const unsigned char* fb = smem + P9_PATCH + (wn * 128 + l31) * 128;
   const int bsw = (l31 >> 1) & 7;
@@ -1449,7 +1455,7 @@ __global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int NK = 9 * nchunk;
-  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((t2 / 3) * PW + (t2 % 3)) * d; };
+  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((((t2 / 3) * PW + (t2 % 3)) * d) << 8) | ((t2 % 3) * d); };      // patch row offset << 8 | column offset
   issue_patch(0);
   issueB(0, 0, 0);
   issueB(1, 0, 1);
