@@ -311,7 +311,9 @@ def main():
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the %d instrumented kernel-by-kernel steps run right after the %d timed ones' % (a.steps, a.steps)
-                                       + ' (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time'}
+                                       + ' (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
+                                       + 'peak is the 2.4 GHz figure: on these N(0,1) operands the chip sustains ~1.65 GHz under this kernel (the same binary on all-zero operands runs '
+                                       + '+26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone, a.model)
         print(json.dumps(out), flush=True)
