@@ -1516,9 +1516,12 @@ __global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
 
 int g_conv_p9 = -1;      // SEGLAND_CONV_P9 / sl_debug_conv_p9
 int g_conv_p9w4 = -1;    // SEGLAND_CONV_P9W4 / sl_debug_conv_p9 bit 1: the four-wave form
-static bool p9_shape(const ConvGemmParams& p) {
+static bool p9_on() {
   if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
-  return g_conv_p9 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
+  return g_conv_p9 != 0;
+}
+static bool p9_shape(const ConvGemmParams& p) {
+  return p9_on() && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
          p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && (long long)p.M >= 32768 &&
          !(p.out2 || p.row_scale);                                       // every epilogue with the tile16 row map (fast: store / statistics / gated addend; generic: bias, folded BN, ReLU, pre-addend)
 }
@@ -2062,7 +2065,7 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   if (v >= 2 && d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
   // the short-K kernel serves the unshaped epilogues (training-mode convs: raw result + statistics, or + addend); folded eval-mode convs of these shapes stay on the tile kernels
   if (v >= 5 && sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
-  if (v >= 5 && d->dtype == SL_BF16 && n256 && (g_conv_p9 != 0) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
+  if (v >= 5 && d->dtype == SL_BF16 && n256 && p9_on() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
       d->C1 == d->Cin && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 && d->H % 16 == 0 && d->W % 16 == 0 && M >= 32768) return 8256256;      // conv_gemm_p9_kernel (unshaped epilogues)
   if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
   if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
