@@ -4,7 +4,9 @@ numpy restatement of dataset/base_dataset.py (crop :140-174, pad :88-104, random
 :29-34, totensor :36-43), of the label re-indexing in dataset/oem.py:113-133 and of the novel-tile rule of dataset/oem_ft.py:197, with the
 random draws made explicit (`draw_train_params` consumes numpy's / random's generators in the reference's order).  Pinned by
 tests/golden/make_golden.py::g17 against the imported reference (cv2.copyMakeBorder, the one OpenCV call on this path, is replaced there by
-its numpy equivalent because OpenCV is not installed in this image; rasterio's read() is fed synthetic arrays).
+its numpy equivalent because OpenCV is not installed in this image; rasterio's read() is fed synthetic arrays).  The fine-tune pair reader
+(dataset/oem_ft.py:72-124 update_base_list, :126-181 _get_supp_list, :189-220 _get_train_sample, :262-299 _filter_and_map_ids) is restated
+at the end and pinned by ::g19 the same way.
 Only tests/ may import this module."""
 import random
 
@@ -80,3 +82,77 @@ def fuse_probability_maps(mats):
     for m in mats[1:]:
         acc += np.asarray(m, dtype=np.float32)
     return np.argmax(acc / len(mats), axis=0).astype(np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------- fine-tune pair reader (dataset/oem_ft.py)
+def ft_tiles(n=12, H=96, W=80, block=16):
+    """Synthetic stand-ins for OpenEarthMap tiles of golden G19 (pure functions of the tile index): ids, images uint8 [H,W,3], labels uint8 [H,W]
+    in the dataset's own numbering (0 = unlabeled, 1..7 base, 8..11 novel).  Class 7 exists in tile 3 only (fewer files than shots: the
+    'extend images with repeating' branch), tiles 0-4 hold base classes only, one tile is unlabeled in its upper part."""
+    import torch
+    from oracle import formula as fm
+    ids, imgs, labs = [], {}, {}
+    for k in range(n):
+        id_ = 't%02d' % k
+        hb, wb = (H + block - 1) // block, (W + block - 1) // block
+        coarse = (fm.uniform01('g19/lab%d' % k, hb * wb) * (8 if k < 5 else 12)).floor().to(torch.uint8).reshape(hb, wb)
+        lab = coarse.repeat_interleave(block, 0).repeat_interleave(block, 1)[:H, :W].numpy().copy()
+        if k != 3:
+            lab[lab == 7] = 1
+        else:
+            lab[:block, :block] = 7
+        if k == 6:
+            lab[:40] = 0
+        img = (fm.uniform01('g19/img%d' % k, H * W * 3) * 256).floor().clamp(0, 255).to(torch.uint8).reshape(H, W, 3).numpy()
+        ids.append(id_); imgs[id_] = img; labs[id_] = lab
+    return ids, imgs, labs
+
+
+def filter_and_map_ids(ids, read_label, base_classes, novel_classes, filter_intersection=False):
+    """oem_ft.py:262-299: class -> list of tile ids holding it (in list order); with filter_intersection a tile counts for its base classes
+    only when it holds no novel class at all."""
+    from collections import defaultdict
+    base_cls_to_ids, novel_cls_to_ids = defaultdict(list), defaultdict(list)
+    for id_ in ids:
+        mask = read_label(id_)
+        label_class = np.unique(mask).tolist()
+        if 0 in label_class:
+            label_class.remove(0)
+        valid_base = set(np.unique(mask).tolist()) & set(base_classes)
+        valid_novel = set(np.unique(mask).tolist()) & set(novel_classes)
+        if valid_base and (not filter_intersection or set(label_class).issubset(set(base_classes))):
+            for cls in valid_base:
+                base_cls_to_ids[cls].append(id_)
+        for cls in valid_novel:
+            novel_cls_to_ids[cls].append(id_)
+    return base_cls_to_ids, novel_cls_to_ids
+
+
+def sample_base_ids(base_cls_to_ids, base_classes, shot):
+    """oem_ft.py:72-124 == :126-181 (update_base_list and _get_supp_list draw identically): per base class `shot` tile ids -- every file once plus
+    random.randint(1, n) - 1 repeats when the class has fewer files than shots, random.choices(range(n), k=shot) otherwise."""
+    out = []
+    for cls in list(base_classes):
+        files = base_cls_to_ids[cls]
+        n = len(files)
+        if n < shot:
+            out += [files[i] for i in range(n)]
+            out += [files[random.randint(1, n) - 1] for _ in range(shot - n)]
+        else:
+            out += [files[j] for j in random.choices(list(range(n)), k=shot)]
+    return out
+
+
+def ft_pair(index, base_id_list, novel_id_list, read_image, read_label, crop_size, ignore_label=255):
+    """oem_ft.py:189-220: random novel support tile (0 -> ignore BEFORE the crop draw, :197), the index-th base tile, two independent
+    crop / pad / flip / rot90 draw sets (novel tile first).  -> (img, lbl, img_b, lbl_b, id, prm, prm_b)"""
+    id_b = base_id_list[index]
+    id_ = random.choice(novel_id_list)
+    image, label = read_image(id_), read_label(id_)
+    label = np.where(label == 0, ignore_label, label).astype(np.uint8)
+    image_b, label_b = read_image(id_b), read_label(id_b)
+    prm = draw_train_params(label, crop_size, ignore_label)
+    img, lbl = prepare_tile(image, label, crop_size, *prm, ignore_label=ignore_label)
+    prm_b = draw_train_params(label_b, crop_size, ignore_label)
+    img_b, lbl_b = prepare_tile(image_b, label_b, crop_size, *prm_b, ignore_label=ignore_label)
+    return img, lbl, img_b, lbl_b, id_, prm, prm_b

@@ -2074,11 +2074,15 @@ extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   return 2000000 + 128000 + (n128 ? 128 : 64);
 }
 
+extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
+// Rows of the BN statistic partials a forward launch writes: derived from the SAME predicate chain as launch_gemm (sl_conv2d_tile_config), so a
+// non-default tuning knob (SEGLAND_CONV_MINTILES, SEGLAND_CONV_VARIANT ...) can never make the caller allocate rows the kernel does not write.
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;
-  if (c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return d->B * cdiv(d->H, C64_T) * cdiv(d->W, C64_T);    // one row per 16 x 16 tile
-  return cdiv(M, block_rows(M, d->KH * d->KW * d->Cin));
+  const int cfg = sl_conv2d_tile_config(d, 0);
+  if (cfg == 7016016) return d->B * cdiv(d->H, C64_T) * cdiv(d->W, C64_T);    // conv_c64k3_kernel: one row per 16 x 16 tile
+  return (int)cdiv(M, (long long)((cfg / 1000) % 1000));
 }
 
 extern "C" int sl_conv2d_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend,

@@ -15,16 +15,20 @@ from .. import _lib
 from ..ops import _p, _s
 
 
-def draw_train_params(label, crop_size, ignore_label=255):
-    """(h_off, w_off, flip, k): base_dataset.py:140-155 (np.random crop offsets, redrawn while the crop is all-ignore), :106-110, :134-138."""
+def draw_train_params(label, crop_size, ignore_label=255, mode='train'):
+    """(h_off, w_off, flip, k): base_dataset.py:140-155 (np.random crop offsets, redrawn while the crop is all-ignore; outside train mode the
+    crop is centred and nothing is drawn for it, :170-172), then :106-110 and :134-138 (one random.random() each for flip and rot90 count)."""
     H, W = label.shape
     ch, cw = crop_size
     mh, mw = max(H - ch, 0), max(W - cw, 0)
-    while True:
-        h_off, w_off = np.random.randint(0, mh + 1), np.random.randint(0, mw + 1)
-        u = np.unique(label[h_off:h_off + ch, w_off:w_off + cw])
-        if not (u.size == 1 and int(u[0]) == ignore_label):
-            break
+    if mode == 'train':
+        while True:
+            h_off, w_off = np.random.randint(0, mh + 1), np.random.randint(0, mw + 1)
+            u = np.unique(label[h_off:h_off + ch, w_off:w_off + cw])
+            if not (u.size == 1 and int(u[0]) == ignore_label):
+                break
+    else:
+        h_off, w_off = int(round(mh / 2.)), int(round(mw / 2.))
     flip = random.random() < 0.5
     k = int(random.random() // 0.25)
     return h_off, w_off, flip, k

@@ -1,4 +1,5 @@
-"""OpenEarthMap readers (counterparts of dataset/oem.py and dataset/oem_ft.py:189-220 of the reference).
+"""OpenEarthMap readers (counterparts of dataset/oem.py of the reference; the fine-tune pair reader of dataset/oem_ft.py is
+segland_amd/dataset/oem_ft.py).
 
 The DataLoader workers only DECODE: a sample is the raw uint8 tile as rasterio returns it plus the random draws of the reference's
 augmentation (made in the worker with the reference's generators, in the reference's order); `gpu_collate` / `TileAugmenter.prepare` then
@@ -53,13 +54,14 @@ class GFSSegTrain(_Raw):
         self.data_list = open(path).read().splitlines()
 
     def __len__(self):
-        return len(self.data_list)
+        return len(self.novel_classes) if self.mode == 'val_supp' else len(self.data_list)        # oem.py:46-50
 
     def __getitem__(self, index):
         id_ = self.data_list[index]
         image = np.ascontiguousarray(np.rollaxis(_read(self.root, 'images', id_), 0, 3))
         label = np.ascontiguousarray(_read(self.root, 'labels', id_)[0])
-        return image, label, draw_train_params(label, self.crop_size, self.ignore_label), id_
+        # mode 'val_supp': the same preparation with a centred crop (base_dataset.py:170-172); flip and rot90 are still drawn (oem.py:70-73)
+        return image, label, draw_train_params(label, self.crop_size, self.ignore_label, self.mode), id_
 
     def augmenter(self, device):
         return TileAugmenter(self.crop_size, MEAN, STD, self.ignore_label, lut=None, device=device)
@@ -71,9 +73,11 @@ class GFSSegVal(_Raw):
     def __init__(self, root, list_path, fold, crop_size=(512, 512), ignore_label=255, base_size=(1024, 1024), resize_label=False,
                  use_novel=True, use_base=True):
         _rasterio()
-        if resize_label:
-            raise RuntimeError('resize_label=True needs cv2.resize (INTER_LINEAR / INTER_NEAREST), which this build does not restate; '
-                               'the reference evaluates with resize_label=False')
+        # resize_label=True (ft_pop.py:165): base_dataset.resize to base_size keeping the aspect ratio, then pad.  For tiles that already have
+        # base_size (OpenEarthMap: 1024 x 1024 with --base-size 1024,1024) the scale factor is 1, cv2.resize returns the tile unchanged and nothing
+        # is padded: that case is exact and supported.  Any other size needs cv2.resize's fixed-point INTER_LINEAR, which this build does not
+        # restate (OpenCV is absent from the image, so it could not be pinned): __getitem__ raises for such a tile.
+        self.resize_label, self.base_size = bool(resize_label), tuple(base_size)
         self.root, self.ignore_label, self.use_novel, self.use_base = root, ignore_label, use_novel, use_base
         self.ids = open(list_path).read().splitlines()
 
@@ -85,6 +89,9 @@ class GFSSegVal(_Raw):
         image = np.ascontiguousarray(np.rollaxis(_read(self.root, 'images', id_), 0, 3))
         lp = osp.join(self.root, 'labels', '%s.tif' % id_)
         label = np.ascontiguousarray(_read(self.root, 'labels', id_)[0]) if os.path.exists(lp) else None
+        if self.resize_label and label is not None and tuple(image.shape[:2]) != self.base_size:
+            raise RuntimeError('GFSSegVal(resize_label=True): tile %s is %dx%d, base_size %dx%d -- only tiles that already have base_size are '
+                               'supported (cv2.resize is not restated in this build)' % ((id_,) + tuple(image.shape[:2]) + self.base_size))
         return image, label, (0, 0, False, 0), id_
 
     def augmenter(self, device, size):

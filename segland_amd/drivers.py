@@ -110,6 +110,17 @@ def batch_to_device(batch, dataset, device, cache={}):
     return aug.prepare(tiles, params)
 
 
+def ft_batch_to_device(batch, dataset, device, cache={}):
+    """(img, mask, img_b, mask_b) on the device from a fine-tune loader batch: ready tensors (synthetic_ft), or raw (novel, base) tile pairs +
+    their draws (dataset/oem_ft.py, synthetic_raw_ft.py), whose 2B tiles are prepared by ONE GPU launch."""
+    if not getattr(dataset, 'pair_tiles', False):
+        return tuple(t.to(device, non_blocking=True) for t in batch[:4])
+    aug = cache.get(id(dataset))
+    if aug is None:
+        aug = cache[id(dataset)] = dataset.augmenter(device)
+    return aug.prepare(batch[0], batch[1])
+
+
 def validate(model, dataloader, num_classes, ignore_label, device):
     """train_base.py:316-340 / ft_pop.py:312-336: logits -> upsample(align_corners=True) -> argmax -> IoU histogram,
     with the upsample+argmax fused in one HIP kernel (no H x W logits) and the histogram in another."""
@@ -119,6 +130,8 @@ def validate(model, dataloader, num_classes, ignore_label, device):
     union = torch.zeros(num_classes, device=device)
     for batch in dataloader:
         img, mask = batch_to_device(batch, dataloader.dataset, device)
+        if mask is None:
+            raise RuntimeError('validate(): the loader delivers unlabeled tiles; scoring needs labels (eval_base --save-prob dumps predictions for unlabeled tiles)')
         with torch.no_grad():
             logits = model(img)
             pred = ops.upsample_argmax(logits.float().contiguous(), mask.shape[1:])
@@ -173,6 +186,6 @@ def checkpoint_or_none(path, allow_random_init, what='--restore-from'):
 def resolve(dataset_pkg, name):
     mod = getattr(dataset_pkg, name, None)
     if mod is None:
-        raise RuntimeError("dataset '%s' is not built in this round (available: synthetic); the OpenEarthMap reader "
-                           "(rasterio/cv2) is row f-2 of SURVEY.md section 8" % name)
+        have = sorted(k for k, v in vars(dataset_pkg).items() if hasattr(v, 'GFSSegTrain'))
+        raise RuntimeError("unknown dataset '%s' (available: %s; 'oem' / 'oem_ft' decode GeoTIFF tiles with rasterio)" % (name, ', '.join(have)))
     return mod

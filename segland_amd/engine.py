@@ -116,7 +116,8 @@ class Engine(object):
         raw = getattr(dataset, 'raw_tiles', False)           # OpenEarthMap readers: workers decode, the GPU prepares the batch (dataset/augment.py)
         collate = None
         if raw:
-            from .dataset.oem import raw_collate as collate
+            from .dataset.oem import raw_collate
+            collate = getattr(dataset, 'collate_fn', None) or raw_collate        # fine-tune pair readers bring their own (dataset/oem_ft.py)
         loader = torch.utils.data.DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, drop_last=train,
                                              shuffle=(train and sampler is None), pin_memory=self.use_cuda and not raw, sampler=sampler,
                                              collate_fn=collate)

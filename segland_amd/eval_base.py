@@ -18,7 +18,8 @@ import torch
 
 from . import dataset as dataset_pkg
 from . import networks
-from .drivers import checkpoint_or_none, compute_dtype, resolve, str2bool
+from . import ops
+from .drivers import batch_to_device, checkpoint_or_none, compute_dtype, resolve, str2bool
 from .engine import Engine
 from .utils import pyt_utils as my_utils
 
@@ -125,14 +126,22 @@ def main(argv=None, ft=False):
                 my_utils.load_model(model, path)
             model.eval()
             cm = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=engine.device)
-            for image, label, ids in test_loader:
-                image, label = image.to(engine.device, non_blocking=True), label.to(engine.device, non_blocking=True)
+            for batch in test_loader:
+                # ready tensors (synthetic) or raw uint8 tiles + draws prepared on the GPU (oem / synthetic_raw: Engine installs raw_collate)
+                image, label = batch_to_device(batch, testset, engine.device)
+                ids = batch[2]
                 with torch.no_grad():
                     logits = model(image)
-                pred, cmb = confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)
-                cm += cmb
+                if label is None:
+                    # unlabeled test tiles (eval_base.py:178-191): nothing to score -- the prediction and the probability dump are the product
+                    size = tuple(image.shape[-2:])
+                    pred = ops.upsample_argmax(logits.float().contiguous(), size)
+                else:
+                    size = tuple(label.shape[-2:])
+                    pred, cmb = confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)
+                    cm += cmb
                 if args.save_prob and args.save_path:
-                    dump_probabilities(logits, label.shape[-2:], pred, ids, osp.join(args.save_path, 'prob_%d' % seed))
+                    dump_probabilities(logits, size, pred, ids, osp.join(args.save_path, 'prob_%d' % seed))
             if engine.distributed:
                 cm = engine.all_reduce_tensor(cm, norm=False)
             cmn = cm.cpu().numpy().astype(np.float64)

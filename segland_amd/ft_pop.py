@@ -12,15 +12,15 @@ import torch.optim as optim
 from . import dataset as dataset_pkg
 from . import networks
 from . import graph_step
-from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, resolve, save_checkpoint, validate
+from .drivers import adjust_learning_rate_poly, build_parser, checkpoint_or_none, compute_dtype, ft_batch_to_device, resolve, save_checkpoint, validate
 from .engine import Engine
 from .loss import get_loss
 from .utils import pyt_utils as my_utils
 
 
-def ft_iteration(model, optimizer, loss_scaler, batch, device):
+def ft_iteration(model, optimizer, loss_scaler, batch, device, dataset=None):
     """Loop body of ft_pop.py:243-256 (single optimizer step, zero_grad afterwards)."""
-    img, mask, img_b, mask_b = (t.to(device, non_blocking=True) for t in batch[:4])
+    img, mask, img_b, mask_b = ft_batch_to_device(batch, dataset, device)
     loss_dict = model(img, mask, img_b, mask_b.contiguous())
     grad_norm = loss_scaler(loss_dict['total_loss'], optimizer, clip_grad=5.0, parameters=model.parameters())
     optimizer.zero_grad()
@@ -38,9 +38,9 @@ def ft_graph_body(model, clip_grad=5.0):
     return body
 
 
-def ft_iteration_graphed(graphed, optimizer, batch, device):
+def ft_iteration_graphed(graphed, optimizer, batch, device, dataset=None):
     """ft_iteration with the model part replayed from one HIP graph."""
-    img, mask, img_b, mask_b = (t.to(device, non_blocking=True) for t in batch[:4])
+    img, mask, img_b, mask_b = ft_batch_to_device(batch, dataset, device)
     loss_dict, grad_norm = graphed(img, mask, img_b, mask_b.contiguous())
     optimizer.step()
     optimizer.zero_grad()
@@ -97,9 +97,9 @@ def main(argv=None):
                     if not args.fix_lr:
                         lr = adjust_learning_rate_poly(optimizer, args.learning_rate, it - 1, max_it, args.power, split)   # per ITERATION here
                     if graphed is not None:
-                        loss_dict, grad_norm = ft_iteration_graphed(graphed, optimizer, batch, engine.device)
+                        loss_dict, grad_norm = ft_iteration_graphed(graphed, optimizer, batch, engine.device, trainset)
                     else:
-                        loss_dict, grad_norm = ft_iteration(model, optimizer, loss_scaler, batch, engine.device)
+                        loss_dict, grad_norm = ft_iteration(model, optimizer, loss_scaler, batch, engine.device, trainset)
                     if i % args.print_frequency == 0:
                         vals = engine.reduce_loss_dict(loss_dict)
                         if engine.is_main:

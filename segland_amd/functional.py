@@ -32,8 +32,19 @@ _register_post_step(_on_optimizer_step)
 
 
 def weights_changed():
-    """For code that mutates parameters behind torch's back (`.data` writes, custom optimizers that are not torch.optim subclasses)."""
+    """For code that mutates parameters behind torch's back (`.data` writes, custom optimizers that are not torch.optim subclasses,
+    HIP-graph replays that contain an optimizer step: no Python hook runs during a replay)."""
     _OPT_EPOCH[0] += 1
+
+
+# BatchNorm running statistics are written by kernels through raw pointers.  An eager train-mode forward bumps the module's own
+# `_sl_rs_epoch`; a HIP-graph replay runs no Python at all, so graph_step bumps this global epoch after every replay.  It is part of
+# the key of every cache derived from running statistics (_bn_eval_coeffs, GFSS_Model._features_graphed).
+_RS_EPOCH = [0]
+
+
+def running_stats_changed():
+    _RS_EPOCH[0] += 1
 
 
 def _wver(w):
@@ -201,7 +212,7 @@ def _bn_eval_coeffs(bn):
     """(mean, invstd, scale, shift) of a BN on its running statistics, cached on the module until any of its four tensors changes
     (58 tiny launches per frozen forward otherwise -- the ft_pop step is launch-bound)."""
     key = (_wver(bn.weight), _wver(bn.bias), bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.eps,
-           bn.__dict__.get('_sl_rs_epoch', 0))      # train-mode forwards update the statistics behind the version counters
+           bn.__dict__.get('_sl_rs_epoch', 0), _RS_EPOCH[0])      # train-mode forwards / graph replays update the statistics behind the version counters
     ent = bn.__dict__.get('_sl_eval')
     if ent is None or ent[0] != key:
         ent = (key, ops.bn_finalize_eval(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))

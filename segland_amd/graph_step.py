@@ -45,6 +45,7 @@ class GraphedStep:
         self.seen, self.key, self.graph = {}, None, None
         self.static_in, self.static_out, self.static_grads = None, None, None
         self.replays, self.failures = 0, 0
+        self.bn_training = True
 
     def _state_key(self, tensors):
         trainable = sum(1 for p in self.model.parameters() if p.requires_grad)
@@ -64,6 +65,7 @@ class GraphedStep:
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             out = self._eager(self.static_in)
         self.graph, self.key, self.static_out = g, key, out
+        self.bn_training = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in self.model.modules())
         STATS['captures'] += 1
         # the gradients the replays write: tensors of the graph's pool that the parameters keep pointing at
         self.static_grads = [(p, p.grad) for p in self.model.parameters() if p.grad is not None]
@@ -98,6 +100,15 @@ class GraphedStep:
         self.graph.replay()
         self.replays += 1
         STATS['replays'] += 1
+        # A replay runs no Python: the optimizer kernel, the BN running-statistics kernels and the weight re-preparation (which sits BEFORE the
+        # optimizer in the captured order, so the prepared copies lag the parameters by one step) all went through raw pointers.  Invalidate every
+        # host-side cache keyed on them (prepared weights, BN eval coefficients, the captured eval feature graph): the next eager forward --
+        # validation between epochs -- must see this replay's weights and statistics.
+        from . import functional
+        if self.optimizer is not None:
+            functional.weights_changed()
+        if self.bn_training:
+            functional.running_stats_changed()
         return self.static_out
 
 

@@ -114,8 +114,8 @@ class GFSS_Model(nn.Module):
         trainable = any(p.requires_grad for p in frozen)
         if self.backbone.training or self.decoder.training or (trainable and torch.is_grad_enabled()):
             return None
-        from ..functional import _OPT_EPOCH              # fused optimizers change trainable weights without a version bump
-        sig = (tuple(img.shape), img.dtype, img.device, _OPT_EPOCH[0] if trainable else 0,
+        from ..functional import _OPT_EPOCH, _RS_EPOCH   # fused optimizers / graph replays change weights and running statistics without a version bump
+        sig = (tuple(img.shape), img.dtype, img.device, _OPT_EPOCH[0] if trainable else 0, _RS_EPOCH[0],
                sum(p._version for p in frozen) + sum(b._version for b in self.backbone.buffers()) + sum(b._version for b in self.decoder.buffers()))
         ent = self.__dict__.get('_sl_graph')
         if ent is None or ent[0] != sig:

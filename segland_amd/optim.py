@@ -98,8 +98,15 @@ class AdamW(torch.optim.Optimizer):
                 if p.requires_grad and p.is_cuda:
                     dev = p.device
                     n += 1
-                    st = self.state.get(p)
-                    counts.add(int(st['step']) if st else 0)
+                    st = self.state[p]
+                    if not st:
+                        # materialise the moments NOW: allocated inside the capture they would live in the graph's pool and their zero-fill
+                        # would be a graph node -- every replay would reset them (GraphedStep(warmup=0), or a parameter whose first gradient
+                        # arrives at capture time)
+                        st['step'] = torch.tensor(0.0)
+                        st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                        st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    counts.add(int(st['step']))
         if dev is None:
             raise RuntimeError('segland_amd.optim.AdamW.capture_begin: no GPU parameters')
         self._cap, self._graph_plan = {}, []

@@ -58,9 +58,11 @@ def main(argv=None):
         assert args.os in (8, 16, 32)
         model_cls = getattr(networks, args.model).GFSS_Model                    # `networks.<model>.GFSS_Model`
         seg_model = model_cls(n_base=args.base_classes, criterion=criterion, backbone=args.backbone, norm_layer=norm,
-                              pretrained_model=(checkpoint_or_none(args.restore_from, args.allow_random_init) if args.start_epoch == 0 else None),
+                              # a true resume (-c state_N.pth) restores every tensor: no pretrained backbone needed, and no existence check on --restore-from
+                              pretrained_model=(checkpoint_or_none(args.restore_from, args.allow_random_init)
+                                                if args.start_epoch == 0 and not engine.continue_state_object else None),
                               dilated=(args.os != 32), os=args.os, compute_dtype=compute_dtype(args))
-        if args.freeze_backbone and checkpoint_or_none(args.restore_from, args.allow_random_init):
+        if args.freeze_backbone and not engine.continue_state_object and checkpoint_or_none(args.restore_from, args.allow_random_init):
             my_utils.load_model(seg_model, args.restore_from, backbone_only=args.finetune, is_restore=not args.finetune)
         params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
         if engine.use_cuda:
@@ -111,7 +113,6 @@ def main(argv=None):
             e1 = epoch + 1
             if engine.is_main and (e1 % 10 == 0 or e1 >= args.num_epoch):
                 save_checkpoint(model, osp.join(args.snapshot_dir, 'epoch_%d.pth' % e1))
-                save_training_state(model, optimizer, osp.join(args.snapshot_dir, 'state_%d.pth' % e1), e1, best, best_epoch)
             if e1 > 35 and (e1 % 10 == 0 or epoch == args.num_epoch - 1):
                 inter, union = validate(model, test_loader, args.base_classes + 1, args.ignore_label, engine.device)
                 inter, union = engine.all_reduce_tensor(inter, norm=False), engine.all_reduce_tensor(union, norm=False)
@@ -121,7 +122,9 @@ def main(argv=None):
                         save_checkpoint(model, osp.join(args.snapshot_dir, 'best.pth'))
                         best, best_epoch = m, e1
                     logger.info('>>>>>>> Evaluation Results: meanIU: {:.2%}, best_IU: {:.2%}, best_epoch: {} <<<<<<<'.format(m, best, best_epoch))
-
+            if engine.is_main and (e1 % 10 == 0 or e1 >= args.num_epoch):
+                # AFTER this epoch's validation, so a resume from state_<e1>.pth carries the epoch's best / best_epoch
+                save_training_state(model, optimizer, osp.join(args.snapshot_dir, 'state_%d.pth' % e1), e1, best, best_epoch)
 
 if __name__ == '__main__':
     main()

@@ -674,7 +674,121 @@ def g18():
     save('g18_fusion', **res)
 
 
-ALL = dict(g18=g18, g17=g17, g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+
+# ------------------------------------------------------------------------------------------ G19: fine-tune pair reader
+def g19():
+    """dataset/oem_ft.py GFSSegTrain as the reference runs it in ft_pop.py:157-160: class -> id lists (_filter_and_map_ids, written to and re-read
+    from train_base_class<c>.txt), the support / base lists (_get_supp_list, update_base_list) and (novel, base) training pairs
+    (_get_train_sample) under fixed seeds, on synthetic tiles fed through the same rasterio stand-in and numpy copyMakeBorder as G17."""
+    import importlib.util
+    import random
+    import shutil
+    import tempfile
+    from oracle import data_oracle as do
+
+    def copy_make_border(src, top, bottom, left, right, border_type, value=0):
+        v = value[0] if isinstance(value, (tuple, list)) else value
+        pads = ((top, bottom), (left, right)) + (((0, 0),) if src.ndim == 3 else ())
+        return np.pad(src, pads, constant_values=v)
+    sys.modules['cv2'].copyMakeBorder = copy_make_border
+    sys.modules['cv2'].BORDER_CONSTANT = 0
+    ids, imgs, labs = do.ft_tiles()
+    arrays = {}
+    for id_ in ids:
+        arrays['R/images/%s.tif' % id_] = np.ascontiguousarray(np.rollaxis(imgs[id_], 2, 0))      # rasterio returns [C,H,W]
+        arrays['R/labels/%s.tif' % id_] = labs[id_][None]
+    rio = types.ModuleType('rasterio')
+    rio.open = lambda path: types.SimpleNamespace(read=lambda: arrays[path])
+    sys.modules['rasterio'] = rio
+    pkg = types.ModuleType('ref_dataset19'); pkg.__path__ = [os.path.join(REF, 'dataset')]
+    sys.modules['ref_dataset19'] = pkg
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location('ref_dataset19.' + name, os.path.join(REF, 'dataset', name + '.py'), submodule_search_locations=None)
+        mod = importlib.util.module_from_spec(spec)
+        mod.__package__ = 'ref_dataset19'
+        sys.modules['ref_dataset19.' + name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    load('base_dataset')
+    oem_ft = load('oem_ft')
+    shot, seed, crop = 2, 123, (64, 64)
+    base_classes, novel_classes = set(range(1, 8)), set(range(8, 12))
+    read_label = lambda i: labs[i]          # noqa: E731
+    read_image = lambda i: imgs[i]          # noqa: E731
+    out = {}
+    for filt in (False, True):
+        tmp = tempfile.mkdtemp(prefix='g19_')
+        list_dir = os.path.join(tmp, 'list')
+        for d in (list_dir, list_dir + '_filter'):
+            os.makedirs(d)
+        lst = os.path.join(list_dir, 'train.txt')
+        open(lst, 'w').write(''.join(i + '\n' for i in ids))
+        b2i, n2i = do.filter_and_map_ids(ids, read_label, base_classes, novel_classes, filter_intersection=False)
+        novel_ids = []
+        for c in sorted(novel_classes):                      # all_<shot>shot_seed<seed>.txt: `shot` support tiles per novel class (an input of the reader)
+            novel_ids += n2i[c][:shot]
+        for d in (list_dir, list_dir + '_filter'):
+            open(os.path.join(d, 'all_%dshot_seed%d.txt' % (shot, seed)), 'w').write(''.join(i + '\n' for i in novel_ids))
+        tag = 'f%d' % int(filt)
+        random.seed(7); np.random.seed(7)
+        ds = oem_ft.GFSSegTrain('R', lst, 0, shot=shot, mode='train', crop_size=crop, base_size=(64, 64), seed=seed, filter=filt)
+        ds.mean, ds.std = [0.5, 0.5, 0.5], [0.5, 0.5, 0.5]          # the values oem.py:26-27 trains with (oem_ft.py keeps BaseDataset's ImageNet defaults -- see below)
+        random.seed(7); np.random.seed(7)
+        b2i_o, _ = do.filter_and_map_ids(ids, read_label, base_classes, novel_classes, filter_intersection=filt)
+        base_o = do.sample_base_ids(b2i_o, base_classes, shot)
+        for c in base_classes:
+            assert list(ds.base_cls_to_ids[c]) == list(b2i_o[c]), ('g19 class map', c)
+            out['%s_cls%d' % (tag, c)] = np.array(b2i_o[c] or [''], dtype='U8')
+        assert ds.base_id_list == base_o and ds.supp_cls_id_list == novel_ids + base_o, 'g19 supp list'
+        assert len(ds) == len(base_o)
+        out[tag + '_base0'] = np.array(base_o, dtype='U8')
+        # a second construction re-reads the class lists from the files the first one wrote
+        random.seed(11)
+        ds2 = oem_ft.GFSSegTrain('R', lst, 0, shot=shot, mode='train', crop_size=crop, base_size=(64, 64), seed=seed, filter=filt)
+        random.seed(11)
+        assert ds2.base_id_list == do.sample_base_ids(b2i_o, base_classes, shot), 'g19 re-read'
+        # pairs, then update_base_list, then more pairs -- one RNG stream throughout
+        random.seed(21); np.random.seed(21)
+        got = [ds[i] for i in (0, 5, len(ds) - 1)]
+        ds.update_base_list()
+        got += [ds[i] for i in (1, 2)]
+        random.seed(21); np.random.seed(21)
+        bl = base_o
+        exp = [do.ft_pair(i, bl, novel_ids, read_image, read_label, crop) for i in (0, 5, len(bl) - 1)]
+        bl = do.sample_base_ids(b2i_o, base_classes, shot)
+        assert ds.base_id_list == bl, 'g19 update_base_list'
+        exp += [do.ft_pair(i, bl, novel_ids, read_image, read_label, crop) for i in (1, 2)]
+        out[tag + '_base1'] = np.array(bl, dtype='U8')
+        for k, (g, e) in enumerate(zip(got, exp)):
+            assert np.array_equal(g[0].numpy(), e[0]) and np.array_equal(g[1].numpy(), e[1]) and np.array_equal(g[2].numpy(), e[2]) \
+                and np.array_equal(g[3].numpy(), e[3]) and g[4] == e[4], 'g19 pair %d' % k
+            out['%s_p%d_img' % (tag, k)] = g[0].numpy()[:, ::4, ::4]
+            out['%s_p%d_lbl' % (tag, k)] = g[1].numpy().astype(np.uint8)
+            out['%s_p%d_imgb' % (tag, k)] = g[2].numpy()[:, ::4, ::4]
+            out['%s_p%d_lblb' % (tag, k)] = g[3].numpy().astype(np.uint8)
+            out['%s_p%d_id' % (tag, k)] = np.array([g[4]], dtype='U8')
+            out['%s_p%d_prm' % (tag, k)] = np.array([list(map(int, e[5])), list(map(int, e[6]))], dtype=np.int32)
+        shutil.rmtree(tmp)
+    out['novel_ids'] = np.array(novel_ids, dtype='U8')
+    # oem_ft.py does NOT override BaseDataset's ImageNet mean / std (oem.py:26-27 does): a fine-tune pair is normalised differently from a
+    # base-training tile.  Reproduced on purpose; one pair with the reader's own defaults:
+    tmp = tempfile.mkdtemp(prefix='g19_')
+    os.makedirs(os.path.join(tmp, 'list'))
+    lst = os.path.join(tmp, 'list', 'train.txt')
+    open(lst, 'w').write(''.join(i + '\n' for i in ids))
+    open(os.path.join(tmp, 'list', 'all_%dshot_seed%d.txt' % (shot, seed)), 'w').write(''.join(i + '\n' for i in novel_ids))
+    random.seed(5); np.random.seed(5)
+    ds = oem_ft.GFSSegTrain('R', lst, 0, shot=shot, mode='train', crop_size=crop, base_size=(64, 64), seed=seed)
+    g = ds[3]
+    out['default_mean'], out['default_std'] = np.array(ds.mean), np.array(ds.std)
+    out['default_img'], out['default_imgb'] = g[0].numpy()[:, ::4, ::4], g[2].numpy()[:, ::4, ::4]
+    out['default_base'] = np.array(ds.base_id_list, dtype='U8')
+    shutil.rmtree(tmp)
+    save('g19_oem_ft', **out)
+
+
+ALL = dict(g19=g19, g18=g18, g17=g17, g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

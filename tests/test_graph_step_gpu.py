@@ -88,6 +88,41 @@ def test_graphed_step_equals_eager(hip, family, dtype):
         assert float(sr['step']) == float(sg['step']) and torch.equal(sr['exp_avg'], sg['exp_avg']) and torch.equal(sr['exp_avg_sq'], sg['exp_avg_sq'])
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_validation_between_replays_sees_fresh_weights_and_statistics(hip, dtype):
+    """train (replays) -> eval -> train (replays ONLY) -> eval: a replay runs no Python, so neither the optimizer post-step hook nor
+    _bn_coeffs bump the host-side cache keys; the second evaluation must still use the weights, the prepared GEMM copies, the BN running
+    statistics and a fresh eval feature graph of THAT moment (train_base validates every 10 epochs through exactly this sequence)."""
+    from segland_amd import graph_step
+    from segland_amd.optim import AdamW
+    from segland_amd.train_base import train_iteration
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    batches = _batches(8, 2, 96, 128)
+
+    def run(model, graphed):
+        opt = AdamW(get_parameters(model, lr=1e-3), lr=1e-3, weight_decay=1e-4)
+        sc = NativeScalerWithGradNormCount()
+        step = graph_step.GraphedTrainStep(train_iteration, model, opt, sc, double_step=True, warmup=2) if graphed else None
+        evals = []
+        for phase in (batches[:5], batches[5:]):
+            model.train()
+            for img, mask in phase:
+                step(img, mask) if graphed else train_iteration(model, opt, sc, img, mask, double_step=True)
+            model.eval()
+            with torch.no_grad():
+                evals.append(model(batches[0][0]).float().cpu())
+        return evals, step
+
+    ref = _pspnet(dtype)
+    got = copy.deepcopy(ref)
+    ev_r, _ = run(ref, False)
+    ev_g, step = run(got, True)
+    assert step.replays >= 5 and step.graph is not None
+    assert not torch.equal(ev_r[0], ev_r[1])                      # the second phase really moved the model
+    assert torch.equal(ev_r[0], ev_g[0])
+    assert torch.equal(ev_r[1], ev_g[1]), 'second validation used stale weights / running statistics: max diff %g' % float((ev_r[1] - ev_g[1]).abs().max())
+
+
 def test_graphed_step_draws_fresh_stochastic_depth(hip):
     """DropPath / Dropout2d inside the graph draw new masks on every replay (torch's graph-safe Philox offsets): two replays on the SAME
     batch with the learning rate at 0 give different losses in train mode."""

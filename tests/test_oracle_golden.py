@@ -1,6 +1,7 @@
 """Pins oracle/pop_oracle.py to the golden vectors generated from the reference
 (tests/golden/make_golden.py).  CPU only.  Bit-exact where the op sequence is identical
 (torch.equal held against the reference at generation time; across machines we allow a few ULP)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -307,3 +308,73 @@ def test_g18_fusion_oracle():
                 arr[:, :, :8] = np.round(arr[:, :, :8])
             maps.append(arr[0])
         assert np.array_equal(do.fuse_probability_maps(maps), g['fused_' + tile])
+
+
+@pytest.mark.parametrize('filt', [False, True])
+def test_g19_pair_reader_lists_and_draws(tmp_path, filt):
+    """Row f-2, the fine-tune pair reader: golden G19 is what dataset/oem_ft.py of the reference produced (class -> id lists, support / base
+    lists before and after update_base_list, (novel, base) pairs with their draws) under fixed seeds.  The numpy oracle AND the product's host
+    logic (segland_amd/dataset/oem_ft.py: lists, draws, the 0 -> ignore rule before the crop draw) must reproduce it from the same seeds."""
+    import random
+    from oracle import data_oracle as do
+    from g19_common import product_reader
+    g = golden('g19_oem_ft')
+    tag = 'f%d' % int(filt)
+    novel_ids = g['novel_ids'].tolist()
+    ids, imgs, labs = do.ft_tiles()
+    base_classes, novel_classes = set(range(1, 8)), set(range(8, 12))
+    # oracle
+    b2i, _ = do.filter_and_map_ids(ids, lambda i: labs[i], base_classes, novel_classes, filter_intersection=filt)
+    for c in base_classes:
+        assert (b2i[c] or ['']) == g['%s_cls%d' % (tag, c)].tolist()
+    random.seed(7); np.random.seed(7)
+    base0 = do.sample_base_ids(b2i, base_classes, 2)
+    assert base0 == g[tag + '_base0'].tolist()
+    # product: same seeds, same lists (first construction scans the labels, the second re-reads the class files it wrote)
+    Reader = product_reader(tmp_path, filt, novel_ids=novel_ids)
+    random.seed(7); np.random.seed(7)
+    ds = Reader()
+    assert ds.base_id_list == base0 and ds.supp_cls_id_list == novel_ids + base0 and len(ds) == len(base0)
+    for c in base_classes:
+        assert (list(ds.base_cls_to_ids[c]) or ['']) == g['%s_cls%d' % (tag, c)].tolist()
+    random.seed(7); np.random.seed(7)
+    assert Reader().base_id_list == base0
+    # pairs: product draws == oracle draws == the reference's
+    random.seed(21); np.random.seed(21)
+    got = [ds[i] for i in (0, 5, len(ds) - 1)]
+    ds.update_base_list()
+    assert ds.base_id_list == g[tag + '_base1'].tolist()
+    got += [ds[i] for i in (1, 2)]
+    random.seed(21); np.random.seed(21)
+    bl = base0
+    exp = [do.ft_pair(i, bl, novel_ids, lambda i: imgs[i], lambda i: labs[i], (64, 64)) for i in (0, 5, len(bl) - 1)]
+    bl = do.sample_base_ids(b2i, base_classes, 2)
+    exp += [do.ft_pair(i, bl, novel_ids, lambda i: imgs[i], lambda i: labs[i], (64, 64)) for i in (1, 2)]
+    for k, (s, e) in enumerate(zip(got, exp)):
+        (tile, tile_b), (prm, prm_b), id_ = s
+        want = g['%s_p%d_prm' % (tag, k)].tolist()
+        assert id_ == e[4] == g['%s_p%d_id' % (tag, k)][0]
+        assert [list(map(int, prm)), list(map(int, prm_b))] == want == [list(map(int, e[5])), list(map(int, e[6]))]
+        assert 0 not in np.unique(tile[1])                      # oem_ft.py:197: unlabeled pixels of the novel tile are ignore
+        assert np.array_equal(e[0][:, ::4, ::4], g['%s_p%d_img' % (tag, k)]) and np.array_equal(e[1].astype(np.uint8), g['%s_p%d_lbl' % (tag, k)])
+        assert np.array_equal(e[2][:, ::4, ::4], g['%s_p%d_imgb' % (tag, k)]) and np.array_equal(e[3].astype(np.uint8), g['%s_p%d_lblb' % (tag, k)])
+        # the product's raw tiles + draws through the oracle's pixel path give the golden pixels too (the GPU test does this with the kernel)
+        io, lo = do.prepare_tile(tile[0], tile[1], (64, 64), *prm)
+        assert np.array_equal(io[:, ::4, ::4], g['%s_p%d_img' % (tag, k)]) and np.array_equal(lo.astype(np.uint8), g['%s_p%d_lbl' % (tag, k)])
+
+
+def test_pair_reader_rejects_what_the_reference_cannot_run(tmp_path):
+    from g19_common import product_reader
+    from segland_amd.dataset.oem_ft import MEAN, STD, PairReader
+    g = golden('g19_oem_ft')
+    assert np.allclose(g['default_mean'], MEAN) and np.allclose(g['default_std'], STD)       # oem_ft.py keeps BaseDataset's ImageNet statistics
+    r = PairReader()
+    with pytest.raises(RuntimeError, match='val_supp'):
+        r._init_lists('x/list/train.txt', 1, 'val_supp', (64, 64), 255, 123, False, True)
+    Reader = product_reader(tmp_path, False, novel_ids=g['novel_ids'].tolist())
+
+    class NoBase(Reader):
+        def __init__(self):
+            self._init_lists(os.path.join(str(tmp_path), 'list', 'train.txt'), 2, 'train', (64, 64), 255, 123, False, False)
+    with pytest.raises(RuntimeError, match='use_base=False'):
+        NoBase()

@@ -557,6 +557,79 @@ def test_train_base_on_raw_tiles_with_workers(hip, tmp_path):
     assert glob.glob(os.path.join(snap, 'epoch_36.pth')) and glob.glob(os.path.join(snap, 'best.pth'))
 
 
+def test_g19_pair_reader_gpu(hip, tmp_path):
+    """Row f-2: the product's fine-tune pair path end to end -- PairReader (lists, draws) -> pair_collate -> PairAugmenter (ONE launch for the 2B
+    tiles) -- bit-exact against golden G19, i.e. against the tensors dataset/oem_ft.py of the reference returned for the same seeds."""
+    import random
+    from g19_common import product_reader
+    from segland_amd.dataset.oem_ft import PairAugmenter, pair_collate
+    g = golden('g19_oem_ft')
+    novel_ids = g['novel_ids'].tolist()
+    for filt in (False, True):
+        tag = 'f%d' % int(filt)
+        random.seed(7); np.random.seed(7)
+        ds = product_reader(tmp_path / tag, filt, novel_ids=novel_ids)()
+        random.seed(21); np.random.seed(21)
+        samples = [ds[i] for i in (0, 5, len(ds) - 1)]
+        ds.update_base_list()
+        samples += [ds[i] for i in (1, 2)]
+        pairs, params, ids = pair_collate(samples)
+        aug = PairAugmenter((64, 64), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 255, device=DEV)         # the statistics G19's pairs were stored with
+        img, mask, img_b, mask_b = aug.prepare(pairs, params)
+        assert mask.dtype == torch.int64 and img.shape == (5, 3, 64, 64)
+        for k in range(5):
+            assert ids[k] == g['%s_p%d_id' % (tag, k)][0]
+            assert np.array_equal(img[k].cpu().numpy()[:, ::4, ::4], g['%s_p%d_img' % (tag, k)]), (tag, k)
+            assert np.array_equal(mask[k].cpu().numpy().astype(np.uint8), g['%s_p%d_lbl' % (tag, k)]), (tag, k)
+            assert np.array_equal(img_b[k].cpu().numpy()[:, ::4, ::4], g['%s_p%d_imgb' % (tag, k)]), (tag, k)
+            assert np.array_equal(mask_b[k].cpu().numpy().astype(np.uint8), g['%s_p%d_lblb' % (tag, k)]), (tag, k)
+    # the reader's own default statistics (BaseDataset's ImageNet mean / std: oem_ft.py never overrides them)
+    random.seed(5); np.random.seed(5)
+    ds = product_reader(tmp_path / 'dflt', False, novel_ids=novel_ids)()
+    assert ds.base_id_list == g['default_base'].tolist()
+    s = ds[3]
+    img, _, img_b, _ = ds.augmenter(DEV).prepare(*pair_collate([s])[:2])
+    assert np.array_equal(img[0].cpu().numpy()[:, ::4, ::4], g['default_img']) and np.array_equal(img_b[0].cpu().numpy()[:, ::4, ::4], g['default_imgb'])
+
+
+def test_ft_pop_on_raw_pairs_with_workers(hip, tmp_path):
+    """ft_pop end to end on the raw pair format (`--dataset synthetic_raw`: synthetic_raw_ft pairs for training, synthetic_raw tiles for the
+    validation): DataLoader workers decode + draw, pair_collate, one augment launch per batch, the graphed fine-tune step, validation."""
+    import glob
+    from segland_amd import ft_pop, graph_step
+    before = dict(graph_step.STATS)
+    snap = str(tmp_path / 'snap_ft_raw')
+    ft_pop.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_raw', '--batch-size', '2', '--input-size', '128,128',
+                 '--base-size', '128,128', '--num-epoch', '2', '--learning-rate', '1e-3', '--print-frequency', '4', '--snapshot-dir', snap, '--shot', '2',
+                 '--num-workers', '2', '--restore-from', '/nonexistent', '--allow-random-init', '--random-seed', '123', '--freeze-backbone', '--update-base'])
+    d = {k: graph_step.STATS[k] - before[k] for k in before}
+    print(d)
+    assert d['failures'] == 0 and d['replays'] >= 4
+    assert glob.glob(os.path.join(snap, 'epoch_1_123.pth'))
+
+
+def test_eval_base_on_raw_tiles_labeled_and_unlabeled(hip, tmp_path, monkeypatch):
+    """eval_base on the raw-tile datasets (Engine installs raw_collate: a batch is lists of numpy tiles): labeled tiles are scored, unlabeled test
+    tiles (label None -- when the reference writes its .mat files, eval_base.py:178-191) are only predicted and dumped."""
+    import scipy.io
+    from segland_amd import eval_base
+    from segland_amd.dataset import synthetic_raw
+    args = ['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_raw', '--base-size', '128,160', '--test-batch-size', '2', '--fp16',
+            '--restore-from', '/nonexistent', '--allow-random-init', '--num-workers', '2']
+    res = eval_base.main(args + ['--save-path', str(tmp_path / 'lab')])
+    assert 123 in res and np.isfinite(res[123][2])
+    orig = synthetic_raw.GFSSegVal.__getitem__
+
+    def unlabeled(self, i):
+        img, _, prm, id_ = orig(self, i)
+        return img, None, prm, id_
+    monkeypatch.setattr(synthetic_raw.GFSSegVal, '__getitem__', unlabeled)
+    out = tmp_path / 'unl'
+    eval_base.main(args[:-2] + ['--num-workers', '0', '--save-path', str(out), '--save-prob'])
+    mats = sorted(os.listdir(out / 'prob_123'))
+    assert len(mats) == 8 and scipy.io.loadmat(str(out / 'prob_123' / mats[0]))['outputs'].shape == (1, 12, 128, 160)
+
+
 # --------------------------------------------------------------------------------------------- f-3: probability dumps and their fusion
 def test_g18_fusion_and_probability_dump(hip, tmp_path):
     """sl_fuse_argmax bit-exact against golden G18 (the reference's fusemat.py run on three models' dumps, ties included); sl_upsample_logits
