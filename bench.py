@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: 512x512 tiles/sec, forward+backward (+clip +AdamW), PSPNet-POP on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N > 1: one rank per GPU -- under torch.distributed.run, or started by bench.py itself
+                                                          as fresh child processes when no launcher set WORLD_SIZE)
 
 A "step" is the loop body of the reference's train_base.py:250-264 over one synthetic batch that is already resident
 in HBM: zero_grad, forward (backbone + PPM + POP head + fused upsample/CE + orth loss), backward, clip_grad_norm_(5.0),
@@ -124,18 +125,44 @@ def cpu_baseline(budget_s, backbone, model='pspnet_pop'):
             ts.append(time.perf_counter() - t0)
         return ts
 
-    t_small = timed(256, 2)[-1]                        # first call is the warm-up
-    size, t = 256, t_small
-    if t_small * 4 * 2 < budget_s:
-        size, t = 512, min(timed(512, 2))
+    # 1 warm-up + >= 3 timed steps, median
+    def median(ts):
+        ts = sorted(ts)
+        return ts[len(ts) // 2]
+    small = timed(256, 4)
+    size, t, n_timed = 256, median(small[1:]), 3        # first call is the warm-up
+    if t * 4 * 4 < budget_s:                            # the full C1 sample (batch 2 at 512x512): 1 warm-up + 3 timed steps fit the budget
+        full = timed(512, 4)
+        size, t = 512, median(full[1:])
     cpu = ''
     try:
         cpu = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except Exception:
         pass
     return {'value': 2.0 * (size * size) / (512.0 * 512.0) / t, 'unit': 'tiles/s', 'cores': threads, 'kind': 'port',
-            'sample': ('oracle/swin_oracle.py' if model == 'swin_pop' else 'oracle/pop_oracle.py') + ' train_step (train_base.py:250-264 body), %s fp32, batch 2 at %dx%d, %.2f s/step after warm-up, '
+            'sample': ('oracle/swin_oracle.py' if model == 'swin_pop' else 'oracle/pop_oracle.py') + ' train_step (train_base.py:250-264 body), %s fp32, batch 2 at %dx%d, median of 3 timed steps after 1 warm-up: %.2f s/step, '
                       '%d threads (cgroup/affinity limit) on %s' % (backbone, size, size, t, threads, cpu)}
+
+
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` as a plain command (no launcher): start the N ranks as FRESH child processes of
+    `python -m torch.distributed.run` -- before this process has made any GPU call (a process that initialised the GPU must never exec or
+    become a rank) -- and pass rank 0's JSON line through.  Returns the exit code.  torch.cuda.device_count() does not initialise the GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print('bench.py --gpus %d: this node exposes %d GPU(s); one rank per GPU is required (RCCL refuses two ranks on one device). '
+              'Run with --gpus %d or fewer.' % (n, have, max(have, 1)), file=sys.stderr, flush=True)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    print('bench: --gpus %d without a launcher: starting %d ranks as child processes: %s' % (n, n, ' '.join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -149,9 +176,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != a.gpus and world > 1:
         a.gpus = world
-    if a.gpus > 1 and world == 1:
-        raise SystemExit('bench.py --gpus %d must be launched as `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py '
-                         '--gpus %d ...` (one rank per GPU); a single process would measure one GPU' % (a.gpus, a.gpus, a.gpus))
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -176,7 +202,14 @@ def main():
     opt = make_optimizer(model, torch_optimizer=a.torch_optimizer)
     net = model
     grad_div = 1
-    if use_ddp:
+    from segland_amd import bucket_step
+    replica = None
+    if use_ddp and not a.torch_optimizer and not a.no_step_graph and bucket_step.eligible(world, True):
+        # N > 1 default: gradient buckets owned by the build -- graph A (forward + backward into the buckets), one RCCL all-reduce per bucket,
+        # graph B (clip + AdamW): three host actions per step instead of ~750 launches under DistributedDataParallel's reducer (bucket_step.py)
+        net = replica = bucket_step.BucketedReplica(model, cap_mb=64)
+        grad_div = world
+    elif use_ddp:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True, bucket_cap_mb=64)
         if not a.torch_optimizer and os.environ.get('SEGLAND_DDP_PLAIN') != '1':
@@ -188,26 +221,35 @@ def main():
     img, mask = batches[0]
     double = not a.single_step
 
+    eager_fn = ((lambda img, mask: replica.train_iteration(opt, img, mask, double)) if replica is not None      # noqa: E731
+                else (lambda img, mask: train_step(net, opt, img, mask, params, double, grad_div)))
     # ---- warm-up; the last warm-up step is instrumented to find the dominant kernel shape
     for i in range(a.warmup):
         if i == a.warmup - 1:
             ops.PROFILER.start()
-        train_step(net, opt, img, mask, params, double, grad_div)
+        eager_fn(img, mask)
     if a.warmup == 0:
         ops.PROFILER.start()
-        train_step(net, opt, img, mask, params, double, grad_div)
+        eager_fn(img, mask)
     torch.cuda.synchronize()
     table = ops.PROFILER.stop()
     table_bytes = ops.PROFILER.stop_bytes()
-    single = {k: v for k, v in table.items() if 'wgrad' not in k}     # families that are exactly one kernel per launch
-    dominant = max(single.values(), key=lambda e: e['ms_total']) if single else None
+    # the kernel with the most time in the step, whichever family it is (in this instrumented pass a weight-gradient span includes its small fixed-order
+    # slab reduce)
+    dominant = max(table.values(), key=lambda e: e['ms_total']) if table else None
 
     # ---- the product's default on one GPU: the whole step replayed as ONE HIP graph (train_base does the same).  A graph replay cannot carry
     # per-launch events, so the K timed steps that give `value` are replays and a SECOND region of K kernel-by-kernel steps right after it
     # carries the event pairs of the roofline kernel (same kernels, same shapes, same process).
     from segland_amd import graph_step
     graphed = None
-    if not a.no_step_graph and not use_ddp and graph_step.eligible(net, opt, dev):
+    if replica is not None:
+        graphed = bucket_step.GraphedBucketStep(replica, opt, double_step=double, warmup=0)
+        for k in range(3):
+            graphed(*batches[k % len(batches)])
+        if graphed.graph is None:
+            graphed = None
+    elif not a.no_step_graph and not use_ddp and graph_step.eligible(net, opt, dev):
         fn = lambda m_, o_, s_, im_, mk_, double_step=True: (train_step(m_, o_, im_, mk_, params, double_step, grad_div), None)      # noqa: E731
         graphed = graph_step.GraphedTrainStep(fn, net, opt, None, double_step=double, warmup=0)
         for k in range(3):                                 # capture + two untimed replays
@@ -231,7 +273,6 @@ def main():
             dist.barrier()
         return time.perf_counter() - t0, marks
 
-    eager_fn = lambda img, mask: train_step(net, opt, img, mask, params, double, grad_div)      # noqa: E731
     # Region 1 -- the K timed steps of `value`: uninstrumented (graph replays on one GPU; kernel by kernel under DDP).
     # Region 2 -- K more steps issued kernel by kernel with HIP-event pairs around every launch of the roofline kernel (each pair costs two
     # ~5.7 us queue markers: 0.3 ms per R50 step, more next to DDP's RCCL stream, so they stay out of the number the driver compares).
@@ -270,7 +311,8 @@ def main():
                                    '(fwd+loss+bwd+clip+AdamW x%d), %d x MI355X' % (a.backbone, a.dtype, a.batch, a.size, a.size, 2 if double else 1, world),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
-            'step_issue': ('one HIP graph replay per step (segland_amd/graph_step.py, the train_base default on one GPU)' if graphed is not None
+            'step_issue': (('two HIP graph replays around one RCCL all-reduce per gradient bucket (segland_amd/bucket_step.py, the train_base default at N > 1)' if replica is not None
+                            else 'one HIP graph replay per step (segland_amd/graph_step.py, the train_base default on one GPU)') if graphed is not None
                            else 'kernel by kernel from Python' + (' under DistributedDataParallel / RCCL' if use_ddp else '')),
         }
         if eager_ms is not None:
@@ -297,21 +339,23 @@ def main():
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, 'profiles', 'r2_traffic.json')      # PMC passes (tools/collect_traffic.py), bytes per launch
-            if os.path.exists(tpath):
-                try:
-                    t = json.load(open(tpath))
-                    if t.get('kernel') == e['family']:
-                        traffic = t.get('hbm_bytes_per_launch')
-                        tsrc = 'NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/r2_traffic.json (tools/collect_traffic.py)'
-                except Exception:
-                    pass
+            for tname in ('r3_traffic.json', 'r3_traffic_wgrad.json', 'r3_traffic_p8.json', 'r2_traffic.json'):      # PMC passes (tools/collect_traffic.py), bytes per launch
+                tpath = os.path.join(ROOT, 'profiles', tname)
+                if traffic is None and os.path.exists(tpath):
+                    try:
+                        t = json.load(open(tpath))
+                        if t.get('kernel') and t['kernel'] == e['family']:
+                            traffic = t.get('hbm_bytes_per_launch')
+                            tsrc = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/%s '
+                                    '(tools/collect_traffic.py)' % tname)
+                    except Exception:
+                        pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'traffic_source': tsrc, 'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the %d instrumented kernel-by-kernel steps run right after the %d timed ones' % (a.steps, a.steps)
-                                       + ' (fwd + data-gradient convs of every shape it serves); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
+                                       + ' (every shape it serves; the fixed-order slab reduce behind a weight-gradient kernel is a separate small launch on the second stream, outside these spans); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
                                        + 'peak is the 2.4 GHz figure: on these N(0,1) operands the chip sustains ~1.65 GHz under this kernel (the same binary on all-zero operands runs '
                                        + '+26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
         if world == 1 and not a.no_cpu_baseline:

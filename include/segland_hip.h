@@ -54,6 +54,9 @@ typedef struct SlConvDesc {
 /* which tile kernel a shape is dispatched to (1000000*variant + 1000*BM + BN; variant 4 = 4-stage LDS ring, 2 = two-stage);
  * mode 0 = forward, 1 = data gradient.  Lets a profiler attribute launches to kernel names. */
 int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
+/* the same for the weight gradient: 1 = conv_wgrad_c64k3_kernel, 2 = conv_wgrad_c64p_kernel, 10000000 + 1000*BN + BC = conv_wgrad_glds_kernel,
+ * 20000000 + ... = conv_wgrad_kernel (+ 500000: rows are pixel pairs); every one is followed by its fixed-order slab reduce. */
+int sl_conv2d_wgrad_config(const SlConvDesc* d);
 
 /* number of row-blocks of the forward kernel == rows of the BN partial-statistics buffer */
 int sl_conv2d_stat_rows(const SlConvDesc* d);
@@ -95,6 +98,13 @@ int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, con
 /* the same, writing into a WIDER gradient tensor dw [Cout][dw_cin_total][KH][KW] at input-channel offset dw_ci_off */
 int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                             int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
+/* the same with the fixed-order slab reduce issued on `reduce_stream` (NULL or == stream: everything on `stream`).  The library orders the two streams with two
+ * lazily created events (MFMA kernel -> reduce; reduce -> the next weight gradient's use of the workspace); the caller makes `stream` wait for the reduces
+ * with sl_stream_join(stream, reduce_stream) before dw is consumed and before `workspace` is used by anything but the next weight gradient. */
+int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                             int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream);
+/* `stream` waits for everything queued on `other` so far (event record + stream wait: legal inside a stream capture) */
+int sl_stream_join(sl_stream_t stream, sl_stream_t other);
 
 /* OIHW float master weight -> w_fwd [Cout][KH][KW][Cin] and/or w_bwd [Cin][KH][KW][Cout] in dtype (either may be NULL) */
 int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,

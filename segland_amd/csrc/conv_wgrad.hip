@@ -852,6 +852,17 @@ extern "C" void sl_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
 // test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 
+// Which kernel sl_conv2d_bwd_weight runs for a shape (bench.py attributes HIP-event timings to rocprof kernel names with it):
+// 1 conv_wgrad_c64k3_kernel, 2 conv_wgrad_c64p_kernel, 10000000 + 1000*BNN + BCC conv_wgrad_glds_kernel, 20000000 + ... conv_wgrad_kernel;
+// + 500000 when the rows are pixel pairs.
+extern "C" int sl_conv2d_wgrad_config(const SlConvDesc* d) {
+  if (!d || d->Cout % 64 || d->Cin % 64) return SL_EINVAL;
+  if (c64k3_eligible(d, d->Cin, 0) && use_tr()) return 1;
+  if (c64p_eligible(d) && use_tr()) return 2;
+  const WgradPlan pl = plan(d);
+  return (pl.glds ? 10000000 : 20000000) + (pl.pair ? 500000 : 0) + 1000 * pl.bnn + pl.bcc;
+}
+
 extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 32) return 0;
   size_t need = plan(d).ws_bytes;
@@ -862,16 +873,65 @@ extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
 
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
+extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream);
 
 extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
                                     void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   return sl_conv2d_bwd_weight_ex(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream);
 }
-
-// dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  return sl_conv2d_bwd_weight_ex2(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, stream, nullptr);
+}
+
+// Slab reduces on a second stream.  The weight gradient has no consumer until the optimizer, and its fixed-order slab reduce (0.9 ms per ResNet-50
+// step in 80 small launches) is pure HBM traffic: issued on `reduce_stream` it runs beside the MFMA-bound data-gradient kernel that follows on `stream`
+// (in a captured step: a parallel branch of the graph).  Two lazily created events order it: main -> reduce after the MFMA kernel, and reduce -> main
+// before the NEXT weight gradient touches the (shared) workspace; the caller joins with sl_stream_join(stream, reduce_stream) before dw is consumed.
+namespace {
+struct ReduceFork {
+  hipEvent_t main_done = nullptr, red_done = nullptr;
+  bool pending = false;
+  int init() {
+    if (main_done) return 0;
+    if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&red_done, hipEventDisableTiming) != hipSuccess) {
+      sl_set_error("conv bwd_weight: hipEventCreate failed"); return SL_EINVAL;
+    }
+    return 0;
+  }
+} g_fork;
+}  // namespace
+
+// stream waits for everything queued on `other` so far (event record + wait; capturable)
+extern "C" int sl_stream_join(sl_stream_t stream, sl_stream_t other) {
+  if (!other || other == stream) return 0;
+  if (int e = g_fork.init()) return e;
+  if (hipEventRecord(g_fork.red_done, (hipStream_t)other) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_fork.red_done, 0) != hipSuccess) {
+    sl_set_error("sl_stream_join: event record / wait failed"); return SL_EINVAL;
+  }
+  g_fork.pending = false;
+  return 0;
+}
+
+// dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
+extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
+  const bool forked = reduce_stream && reduce_stream != stream;
+  if (g_fork.pending) {                          // a reduce of the previous call may still read the workspace this call overwrites
+    if (hipStreamWaitEvent((hipStream_t)stream, g_fork.red_done, 0) != hipSuccess) { sl_set_error("conv bwd_weight: hipStreamWaitEvent failed"); return SL_EINVAL; }
+    g_fork.pending = false;
+  }
+  if (forked) { if (int e = g_fork.init()) return e; }
+  // after the MFMA kernel: hand over to the reduce stream; after the reduce kernels: mark them for the next call / the join
+  auto fork = [&]() -> hipStream_t {
+    if (!forked) return (hipStream_t)stream;
+    (void)hipEventRecord(g_fork.main_done, (hipStream_t)stream);
+    (void)hipStreamWaitEvent((hipStream_t)reduce_stream, g_fork.main_done, 0);
+    return (hipStream_t)reduce_stream;
+  };
+  auto reduced = [&]() { if (forked) { (void)hipEventRecord(g_fork.red_done, (hipStream_t)reduce_stream); g_fork.pending = true; } };
   SL_REQUIRE(dw_ci_off >= 0 && dw_ci_off + d->Cin <= dw_cin_total, "conv bwd_weight: bad dw channel window");
   const int bke = d->dtype == SL_BF16 ? 64 : 32;
   const int c2 = d->Cin - d->C1;
@@ -889,9 +949,11 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
     hipLaunchKernelGGL(conv_wgrad_c64k3_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, d->B, d->H, d->W, ntiles);
     SL_LAUNCH_CHECK("conv_wgrad_c64k3_kernel");
     float* sum = (float*)workspace + (size_t)nblk * 64 * 64 * 9;
-    if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, stream)) return e;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
+    hipStream_t rs = fork();
+    if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, (sl_stream_t)rs)) return e;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, rs, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
+    reduced();
     return 0;
   }
   if (c64p_eligible(d) && use_tr()) {
@@ -908,9 +970,11 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
     SL_LAUNCH_CHECK("conv_wgrad_c64p_kernel");
     const long long total = (long long)d->Cout * d->Cin;
     float* sum = (float*)workspace + (size_t)nslab * total;
-    if (int e = sl_colsum_finalize((const float*)workspace, nslab, (int)total, sum, stream)) return e;          // fixed-order column sums over the slabs (one block per 64 numbers)
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off);
+    hipStream_t rs = fork();
+    if (int e = sl_colsum_finalize((const float*)workspace, nslab, (int)total, sum, (sl_stream_t)rs)) return e;          // fixed-order column sums over the slabs (one block per 64 numbers)
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off);
     SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
+    reduced();
     return 0;
   }
   const WgradPlan pl = plan(d);
@@ -930,6 +994,7 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
   else e = launch_wgrad<bf16_t, false>(pl, p, st);
   if (e) return e;
   SL_REQUIRE(pl.taps <= 49, "conv bwd_weight: kernel window larger than 7x7");
+  st = fork();
   if (pl.pair) {
     const long long total = (long long)d->Cout * d->Cin * pl.taps;
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
@@ -940,5 +1005,6 @@ extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
   }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
+  reduced();
   return 0;
 }

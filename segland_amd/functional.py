@@ -258,7 +258,8 @@ _WGRAD_STREAM = os.environ.get('SEGLAND_WGRAD_STREAM', '0') == '1'     # measure
 
 def wgrad_async(x, dy, spec, x2=None, out=None, out_ci_off=0):
     if not _WGRAD_STREAM or (ops.PROFILER.on and ops.PROFILER.only is None):
-        return ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=out, out_ci_off=out_ci_off)
+        # default: MFMA kernel on the main stream, its slab reduce on the second stream (joined by wgrad_join at the end of the block backward)
+        return ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=out, out_ci_off=out_ci_off, fork_reduce=True)
     main = torch.cuda.current_stream()
     ent = _SIDE.get(x.device)
     if ent is None:
@@ -278,6 +279,7 @@ def wgrad_async(x, dy, spec, x2=None, out=None, out_ci_off=0):
 
 def wgrad_join():
     """Make every weight gradient launched so far visible to the current stream (called before gradients leave a backward)."""
+    ops.wgrad_reduce_join()
     for dev, ent in _SIDE.items():
         if ent[1]:
             torch.cuda.current_stream(dev).wait_stream(ent[0])
@@ -448,7 +450,7 @@ class PPMFn(torch.autograd.Function):
         _, wbf = prepared(bt[3].weight, x4.dtype)
         dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
         gwf = grad_dst(bt[3].weight) if need_w else None
-        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf), gwf) if need_w else None
+        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf, fork_reduce=True), gwf) if need_w else None
         dbias = ops.colsum_rows(dfeat) if need_w else None
         if ctx.fact:
             N = bt[0].out_channels
@@ -560,13 +562,14 @@ def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x):
     _, w2b = prepared(cls[2].weight, X.dtype)
     dh1 = ops.conv2d_bwd_data(dh2, w2b, spec_of(cls[2]), (1, R), mask_src=h1)
     g2 = grad_dst(cls[2].weight) if need_w else None
-    dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2), g2) if need_w else None
+    dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2, fork_reduce=True), g2) if need_w else None
     dX = None
     if need_x:
         _, w1b = prepared(cls[0].weight, X.dtype)
         dX = ops.conv2d_bwd_data(dh1, w1b, spec_of(cls[0]), (1, R)).view(R, Cn)
     g1 = grad_dst(cls[0].weight) if need_w else None
-    dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1), g1) if need_w else None
+    dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1, fork_reduce=True), g1) if need_w else None
+    ops.wgrad_reduce_join()
     return dX, dw1, dw2, (dw3.view_as(cls[4].weight) if need_w else None)
 
 

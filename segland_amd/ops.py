@@ -63,7 +63,16 @@ class _Profiler:
 
     def family(self, kind, d):
         if kind == 'conv_wgrad':
-            return 'conv_wgrad (kernel + slab reduce)'
+            # the kernel rocprofv3 names.  Its deterministic slab reduce (a separate small launch) is inside the span in the instrumented per-shape
+            # pass and beside it, on the second stream, in the timed regions (conv2d_bwd_weight fork_reduce)
+            cfg = _lib.lib().sl_conv2d_wgrad_config(C.byref(d))
+            dts = 'bf16' if d.dtype == SL_BF16 else 'f32'
+            if cfg == 1:
+                return 'conv_wgrad_c64k3_kernel'
+            if cfg == 2:
+                return 'conv_wgrad_c64p_kernel'
+            name = 'conv_wgrad_glds_kernel' if cfg // 10000000 == 1 else 'conv_wgrad_kernel'
+            return '%s<%s, %d, %d>%s' % (name, dts, (cfg % 500000) // 1000, cfg % 1000, ' pixel pairs' if (cfg // 500000) % 2 else '')
         cfg = _lib.lib().sl_conv2d_tile_config(C.byref(d), 0 if kind == 'conv_fwd' else 1)
         return '%s<%s, %d, %d>' % (self.FAMILY.get(cfg // 1000000, '?'), 'bf16' if d.dtype == SL_BF16 else 'f32', (cfg // 1000) % 1000, cfg % 1000)
 
@@ -227,9 +236,10 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
 _ws_cache = {}
 
 
-def workspace(nbytes, dev):
-    """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream)."""
-    key = (dev, _s())
+def workspace(nbytes, dev, tag=None):
+    """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream).  `tag`: a separate buffer
+    (the weight-gradient slabs, which a reduce on the second stream may still be reading when the next op on this stream starts)."""
+    key = (dev, _s(), tag)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
@@ -237,18 +247,56 @@ def workspace(nbytes, dev):
     return w
 
 
-def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0):
-    """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off."""
+# Slab reduces of the weight gradients on a second stream (csrc/conv_wgrad.hip: sl_conv2d_bwd_weight_ex2): the reduce of layer k runs beside the
+# MFMA-bound data gradient of layer k that follows on the main stream.  Only callers that join before the gradient leaves their backward
+# (wgrad_reduce_join) may ask for it.  SEGLAND_WGRAD_REDUCE_STREAM=0 keeps everything on one stream.
+import os as _os
+_RED_FORK = _os.environ.get('SEGLAND_WGRAD_REDUCE_STREAM', '1') != '0'
+_red_streams = {}
+_red_pending = [False]
+
+
+def _reduce_stream(dev):
+    st = _red_streams.get(dev)
+    if st is None:
+        st = _red_streams[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0, fork_reduce=False):
+    """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off.
+    fork_reduce: the slab reduce goes to the second stream; the caller MUST call wgrad_reduce_join() before dw is read or handed to autograd."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     need = _lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d))
-    ws = workspace(need, x.device)
+    fork = fork_reduce and _RED_FORK and not (PROFILER.on and PROFILER.only is None)     # the instrumented per-shape pass times kernel + reduce on one stream
+    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
+    if cur is not None and cur.numel() < need:
+        wgrad_reduce_join()                       # the buffer is about to be replaced: no reduce on the second stream may still be reading the old one
+    ws = workspace(need, x.device, 'wgrad')
     dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
     tot = dw.shape[1]
     tok = PROFILER.begin('conv_wgrad', d)
-    check(_lib.lib().sl_conv2d_bwd_weight_ex(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
+    red = None
+    if fork:
+        rs = _reduce_stream(x.device)
+        red = rs.cuda_stream
+        _red_pending[0] = True
+    check(_lib.lib().sl_conv2d_bwd_weight_ex2(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s(), red), 'conv2d_bwd_weight')
     PROFILER.end(tok)
     return dw
+
+
+def wgrad_reduce_join():
+    """The current stream waits for every slab reduce issued on the second stream so far."""
+    if _red_pending[0]:
+        dev = torch.cuda.current_device()
+        rs = _red_streams.get(torch.device('cuda', dev))
+        if rs is None and _red_streams:
+            rs = list(_red_streams.values())[0]
+        if rs is not None:
+            check(_lib.lib().sl_stream_join(_s(), rs.cuda_stream), 'stream_join')
+        _red_pending[0] = False
 
 
 # --------------------------------------------------------------------------------------------- batch norm

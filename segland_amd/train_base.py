@@ -13,6 +13,7 @@ import torch.optim as optim
 
 from . import dataset as dataset_pkg
 from . import networks
+from . import bucket_step
 from . import graph_step
 from .drivers import adjust_learning_rate_poly, batch_to_device, build_parser, load_training_state, save_training_state, checkpoint_or_none, compute_dtype, miou, resolve, save_checkpoint, validate
 from .engine import Engine
@@ -70,13 +71,18 @@ def main(argv=None):
             optimizer = AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
         else:
             optimizer = optim.AdamW(params, lr=args.learning_rate, weight_decay=args.weight_decay)
-        model = engine.data_parallel(seg_model, sum_gradients=engine.use_cuda)      # our AdamW divides by the world size inside its kernel
+        model = engine.data_parallel(seg_model, sum_gradients=engine.use_cuda,      # our AdamW divides by the world size inside its kernel
+                                     graphable=engine.use_cuda and not args.no_step_graph)
         loss_scaler = my_utils.NativeScalerWithGradNormCount(engine.grad_div)
         if engine.is_main:
             os.makedirs(args.snapshot_dir, exist_ok=True)
 
         step = train_iteration
-        if not args.no_step_graph and graph_step.eligible(model, optimizer, engine.device):
+        if isinstance(model, bucket_step.BucketedReplica):
+            # N > 1 ranks: graph A (forward + backward into the gradient buckets), one all-reduce per bucket, graph B (clip + AdamW)
+            graphed = bucket_step.GraphedBucketStep(model, optimizer, double_step=not args.single_step)
+            step = lambda m, o, s, img, mask, double_step: graphed(img, mask)      # noqa: E731
+        elif not args.no_step_graph and graph_step.eligible(model, optimizer, engine.device):
             graphed = graph_step.GraphedTrainStep(train_iteration, model, optimizer, loss_scaler, double_step=not args.single_step)
             step = lambda m, o, s, img, mask, double_step: graphed(img, mask)      # noqa: E731  (one HIP graph launch per step)
 

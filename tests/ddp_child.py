@@ -4,7 +4,8 @@ world_size-1 RCCL run of the PRODUCT: segland_amd.GFSS_Model on the HIP kernels,
 (DistributedDataParallel, gradient_as_bucket_view, engine.py:71 of the reference), stepped by segland_amd.optim.AdamW with the
 train_base.py:250-264 loop body.  The process group is created before any GPU work of this process.  Prints one JSON line.
 
-    python tests/ddp_child.py <mode: 0 | force (SyncBN semantics) | inplace (sum-only all-reduce + gradients written into the bucket views)> <port>
+    python tests/ddp_child.py <mode: 0 | force (SyncBN semantics) | inplace (sum-only all-reduce + gradients written into the bucket views)
+                               | bucket (bucket_step.BucketedReplica: two HIP graphs around RCCL all-reduces of the build's own buckets)> <port>
 """
 import json
 import os
@@ -39,7 +40,8 @@ def main():
         img = fm.formula_image(4, 128, 128, 'ddp1/img').to(dev)
         mask = fm.formula_mask(4, 128, 128, 8, 'ddp1/mask', block=16, ignore_rows=6).to(dev)
 
-        inplace = sync == 'inplace'
+        inplace = sync in ('inplace', 'bucket')
+        bucket = sync == 'bucket'
         hits = [0]
         if inplace:
             real = sf.grad_dst
@@ -57,19 +59,28 @@ def main():
             fm.load_formula_weights(m)
             m = m.to(dev).train()
             opt = AdamW(get_parameters(m, lr=1e-4), lr=1e-4, weight_decay=1e-4)
-            net = engine.data_parallel(m, sum_gradients=inplace) if wrapped else m
-            if wrapped:
+            net = engine.data_parallel(m, sum_gradients=inplace, graphable=bucket) if wrapped else m
+            step = None
+            if wrapped and bucket:
+                from segland_amd import bucket_step
+                assert isinstance(net, bucket_step.BucketedReplica)
+                step = bucket_step.GraphedBucketStep(net, opt, double_step=True, warmup=1)
+            elif wrapped:
                 assert isinstance(net, nn.parallel.DistributedDataParallel)
             scaler = NativeScalerWithGradNormCount(engine.grad_div if wrapped else 1)
             losses = []
-            for it in range(3 if inplace else 2):
+            for it in range(5 if bucket else (3 if inplace else 2)):
                 hits[0] = 0
-                d, gn = train_iteration(net, opt, scaler, img, mask, double_step=True)
+                d, gn = step(img, mask) if step is not None else train_iteration(net, opt, scaler, img, mask, double_step=True)
                 losses.append([float(d['total_loss']), float(gn)])
-            if wrapped and inplace:
+            if step is not None:
+                out['bucket_replays'], out['bucket_failures'], out['buckets'] = step.replays, step.a.failures + step.b.failures, len(net.buckets)
+            if wrapped and inplace and not bucket:
                 out['inplace_writes_last_step'] = hits[0]
                 out['grads_alias_cached_views'] = sum(1 for p in m.parameters() if p.grad is not None and getattr(p, '_sl_gview', None) is not None
                                                       and p.grad.data_ptr() == p._sl_gview.data_ptr())
+            if wrapped and bucket:
+                out['grads_alias_cached_views'] = sum(1 for p in m.parameters() if p.grad is not None and p.grad.data_ptr() == net.views[id(p)].data_ptr())
             if wrapped:                        # gradients are views into DDP's flat buckets (gradient_as_bucket_view)
                 bucket_views = sum(1 for p in m.parameters() if p.grad is not None and p.grad._base is not None)
                 out['bucket_view_grads'] = bucket_views
@@ -91,7 +102,7 @@ def main():
                 worst, worst_key = e, k
         out.update(sync=sync, worst_param_rel=worst, worst_key=worst_key, losses=losses, ref_losses=ref_losses,
                    logits_rel=float((logits - ref_logits).abs().max() / ref_logits.abs().max()),
-                   n_params=len(ref_sd), bn1_tracked=int(sd['backbone.bn1.num_batches_tracked']))
+                   n_params=len(ref_sd), bn1_tracked=int(sd['backbone.bn1.num_batches_tracked']), ref_bn1_tracked=int(ref_sd['backbone.bn1.num_batches_tracked']))
     print('DDP_CHILD ' + json.dumps(out), flush=True)
 
 

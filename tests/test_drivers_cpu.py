@@ -176,3 +176,30 @@ def test_ddp_over_gloo_matches_single_process():
         np.testing.assert_allclose(g, ref[k].grad.numpy(), rtol=2e-4, atol=1e-7, err_msg=k)
     ref_norm = float(torch.stack([p.grad.norm() for p in m.parameters() if p.grad is not None]).norm())
     np.testing.assert_allclose(gnorm, ref_norm, rtol=1e-4)
+
+
+def test_bench_self_launch_starts_fresh_child_ranks(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher (how the driver may invoke the scaling bench): the parent starts N ranks through
+    torch.distributed.run as CHILD processes before touching the GPU; on a node with fewer GPUs it reports the rank-count problem."""
+    import importlib.util
+    import subprocess
+    import sys
+    import torch
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    assert bench.self_launch(2, ['--gpus', '2']) == 3
+    assert 'exposes 1 GPU' in capsys.readouterr().err
+    calls = []
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    assert bench.self_launch(4, ['--gpus', '4', '--steps', '5']) == 0
+    cmd, env = calls[0]
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert '--master-addr' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-4:] == ['--gpus', '4', '--steps', '5']
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # end to end in a real child: no GPU in this container -> the rank-count message and exit code 3, not a usage error
+    r = subprocess.run([sys.executable, bench.__file__, '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+    assert r.returncode == 3 and 'one rank per GPU' in r.stderr and 'usage' not in r.stderr.lower(), (r.returncode, r.stderr[-500:])

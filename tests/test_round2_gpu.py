@@ -627,7 +627,7 @@ def test_eval_base_on_raw_tiles_labeled_and_unlabeled(hip, tmp_path, monkeypatch
     out = tmp_path / 'unl'
     eval_base.main(args[:-2] + ['--num-workers', '0', '--save-path', str(out), '--save-prob'])
     mats = sorted(os.listdir(out / 'prob_123'))
-    assert len(mats) == 8 and scipy.io.loadmat(str(out / 'prob_123' / mats[0]))['outputs'].shape == (1, 12, 128, 160)
+    assert len(mats) == 8 and scipy.io.loadmat(str(out / 'prob_123' / mats[0]))['outputs'].shape == (1, 8, 128, 160)      # base evaluation: bg + 7 base classes
 
 
 # --------------------------------------------------------------------------------------------- f-3: probability dumps and their fusion
