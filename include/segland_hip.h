@@ -90,6 +90,15 @@ int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, con
 int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
                        const void* mask_src, void* dx, sl_stream_t stream);
 
+/* Data gradient + the reduce pass of the BatchNorm backward below it, in one kernel (resnet.py:57-78 backward: conv3 <- bn2/relu, conv2 <- bn1/relu).
+ * The result is the gradient wrt a = relu(bn(c)); the epilogue gates it with the ReLU bits of `gate` (1 byte per 16-byte vector of dx), stores the gated
+ * gradient g in dx and writes per-row-block column sums (sum g, sum g * (bn_x - mean) * invstd) to stat_partial [rows][2][Cin] -- the partials that
+ * sl_bn_bwd_reduce would produce in a separate pass over g and bn_x; sl_bn_bwd_finalize / sl_bn_bwd_apply(relu_mask = NULL) consume them unchanged.
+ * sl_conv2d_bwd_data_bnstat_rows: rows of stat_partial, or 0 when the shape is not served (then: sl_conv2d_bwd_data + sl_bn_bwd_reduce). */
+int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d);
+int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const uint8_t* gate, const void* bn_x, const float* bn_mean,
+                              const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
+
 /* dw (float, OIHW [Cout][Cin][KH][KW]) = sum over pixels of dy (x) x.  Deterministic split-K through `workspace`. */
 size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);
 int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
@@ -151,6 +160,15 @@ int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long long count, c
 int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const uint8_t* relu_mask, const void* x, const float* cA,
                     const float* cB, const float* cC, const float* mean, void* dx, void* dres, long long rows, int C,
                     sl_stream_t stream);
+
+/* Two BatchNorms whose outputs were added before ONE ReLU -- bn3 and the downsample BN of the first bottleneck of a stage (resnet.py:71-76) -- share the gated
+ * gradient g = dy * relu'(out): one sweep over dy and the ReLU bits serves both reduce passes (partial1 / partial2, each [rows][2][C] like sl_bn_bwd_reduce)
+ * and both apply passes (dx1 / dx2).  The largest tensor of the block is read twice instead of four times. */
+int sl_bn_bwd_reduce2(int dtype, const void* dy, const uint8_t* relu_mask, const void* x1, const float* mean1, const float* invstd1, float* partial1,
+                      const void* x2, const float* mean2, const float* invstd2, float* partial2, long long rows, int C, sl_stream_t stream);
+int sl_bn_bwd_apply2(int dtype, const void* dy, const uint8_t* relu_mask, const void* x1, const float* cA1, const float* cB1, const float* cC1,
+                     const float* mean1, void* dx1, const void* x2, const float* cA2, const float* cB2, const float* cC2, const float* mean2, void* dx2,
+                     long long rows, int C, sl_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ stem
  * resnet.py:86-90,124-125: conv 7x7 s2 p3 3->64 on the NCHW float image, BN, ReLU, maxpool 3x3 s2 p1. */
@@ -229,6 +247,13 @@ int sl_ppm_fact_scatter(const SlPpmDesc* d, int N, const void* dcb, float* gq, v
 int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, float* proj, void* bg, long long R,
                          int C, sl_stream_t stream);
 /* rows of +S and -S appended to an MLP input matrix: dst[2*Kt][C] = [S ; -S] in dtype */
+/* Prototype preparation (pspnet_pop.py:96-99,170-171,185-186,236-239 + criterion.py:37-43) in one launch: Sa / Sb = L2-normalised rows of Ea [Ka][C] / Eb [Kb][C]
+ * (eps 1e-12), G [Ka][Ka+Kb] = Sa [Sa ; Sb]^T, orth[0] = mean |G[i][j]| over j > i, inv_norm [Ka+Kb] for the backward.  Kb may be 0 (base training: G = S S^T). */
+int sl_pop_proto_fwd(const float* Ea, int Ka, const float* Eb, int Kb, int C, float* Sa, float* Sb, float* inv_norm, float* G, float* orth,
+                     sl_stream_t stream);
+/* gradients wrt Ea / Eb (either may be NULL) from dSa / dSb (may be NULL = zero) and the scalar dorth (may be NULL) */
+int sl_pop_proto_bwd(const float* Sa, int Ka, const float* Sb, int Kb, int C, const float* inv_norm, const float* G, const float* dSa,
+                     const float* dSb, const float* dorth, float* dEa, float* dEb, sl_stream_t stream);
 int sl_pop_proto_rows(int dtype, const float* S, int Kt, int C, void* dst, sl_stream_t stream);
 /* z[r] = h[r] . w   (classifier.4, Cout = 1; h is the post-ReLU activation) */
 int sl_rowdot_fwd(int dtype, const void* h, const float* w, float* z, long long R, int C, sl_stream_t stream);

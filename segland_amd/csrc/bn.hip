@@ -126,12 +126,16 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x
 
 // ------------------------------------------------------------------------------------------------ backward reduce
 // partial[blk][0][c] = sum g, partial[blk][1][c] = sum g * (x - mean) * invstd over the block's rows
-template <typename T>
+// DUAL: a second BatchNorm whose output was added to the first one's before the same ReLU (bn3 + downsample BN of a bottleneck, resnet.py:71-76): both backward
+// passes gate the SAME gradient, so one sweep over dy and the bits serves both (x2, mean2, invstd2 -> part2)
+template <typename T, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            float* __restrict__ part, long long rows, int C) {
+                                                            float* __restrict__ part, long long rows, int C,
+                                                            const T* __restrict__ x2 = nullptr, const float* __restrict__ mean2 = nullptr, const float* __restrict__ invstd2 = nullptr,
+                                                            float* __restrict__ part2 = nullptr) {
   constexpr int V = Vec16<T>::N;
-  __shared__ float red[2 * 256 * V];
+  __shared__ float red[(DUAL ? 3 : 2) * 256 * V];
   const unsigned lb = blockIdx.x;
   const int nvec = C / V;
   const int tpr = nvec < 256 ? nvec : 256;      // threads per row
@@ -140,12 +144,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   // block b owns the row groups b, b + nblk, b + 2 nblk, ...: the chip reads ONE moving window of the tensor, like the streaming passes
   // (measured 4.2 vs 4.0 TB/s for a contiguous row range per block; 2 or 4 rows in flight per thread were SLOWER: 3.9 / 3.2 TB/s)
   const long long r_begin = (long long)lb * rpb, r_end = rows, rstep = (long long)gridDim.x * rpb;
+  constexpr int NS = DUAL ? 3 : 2;
   for (int vc = tc; vc < nvec; vc += tpr) {
-    float s1[V], s2[V], mu[V], is[V];
+    float s1[V], s2[V], s3[V], mu[V], is[V], mu2[V], is2[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = mean[vc * V + k]; is[k] = invstd[vc * V + k]; }
+    for (int k = 0; k < V; ++k) {
+      s1[k] = 0.f; s2[k] = 0.f; s3[k] = 0.f; mu[k] = mean[vc * V + k]; is[k] = invstd[vc * V + k];
+      if (DUAL) { mu2[k] = mean2[vc * V + k]; is2[k] = invstd2[vc * V + k]; }
+    }
     if (tr < rpb) {
-      auto acc = [&](const uint4& gq, const uint4& xq, const uint4& yq, unsigned mb) {
+      auto acc = [&](const uint4& gq, const uint4& xq, const uint4& yq, unsigned mb, const uint4& x2q) {
         float g[V], xv[V], yv[V];
         unpack16<T>(gq, g);
         unpack16<T>(xq, xv);
@@ -159,27 +167,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         }
 #pragma unroll
         for (int k = 0; k < V; ++k) { s1[k] += g[k]; s2[k] += g[k] * ((xv[k] - mu[k]) * is[k]); }
+        if (DUAL) {
+          float x2v[V];
+          unpack16<T>(x2q, x2v);
+#pragma unroll
+          for (int k = 0; k < V; ++k) s3[k] += g[k] * ((x2v[k] - mu2[k]) * is2[k]);
+        }
       };
       long long r = r_begin + tr;
       for (; r < r_end; r += rstep) {
         const size_t o = (size_t)r * nvec + vc;
-        uint4 yq = make_uint4(0, 0, 0, 0);
+        uint4 yq = make_uint4(0, 0, 0, 0), x2q = make_uint4(0, 0, 0, 0);
         if (!mask && y) yq = ((const uint4*)y)[o];
-        acc(((const uint4*)dy)[o], ((const uint4*)x)[o], yq, mask ? mask[o] : 0u);
+        if (DUAL) x2q = ((const uint4*)x2)[o];
+        acc(((const uint4*)dy)[o], ((const uint4*)x)[o], yq, mask ? mask[o] : 0u, x2q);
       }
     }
     // reduce over the rpb row-lanes that share this channel vector
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < V; ++k) { red[(threadIdx.x * V + k) * 2 + 0] = s1[k]; red[(threadIdx.x * V + k) * 2 + 1] = s2[k]; }
+    for (int k = 0; k < V; ++k) {
+      red[(threadIdx.x * V + k) * NS + 0] = s1[k]; red[(threadIdx.x * V + k) * NS + 1] = s2[k];
+      if (DUAL) red[(threadIdx.x * V + k) * NS + 2] = s3[k];
+    }
     __syncthreads();
     if (tr == 0) {
 #pragma unroll
       for (int k = 0; k < V; ++k) {
-        float a = 0.f, b = 0.f;
-        for (int j = 0; j < rpb; ++j) { a += red[((j * tpr + tc) * V + k) * 2 + 0]; b += red[((j * tpr + tc) * V + k) * 2 + 1]; }
+        float a = 0.f, b = 0.f, c3 = 0.f;
+        for (int j = 0; j < rpb; ++j) {
+          a += red[((j * tpr + tc) * V + k) * NS + 0]; b += red[((j * tpr + tc) * V + k) * NS + 1];
+          if (DUAL) c3 += red[((j * tpr + tc) * V + k) * NS + 2];
+        }
         part[((size_t)lb * 2 + 0) * C + vc * V + k] = a;
         part[((size_t)lb * 2 + 1) * C + vc * V + k] = b;
+        if (DUAL) { part2[((size_t)lb * 2 + 0) * C + vc * V + k] = a; part2[((size_t)lb * 2 + 1) * C + vc * V + k] = c3; }
       }
     }
   }
@@ -206,35 +228,41 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_bwd_finalize_kernel(const 
   }
 }
 
-template <typename T, bool FIXEDC>
+template <typename T, bool FIXEDC, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                     const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
-                                    const float* __restrict__ mean, T* __restrict__ dx, T* __restrict__ dres, unsigned nvec, unsigned nvc) {
+                                    const float* __restrict__ mean, T* __restrict__ dx, T* __restrict__ dres, unsigned nvec, unsigned nvc,
+                                    const T* __restrict__ x2 = nullptr, const float* __restrict__ cA2 = nullptr, const float* __restrict__ cB2 = nullptr,
+                                    const float* __restrict__ cC2 = nullptr, const float* __restrict__ mean2 = nullptr, T* __restrict__ dx2 = nullptr) {
   constexpr int V = Vec16<T>::N;
   float a_[V], b_[V], c_[V], cc[V];      // dx = a*g + b*(x - c) + cc
-  if (FIXEDC) {
-    const unsigned c = (threadIdx.x % nvc) * V;
+  float a2[V], b2[V], c2[V], cc2[V];     // DUAL: the second BatchNorm fed by the same gated gradient
+  auto coeffs = [&](unsigned c) {
 #pragma unroll
-    for (int k = 0; k < V; ++k) { a_[k] = cA[c + k]; b_[k] = cB[c + k]; c_[k] = mean[c + k]; cc[k] = cC[c + k]; }
-  }
+    for (int k = 0; k < V; ++k) {
+      a_[k] = cA[c + k]; b_[k] = cB[c + k]; c_[k] = mean[c + k]; cc[k] = cC[c + k];
+      if (DUAL) { a2[k] = cA2[c + k]; b2[k] = cB2[c + k]; c2[k] = mean2[c + k]; cc2[k] = cC2[c + k]; }
+    }
+  };
+  if (FIXEDC) coeffs((threadIdx.x % nvc) * V);
   const unsigned nchunk = (nvec + 511u) >> 9;          // 512 consecutive vectors per block-iteration
   for (unsigned ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
     const unsigned i0 = (ch << 9) + threadIdx.x;
-    uint4 gv[2], xv[2], yv[2];
+    uint4 gv[2], xv[2], yv[2], x2v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const unsigned i = i0 + u * 256u;
-      if (i < nvec) { gv[u] = ((const uint4*)dy)[i]; xv[u] = ((const uint4*)x)[i]; if (y && !mask) yv[u] = ((const uint4*)y)[i]; }
+      if (i < nvec) {
+        gv[u] = ((const uint4*)dy)[i]; xv[u] = ((const uint4*)x)[i];
+        if (y && !mask) yv[u] = ((const uint4*)y)[i];
+        if (DUAL) x2v[u] = ((const uint4*)x2)[i];
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const unsigned i = i0 + u * 256u;
       if (i >= nvec) break;
-      if (!FIXEDC) {
-        const unsigned c = (i % nvc) * V;
-#pragma unroll
-        for (int k = 0; k < V; ++k) { a_[k] = cA[c + k]; b_[k] = cB[c + k]; c_[k] = mean[c + k]; cc[k] = cC[c + k]; }
-      }
+      if (!FIXEDC) coeffs((i % nvc) * V);
       float g[V], xx[V], yy[V], o[V];
       unpack16<T>(gv[u], g);
       unpack16<T>(xv[u], xx);
@@ -251,6 +279,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       for (int k = 0; k < V; ++k) o[k] = a_[k] * g[k] + b_[k] * (xx[k] - c_[k]) + cc[k];
       ((uint4*)dx)[i] = pack16<T>(o);
       if (dres) ((uint4*)dres)[i] = pack16<T>(g);
+      if (DUAL) {
+        float x2x[V];
+        unpack16<T>(x2v[u], x2x);
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = a2[k] * g[k] + b2[k] * (x2x[k] - c2[k]) + cc2[k];
+        ((uint4*)dx2)[i] = pack16<T>(o);
+      }
     }
   }
 }
@@ -359,5 +394,49 @@ extern "C" int sl_bn_bwd_apply(int dtype, const void* dy, const void* y, const u
   if (dtype == SL_BF16) return launch_bn_apply<bf16_t>(dy, y, relu_mask, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
   if (dtype == SL_F32) return launch_bn_apply<float>(dy, y, relu_mask, x, cA, cB, cC, mean, dx, dres, rows, C, (hipStream_t)stream);
   SL_REQUIRE(false, "bn_bwd_apply: bad dtype");
+  return 0;
+}
+
+// Two BatchNorms behind one ReLU (bn3 + the downsample BN of the first bottleneck of a stage): ONE sweep over dy and the ReLU bits for both reduces / both applies.
+extern "C" int sl_bn_bwd_reduce2(int dtype, const void* dy, const uint8_t* relu_mask, const void* x1, const float* mean1, const float* invstd1, float* partial1,
+                                 const void* x2, const float* mean2, const float* invstd2, float* partial2, long long rows, int C, sl_stream_t stream) {
+  SL_REQUIRE(dy && x1 && x2 && mean1 && invstd1 && mean2 && invstd2 && partial1 && partial2 && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_reduce2: bad args");
+  const int nblk = reduce_blocks(rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SL_BF16)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, true>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)nullptr, relu_mask, (const bf16_t*)x1, mean1, invstd1, partial1, rows, C,
+                       (const bf16_t*)x2, mean2, invstd2, partial2);
+  else if (dtype == SL_F32)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, true>), dim3(nblk), dim3(256), 0, st, (const float*)dy, (const float*)nullptr, relu_mask, (const float*)x1, mean1, invstd1, partial1, rows, C,
+                       (const float*)x2, mean2, invstd2, partial2);
+  else SL_REQUIRE(false, "bn_bwd_reduce2: bad dtype");
+  SL_LAUNCH_CHECK("bn_bwd_reduce_kernel<dual>");
+  return 0;
+}
+
+template <typename T>
+static int launch_bn_apply2(const void* dy, const uint8_t* mask, const void* x1, const float* cA1, const float* cB1, const float* cC1, const float* mean1, void* dx1,
+                            const void* x2, const float* cA2, const float* cB2, const float* cC2, const float* mean2, void* dx2, long long rows, int C, hipStream_t st) {
+  constexpr int V = Vec16<T>::N;
+  const long long nvec = rows * C / V;
+  SL_REQUIRE(nvec < (1ll << 31), "bn_bwd_apply2: tensor too large");
+  const unsigned nvc = C / V;
+  const bool fixed = nvc <= 256 && 256 % nvc == 0;
+  const int blocks = ew_blocks((nvec + 1) / 2);
+  if (fixed) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)nullptr, mask, (const T*)x1, cA1, cB1, cC1, mean1, (T*)dx1, (T*)nullptr,
+                                (unsigned)nvec, nvc, (const T*)x2, cA2, cB2, cC2, mean2, (T*)dx2);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3(blocks), dim3(256), 0, st, (const T*)dy, (const T*)nullptr, mask, (const T*)x1, cA1, cB1, cC1, mean1, (T*)dx1, (T*)nullptr,
+                          (unsigned)nvec, nvc, (const T*)x2, cA2, cB2, cC2, mean2, (T*)dx2);
+  SL_LAUNCH_CHECK("bn_bwd_apply_kernel<dual>");
+  return 0;
+}
+
+extern "C" int sl_bn_bwd_apply2(int dtype, const void* dy, const uint8_t* relu_mask, const void* x1, const float* cA1, const float* cB1, const float* cC1,
+                                const float* mean1, void* dx1, const void* x2, const float* cA2, const float* cB2, const float* cC2, const float* mean2, void* dx2,
+                                long long rows, int C, sl_stream_t stream) {
+  SL_REQUIRE(dy && x1 && x2 && cA1 && cB1 && cC1 && mean1 && dx1 && cA2 && cB2 && cC2 && mean2 && dx2 && rows > 0 && C > 0 && C % 8 == 0, "bn_bwd_apply2: bad args");
+  if (dtype == SL_BF16) return launch_bn_apply2<bf16_t>(dy, relu_mask, x1, cA1, cB1, cC1, mean1, dx1, x2, cA2, cB2, cC2, mean2, dx2, rows, C, (hipStream_t)stream);
+  if (dtype == SL_F32) return launch_bn_apply2<float>(dy, relu_mask, x1, cA1, cB1, cC1, mean1, dx1, x2, cA2, cB2, cC2, mean2, dx2, rows, C, (hipStream_t)stream);
+  SL_REQUIRE(false, "bn_bwd_apply2: bad dtype");
   return 0;
 }

@@ -28,6 +28,12 @@ struct ConvGemmParams {
   const void* pre_addend;               // [M][N] added to the accumulators BEFORE statistics / bias (factorised PPM priors) or null
   const unsigned char* addend_mask;     // relu bits (1 byte per 16-byte vector) gating the addend, or null
   float* stat_partial;                  // [gridM][2][N] or null
+  // BatchNorm-backward statistics in a data-gradient epilogue (MODE 3 of the fast store phase): the result is the gradient wrt the ACTIVATION a = relu(bn(c)) of the
+  // previous layer; it is gated with that ReLU's bits, stored, and its column sums (sum g, sum g * (c - mean) * invstd) go to stat_partial -- what bn_bwd_reduce would
+  // compute in a pass of its own over g and c
+  const unsigned char* gate;            // relu bits of the OUTPUT positions (1 byte per 16-byte vector) or null
+  const void* bn_x;                     // [M][N] the BN input c
+  const float* bn_mean; const float* bn_invstd;   // [N]
   const float* row_scale;               // [B] per-sample multiplier of (acc * scale + bias), applied before the addend (DropPath), or null
   void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
@@ -349,7 +355,43 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
     const size_t goff = (grow * p.N + ncol) * sizeof(T);
     unsigned char* o = (unsigned char*)p.out + goff;
     const unsigned char* l = smem + r0 * G::PITCH + cc * 16;
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 3) {
+      // gate with the ReLU bits of these positions, store, accumulate (sum g, sum g * xhat) per column with xhat = (c - mean) * invstd exactly as bn_bwd_reduce forms it
+      const unsigned char* xs = (const unsigned char*)p.bn_x + goff;
+      const unsigned char* gb = p.gate + goff / 16;
+      f2_t mu[EPC / 2], is[EPC / 2];
+#pragma unroll
+      for (int e = 0; e < EPC / 2; ++e) {
+        mu[e] = (f2_t){p.bn_mean[ncol + 2 * e], p.bn_mean[ncol + 2 * e + 1]};
+        is[e] = (f2_t){p.bn_invstd[ncol + 2 * e], p.bn_invstd[ncol + 2 * e + 1]};
+      }
+      constexpr int CH3 = SPLIT ? 2 : CH;          // the persistent half-tile kernel is at its register limit: two rows in flight there
+#pragma unroll 1
+      for (int it0 = 0; it0 < NIT; it0 += CH3) {
+        uint4 xv[CH3]; unsigned bits[CH3];
+#pragma unroll
+        for (int u = 0; u < CH3; ++u) { xv[u] = *(const uint4*)(xs + soff(it0 + u)); bits[u] = gb[soff(it0 + u) / 16]; }
+#pragma unroll
+        for (int u = 0; u < CH3; ++u) {
+          uint4 raw = *(const uint4*)(l + (it0 + u) * (RS * G::PITCH));
+          const unsigned b = bits[u];
+          if constexpr (sizeof(T) == 2) {
+            raw.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
+            raw.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
+            raw.z &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
+            raw.w &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
+          } else {
+            raw.x &= (unsigned)__builtin_amdgcn_sbfe(b, 0, 1); raw.y &= (unsigned)__builtin_amdgcn_sbfe(b, 1, 1);
+            raw.z &= (unsigned)__builtin_amdgcn_sbfe(b, 2, 1); raw.w &= (unsigned)__builtin_amdgcn_sbfe(b, 3, 1);
+          }
+          st16(o + soff(it0 + u), raw);
+          f2_t v[EPC / 2], w[EPC / 2];
+          unpack2(raw, v); unpack2(xv[u], w);
+#pragma unroll
+          for (int e = 0; e < EPC / 2; ++e) { ssum[e] += v[e]; ssq[e] += v[e] * ((w[e] - mu[e]) * is[e]); }
+        }
+      }
+    } else if constexpr (MODE == 1) {
       if (p.stat_partial) {
 #pragma unroll 4
         for (int it = 0; it < NIT; ++it) {
@@ -411,7 +453,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
     }
     lds_barrier();
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 1 || MODE == 3) {
     if (p.stat_partial) {
       float fs[EPC], fq[EPC];
 #pragma unroll
@@ -453,7 +495,10 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
   const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2;
   // Returns the number of vector-memory instructions the wave issued (loads + stores; every path below issues the same count in every wave), or -1 when that is
   // not a compile-time fact of the path: the persistent half-tile kernel uses it to wait for loads that are OLDER than these instructions without waiting for them.
-  if (full && !shaped && !p.addend) {
+  if (full && !shaped && !p.addend && p.gate) {
+    conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    return SPLIT ? 49 : -1;                                             // 2 passes x 8 sweeps x (BN input + gate byte + store), + the statistic partial
+  } else if (full && !shaped && !p.addend) {
     if constexpr (SPLIT) asm volatile("; EPI_BEGIN mode1");
     conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     if constexpr (SPLIT) asm volatile("; EPI_END mode1");
@@ -1121,7 +1166,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
     if (nk > 1) {
       issueB(0, tap2, ct2, p8_slot_b0(1)); issueA(0, tap2, ct2, p8_slot_a0(1)); issueA(1, tap2, ct2, p8_slot_a1(1)); issueB(1, tap2, ct2, p8_slot_b1(1));
       // K-tile 0 must have landed.  Younger than its loads: the 8 LDS-DMA just issued and the `younger` loads / stores of the previous tile's epilogue, which need not be waited for
-      switch (younger) { case 16: wait_vmcnt<24>(); break; case 17: wait_vmcnt<25>(); break; case 32: wait_vmcnt<40>(); break; case 48: wait_vmcnt<56>(); break; default: wait_vmcnt<8>(); }
+      switch (younger) { case 16: wait_vmcnt<24>(); break; case 17: wait_vmcnt<25>(); break; case 32: wait_vmcnt<40>(); break; case 48: wait_vmcnt<56>(); break; case 49: wait_vmcnt<57>(); break; default: wait_vmcnt<8>(); }
     } else wait_vmcnt<0>();
     adv(tap2, ct2);
     __builtin_amdgcn_s_barrier();
@@ -1991,12 +2036,12 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
   if constexpr (sizeof(T) == 2) {
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
-        !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2))
+        !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
       return launch_c64k3(p, st);
   }
   if constexpr (sizeof(T) == 2) {
     if (v >= 5 && sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
-        !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask) &&
+        !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate) && !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask) &&
         (!p.addend_mask || (p.N % 128 == 0 && p.N <= 1024)))
       return launch_sk(p, st);
   }
@@ -2148,6 +2193,34 @@ extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const voi
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
   p.addend = addend; p.mask_src = mask_src; p.addend_mask = addend ? addend_mask : nullptr;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// Data gradient whose result is gated with the ReLU bits of its own positions and reduced for the BatchNorm backward of the layer below (see ConvGemmParams::gate).
+// rows of stat_partial: sl_conv2d_bwd_data_bnstat_rows(d), 0 = this shape is not served (the caller runs sl_conv2d_bwd_data + sl_bn_bwd_reduce instead): served are the
+// shapes that the tile kernels with the LDS-staged store phase take (half-tile, 3x3 patch, ring, two-stage) when every row block is full.
+extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
+  if (!d) return 0;
+  static const bool off = getenv("SEGLAND_BN_FUSE") && getenv("SEGLAND_BN_FUSE")[0] == '0';
+  if (off || conv_variant() < 2) return 0;
+  const int cfg = sl_conv2d_tile_config(d, 1);
+  const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
+  const long long M = (long long)d->B * d->H * d->W;
+  if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2) || bm <= 0 || M % bm != 0) return 0;
+  return (int)(M / bm);
+}
+
+extern "C" int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const uint8_t* gate, const void* bn_x, const float* bn_mean,
+                                         const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && dx && gate && bn_x && bn_mean && bn_invstd && stat_partial, "conv bwd_data_bnstat: null buffer");
+  SL_REQUIRE(sl_conv2d_bwd_data_bnstat_rows(d) > 0, "conv bwd_data_bnstat: shape not served (sl_conv2d_bwd_data_bnstat_rows == 0)");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

@@ -377,6 +377,95 @@ int pop_dispatch(int dtype, int C, F&& f) {
   return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Prototype preparation in ONE launch (forward) / ONE launch (backward): S = F.normalize(E, p=2, dim=-1) (pspnet_pop.py:96-99,170-171), the prototype
+// similarity G = S_a [S_a ; S_b]^T (pspnet_pop.py:185-186 base: S_b empty, G = S S^T;  :236-239 ft: a = novel, b = base) and the orthogonality term
+// mean |G[i][j]|, j > i (criterion.py:37-43, also for the rectangular ft matrix).  In torch this is ~50 launches of 5 us each per step (normalize, matmul,
+// gather, abs, mean and their autograd mirrors) -- 1 % of the ResNet-50 step.  K <= 16 rows of C <= 1024 numbers: one block, everything in the LDS.
+constexpr int PP_KMAX = 32;
+__global__ __launch_bounds__(256) void pop_proto_fwd_kernel(const float* __restrict__ Ea, int Ka, const float* __restrict__ Eb, int Kb, int C,
+                                                            float* __restrict__ Sa, float* __restrict__ Sb, float* __restrict__ inv_norm, float* __restrict__ G,
+                                                            float* __restrict__ orth) {
+  extern __shared__ float sm[];                     // [Ka + Kb][C] normalised rows, then [Ka][Ka + Kb] similarities
+  __shared__ float nrm[PP_KMAX];
+  const int Kt = Ka + Kb, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = wave; k < Kt; k += 4) {              // one wavefront per row: sum of squares in a fixed order
+    const float* e = k < Ka ? Ea + (size_t)k * C : Eb + (size_t)(k - Ka) * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += e[c] * e[c];
+    s = wave_sum(s);
+    if (lane == 0) nrm[k] = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  }
+  __syncthreads();
+  for (int i = tid; i < Kt * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    const float v = (k < Ka ? Ea[(size_t)k * C + c] : Eb[(size_t)(k - Ka) * C + c]) * nrm[k];
+    sm[i] = v;
+    if (k < Ka) Sa[i] = v; else Sb[(size_t)(k - Ka) * C + c] = v;
+  }
+  if (tid < Kt) inv_norm[tid] = nrm[tid];
+  __syncthreads();
+  float* gs = sm + Kt * C;
+  for (int pr = wave; pr < Ka * Kt; pr += 4) {
+    const int i = pr / Kt, j = pr - i * Kt;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += sm[i * C + c] * sm[j * C + c];
+    s = wave_sum(s);
+    if (lane == 0) { gs[pr] = s; G[pr] = s; }
+  }
+  __syncthreads();
+  if (tid == 0) {                                   // row-major over the strict upper triangle, like the reference's boolean-mask selection
+    float s = 0.f; int n = 0;
+    for (int i = 0; i < Ka; ++i)
+      for (int j = i + 1; j < Kt; ++j) { s += fabsf(gs[i * Kt + j]); ++n; }
+    orth[0] = n ? s / (float)n : 0.f;
+  }
+}
+
+// dE = normalize' (dS + d orth): dS_total[k] = dS[k] + sum over the similarity entries the row takes part in; dE[k] = (dS_total[k] - S[k] (S[k] . dS_total[k])) * inv_norm[k]
+__global__ __launch_bounds__(256) void pop_proto_bwd_kernel(const float* __restrict__ Sa, int Ka, const float* __restrict__ Sb, int Kb, int C,
+                                                            const float* __restrict__ inv_norm, const float* __restrict__ G, const float* __restrict__ dSa,
+                                                            const float* __restrict__ dSb, const float* __restrict__ dorth, float* __restrict__ dEa, float* __restrict__ dEb) {
+  extern __shared__ float sm[];                     // [Kt][C] S, [Kt][C] dS_total
+  __shared__ float coef[PP_KMAX * PP_KMAX];         // d orth / d G[i][j]
+  __shared__ float dots[PP_KMAX];
+  const int Kt = Ka + Kb, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n = 0;
+  for (int i = 0; i < Ka; ++i) n += Kt - i - 1 > 0 ? Kt - i - 1 : 0;
+  const float go = (dorth && n) ? dorth[0] / (float)n : 0.f;
+  for (int pr = tid; pr < Ka * Kt; pr += 256) {
+    const int i = pr / Kt, j = pr - i * Kt;
+    const float g = G[pr];
+    coef[pr] = j > i ? go * (g > 0.f ? 1.f : (g < 0.f ? -1.f : 0.f)) : 0.f;     // torch.sign(0) = 0
+  }
+  for (int i = tid; i < Kt * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    sm[i] = k < Ka ? Sa[i] : Sb[(size_t)(k - Ka) * C + c];
+  }
+  __syncthreads();
+  float* dt = sm + Kt * C;
+  for (int i = tid; i < Kt * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    float v = k < Ka ? (dSa ? dSa[i] : 0.f) : (dSb ? dSb[(size_t)(k - Ka) * C + c] : 0.f);
+    if (k < Ka) for (int j = 0; j < Kt; ++j) v += coef[k * Kt + j] * sm[j * C + c];      // G[k][j] = S_k . S_j as row k
+    for (int i2 = 0; i2 < Ka; ++i2) v += coef[i2 * Kt + k] * sm[i2 * C + c];               // G[i2][k] as column k
+    dt[i] = v;
+  }
+  __syncthreads();
+  for (int k = wave; k < Kt; k += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += sm[k * C + c] * dt[k * C + c];
+    s = wave_sum(s);
+    if (lane == 0) dots[k] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < Kt * C; i += 256) {
+    const int k = i / C, c = i - k * C;
+    const float v = (dt[i] - sm[i] * dots[k]) * inv_norm[k];
+    if (k < Ka) { if (dEa) dEa[i] = v; } else if (dEb) dEb[(size_t)(k - Ka) * C + c] = v;
+  }
+}
 }  // namespace
 
 extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, float* proj, void* bg, long long R,
@@ -391,6 +480,27 @@ extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S
         else hipLaunchKernelGGL((pop_decompose_fwd_kernel<T, decltype(nv)::value, decltype(lpr)::value, 16>), dim3(blocks), dim3(256), lds, st, (const T*)feats, S, Kt, proj, (T*)bg, R, C);
         return 0; })) return e;
   SL_LAUNCH_CHECK("pop_decompose_fwd_kernel");
+  return 0;
+}
+
+
+extern "C" int sl_pop_proto_fwd(const float* Ea, int Ka, const float* Eb, int Kb, int C, float* Sa, float* Sb, float* inv_norm, float* G, float* orth,
+                                sl_stream_t stream) {
+  SL_REQUIRE(Ea && Sa && inv_norm && G && orth && Ka >= 1 && Kb >= 0 && Ka + Kb <= PP_KMAX && C > 0 && (Kb == 0 || (Eb && Sb)), "pop_proto_fwd: bad args");
+  const size_t lds = ((size_t)(Ka + Kb) * C + (size_t)Ka * (Ka + Kb)) * sizeof(float);
+  SL_REQUIRE(lds <= 60 * 1024, "pop_proto_fwd: %d prototypes of %d channels do not fit one block", Ka + Kb, C);
+  hipLaunchKernelGGL(pop_proto_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, Ea, Ka, Eb, Kb, C, Sa, Sb, inv_norm, G, orth);
+  SL_LAUNCH_CHECK("pop_proto_fwd_kernel");
+  return 0;
+}
+
+extern "C" int sl_pop_proto_bwd(const float* Sa, int Ka, const float* Sb, int Kb, int C, const float* inv_norm, const float* G, const float* dSa,
+                                const float* dSb, const float* dorth, float* dEa, float* dEb, sl_stream_t stream) {
+  SL_REQUIRE(Sa && inv_norm && G && Ka >= 1 && Kb >= 0 && Ka + Kb <= PP_KMAX && C > 0 && (Kb == 0 || Sb), "pop_proto_bwd: bad args");
+  const size_t lds = 2 * (size_t)(Ka + Kb) * C * sizeof(float);
+  SL_REQUIRE(lds <= 60 * 1024, "pop_proto_bwd: %d prototypes of %d channels do not fit one block", Ka + Kb, C);
+  hipLaunchKernelGGL(pop_proto_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, Sa, Ka, Sb, Kb, C, inv_norm, G, dSa, dSb, dorth, dEa, dEb);
+  SL_LAUNCH_CHECK("pop_proto_bwd_kernel");
   return 0;
 }
 

@@ -225,29 +225,45 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
+_BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'
+
+
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
-                bits=None, addend_bits=None):
-    """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres).
+                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None):
+    """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres, partial_below).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
-    `addend_bits` gate) is accumulated into dx by the dgrad epilogue."""
+    `addend_bits` gate) is accumulated into dx by the dgrad epilogue.
+    pre_partial: dy is ALREADY gated and the BN-backward column sums of this layer were produced by the epilogue that wrote it (no reduce pass).
+    below = (bits, c, mean, invstd) of the BatchNorm + ReLU that produced x: when the data gradient of this conv runs on a kernel with the staged
+    store phase, its epilogue gates dx with those bits and emits that layer's column sums (partial_below is then not None and dx is gated).
+    bn_done = (dc, dgamma, dbeta): the BatchNorm part was already done by the caller (ops.bn_bwd2: two BatchNorms behind one ReLU in one sweep)."""
     gw, gg, gb = (grad_dst(conv.weight), grad_dst(bn.weight), grad_dst(bn.bias)) if need_dw else (None, None, None)
-    dc, dres, dgamma, dbeta = ops.bn_bwd(dy, None if bits is not None else y_mask, c, mean, invstd, bn.weight, train=bn.training,
-                                         want_dres=want_dres, mask=bits, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb)
-    dgamma, dbeta = grad_alias(dgamma, gg), grad_alias(dbeta, gb)
+    if bn_done is not None:
+        (dc, dgamma, dbeta), dres = bn_done, None
+    else:
+        dc, dres, dgamma, dbeta = ops.bn_bwd(dy, None if (bits is not None or pre_partial is not None) else y_mask, c, mean, invstd, bn.weight, train=bn.training,
+                                             want_dres=want_dres, mask=None if pre_partial is not None else bits, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb,
+                                             pre_partial=pre_partial)
+        dgamma, dbeta = grad_alias(dgamma, gg), grad_alias(dbeta, gb)
     spec = spec_of(conv)
-    dx = dw = None
+    dx = dw = part_below = None
     late = _WGRAD_STREAM and os.environ.get('SEGLAND_WGRAD_LATE', '1') == '1'
     if need_dw and not late:
         dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
-        dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
-                                 C1=(x.shape[3] if x2 is not None else None), out=dx_out)
+        if below is not None and _BN_FUSE and addend is None and x2 is None and dx_out is None:
+            r = ops.conv2d_bwd_data_bnstat(dc, wb, spec, x.shape[1:3], *below)
+            if r is not None:
+                dx, part_below = r
+        if dx is None:
+            dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
+                                     C1=(x.shape[3] if x2 is not None else None), out=dx_out)
     if need_dw and late:
         # side stream, released only AFTER the data gradient: the MFMA-bound wgrad then runs beside the HBM-bound BN backward of the
         # previous layer (its waves fit next to the wgrad block on a CU) instead of time-slicing the CUs with the dgrad kernel
         dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
-    return dx, dw, dgamma, dbeta, dres
+    return dx, dw, dgamma, dbeta, dres, part_below
 
 
 # Weight gradients have no consumer until the optimizer: they run on a second HIP stream so that their MFMA-bound
@@ -351,18 +367,31 @@ class BottleneckFn(torch.autograd.Function):
         dout = dout.contiguous()
         need_w = ctx.needs_input_grad[2]            # params are all-or-nothing frozen in this model family
         need_x = ctx.needs_input_grad[0]
-        da2, dw3, dg3, db3, _ = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3)
-        da1, dw2, dg2, db2, _ = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=k2)
+        # the data gradients of conv3 and conv2 gate their result with the ReLU bits of the layer below and emit its BN-backward column sums in the epilogue
+        # (where the kernel has the staged store phase: layer3 / layer4 at the bench shapes): that layer's reduce pass over (g, c) disappears
+        done3 = doned = None
+        if ctx.has_ds and _BN_FUSE and k3 is not None and blk.bn3.training and blk.downsample[1].training and not sync_world(blk.bn3):
+            # bn3 and the downsample BN sit behind the same ReLU: one sweep over dout and its bits for both reduces, one for both applies (ops.bn_bwd2)
+            cd, md, idd = sv[14:17]
+            bnd = blk.downsample[1]
+            g3, b3, gd_, bd_ = (grad_dst(blk.bn3.weight), grad_dst(blk.bn3.bias), grad_dst(bnd.weight), grad_dst(bnd.bias)) if need_w else (None,) * 4
+            dc3, dg3_, db3_, dcd, dgd_, dbd_ = ops.bn_bwd2(dout, k3, c3, m3, i3, blk.bn3.weight, cd, md, idd, bnd.weight, (g3, b3), (gd_, bd_))
+            done3 = (dc3, grad_alias(dg3_, g3), grad_alias(db3_, b3))
+            doned = (dcd, grad_alias(dgd_, gd_), grad_alias(dbd_, bd_))
+        da2, dw3, dg3, db3, _, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3,
+                                                below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3)
+        da1, dw2, dg2, db2, _, p1 = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=None if p2 is not None else k2, pre_partial=p2,
+                                                below=(k1, c1, m1, i1) if blk.bn1.training else None)
         grads_ds = ()
         if ctx.has_ds:
             cd, md, idd = sv[14:17]
-            dxd, dwd, dgd, dbd, _ = conv_bn_bwd(dout, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w, bits=k3)
+            dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned)
             grads_ds = (dwd, dgd, dbd)
             addend, abits = dxd, None
         else:
             addend, abits = dout, k3                # identity shortcut: dout * relu'(out), gated inside the dgrad epilogue
-        dx, dw1, dg1, db1, _ = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
-                                           addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=k1)
+        dx, dw1, dg1, db1, _, _ = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
+                                              addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1)
         wgrad_join()
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
 
@@ -479,7 +508,7 @@ class PPMFn(torch.autograd.Function):
                 ops.ppm_dwq_scatter(dwq, dwb, Cs, nl)
                 dwb = grad_alias(dwb, gwb)
         else:
-            dcat, dwb, dgb, dbb, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
+            dcat, dwb, dgb, dbb, _, _ = conv_bn_bwd(dab, ab, cb, priors, bt[0], bt[1], mb, ib, True, need_w, x2=x4)
             dstage = ops.ppm_upsample_bwd(dcat, x4.shape, sizes, Cs)
             cat_off = len(sizes) * Cs
         dc_all = torch.empty_like(stage_act)
@@ -662,6 +691,36 @@ class PopHeadFn(torch.autograd.Function):
 
 def cls_params(cls):
     return [cls[0].weight, cls[2].weight, cls[4].weight]
+
+
+class ProtoFn(torch.autograd.Function):
+    """F.normalize of the prototype embeddings (pspnet_pop.py:96-99), their similarity matrix (:185-186 / :236-239) and the orthogonality term
+    (criterion.py:37-43) as ONE kernel forward and ONE backward (torch: ~50 launches of 5 us).  forward(Ea [Ka,C], Eb [Kb,C] | None) ->
+    (Sa, Sb | empty, orth []): rows of the similarity are the `a` prototypes, columns [a ; b]."""
+
+    @staticmethod
+    def forward(ctx, Ea, Eb):
+        Ea = Ea.detach().float().contiguous()
+        Ebc = None if Eb is None else Eb.detach().float().contiguous()
+        Sa, Sb, inv, G, orth = ops.pop_proto_fwd(Ea, Ebc)
+        ctx.has_b = Eb is not None
+        ctx.save_for_backward(Sa, inv, G, *([Sb] if ctx.has_b else []))
+        return Sa, (Sb if ctx.has_b else Sa.new_empty(0)), orth.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dSa, dSb, dorth):
+        sv = ctx.saved_tensors
+        Sa, inv, G = sv[:3]
+        Sb = sv[3] if ctx.has_b else None
+        need_a, need_b = ctx.needs_input_grad[0], ctx.has_b and ctx.needs_input_grad[1]
+        if not (need_a or need_b):
+            return None, None
+        dSa = None if dSa is None else dSa.float().contiguous()
+        dSb = None if (dSb is None or not ctx.has_b) else dSb.float().contiguous()
+        dorth = None if dorth is None else dorth.float().reshape(1).contiguous()
+        dEa, dEb = ops.pop_proto_bwd(Sa, Sb, inv, G, dSa, dSb, dorth, need_a, need_b)
+        return dEa, dEb
 
 
 # ------------------------------------------------------------------------------------------------ loss

@@ -6,6 +6,14 @@ import torch.nn as nn
 from ..functional import UpsampleCEFn
 
 
+class OrthTerm:
+    """The orthogonality term already evaluated by the model's fused prototype kernel (functional.ProtoFn), handed to OrthLoss in the place of
+    the similarity matrix it would be computed from.  A plain tensor `proto_sim` still works (the reference's call)."""
+
+    def __init__(self, value):
+        self.value = value
+
+
 class OrthLoss(nn.Module):
     def __init__(self, ignore_index=255, reduction='mean'):
         super().__init__()
@@ -19,6 +27,8 @@ class OrthLoss(nn.Module):
         # mean |.| over the strict upper triangle, also of a rectangular [K1,K2] matrix (criterion.py:37-43)
         # the reference selects with a boolean mask (a host synchronisation: the element count comes back); the same elements in the same
         # row-major order through constant indices keep the step free of read-backs (HIP-graph capture, graph_step.py) and the sum bit-identical
+        if isinstance(proto_sim, OrthTerm):
+            return proto_sim.value
         key = (tuple(proto_sim.shape), proto_sim.device)
         idx = self._triu.get(key)
         if idx is None:

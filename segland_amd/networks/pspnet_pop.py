@@ -12,9 +12,14 @@ import torch
 import torch.nn as nn
 from torch.nn import functional as F
 
+import os
+
 from .. import ops
-from ..functional import PopHeadFn, PPMFn, cls_params, flush_num_batches_tracked, ppm_params, refresh_weights
+from ..functional import PopHeadFn, PPMFn, ProtoFn, cls_params, flush_num_batches_tracked, ppm_params, refresh_weights
+from ..loss.criterion import OrthLoss, OrthTerm
 from .backbones import get_backbone
+
+_PROTO_FUSED = os.environ.get('SEGLAND_PROTO_FUSED', '1') != '0'
 
 
 class PSPModule(nn.Module):
@@ -147,27 +152,39 @@ class GFSS_Model(nn.Module):
         graph.replay()
         return static_out.clone()
 
-    def _head(self, feat):
-        sb = F.normalize(self.base_emb.float(), p=2, dim=-1)
+    def _protos(self):
+        """(sb, sn | None, orth term): normalised prototypes + the orthogonality term of this mode's similarity matrix (base: sb sb^T, :185-186;
+        ft: sn [sn ; sb]^T, :236-239), one kernel (functional.ProtoFn).  SEGLAND_PROTO_FUSED=0: the torch ops."""
+        if not _PROTO_FUSED or not self.base_emb.is_cuda:
+            sb = F.normalize(self.base_emb.float(), p=2, dim=-1)
+            return sb, (F.normalize(self.novel_emb.float(), p=2, dim=-1) if self.is_ft else None), None
         if self.is_ft:
-            sn = F.normalize(self.novel_emb.float(), p=2, dim=-1)
-            return PopHeadFn.apply(feat, sb, sn, self, *cls_params(self.classifier), *cls_params(self.classifier_n)), sb, sn
-        return PopHeadFn.apply(feat, sb, None, self, *cls_params(self.classifier)), sb, None
+            sn, sb, orth = ProtoFn.apply(self.novel_emb, self.base_emb)
+            return sb, sn, orth
+        sb, _, orth = ProtoFn.apply(self.base_emb, None)
+        return sb, None, orth
+
+    def _head(self, feat):
+        sb, sn, orth = self._protos()
+        if self.is_ft:
+            return PopHeadFn.apply(feat, sb, sn, self, *cls_params(self.classifier), *cls_params(self.classifier_n)), sb, sn, orth
+        return PopHeadFn.apply(feat, sb, None, self, *cls_params(self.classifier)), sb, None, orth
 
     def forward_all(self, img, mask=None):
-        preds, _, _ = self._head(self._features(img))
-        return preds
+        return self._head(self._features(img))[0]
 
     def forward_base(self, img, mask=None):
-        preds, sb, _ = self._head(self._features(img))
+        preds, sb, _, orth = self._head(self._features(img))
         if self.criterion is not None and mask is not None:
+            if orth is not None and isinstance(self.criterion, OrthLoss):
+                return self.criterion(preds, mask, proto_sim=OrthTerm(orth))
             proto_sim = torch.matmul(sb, sb.t())                       # [Kb,Kb] (pspnet_pop.py:185-186)
             return self.criterion(preds, mask, proto_sim=proto_sim)
         return preds
 
     def forward_novel(self, img, mask, img_b, mask_b):
         img_full = torch.cat([img, img_b], dim=0)
-        preds, sb, sn = self._head(self._features(img_full))
+        preds, sb, sn, orth = self._head(self._features(img_full))
         B = img_full.shape[0]
         kb = self.n_base
         # pseudo-label the base tiles' background with the novel head (pspnet_pop.py:221-231); mutates mask_b in place
@@ -177,6 +194,8 @@ class GFSS_Model(nn.Module):
         ops.pseudo_label_(preds2_b, mask_b, kb)
         if self.criterion is not None and mask is not None:
             mask_all = torch.cat([mask, mask_b], dim=0)
+            if orth is not None and isinstance(self.criterion, OrthLoss):
+                return self.criterion(preds, mask_all, is_ft=True, proto_sim=OrthTerm(orth))
             proto_sim = torch.matmul(sn, torch.cat([sn, sb], dim=0).t())   # [Kn, Kn+Kb] (pspnet_pop.py:236-239)
             return self.criterion(preds, mask_all, is_ft=True, proto_sim=proto_sim)
         return preds

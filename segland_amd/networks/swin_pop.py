@@ -155,14 +155,15 @@ class GFSS_Model(pspnet_pop.GFSS_Model):
 
     def _head(self, feat):
         P, d = feat.shape[-1], self.d_model
-        sb = F.pad(F.normalize(self.base_emb.float(), p=2, dim=-1), (0, P - d))
+        sb0, sn0, orth = self._protos()                    # normalised prototypes + orthogonality term (one kernel, pspnet_pop.GFSS_Model._protos)
+        sb = F.pad(sb0, (0, P - d))
         cls = self._padded_cls(self.classifier, P)
         pc = [cls[0].weight, cls[2].weight, cls[4].weight]
         if self.is_ft:
-            sn = F.pad(F.normalize(self.novel_emb.float(), p=2, dim=-1), (0, P - d))
+            sn = F.pad(sn0, (0, P - d))
             cls_n = self._padded_cls(self.classifier_n, P)
             holder = types.SimpleNamespace(classifier=cls, classifier_n=cls_n)
             preds = PopHeadFn.apply(feat, sb, sn, holder, *pc, cls_n[0].weight, cls_n[2].weight, cls_n[4].weight)
-            return preds, sb[:, :d], sn[:, :d]
+            return preds, sb0, sn0, orth
         holder = types.SimpleNamespace(classifier=cls, classifier_n=None)
-        return PopHeadFn.apply(feat, sb, None, holder, *pc), sb[:, :d], None
+        return PopHeadFn.apply(feat, sb, None, holder, *pc), sb0, None, orth

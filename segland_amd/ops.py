@@ -233,6 +233,25 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
     return dx
 
 
+def conv2d_bwd_data_bnstat(dy, wb, spec, in_hw, gate, bn_x, mean, invstd):
+    """Data gradient gated with the ReLU bits `gate` of its own positions + the reduce pass of the BatchNorm backward below it in the epilogue
+    (csrc/conv_gemm.hip MODE 3).  -> (g, partial [rows][2][Cin]) or None when the shape is not served (caller: conv2d_bwd_data + bn_bwd)."""
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    rows = L.sl_conv2d_bwd_data_bnstat_rows(C.byref(d))
+    if rows <= 0:
+        return None
+    dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    part = _f32((rows, 2, spec.cin), dy.device)
+    tok = PROFILER.begin('conv_dgrad', d)
+    check(L.sl_conv2d_bwd_data_bnstat(C.byref(d), _p(dy), _p(wb), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()), 'conv2d_bwd_data_bnstat')
+    if tok is not None:
+        PROFILER.end(tok, bn_x.numel() * bn_x.element_size() + gate.numel())
+    return dx, part
+
+
 _ws_cache = {}
 
 
@@ -249,9 +268,11 @@ def workspace(nbytes, dev, tag=None):
 
 # Slab reduces of the weight gradients on a second stream (csrc/conv_wgrad.hip: sl_conv2d_bwd_weight_ex2): the reduce of layer k runs beside the
 # MFMA-bound data gradient of layer k that follows on the main stream.  Only callers that join before the gradient leaves their backward
-# (wgrad_reduce_join) may ask for it.  SEGLAND_WGRAD_REDUCE_STREAM=0 keeps everything on one stream.
+# (wgrad_reduce_join) may ask for it.  MEASURED NEGATIVE (same box, A/B/A/B, profiles/r3_ab_switches.txt): 27.10 ms per step with the fork,
+# 26.53 without -- every fork / join is a pair of cross-branch dependencies in the captured graph, which cost more than the 9 us reduce they
+# hide.  Off by default; SEGLAND_WGRAD_REDUCE_STREAM=1 switches it on.
 import os as _os
-_RED_FORK = _os.environ.get('SEGLAND_WGRAD_REDUCE_STREAM', '1') != '0'
+_RED_FORK = _os.environ.get('SEGLAND_WGRAD_REDUCE_STREAM', '0') == '1'
 _red_streams = {}
 _red_pending = [False]
 
@@ -328,20 +349,27 @@ def bn_act(x, scale, shift, residual=None, relu=True, out=None, want_mask=False)
     return (y, mask) if want_mask else y
 
 
-def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None, sync_world=0, dgamma_out=None, dbeta_out=None):
+def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None, out=None, sync_world=0, dgamma_out=None, dbeta_out=None,
+           pre_partial=None):
     """Returns (dx, dres, dgamma, dbeta).  ReLU gate of dy: `mask` (bit mask from bn_act) if given, else y > 0 if y is given.
     sync_world > 0 (SyncBatchNorm semantics, torch/nn/modules/_functions.py): the two column sums that enter dx are all-reduced over
-    the process group and the element count is the global one; dgamma / dbeta stay local (DDP averages them like any gradient)."""
+    the process group and the element count is the global one; dgamma / dbeta stay local (DDP averages them like any gradient).
+    pre_partial: the (sum g, sum g * xhat) partials already produced by the data-gradient epilogue that wrote dy (conv2d_bwd_data_bnstat: dy is
+    gated already, no reduce pass runs here)."""
     Cn = x.shape[-1]
     rows = x.numel() // Cn
     L = _lib.lib()
-    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
-    part = _f32((nblk, 2, Cn), x.device)
     nb = x.numel() * x.element_size()
     gate = (mask.numel() if mask is not None else (nb if y is not None else 0))
-    tok = PROFILER.begin_bytes('bn_bwd_reduce', 2 * nb + gate)
-    check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
-    PROFILER.end_bytes(tok)
+    if pre_partial is not None:
+        assert mask is None and y is None
+        part, nblk = pre_partial, pre_partial.shape[0]
+    else:
+        nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
+        part = _f32((nblk, 2, Cn), x.device)
+        tok = PROFILER.begin_bytes('bn_bwd_reduce', 2 * nb + gate)
+        check(L.sl_bn_bwd_reduce(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(mean), _p(invstd), _p(part), rows, Cn, _s()), 'bn_bwd_reduce')
+        PROFILER.end_bytes(tok)
     o = _f32((5, Cn), x.device)
     # dgamma_out / dbeta_out: write the parameter gradients straight into the caller's buffers (DDP bucket views, functional.grad_dst)
     dg = o[0] if dgamma_out is None else dgamma_out
@@ -361,6 +389,35 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     check(L.sl_bn_bwd_apply(dt(x), _p(dy), _p(y), _p(mask), _p(x), _p(o[2]), _p(o[3]), _p(o[4]), _p(mean), _p(dx), _p(dres), rows, Cn, _s()), 'bn_bwd_apply')
     PROFILER.end_bytes(tok)
     return dx, dres, dg, db
+
+
+def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, outs1=(None, None), outs2=(None, None)):
+    """Train-mode backward of TWO BatchNorms whose outputs were added before one ReLU (bn3 + downsample BN, resnet.py:71-76): both see the gradient
+    dy gated by `mask`; dy and the bits are swept once per pass for both.  -> (dx1, dgamma1, dbeta1, dx2, dgamma2, dbeta2)."""
+    Cn = x1.shape[-1]
+    rows = x1.numel() // Cn
+    L = _lib.lib()
+    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
+    part = _f32((2, nblk, 2, Cn), x1.device)
+    nb = x1.numel() * x1.element_size()
+    tok = PROFILER.begin_bytes('bn_bwd_reduce', 3 * nb + mask.numel())
+    check(L.sl_bn_bwd_reduce2(dt(x1), _p(dy), _p(mask), _p(x1), _p(mean1), _p(invstd1), _p(part[0]), _p(x2), _p(mean2), _p(invstd2), _p(part[1]), rows, Cn, _s()),
+          'bn_bwd_reduce2')
+    PROFILER.end_bytes(tok)
+    o = _f32((2, 5, Cn), x1.device)
+    res = []
+    for k, (gamma, mean, invstd, outs) in enumerate(((gamma1, mean1, invstd1, outs1), (gamma2, mean2, invstd2, outs2))):
+        dg = o[k, 0] if outs[0] is None else outs[0]
+        db = o[k, 1] if outs[1] is None else outs[1]
+        check(L.sl_bn_bwd_finalize(_p(part[k]), nblk, Cn, rows, _p(gamma), _p(mean), _p(invstd), 1, _p(dg), _p(db), _p(o[k, 2]), _p(o[k, 3]), _p(o[k, 4]), _s()),
+              'bn_bwd_finalize')
+        res.append((dg, db))
+    dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
+    tok = PROFILER.begin_bytes('bn_bwd_apply', 5 * nb + mask.numel())
+    check(L.sl_bn_bwd_apply2(dt(x1), _p(dy), _p(mask), _p(x1), _p(o[0, 2]), _p(o[0, 3]), _p(o[0, 4]), _p(mean1), _p(dx1),
+                             _p(x2), _p(o[1, 2]), _p(o[1, 3]), _p(o[1, 4]), _p(mean2), _p(dx2), rows, Cn, _s()), 'bn_bwd_apply2')
+    PROFILER.end_bytes(tok)
+    return dx1, res[0][0], res[0][1], dx2, res[1][0], res[1][1]
 
 
 _zeros_cache = {}
@@ -760,3 +817,24 @@ def nchw_f32_to_nhwc(x, dtype):
     out = torch.empty((B, H, W, Cn), dtype=dtype, device=x.device)
     check(_lib.lib().sl_nchw_f32_to_nhwc(_DT[dtype], _p(x), _p(out), B, H, W, Cn, _s()), 'nchw_f32_to_nhwc')
     return out
+
+
+# --------------------------------------------------------------------------------------------- prototype preparation
+def pop_proto_fwd(Ea, Eb=None):
+    """(Sa, Sb, inv_norm, G, orth): L2-normalised prototypes, G = Sa [Sa ; Sb]^T and mean |G[i][j]|, j > i, in one launch."""
+    Ka, Cn = Ea.shape
+    Kb = 0 if Eb is None else Eb.shape[0]
+    Sa, Sb = torch.empty_like(Ea), (None if Eb is None else torch.empty_like(Eb))
+    aux = _f32((Ka + Kb + Ka * (Ka + Kb) + 1,), Ea.device)
+    inv, G, orth = aux[:Ka + Kb], aux[Ka + Kb:Ka + Kb + Ka * (Ka + Kb)], aux[Ka + Kb + Ka * (Ka + Kb):]
+    check(_lib.lib().sl_pop_proto_fwd(_p(Ea), Ka, _p(Eb), Kb, Cn, _p(Sa), _p(Sb), _p(inv), _p(G), _p(orth), _s()), 'pop_proto_fwd')
+    return Sa, Sb, inv, G, orth
+
+
+def pop_proto_bwd(Sa, Sb, inv, G, dSa, dSb, dorth, need_a=True, need_b=False):
+    Ka, Cn = Sa.shape
+    Kb = 0 if Sb is None else Sb.shape[0]
+    dEa = torch.empty_like(Sa) if need_a else None
+    dEb = torch.empty_like(Sb) if (need_b and Sb is not None) else None
+    check(_lib.lib().sl_pop_proto_bwd(_p(Sa), Ka, _p(Sb), Kb, Cn, _p(inv), _p(G), _p(dSa), _p(dSb), _p(dorth), _p(dEa), _p(dEb), _s()), 'pop_proto_bwd')
+    return dEa, dEb

@@ -72,7 +72,8 @@ def main():
             for it in range(5 if bucket else (3 if inplace else 2)):
                 hits[0] = 0
                 d, gn = step(img, mask) if step is not None else train_iteration(net, opt, scaler, img, mask, double_step=True)
-                losses.append([float(d['total_loss']), float(gn)])
+                losses.append([float(d['total_loss'].detach()), float(gn)])
+                print('ddp_child: wrapped %s iteration %d done' % (wrapped, it), file=sys.stderr, flush=True)
             if step is not None:
                 out['bucket_replays'], out['bucket_failures'], out['buckets'] = step.replays, step.a.failures + step.b.failures, len(net.buckets)
             if wrapped and inplace and not bucket:
@@ -84,9 +85,11 @@ def main():
             if wrapped:                        # gradients are views into DDP's flat buckets (gradient_as_bucket_view)
                 bucket_views = sum(1 for p in m.parameters() if p.grad is not None and p.grad._base is not None)
                 out['bucket_view_grads'] = bucket_views
+            print('ddp_child: wrapped %s training done' % wrapped, file=sys.stderr, flush=True)
             m.eval()
             with torch.no_grad():
                 logits = m(img).float().cpu()
+            print('ddp_child: wrapped %s eval done' % wrapped, file=sys.stderr, flush=True)
             return {k: v.detach().float().cpu() for k, v in m.state_dict().items()}, losses, logits
 
         sf.set_sync_bn('0')

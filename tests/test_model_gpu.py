@@ -171,7 +171,7 @@ def test_g2_head(hip, dtype):
     tol = TOLS[dtype]
     feats = fm.sym('g2/feats', (2, 512, 8, 8), 1.0)
     fg = nhwc(feats, dtype).requires_grad_(True)
-    preds, _, _ = m._head(fg)
+    preds = m._head(fg)[0]
     coef = fm.sym('g2/coef', (2, 8, 8, 8), 1.0).to(DEV)
     (preds * coef).sum().backward()
     check(preds, g['preds'], tol, 'preds')
@@ -182,7 +182,7 @@ def test_g2_head(hip, dtype):
     check_grad(m.classifier[4].weight.grad[0, :, 0, 0], g['d_cls4'], GTOLS[dtype], 'd_cls4')
     m2 = build(True, 4, dtype=dtype, criterion=False).eval()
     with torch.no_grad():
-        pa, _, _ = m2._head(fg.detach())
+        pa = m2._head(fg.detach())[0]
     check(pa, golden('g2_head_all')['preds'], tol, 'preds_all')
 
 

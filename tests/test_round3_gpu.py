@@ -74,3 +74,174 @@ def test_bucket_step_two_ranks_equals_ddp(hip, tmp_path):
     print('worst parameter / buffer difference %.3e (%s)' % (worst, key))
     assert worst <= 1e-5, (worst, key)
     assert float((d['logits'] - b['logits']).abs().max() / d['logits'].abs().max()) <= 1e-5
+
+
+# --------------------------------------------------------------------------------------------- the bench's big 3x3 shapes against fp32 torch, in isolation
+@pytest.mark.parametrize('C_,N,dil', [(2048, 512, 1), (512, 512, 4)])
+def test_patch_kernel_bench_shapes_vs_fp32_torch(hip, C_, N, dil):
+    """The two 3x3 shapes the bench spends 4.2 ms per step on (the PPM conv 2048 -> 512 d1 and layer4.conv2 512 -> 512 d4, 16 tiles of 64 x 64 pixels) on the patch
+    kernel, forward AND data gradient, against fp32 F.conv2d / its autograd on the CPU for one image of the batch (the last: every tile row map and the batch offset are
+    exercised) -- round 2 compared these shapes with torch only through bit-equality with the half-tile kernel."""
+    from segland_amd import _lib, ops
+    import ctypes
+    dtype = torch.bfloat16
+    B, H, W = 16, 64, 64
+    g = torch.Generator(device='cpu').manual_seed(C_ * 3 + dil)
+    x = torch.randn(B, H, W, C_, generator=g).to(dtype)
+    w = (torch.randn(N, C_, 3, 3, generator=g) * (3.0 / (9 * C_)) ** 0.5).to(dtype).float()
+    dy = torch.randn(B, H, W, N, generator=g).to(dtype)
+    spec = ops.ConvSpec(C_, N, 3, 1, dil, dil)
+    d = ops.conv_desc(dtype, B, H, W, spec)
+    assert hip.sl_conv2d_tile_config(ctypes.byref(d), 0) // 1000000 == 8 and hip.sl_conv2d_tile_config(ctypes.byref(d), 1) // 1000000 == 8, 'not on conv_gemm_p9_kernel'
+    wf, wb = ops.weight_prep(w.to(DEV), dtype)
+    y, part = ops.conv2d_fwd(x.to(DEV), wf, spec, want_stats=True)
+    dx = ops.conv2d_bwd_data(dy.to(DEV), wb, spec, (H, W))
+    torch.cuda.synchronize()
+    b = B - 1
+    xi = x[b].float().permute(2, 0, 1)[None].requires_grad_(True)
+    ref = F.conv2d(xi, w, None, 1, dil, dil)
+    ref.backward(dy[b].float().permute(2, 0, 1)[None])
+    tol = 2.5e-2                                                   # bf16 storage of the result (2^-8 relative) on top of fp32 accumulation
+    yr = ref[0].permute(1, 2, 0)
+    err = float((y[b].float().cpu() - yr).abs().max()) / float(yr.abs().max())
+    dxr = xi.grad[0].permute(1, 2, 0)
+    errd = float((dx[b].float().cpu() - dxr).abs().max()) / float(dxr.abs().max())
+    print('%d -> %d d%d: forward max err %.2e of scale, data gradient %.2e' % (C_, N, dil, err, errd))
+    assert err <= tol and errd <= tol
+    # the statistics partials are the column sums of the STORED (rounded) result
+    s = part.sum(0).cpu()
+    yf = y.float().reshape(-1, N).cpu()
+    assert float((s[0] - yf.sum(0)).abs().max()) <= 1e-3 * float(yf.abs().sum(0).max())
+    assert float((s[1] - (yf * yf).sum(0)).abs().max()) <= 1e-3 * float((yf * yf).sum(0).max())
+
+
+# --------------------------------------------------------------------------------------------- fused prototype preparation
+@pytest.mark.parametrize('Ka,Kb,C_', [(7, 0, 512), (4, 7, 512), (7, 0, 96), (4, 7, 96)])
+def test_proto_fn_vs_torch(hip, Ka, Kb, C_):
+    """functional.ProtoFn (normalize + similarity matrix + orthogonality term, one kernel each way) against the torch ops of pspnet_pop.py:96-99,185-186,
+    236-239 and criterion.py:37-43 (incl. the rectangular [Kn, Kn+Kb] matrix of fine-tuning and its strict-upper-triangle selection), values and gradients."""
+    from segland_amd.functional import ProtoFn
+    Ea = fm.sym('proto/a%d%d' % (Ka, C_), (Ka, C_), 1.0).to(DEV).requires_grad_(True)
+    Eb = fm.sym('proto/b%d%d' % (Kb, C_), (Kb, C_), 1.0).to(DEV).requires_grad_(True) if Kb else None
+    gSa = fm.sym('proto/ga', (Ka, C_), 1.0).to(DEV)
+    gSb = fm.sym('proto/gb', (Kb, C_), 1.0).to(DEV) if Kb else None
+    Sa, Sb, orth = ProtoFn.apply(Ea, Eb)
+    loss = (Sa * gSa).sum() + 10.0 * orth + ((Sb * gSb).sum() if Kb else 0.0)
+    loss.backward()
+    got = (Sa.detach(), orth.detach(), Ea.grad.clone(), Eb.grad.clone() if Kb else None)
+    Ra = Ea.detach().clone().requires_grad_(True)
+    Rb = Eb.detach().clone().requires_grad_(True) if Kb else None
+    sa = F.normalize(Ra, p=2, dim=-1)
+    sb = F.normalize(Rb, p=2, dim=-1) if Kb else None
+    sim = torch.matmul(sa, (torch.cat([sa, sb], 0) if Kb else sa).t())
+    o = torch.abs(sim[torch.triu(torch.ones_like(sim), diagonal=1) == 1]).mean()
+    ((sa * gSa).sum() + 10.0 * o + ((sb * gSb).sum() if Kb else 0.0)).backward()
+    assert float((got[0] - sa.detach()).abs().max()) <= 1e-6
+    assert abs(float(got[1]) - float(o)) <= 1e-6 * max(1.0, abs(float(o)))
+    assert float((got[2] - Ra.grad).abs().max()) <= 2e-5 * float(Ra.grad.abs().max())
+    if Kb:
+        assert float((Sb.detach() - sb.detach()).abs().max()) <= 1e-6
+        assert float((got[3] - Rb.grad).abs().max()) <= 2e-5 * float(Rb.grad.abs().max())
+
+
+# --------------------------------------------------------------------------------------------- Swin-T at the bench shape of config 5
+@pytest.mark.timeout(900)
+def test_swin_t_b8_512_bf16_step(hip):
+    """BASELINE config 5 per GPU: Swin-T POP, bf16, 8 tiles of 512 x 512, one train_base.py iteration (train mode, DropPath / Dropout2d scales fixed to 1 so the two
+    dtypes see the same network): every gradient finite, loss within 2 % of the exact-fp32 mode, gradient norms per optimizer group within 10 %.  (The goldens G13-G16
+    pin the arithmetic at 128 x 160.)"""
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.swin_pop import GFSS_Model
+    img = fm.formula_image(8, 512, 512, 'sw512/img').to(DEV)
+    mask = fm.formula_mask(8, 512, 512, 8, 'sw512/mask', block=32, ignore_rows=40).to(DEV)
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='swin-t', pretrained_model=None, compute_dtype=dt)
+        fm.load_formula_weights(m)
+        m = m.to(DEV).train()
+        m.backbone.drop_path_hook = lambda index, B, p: torch.full((B,), 1.0, device=DEV)
+        m.decoder.dropout2d_hook = lambda B, Cn, p: torch.full((B, Cn), 1.0, device=DEV)
+        d = m(img, mask)
+        d['total_loss'].backward()
+        grads = {k: p.grad.detach().float() for k, p in m.named_parameters() if p.grad is not None}
+        assert len(grads) >= 150 and all(torch.isfinite(g).all() for g in grads.values())
+        gn = {}
+        for grp, sel in (('backbone', lambda k: 'backbone' in k), ('head', lambda k: 'backbone' not in k)):
+            gn[grp] = float(torch.sqrt(sum((g.double() ** 2).sum() for k, g in grads.items() if sel(k))))
+        res[dt] = (float(d['total_loss'].detach()), float(d['seg_loss'].detach()), gn)
+        del m, d, grads
+        torch.cuda.empty_cache()
+    print('Swin-T B=8 512x512: fp32', res[torch.float32], ' bf16', res[torch.bfloat16])
+    a, b = res[torch.float32], res[torch.bfloat16]
+    assert abs(a[0] - b[0]) <= 2e-2 * abs(a[0]) and abs(a[1] - b[1]) <= 2e-2 * abs(a[1])
+    for grp in a[2]:
+        assert abs(a[2][grp] - b[2][grp]) <= 0.1 * a[2][grp], (grp, a[2][grp], b[2][grp])
+
+
+# --------------------------------------------------------------------------------------------- BatchNorm-backward statistics in the data-gradient epilogue
+@pytest.mark.parametrize('cin,cout,k,dil,dtype', [(512, 2048, 1, 1, torch.bfloat16), (256, 1024, 1, 1, torch.bfloat16), (512, 512, 3, 4, torch.bfloat16),
+                                                  (256, 256, 3, 2, torch.bfloat16), (128, 128, 3, 1, torch.bfloat16), (128, 256, 1, 1, torch.float32)])
+def test_dgrad_epilogue_emits_bn_backward_statistics(hip, cin, cout, k, dil, dtype):
+    """sl_conv2d_bwd_data_bnstat (resnet.py:57-78 backward, conv3 <- bn2 + relu and conv2 <- bn1 + relu): the data gradient gated with the ReLU bits of the layer
+    below must equal the plain data gradient with the same bits applied BIT FOR BIT, and the column sums its epilogue emits must equal what the separate
+    bn_bwd_reduce pass computes over (g, c) -- on every kernel family with the staged store phase (half-tile, patch, ring; bf16 and exact fp32)."""
+    from segland_amd import _lib, ops
+    import ctypes
+    B, H, W = 16, 64, 64
+    g = torch.Generator(device='cpu').manual_seed(cin + cout + k)
+    spec = ops.ConvSpec(cin, cout, k, 1, dil if k == 3 else 0, dil)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (3.0 / (k * k * cin)) ** 0.5).to(DEV)
+    _, wb = ops.weight_prep(w, dtype)
+    dy = torch.randn(B, H, W, cout, generator=g).to(dtype).to(DEV)
+    c = (torch.randn(B, H, W, cin, generator=g) * 2 + 0.5).to(dtype).to(DEV)
+    bits = torch.randint(0, 256, (c.numel() * c.element_size() // 16,), dtype=torch.uint8, generator=g).to(DEV)
+    mean = torch.randn(cin, generator=g).to(DEV) * 0.3 + 0.5
+    invstd = (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    d = ops.conv_desc(dtype, B, H, W, spec)
+    rows = hip.sl_conv2d_bwd_data_bnstat_rows(ctypes.byref(d))
+    assert rows > 0, 'shape not served by the fused epilogue'
+    gg, part = ops.conv2d_bwd_data_bnstat(dy, wb, spec, (H, W), bits, c, mean, invstd)
+    plain = ops.conv2d_bwd_data(dy, wb, spec, (H, W))
+    epv = 16 // c.element_size()
+    keep = ((bits.view(-1, 1).int() >> torch.arange(epv, device=DEV).view(1, -1)) & 1).bool().view(B, H, W, cin)
+    ref_g = torch.where(keep, plain, torch.zeros_like(plain))
+    assert torch.equal(gg, ref_g), 'gated data gradient differs from the plain one with the bits applied'
+    assert part.shape == (rows, 2, cin)
+    L = _lib.lib()
+    nblk = L.sl_bn_bwd_reduce_rows(B * H * W, cin)
+    rp = torch.empty((nblk, 2, cin), dtype=torch.float32, device=DEV)
+    _lib.check(L.sl_bn_bwd_reduce(ops.dt(c), ops._p(plain), None, ops._p(bits), ops._p(c), ops._p(mean), ops._p(invstd), ops._p(rp), B * H * W, cin, ops._s()), 'reduce')
+    s_f, s_r = part.double().sum(0), rp.double().sum(0)
+    gf = ref_g.double()
+    scale1 = float(gf.abs().sum((0, 1, 2)).max())
+    xh = (c.double() - mean.double()) * invstd.double()
+    scale2 = float((gf * xh).abs().sum((0, 1, 2)).max())
+    print('%d->%d k%d: sum g %.2e / sum g xhat %.2e of scale (fused vs reduce pass)' % (cin, cout, k, float((s_f[0] - s_r[0]).abs().max()) / scale1, float((s_f[1] - s_r[1]).abs().max()) / scale2))
+    assert float((s_f[0] - s_r[0]).abs().max()) <= 1e-5 * scale1 and float((s_f[1] - s_r[1]).abs().max()) <= 1e-5 * scale2
+    # and through ops.bn_bwd: the same dx as the unfused chain (coefficients from fp32 partials summed in fp64: equal to rounding of the coefficients)
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    dx_f, _, dg_f, db_f = ops.bn_bwd(gg, None, c, mean, invstd, gamma, pre_partial=part)
+    dx_r, _, dg_r, db_r = ops.bn_bwd(plain, None, c, mean, invstd, gamma, mask=bits)
+    assert float((dg_f - dg_r).abs().max()) <= 1e-4 * float(dg_r.abs().max()) and float((db_f - db_r).abs().max()) <= 1e-4 * float(db_r.abs().max())
+    assert float((dx_f.float() - dx_r.float()).abs().max()) <= 2e-2 * float(dx_r.float().abs().max())
+
+
+@pytest.mark.parametrize('Cn,dtype', [(256, torch.bfloat16), (2048, torch.bfloat16), (1024, torch.float32), (96 * 8, torch.bfloat16)])
+def test_dual_bn_backward_equals_two_single_passes(hip, Cn, dtype):
+    """ops.bn_bwd2 (bn3 + downsample BN behind one ReLU, resnet.py:71-76: one sweep over the gradient and the ReLU bits for both) against two ops.bn_bwd calls:
+    same per-thread accumulation order and formulas, so input gradients, dgamma and dbeta must be bit-identical."""
+    from segland_amd import ops
+    rows = 4 * 32 * 32
+    g = torch.Generator(device='cpu').manual_seed(Cn)
+    dy = torch.randn(rows, Cn, generator=g).to(dtype).to(DEV)
+    x1 = (torch.randn(rows, Cn, generator=g) * 1.5 + 0.3).to(dtype).to(DEV)
+    x2 = (torch.randn(rows, Cn, generator=g) * 0.7 - 0.2).to(dtype).to(DEV)
+    bits = torch.randint(0, 256, (dy.numel() * dy.element_size() // 16,), dtype=torch.uint8, generator=g).to(DEV)
+    st = [t.to(DEV) for t in (torch.randn(Cn, generator=g) * 0.2, torch.rand(Cn, generator=g) + 0.5, torch.rand(Cn, generator=g) + 0.5,
+                              torch.randn(Cn, generator=g) * 0.2, torch.rand(Cn, generator=g) + 0.5, torch.rand(Cn, generator=g) + 0.5)]
+    m1, i1, g1, m2, i2, g2 = st
+    a = ops.bn_bwd2(dy, bits, x1, m1, i1, g1, x2, m2, i2, g2)
+    r1 = ops.bn_bwd(dy, None, x1, m1, i1, g1, mask=bits)
+    r2 = ops.bn_bwd(dy, None, x2, m2, i2, g2, mask=bits)
+    assert torch.equal(a[0], r1[0]) and torch.equal(a[1], r1[2]) and torch.equal(a[2], r1[3])
+    assert torch.equal(a[3], r2[0]) and torch.equal(a[4], r2[2]) and torch.equal(a[5], r2[3])
