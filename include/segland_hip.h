@@ -262,6 +262,10 @@ int sl_rowdot_bwd_rows(long long R, int C);
 int sl_rowdot_bwd(int dtype, const void* h, const float* w, const float* dz, void* dh, float* partial, long long R,
                   int C, sl_stream_t stream);
 /* out[c] = sum_blk partial[blk][c] */
+/* per-channel sums over the rows of an NHWC activation tensor [rows][C] (nn.Linear / conv bias gradients): partial[sl_colsum_rows_blocks][C], to be summed by
+ * sl_colsum_finalize / sl_colsum_finalize_multi (fixed order: bit-stable) */
+int sl_colsum_rows_blocks(long long rows, int C, int dtype);
+int sl_colsum_rows_partial(int dtype, const void* x, long long rows, int C, float* partial, sl_stream_t stream);
 int sl_colsum_finalize(const float* partial, int nblk, int C, float* out, sl_stream_t stream);
 /* the same for up to SL_COLSUM_MAX independent partial buffers in ONE launch (host struct, read during the call) */
 #define SL_COLSUM_MAX 12

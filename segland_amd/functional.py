@@ -225,7 +225,8 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
-_BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'
+_BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm.hip MODE 3)
+_BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
@@ -370,7 +371,7 @@ class BottleneckFn(torch.autograd.Function):
         # the data gradients of conv3 and conv2 gate their result with the ReLU bits of the layer below and emit its BN-backward column sums in the epilogue
         # (where the kernel has the staged store phase: layer3 / layer4 at the bench shapes): that layer's reduce pass over (g, c) disappears
         done3 = doned = None
-        if ctx.has_ds and _BN_FUSE and k3 is not None and blk.bn3.training and blk.downsample[1].training and not sync_world(blk.bn3):
+        if ctx.has_ds and _BN_DUAL and k3 is not None and blk.bn3.training and blk.downsample[1].training and not sync_world(blk.bn3):
             # bn3 and the downsample BN sit behind the same ReLU: one sweep over dout and its bits for both reduces, one for both applies (ops.bn_bwd2)
             cd, md, idd = sv[14:17]
             bnd = blk.downsample[1]

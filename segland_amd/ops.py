@@ -424,19 +424,17 @@ _zeros_cache = {}
 
 
 def colsum_rows(t, batch=None):
-    """Per-channel sum over all rows of an NHWC tensor (conv bias gradient) via the BN reduce kernel (S1 with no mask)."""
+    """Per-channel sum over all rows of an NHWC tensor (nn.Linear / conv bias gradient): csrc/pop_head.hip colsum_rows_partial + a fixed-order finalize
+    (batch: an ops.ColsumBatch whose run() finalizes several of them in one launch)."""
     Cn = t.shape[-1]
     rows = t.numel() // Cn
     L = _lib.lib()
-    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
-    part = _f32((nblk, 2, Cn), t.device)
-    z = _zeros_cache.get((Cn, t.device))
-    if z is None:
-        z = _zeros_cache[(Cn, t.device)] = _f32((2, Cn), t.device, zero=True)          # read-only (mean 0, invstd 0): shared by every call
-    check(L.sl_bn_bwd_reduce(dt(t), _p(t), None, None, _p(t), _p(z[0]), _p(z[1]), _p(part), rows, Cn, _s()), 'bn_bwd_reduce(colsum)')
+    nblk = L.sl_colsum_rows_blocks(rows, Cn, dt(t))
+    part = _f32((nblk, Cn), t.device)
+    check(L.sl_colsum_rows_partial(dt(t), _p(t), rows, Cn, _p(part), _s()), 'colsum_rows_partial')
     if batch is not None:
-        return batch.add(part)[0]                     # filled by batch.run()
-    return colsum(part)[0].contiguous()
+        return batch.add(part)                        # filled by batch.run()
+    return colsum(part).contiguous()
 
 
 # --------------------------------------------------------------------------------------------- stem

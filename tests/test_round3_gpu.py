@@ -245,3 +245,21 @@ def test_dual_bn_backward_equals_two_single_passes(hip, Cn, dtype):
     r2 = ops.bn_bwd(dy, None, x2, m2, i2, g2, mask=bits)
     assert torch.equal(a[0], r1[0]) and torch.equal(a[1], r1[2]) and torch.equal(a[2], r1[3])
     assert torch.equal(a[3], r2[0]) and torch.equal(a[4], r2[2]) and torch.equal(a[5], r2[3])
+
+
+@pytest.mark.parametrize('rows,Cn,dtype', [(8 * 32 * 32, 1536, torch.bfloat16), (8 * 128 * 128, 384, torch.bfloat16), (8 * 16 * 16, 3072, torch.bfloat16),
+                                           (1000, 128, torch.float32), (7, 96 * 8, torch.bfloat16)])
+def test_colsum_rows_kernel(hip, rows, Cn, dtype):
+    """ops.colsum_rows (bias gradients of nn.Linear / conv: swintransformer.py:31-40,96-99, pspnet_pop.py:29) against a float64 torch sum; one launch +
+    fixed-order finalize, also through a ColsumBatch."""
+    from segland_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(rows + Cn)
+    x = torch.randn(rows, Cn, generator=g).to(dtype).to(DEV)
+    ref = x.double().sum(0)
+    scale = float(x.double().abs().sum(0).max())
+    got = ops.colsum_rows(x)
+    assert got.shape == (Cn,) and float((got.double() - ref).abs().max()) <= 1e-6 * scale
+    b = ops.ColsumBatch()
+    o1, o2 = ops.colsum_rows(x, batch=b), ops.colsum_rows(x[: max(1, rows // 2)].contiguous(), batch=b)
+    b.run()
+    assert torch.equal(o1, got) and float((o2.double() - x[: max(1, rows // 2)].double().sum(0)).abs().max()) <= 1e-6 * scale
