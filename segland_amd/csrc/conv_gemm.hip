@@ -2017,7 +2017,7 @@ static int small_k() {
 }
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 static int min_tiles256() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_MINTILES", 96); return v; }
-static int ring128_min() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_RING128_MIN", 512); return v; }
+static int ring128_min() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_RING128_MIN", 16); return v; }      // 128-row blocks from which the 4-stage ring replaces the 2-stage kernel (512 until round 3: Swin-T stage 3 / 4 GEMMs of 8 192 / 2 048 tokens gain 4 %, ResNet-50 unchanged)
 static int block_rows(long long M, int ktot) { return (conv_variant() >= 3 && M >= 256LL * min_tiles256() && ktot > small_k()) ? 256 : 128; }
 
 template <typename T>
