@@ -355,7 +355,7 @@ def main():
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the %d instrumented kernel-by-kernel steps run right after the %d timed ones' % (a.steps, a.steps)
-                                       + ' (every shape it serves; the fixed-order slab reduce behind a weight-gradient kernel is a separate small launch on the second stream, outside these spans); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
+                                       + ' (every shape it serves; a weight-gradient span includes the small fixed-order slab reduce launched behind the kernel); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
                                        + 'peak is the 2.4 GHz figure: on these N(0,1) operands the chip sustains ~1.65 GHz under this kernel (the same binary on all-zero operands runs '
                                        + '+26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
         if world == 1 and not a.no_cpu_baseline:
