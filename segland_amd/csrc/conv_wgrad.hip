@@ -782,6 +782,14 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M) {
     const bool wide = d->dtype == SL_BF16;          // f32 stages are twice as large: 128-wide tiles keep the ring in 128 KiB
     pl.bnn = (wide && d->Cout % 256 == 0) ? 256 : 128;
     pl.bcc = (wide && d->C1 % 256 == 0 && c2 % 256 == 0) ? 256 : 128;
+    // few output tiles (a 256 x 1024 gradient is FOUR 256 x 256 tiles: 64 splits over the pixels, 64 MB of slabs for 1 MB of gradient): tuning hook -- with at most
+    // SEGLAND_WGRAD_SMALLTILE_MAX 256 x 256 tiles (x taps) the n side drops to 128 rows, i.e. twice the tiles, half the splits and slab bytes
+    static const int small_max = getenv("SEGLAND_WGRAD_SMALLTILE_MAX") ? atoi(getenv("SEGLAND_WGRAD_SMALLTILE_MAX")) : 4;      // measured (profiles/r3_ab_wgrad_tiles.txt): 4 -> -0.16 ms per ResNet-50 step (the 1x1 256 <-> 1024 and 512 -> 512 gradients), 9 (adds the 3x3 256 -> 256 layers) +0.03, 36 +0.6
+    if (small_max > 0 && pl.bnn == 256 && pl.bcc == 256 && (long long)(d->Cout / 256) * (d->Cin / 256) * d->KH * d->KW <= small_max) {
+      static const int both = getenv("SEGLAND_WGRAD_SMALLTILE_BOTH") ? atoi(getenv("SEGLAND_WGRAD_SMALLTILE_BOTH")) : 0;
+      pl.bnn = 128;
+      if (both) pl.bcc = 128;
+    }
   } else {
     pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
     pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;

@@ -571,32 +571,48 @@ def ppm_params(dec):
 
 
 # ------------------------------------------------------------------------------------------------ POP head
-def _mlp_fwd(X, cls):
-    """classifier MLP (pspnet_pop.py:46-52) on rows X [R,512]: two MFMA 1x1 convs with fused ReLU, then a row dot."""
+def _row_parts(R, big):
+    """Row ranges the MLP GEMMs run on: the pixel rows (a multiple of 256: whole 256-row tiles, ONE round of the persistent tile kernel on 256 CUs) and the
+    handful of prototype rows behind them as a launch of their own -- in one launch 65 536 + 14 rows are 257 tiles, i.e. a second round for 14 rows (measured: the
+    512 -> 512 GEMMs of the head ran at 375 TFLOP/s, half of what the same kernel reaches on 65 536 rows)."""
+    if big and 0 < big < R and big % 256 == 0 and big >= 256 * 96:
+        return [(0, big), (big, R)]
+    return [(0, R)]
+
+
+def _mlp_fwd(X, cls, big=0):
+    """classifier MLP (pspnet_pop.py:46-52) on rows X [R,512]: two MFMA 1x1 convs with fused ReLU, then a row dot.  big: number of leading pixel rows (see _row_parts)."""
     R, Cn = X.shape
-    x4 = X.view(1, 1, R, Cn)
     w1f, _ = prepared(cls[0].weight, X.dtype)
     w2f, _ = prepared(cls[2].weight, X.dtype)
-    h1, _ = ops.conv2d_fwd(x4, w1f, spec_of(cls[0]), relu=True)
-    h2, _ = ops.conv2d_fwd(h1, w2f, spec_of(cls[2]), relu=True)
+    h1, h2 = torch.empty_like(X), torch.empty_like(X)
+    for a, b in _row_parts(R, big):
+        ops.conv2d_fwd(X[a:b].view(1, 1, b - a, Cn), w1f, spec_of(cls[0]), relu=True, out=h1[a:b].view(1, 1, b - a, Cn))
+        ops.conv2d_fwd(h1[a:b].view(1, 1, b - a, Cn), w2f, spec_of(cls[2]), relu=True, out=h2[a:b].view(1, 1, b - a, Cn))
     w3 = cls[4].weight.detach().view(-1)
-    z = ops.rowdot_fwd(h2.view(R, Cn), w3)
-    return h1, h2, z
+    z = ops.rowdot_fwd(h2, w3)
+    return h1.view(1, 1, R, Cn), h2.view(1, 1, R, Cn), z
 
 
-def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x):
+def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x, big=0):
     R, Cn = X.shape
     w3 = cls[4].weight.detach().view(-1)
     dh2, dw3 = ops.rowdot_bwd(h2.view(R, Cn), w3, dz)
-    dh2 = dh2.view(1, 1, R, Cn)
+    h1r = h1.view(R, Cn)
     _, w2b = prepared(cls[2].weight, X.dtype)
-    dh1 = ops.conv2d_bwd_data(dh2, w2b, spec_of(cls[2]), (1, R), mask_src=h1)
+    dh1 = torch.empty_like(dh2)
+    parts = _row_parts(R, big)
+    for a, b in parts:
+        ops.conv2d_bwd_data(dh2[a:b].view(1, 1, b - a, Cn), w2b, spec_of(cls[2]), (1, b - a), mask_src=h1r[a:b].view(1, 1, b - a, Cn), out=dh1[a:b].view(1, 1, b - a, Cn))
+    dh2, dh1 = dh2.view(1, 1, R, Cn), dh1.view(1, 1, R, Cn)
     g2 = grad_dst(cls[2].weight) if need_w else None
     dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2, fork_reduce=True), g2) if need_w else None
     dX = None
     if need_x:
         _, w1b = prepared(cls[0].weight, X.dtype)
-        dX = ops.conv2d_bwd_data(dh1, w1b, spec_of(cls[0]), (1, R)).view(R, Cn)
+        dX = torch.empty_like(X)
+        for a, b in parts:
+            ops.conv2d_bwd_data(dh1[0, 0, a:b].view(1, 1, b - a, Cn), w1b, spec_of(cls[0]), (1, b - a), out=dX[a:b].view(1, 1, b - a, Cn))
     g1 = grad_dst(cls[0].weight) if need_w else None
     dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1, fork_reduce=True), g1) if need_w else None
     ops.wgrad_reduce_join()
@@ -625,7 +641,7 @@ class PopHeadFn(torch.autograd.Function):
         proj = ops.pop_decompose_into(feats2d, S, X[:R])
         ops.pop_proto_rows(S_main, X[R:])
         cls_main = model.classifier_n if ft else model.classifier
-        h1, h2, z = _mlp_fwd(X, cls_main)
+        h1, h2, z = _mlp_fwd(X, cls_main, big=R)
         if ft:
             Xb = torch.empty((2 * Kb, Cn), dtype=feat.dtype, device=feat.device)
             ops.pop_proto_rows(S_b.contiguous(), Xb)
@@ -660,7 +676,7 @@ class PopHeadFn(torch.autograd.Function):
             dz = torch.cat([dz_bg, da[Kb:], db[Kb:]]).contiguous()
         else:
             dz = torch.cat([dz_bg, da, db]).contiguous()
-        dX, dw1, dw2, dw3 = _mlp_bwd(X, h1, h2, cls_main, dz, need_w_main, need_feat or need_sb or need_sn)
+        dX, dw1, dw2, dw3 = _mlp_bwd(X, h1, h2, cls_main, dz, need_w_main, need_feat or need_sb or need_sn, big=R)
         gb = (None, None, None)
         dS = None
         dfeat = None

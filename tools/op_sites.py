@@ -28,6 +28,6 @@ for ev in prof.events():
     if not ev.kernels:
         continue
     site = next((s for s in (ev.stack or []) if 'segland_amd' in s or 'bench.py' in s), '?')
-    sites[(ev.name, site.split('/root/repo/')[-1] if '/root/repo/' in site else site[-80:])] += len(ev.kernels)
+    sites[(ev.name, ('segland_amd/' + site.split('segland_amd/')[-1]) if 'segland_amd/' in site else site[-80:])] += len(ev.kernels)
 for (name, site), n in sites.most_common(60):
     print('%4d  %-28s %s' % (n, name, site))
