@@ -99,6 +99,14 @@ int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d);
 int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const uint8_t* gate, const void* bn_x, const float* bn_mean,
                               const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
 
+/* The same across a block boundary: dx = data gradient + `addend` (the shortcut gradient, already gated) is the gradient wrt the PREVIOUS bottleneck's output
+ * relu(bn3(c3) + res); the epilogue gates it with that ReLU's bits (`gate`) and reduces it against bn_x = c3: the previous block's bn3 backward needs no reduce
+ * pass and receives its gradient gated.  Shapes of the pixel-stationary kernel only (1x1 stride 1, Cout = 64 / 128 / 256, Cin % 128 == 0, Cin <= 1024,
+ * B*H*W % 256 == 0, bf16); sl_conv2d_bwd_data_addend_bnstat_rows = rows of stat_partial, 0 = not served. */
+int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d);
+int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
+                                     const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
+
 /* dw (float, OIHW [Cout][Cin][KH][KW]) = sum over pixels of dy (x) x.  Deterministic split-K through `workspace`. */
 size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);
 int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,

@@ -1773,8 +1773,8 @@ __device__ __forceinline__ float sk_sum_8_16_32(float v) {
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
-template <int KS, int MODE, bool SKEW>       // MODE 1: store (+ statistics), 2: + (bit-gated) addend
-__global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(ConvGemmParams p) {
+template <int KS, int MODE, bool SKEW>       // MODE 1: store (+ statistics), 2: + (bit-gated) addend, 5: + addend, result gated with the ReLU bits of its own positions + BN-backward column sums (ConvGemmParams::gate)
+__global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm_sk_kernel(ConvGemmParams p) {      // MODE 5 holds 81 KiB of LDS at KS = 4: one block per CU whatever the registers allow
   using G = SkGeom<KS>;
   using T = bf16_t;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -1818,14 +1818,15 @@ __global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(Conv
   float* red = (float*)(smem + G::OFF_RED);
   const int srow = lane >> 3, sch = lane & 7;                          // store phase: row it * 8 + srow, 16-byte chunk sch of the wave's 32 x 64 patch (a full 128-byte line per row)
   const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
-  uint4 addv[4];
+  uint4 addv[4], cxv[4];                                               // MODE 5: cxv = the BN input c of the result's positions
+  float bmu[8], bis[8];
   // the gate bytes of the block's 256 rows (N / 8 per row, contiguous over the rows) are copied to the LDS once: read step by step from global memory, each step would
   // pull 8 useful bytes out of every row's line, and 256 lines per step do not survive in the 32 KiB L1 next to the addend stream (measured: 58 -> 73 us on 1024 -> 256)
   const int mpitch = p.N / 8 + 16;
-  unsigned char* msk = smem + G::OFF_RED;
-  if (MODE == 2 && p.addend_mask) {
+  unsigned char* msk = smem + (MODE == 5 ? G::LDS : G::OFF_RED);       // MODE 5 keeps the statistic partials too: its gate bytes sit behind them
+  if ((MODE == 2 && p.addend_mask) || MODE == 5) {
     const int cpr = p.N / 128;                                         // 16-byte chunks per row
-    const unsigned char* src = p.addend_mask + (size_t)bm * 256 * (p.N / 8);
+    const unsigned char* src = (MODE == 5 ? p.gate : p.addend_mask) + (size_t)bm * 256 * (p.N / 8);
     for (int e = tid; e < 256 * cpr; e += 512) {
       const int row = e / cpr, c = e - row * cpr;
       *(uint4*)(msk + row * mpitch + c * 16) = *(const uint4*)(src + (size_t)e * 16);
@@ -1835,10 +1836,16 @@ __global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(Conv
   auto multiply = [&](int s) {
     const int cur = s & 1;
     if (issuer && s + 1 < NS) issueB(s + 1, cur ^ 1);
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 || MODE == 5) {
       const int ncol = s * 64 + sch * 8;
 #pragma unroll
       for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
+      if constexpr (MODE == 5) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) cxv[it] = *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bmu[e] = p.bn_mean[ncol + e]; bis[e] = p.bn_invstd[ncol + e]; }
+      }
     }
     f32x16_t acc[2];
 #pragma unroll
@@ -1887,7 +1894,7 @@ __global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(Conv
         }
       } else {
         uint4 ad = addv[it];
-        if (p.addend_mask) {
+        if (MODE == 2 && p.addend_mask) {
           const unsigned b = msk[(wave * 32 + it * 8 + srow) * mpitch + s * 8 + sch];
           ad.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
           ad.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
@@ -1901,10 +1908,26 @@ __global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(Conv
           const f32x2_t v = (f32x2_t){__uint_as_float(rw[c] << 16) + __uint_as_float(aw[c] << 16), __uint_as_float(rw[c] & 0xffff0000u) + __uint_as_float(aw[c] & 0xffff0000u)};
           ow[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
         }
+        if constexpr (MODE == 5) {
+          // gate the ROUNDED sum with the ReLU bits of its own positions (what the separate passes would see), then the column sums of g and g * xhat
+          const unsigned b = msk[(wave * 32 + it * 8 + srow) * mpitch + s * 8 + sch];
+          ow[0] &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
+          ow[1] &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
+          ow[2] &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
+          ow[3] &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
+          const unsigned xw[4] = {cxv[it].x, cxv[it].y, cxv[it].z, cxv[it].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float glo = __uint_as_float(ow[c] << 16), ghi = __uint_as_float(ow[c] & 0xffff0000u);
+            const float xlo = __uint_as_float(xw[c] << 16), xhi = __uint_as_float(xw[c] & 0xffff0000u);
+            sa[2 * c] += glo; sq[2 * c] += glo * ((xlo - bmu[2 * c]) * bis[2 * c]);
+            sa[2 * c + 1] += ghi; sq[2 * c + 1] += ghi * ((xhi - bmu[2 * c + 1]) * bis[2 * c + 1]);
+          }
+        }
         st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
       }
     }
-    if (MODE == 1 && p.stat_partial) {                                 // lanes 8 apart share the column octet
+    if ((MODE == 1 || MODE == 5) && p.stat_partial) {                  // lanes 8 apart share the column octet
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sa[e] = sk_sum_8_16_32(sa[e]); sq[e] = sk_sum_8_16_32(sq[e]); }
       if (lane < 8) {
@@ -1915,7 +1938,7 @@ __global__ __launch_bounds__(512, KS == 4 ? 4 : 2) void conv_gemm_sk_kernel(Conv
     }
   };
   auto finalize = [&](int s, int t0) {                                 // 128 threads from t0 on, after the barrier behind the last store phase of step s
-    if (MODE == 1 && p.stat_partial && tid >= t0 && tid < t0 + 128) {
+    if ((MODE == 1 || MODE == 5) && p.stat_partial && tid >= t0 && tid < t0 + 128) {
       const int which = ((tid - t0) >> 6) & 1, col = tid & 63;
       const float* r0 = red + ((s & 1) * 16 + which) * 64 + col;
       float t = 0.f;
@@ -1970,7 +1993,8 @@ template <int KS, int MODE, bool SKEW>
 int launch_sk_t(ConvGemmParams& p, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_sk_kernel<KS, MODE, SKEW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  const int lds = MODE == 2 && p.addend_mask ? SkGeom<KS>::OFF_RED + 256 * (p.N / 8 + 16) : SkGeom<KS>::LDS;      // statistic partials or the block's gate bytes behind the staging patches
+  const int lds = MODE == 5 ? SkGeom<KS>::LDS + 256 * (p.N / 8 + 16)
+                            : (MODE == 2 && p.addend_mask ? SkGeom<KS>::OFF_RED + 256 * (p.N / 8 + 16) : SkGeom<KS>::LDS);      // statistic partials and / or the block's gate bytes behind the staging patches
   hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, MODE, SKEW>), dim3(p.M / 256), dim3(512), lds, st, p);
   SL_LAUNCH_CHECK("conv_gemm_sk_kernel");
   return 0;
@@ -1984,6 +2008,7 @@ int launch_sk(ConvGemmParams& p, hipStream_t st) {
   // memory traffic (data gradient 1024 -> 256: 41 -> 47 us, with addend 58 -> 67 us).  bit 0: statistics, bit 1: plain store, bit 2: addend
   static const int skew = getenv("SEGLAND_CONV_SK_SKEW") ? atoi(getenv("SEGLAND_CONV_SK_SKEW")) : 1;
   p.gridM = p.M / 256; p.gridN = 1;
+  if (p.gate) return launch_sk_k<5, false>(p, st);
   if (p.addend) return (skew & 4) ? launch_sk_k<2, true>(p, st) : launch_sk_k<2, false>(p, st);
   return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);
 }
@@ -2041,8 +2066,8 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   }
   if constexpr (sizeof(T) == 2) {
     if (v >= 5 && sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
-        !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate) && !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask) &&
-        (!p.addend_mask || (p.N % 128 == 0 && p.N <= 1024)))
+        !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
+        (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
       return launch_sk(p, st);
   }
   if constexpr (sizeof(T) == 2) {
@@ -2221,6 +2246,32 @@ extern "C" int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, co
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
   p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// The same across a block boundary (resnet.py:71-78 backward): the data gradient of conv1 plus the shortcut gradient `addend` IS the gradient wrt the previous block's
+// output relu(bn3(c3) + res); gated with that ReLU's bits and reduced against c3 it hands the previous block its bn3 backward column sums -- its reduce pass over
+// (dout, c3) disappears, and dout arrives gated.  Served: the shapes of the pixel-stationary kernel (1x1, K = 64 / 128 / 256, N % 128 == 0, N <= 1024, M % 256 == 0).
+extern "C" int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d) {
+  if (!d) return 0;
+  static const bool off = getenv("SEGLAND_BN_FUSE_CROSS") && getenv("SEGLAND_BN_FUSE_CROSS")[0] == '0';
+  const long long M = (long long)d->B * d->H * d->W;
+  if (off || conv_variant() < 5 || d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (!sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->Cout, d->Cout, d->Cin, M) || d->Cin % 128 != 0 || d->Cin > 1024) return 0;
+  return (int)(M / 256);
+}
+
+extern "C" int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
+                                                const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && dx && addend && gate && bn_x && bn_mean && bn_invstd && stat_partial, "conv bwd_data_addend_bnstat: null buffer");
+  SL_REQUIRE(sl_conv2d_bwd_data_addend_bnstat_rows(d) > 0, "conv bwd_data_addend_bnstat: shape not served (sl_conv2d_bwd_data_addend_bnstat_rows == 0)");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.addend = addend; p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

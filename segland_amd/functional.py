@@ -227,17 +227,20 @@ def _frozen(ctx, *bns):
 
 _BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm.hip MODE 3)
 _BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
+_BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
-                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None):
+                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None):
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres, partial_below).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue.
     pre_partial: dy is ALREADY gated and the BN-backward column sums of this layer were produced by the epilogue that wrote it (no reduce pass).
     below = (bits, c, mean, invstd) of the BatchNorm + ReLU that produced x: when the data gradient of this conv runs on a kernel with the staged
     store phase, its epilogue gates dx with those bits and emits that layer's column sums (partial_below is then not None and dx is gated).
-    bn_done = (dc, dgamma, dbeta): the BatchNorm part was already done by the caller (ops.bn_bwd2: two BatchNorms behind one ReLU in one sweep)."""
+    bn_done = (dc, dgamma, dbeta): the BatchNorm part was already done by the caller (ops.bn_bwd2: two BatchNorms behind one ReLU in one sweep).
+    prev3 = (bits, c3, mean, invstd) of the PREVIOUS bottleneck's bn3 + output ReLU: dx (with its addend, which must be gated already) is that block's incoming
+    gradient; where the pixel-stationary kernel serves the shape it is gated there and reduced against c3 (partial_below = that block's bn3 column sums)."""
     gw, gg, gb = (grad_dst(conv.weight), grad_dst(bn.weight), grad_dst(bn.bias)) if need_dw else (None, None, None)
     if bn_done is not None:
         (dc, dgamma, dbeta), dres = bn_done, None
@@ -255,6 +258,10 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
         _, wb = prepared(conv.weight, c.dtype)
         if below is not None and _BN_FUSE and addend is None and x2 is None and dx_out is None:
             r = ops.conv2d_bwd_data_bnstat(dc, wb, spec, x.shape[1:3], *below)
+            if r is not None:
+                dx, part_below = r
+        if prev3 is not None and addend is not None and addend_bits is None and x2 is None and dx_out is None:
+            r = ops.conv2d_bwd_data_addend_bnstat(dc, wb, spec, x.shape[1:3], addend, *prev3)
             if r is not None:
                 dx, part_below = r
         if dx is None:
@@ -350,6 +357,9 @@ class BottleneckFn(torch.autograd.Function):
         c3, out, m3, i3, k3 = conv_bn_fwd(a2, blk.conv3, blk.bn3, relu=blk.last_relu, residual=res, want_mask=True)
         ctx.blk = blk
         ctx.has_ds = blk.downsample is not None
+        # the next bottleneck's backward produces this block's incoming gradient: it may gate it and reduce it against c3 right there (_BN_CROSS)
+        blk.__dict__['_sl_bn3'] = (k3, c3, m3, i3) if (_BN_CROSS and k3 is not None and blk.bn3.training and not ctx.has_ds and any(ctx.needs_input_grad)) else None
+        blk.__dict__['_sl_pre3'] = None
         saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3]
         if ctx.has_ds:
             saved += [cd, md, idd]
@@ -370,6 +380,14 @@ class BottleneckFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         # the data gradients of conv3 and conv2 gate their result with the ReLU bits of the layer below and emit its BN-backward column sums in the epilogue
         # (where the kernel has the staged store phase: layer3 / layer4 at the bench shapes): that layer's reduce pass over (g, c) disappears
+        # this block's incoming gradient may have been gated and reduced against c3 by the block behind it (its conv1 data gradient epilogue): the tensor
+        # autograd hands over must be exactly the one that epilogue wrote (a second consumer of this block's output would have made autograd sum into a new one)
+        pre3 = blk.__dict__.get('_sl_pre3')
+        blk.__dict__['_sl_pre3'] = None
+        blk.__dict__['_sl_bn3'] = None
+        p3 = None
+        if pre3 is not None and pre3[0] == dout.data_ptr() and pre3[1] == tuple(dout.shape) and not ctx.has_ds:
+            p3, k3 = pre3[2], None                   # dout is gated already: no bits for bn3, none for the identity shortcut
         done3 = doned = None
         if ctx.has_ds and _BN_DUAL and k3 is not None and blk.bn3.training and blk.downsample[1].training and not sync_world(blk.bn3):
             # bn3 and the downsample BN sit behind the same ReLU: one sweep over dout and its bits for both reduces, one for both applies (ops.bn_bwd2)
@@ -379,8 +397,16 @@ class BottleneckFn(torch.autograd.Function):
             dc3, dg3_, db3_, dcd, dgd_, dbd_ = ops.bn_bwd2(dout, k3, c3, m3, i3, blk.bn3.weight, cd, md, idd, bnd.weight, (g3, b3), (gd_, bd_))
             done3 = (dc3, grad_alias(dg3_, g3), grad_alias(db3_, b3))
             doned = (dcd, grad_alias(dgd_, gd_), grad_alias(dbd_, bd_))
-        da2, dw3, dg3, db3, _, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3,
-                                                below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3)
+        # the block in front of this one can take its bn3 column sums from this block's conv1 data gradient only if the shortcut gradient enters that epilogue
+        # gated already: either dout arrived gated (p3), or the shortcut is a downsample branch, or -- the start of a chain inside a stage -- bn3's apply pass
+        # also writes the gated gradient (one extra write of dout's size, repaid by every block further up the stage)
+        prev = blk.__dict__.get('_sl_prev')
+        prev3 = prev.__dict__.get('_sl_bn3') if (prev is not None and need_x and _BN_CROSS) else None
+        if prev3 is not None and (prev3[1].shape != x.shape or prev3[1].dtype != x.dtype or not ops.conv2d_bwd_data_addend_bnstat_ok(x, spec_of(blk.conv1))):
+            prev3 = None
+        want_dres = prev3 is not None and not ctx.has_ds and k3 is not None and p3 is None and done3 is None
+        da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,
+                                                   below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres)
         da1, dw2, dg2, db2, _, p1 = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=None if p2 is not None else k2, pre_partial=p2,
                                                 below=(k1, c1, m1, i1) if blk.bn1.training else None)
         grads_ds = ()
@@ -389,10 +415,17 @@ class BottleneckFn(torch.autograd.Function):
             dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned)
             grads_ds = (dwd, dgd, dbd)
             addend, abits = dxd, None
+        elif dres is not None:
+            addend, abits = dres, None              # identity shortcut, gated by bn3's apply pass (chain start, see above)
         else:
-            addend, abits = dout, k3                # identity shortcut: dout * relu'(out), gated inside the dgrad epilogue
-        dx, dw1, dg1, db1, _, _ = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
-                                              addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1)
+            addend, abits = dout, k3                # identity shortcut: dout * relu'(out), gated inside the dgrad epilogue (k3 None: dout arrived gated)
+        if abits is not None:
+            prev3 = None
+        dx, dw1, dg1, db1, _, pp = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
+                                               addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1,
+                                               prev3=prev3)
+        if pp is not None and prev3 is not None:
+            prev.__dict__['_sl_pre3'] = (dx.data_ptr(), tuple(dx.shape), pp)
         wgrad_join()
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
 

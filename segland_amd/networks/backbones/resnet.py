@@ -73,7 +73,10 @@ class ResNet(nn.Module):
 
     def base_forward(self, img):
         x = self.forward_base_in(img)
+        prev = None
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             for blk in stage:
+                blk.__dict__['_sl_prev'] = prev       # the block whose output is this block's ONLY input: its bn3 backward statistics can ride on this block's conv1 data gradient
                 x = blk(x)
+                prev = blk
         return x

@@ -252,6 +252,34 @@ def conv2d_bwd_data_bnstat(dy, wb, spec, in_hw, gate, bn_x, mean, invstd):
     return dx, part
 
 
+def conv2d_bwd_data_addend_bnstat_ok(x, spec):
+    """Would conv2d_bwd_data_addend_bnstat serve the data gradient of conv `spec` on input x [B,H,W,Cin]?"""
+    if x.dtype != torch.bfloat16:
+        return False
+    B, H, W, _ = x.shape
+    return _lib.lib().sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(conv_desc(x.dtype, B, H, W, spec, None))) > 0
+
+
+def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean, invstd):
+    """dx = data gradient + addend, gated with the ReLU bits `gate` of the block output it is the gradient of, + that block's bn3 backward column
+    sums (csrc/conv_gemm.hip: pixel-stationary kernel MODE 5).  -> (g, partial [rows][2][Cin]) or None when the shape is not served."""
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    rows = L.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d)) if dy.dtype == torch.bfloat16 else 0
+    if rows <= 0:
+        return None
+    dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    part = _f32((rows, 2, spec.cin), dy.device)
+    tok = PROFILER.begin('conv_dgrad', d)
+    check(L.sl_conv2d_bwd_data_addend_bnstat(C.byref(d), _p(dy), _p(wb), _p(addend), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()),
+          'conv2d_bwd_data_addend_bnstat')
+    if tok is not None:
+        PROFILER.end(tok, addend.numel() * addend.element_size() + bn_x.numel() * bn_x.element_size() + gate.numel())
+    return dx, part
+
+
 _ws_cache = {}
 
 
