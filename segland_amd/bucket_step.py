@@ -5,16 +5,18 @@ DistributedDataParallel runs its reducer (Python/C++ hooks inside backward) and 
 GPU time itself.  `BucketedReplica` keeps the reference's semantics (engine.py:69-74: one replica per GPU, gradients
 averaged over the ranks, `module.`-prefixed state_dict) with a structure that needs the host three times per step:
 
-    graph A   zero_grad, forward, loss, backward -- the block backwards write every parameter gradient straight into flat fp32 buckets
-              (functional.grad_dst; the few gradients autograd produces itself are copied in at the end of the graph)
-    eager     one SUM all-reduce per bucket on the process group (RCCL over xGMI; nothing of RCCL is captured)
+    graph A1  zero_grad, forward, loss, backward down to the model's cut tensors (ResNet: the output of layer3) -- the block backwards write every
+              parameter gradient straight into flat fp32 buckets (functional.grad_dst; the few gradients autograd produces itself are copied in)
+    eager     SUM all-reduce of the LATE buckets (head, decoder, layer4: 82 % of ResNet-50's bytes), asynchronous on the process group's stream
+    graph A2  the rest of the backward (runs while those buckets travel)
+    eager     SUM all-reduce of the early buckets; the current stream then waits for all of them (RCCL over xGMI; nothing of RCCL is captured)
     graph B   gradient-norm clip + both AdamW steps of the loop body; the 1 / world_size of the mean lives in the optimizer kernel
 
 The parameter-gradient exchange is the path's only collective.  Per-GPU BatchNorm statistics only: SyncBatchNorm's per-layer
 collectives (SEGLAND_SYNC_BN=1) cannot sit inside a captured forward, `eligible()` says no and the caller keeps DistributedDataParallel.
-What the two-graph form gives up is the overlap of the all-reduce with the backward (190 MB for ResNet-50: ~1 ms of a 26 ms step at 8 GPUs
-against the 2.5-3 % the DistributedDataParallel wrapper costs at any world size); SEGLAND_BUCKET_STEP=0 keeps
-DistributedDataParallel with the in-place bucket gradients of engine.enable_inplace_bucket_gradients."""
+Exposed communication: the early buckets only (34 MB for ResNet-50 against 190 MB without the cut, SEGLAND_BUCKET_CUT=0); the DistributedDataParallel wrapper
+costs 2-3 % at any world size.  SEGLAND_BUCKET_STEP=0 keeps DistributedDataParallel with the in-place bucket gradients of
+engine.enable_inplace_bucket_gradients."""
 import os
 
 import torch
@@ -34,9 +36,13 @@ def eligible(world_size, use_cuda):
 class BucketedReplica(nn.Module):
     """One model replica of a data-parallel job.  `.module` and the `module.` key prefix like DistributedDataParallel / nn.DataParallel.
     Construction broadcasts rank 0's parameters and buffers (DistributedDataParallel does the same); flat gradient buckets are laid out
-    in REVERSE parameter order (the order the backward produces them), `cap_mb` each."""
+    in REVERSE parameter order (the order the backward produces them), `cap_mb` each.
 
-    def __init__(self, module, process_group=None, cap_mb=64):
+    cut (default on when the model offers it): the backward is run in two halves -- from the loss down to the model's cut tensors (ResNet: the output of
+    layer3; Swin: the backbone's four feature maps), then from there to the image -- with the gradients of the LATE parameters (head, decoder, layer4: 82 % of
+    ResNet-50's bytes) in buckets of their own: their all-reduce travels while the second half runs."""
+
+    def __init__(self, module, process_group=None, cap_mb=64, cut=None):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -46,8 +52,15 @@ class BucketedReplica(nn.Module):
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, 0, group=process_group)
+        if cut is None:
+            # measured at world size 1 (profiles/r3_ddp_overhead*.txt): the third graph and the second round of collectives cost 0.4 ms per ResNet-50 step and 0.8 ms per
+            # Swin-T step; what the cut hides at 8 GPUs is ~0.85 ms (156 of 190 MB) for ResNet-50 but only the decoder's share for Swin-T -- the model says which way it goes
+            env = os.environ.get('SEGLAND_BUCKET_CUT')
+            cut = (env != '0') if env is not None else bool(getattr(module, 'bucket_cut_default', False))
+        self.cut = bool(cut) and hasattr(module, 'late_parameters') and hasattr(module, 'cut_tensors')
         self.cap = int(cap_mb * (1 << 20)) // 4
-        self.buckets, self.views, self.layout = [], {}, None
+        self.buckets, self.late_buckets, self.views, self.layout = [], 0, {}, None
+        self._cuts = None
         self._build()
 
     def forward(self, *a, **k):
@@ -56,44 +69,60 @@ class BucketedReplica(nn.Module):
     def _trainable(self):
         return [p for p in self.module.parameters() if p.requires_grad]
 
-    def _build(self):
+    def _groups(self):
+        """(late, early) trainable parameters; without a cut everything is 'late' (one backward, one round of all-reduces)."""
         params = self._trainable()
-        layout = tuple((id(p), p.numel()) for p in params)
+        if not self.cut:
+            return params, []
+        late_ids = {id(p) for p in self.module.late_parameters()}
+        return [p for p in params if id(p) in late_ids], [p for p in params if id(p) not in late_ids]
+
+    def _build(self):
+        late, early = self._groups()
+        layout = tuple((id(p), p.numel()) for p in late) + ('|',) + tuple((id(p), p.numel()) for p in early)
         if layout == self.layout:
             return
         for p in self.module.parameters():
             if hasattr(p, '_sl_gview'):
                 del p._sl_gview
-        self.buckets, self.views, chunk, n = [], {}, [], 0
-        dev = params[0].device
+        self.buckets, self.views = [], {}
+        dev = (late + early)[0].device
 
-        def flush():
-            if chunk:
-                flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in chunk), dtype=torch.float32, device=dev)     # 256-byte aligned views
-                off = 0
-                for p in chunk:
-                    v = flat[off:off + p.numel()].view(p.shape)
-                    self.views[id(p)] = v
-                    p._sl_gview = v
-                    off += -(-p.numel() // 64) * 64
-                self.buckets.append(flat)
-        for p in reversed(params):
-            if p.dtype != torch.float32 or not p.is_contiguous():
-                raise RuntimeError('BucketedReplica: contiguous float32 parameters only')
-            if n + p.numel() > self.cap and chunk:
-                flush()
-                chunk, n = [], 0
-            chunk.append(p)
-            n += p.numel()
-        flush()
+        def lay_out(params):
+            chunk, n = [], 0
+
+            def flush():
+                if chunk:
+                    flat = torch.zeros(sum(-(-p.numel() // 64) * 64 for p in chunk), dtype=torch.float32, device=dev)     # 256-byte aligned views
+                    off = 0
+                    for p in chunk:
+                        v = flat[off:off + p.numel()].view(p.shape)
+                        self.views[id(p)] = v
+                        p._sl_gview = v
+                        off += -(-p.numel() // 64) * 64
+                    self.buckets.append(flat)
+            for p in reversed(params):
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError('BucketedReplica: contiguous float32 parameters only')
+                if n + p.numel() > self.cap and chunk:
+                    flush()
+                    chunk, n = [], 0
+                chunk.append(p)
+                n += p.numel()
+            flush()
+        lay_out(late)
+        self.late_buckets = len(self.buckets)
+        lay_out(early)
         self.layout = layout
+        if hasattr(self.module, 'enable_backward_cut'):
+            self.module.enable_backward_cut(self.cut and bool(early))
 
-    def adopt_gradients(self):
-        """After backward: every .grad IS (an alias of) its bucket view.  Block backwards wrote most of them in place (functional.grad_dst);
+    def adopt_gradients(self, params=None):
+        """After (a half of the) backward: every .grad IS (an alias of) its bucket view.  Block backwards wrote most of them in place (functional.grad_dst);
         a gradient autograd produced itself is copied in; a parameter that received none counts as zero (DistributedDataParallel's
         find_unused_parameters=False would raise -- every parameter of the POP path receives a gradient)."""
         dst, src, zero = [], [], []
-        for p in self._trainable():
+        for p in (self._trainable() if params is None else params):
             v = self.views[id(p)]
             g = p.grad
             if g is None:
@@ -108,59 +137,164 @@ class BucketedReplica(nn.Module):
         if zero:
             torch._foreach_zero_(zero)
 
-    def all_reduce(self, which=None):
-        """SUM over the ranks, one collective per bucket, on the process group's stream (ordered after the current stream's work)."""
+    def all_reduce(self, which=None, async_op=False):
+        """SUM over the ranks, one collective per bucket, on the process group's stream (ordered after the current stream's work).
+        which: 'late' / 'early' / None (all).  async_op: returns the work handles (wait() makes the current stream wait for them)."""
+        works = []
         if self.active:                                   # also at world size 1 (SEGLAND_FORCE_DDP=1): the same calls, RCCL copies
-            for k, flat in enumerate(self.buckets):
-                if which is None or k in which:
-                    dist.all_reduce(flat, group=self.group)
+            lo, hi = (0, self.late_buckets) if which == 'late' else ((self.late_buckets, len(self.buckets)) if which == 'early' else (0, len(self.buckets)))
+            for flat in self.buckets[lo:hi]:
+                w = dist.all_reduce(flat, group=self.group, async_op=async_op)
+                if async_op:
+                    works.append(w)
+        return works
 
     def train_step_parts(self, optimizer, double_step=True, clip_grad=5.0):
-        """(backward_part(img, mask) -> loss dict, update_part() -> gradient norm): train_base.train_iteration cut at the all-reduce."""
+        """(backward_late(img, mask) -> loss dict, backward_early(), update_part() -> gradient norm): train_base.train_iteration cut at the all-reduces."""
         from .optim import clip_coefficient
 
-        def backward_part(img, mask):
+        def backward_late(img, mask):
             self._build()
+            late, early = self._groups()
             optimizer.zero_grad(set_to_none=True)
             loss_dict = self.module(img, mask)
-            loss_dict['total_loss'].backward()
-            self.adopt_gradients()
+            cuts = self.module.cut_tensors() if (self.cut and early) else None
+            if cuts:
+                torch.autograd.backward(loss_dict['total_loss'], inputs=[leaf for _, leaf in cuts] + late)
+                self._cuts = list(cuts)
+                self.adopt_gradients(late)
+            else:
+                loss_dict['total_loss'].backward()
+                self._cuts = None
+                self.adopt_gradients()
             return loss_dict
+
+        def backward_early():
+            if self._cuts:
+                _, early = self._groups()
+                torch.autograd.backward([t for t, _ in self._cuts], [leaf.grad for _, leaf in self._cuts], inputs=early)
+                self._cuts = None
+                self.module.clear_cut()               # the stash holds this step's autograd graph (and its stream-bound AccumulateGrad nodes) alive
+                self.adopt_gradients(early)
 
         def update_part():
             params = [p for p in self._trainable() if p.grad is not None]
             norm, coef = clip_coefficient(params, clip_grad, self.world)
             optimizer.step(repeat=2 if double_step else 1, grad_scale=coef)
             return norm
-        return backward_part, update_part
+        return backward_late, backward_early, update_part
+
+    def _run(self, parts, img, mask, call):
+        """The step with the all-reduce of the late buckets issued between the two backward halves (travelling beside the second one)."""
+        bwd1, bwd2, upd = parts
+        loss = call(bwd1, img, mask)
+        two = self.cut and self.late_buckets < len(self.buckets)
+        works = self.all_reduce('late' if two else None, async_op=True)
+        if two:
+            call(bwd2)
+            works += self.all_reduce('early', async_op=True)
+        for w in works:
+            w.wait()
+        return loss, call(upd)
 
     def train_iteration(self, optimizer, img, mask, double_step=True):
         """The loop body of train_base.py:250-264 issued kernel by kernel (what GraphedBucketStep replays)."""
-        bwd, upd = self.train_step_parts(optimizer, double_step)
-        loss = bwd(img, mask)
-        self.all_reduce()
-        return loss, upd()
+        return self._run(self.train_step_parts(optimizer, double_step), img, mask, lambda f, *a: f(*a))
 
 
 class GraphedBucketStep:
-    """Callable with the signature and results of train_base.train_iteration for a BucketedReplica: graph A, bucket all-reduces, graph B."""
+    """Callable with the signature and results of train_base.train_iteration for a BucketedReplica: graph A1 (forward + backward down to the cut), all-reduce of the
+    late buckets (asynchronous), graph A2 (rest of the backward), all-reduce of the early buckets, graph B (clip + AdamW).  The graphs are captured together (after
+    `warmup` eager steps per input signature) and replayed in capture order from one memory pool; if any capture fails the step stays kernel by kernel."""
 
     def __init__(self, replica, optimizer, double_step=True, warmup=3):
-        bwd, upd = replica.train_step_parts(optimizer, double_step)
-        self.replica = replica
-        self.a = graph_step.GraphedStep(bwd, replica, None, warmup)
-        self.b = graph_step.GraphedStep(lambda: upd(), replica, optimizer, warmup)
+        self.replica, self.optimizer, self.warmup = replica, optimizer, warmup
+        self.parts = replica.train_step_parts(optimizer, double_step)
+        self.seen, self.key, self.graphs = {}, None, None
+        self.static_in, self.outs, self.static_grads = None, None, None
+        self.replays, self.failures = 0, 0
+        self.bn_training = True
+
+    def _state_key(self, tensors):
+        m = self.replica
+        return tuple((tuple(t.shape), t.dtype) for t in tensors) + (sum(1 for p in m.parameters() if p.requires_grad), sum(1 for x in m.modules() if x.training))
+
+    def _eager(self, img, mask):
+        loss, norm = self.replica._run(self.parts, img, mask, lambda f, *a: graph_step._detached(f(*a)))
+        return loss, norm
+
+    def _capture(self, img, mask, key):
+        self.graphs = None
+        self.static_in = (img.clone(), mask.clone())
+        self.optimizer.capture_begin()
+        graphs, outs, pool = [], [], None
+        torch.cuda.synchronize()
+
+        def call(fn, *args):
+            nonlocal pool
+            g = torch.cuda.CUDAGraph()
+            a = self.static_in if args else ()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                out = graph_step._detached(fn(*a))
+            if pool is None:
+                pool = g.pool()
+            if fn is self.parts[2]:
+                self.optimizer.graph_prepare()
+            g.replay()                                # a captured part has not run: execute it before the collective / the next part that consumes it
+            graphs.append(g); outs.append(out)
+            return out
+        loss, norm = self.replica._run(self.parts, img, mask, call)
+        self.graphs, self.outs, self.key = graphs, (loss, norm), key
+        self.bn_training = any(isinstance(x, torch.nn.modules.batchnorm._BatchNorm) and x.training for x in self.replica.modules())
+        self.static_grads = [(p, p.grad) for p in self.replica.parameters() if p.grad is not None]
+        graph_step.STATS['captures'] += 1
+        return loss, norm
 
     def __call__(self, img, mask):
-        loss = self.a(img, mask)
-        self.replica.all_reduce()
-        norm = self.b()
-        return loss, norm
+        key = self._state_key((img, mask))
+        if key != self.key or self.graphs is None:
+            n = self.seen.get(key, 0)
+            if n < self.warmup:
+                self.seen[key] = n + 1
+                return self._eager(img, mask)
+            try:
+                out = self._capture(img, mask, key)
+                self._invalidate()
+                return out
+            except Exception as e:
+                self.graphs, self.key = None, None
+                self.failures += 1
+                graph_step.STATS['failures'] += 1
+                torch.cuda.synchronize()
+                import logging
+                logging.getLogger('Segmentation').warning('bucket_step: capture failed (%s: %s); %s', type(e).__name__, str(e).splitlines()[0] if str(e) else '',
+                                                          'one more eager step, then another attempt' if self.failures < 3 else 'staying eager')
+                if self.failures >= 3:
+                    self.warmup = float('inf')
+                return self._eager(img, mask)
+        for dst, src in zip(self.static_in, (img, mask)):
+            dst.copy_(src, non_blocking=True)
+        for p, g in self.static_grads:
+            if p.grad is not g:
+                p.grad = g
+        it = iter(self.graphs)
+
+        def call(fn, *args):
+            if fn is self.parts[2]:
+                self.optimizer.graph_prepare()
+            next(it).replay()
+        self.replica._run(self.parts, img, mask, call)
+        self.replays += 1
+        graph_step.STATS['replays'] += 1
+        self._invalidate()
+        return self.outs
+
+    def _invalidate(self):
+        from . import functional
+        functional.weights_changed()
+        if self.bn_training:
+            functional.running_stats_changed()
 
     @property
     def graph(self):
-        return self.a.graph if (self.a.graph is not None and self.b.graph is not None) else None
-
-    @property
-    def replays(self):
-        return min(self.a.replays, self.b.replays)
+        return self.graphs

@@ -72,6 +72,7 @@ class ResNet(nn.Module):
         return StemFn.apply(img.float().contiguous(), self.conv1.weight, self.bn1.weight, self.bn1.bias, self, self.compute_dtype)
 
     def base_forward(self, img):
+        self.__dict__['_sl_cut'] = None                # first: the stashed tensors hold the previous step's autograd graph (and its AccumulateGrad nodes) alive
         x = self.forward_base_in(img)
         prev = None
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -79,4 +80,11 @@ class ResNet(nn.Module):
                 blk.__dict__['_sl_prev'] = prev       # the block whose output is this block's ONLY input: its bn3 backward statistics can ride on this block's conv1 data gradient
                 x = blk(x)
                 prev = blk
+            if stage is self.layer3 and self.__dict__.get('_sl_want_cut') and x.requires_grad:
+                # GFSS_Model.cut_tensors(): where a data-parallel backward is cut in two (bucket_step.py).  The graph is really cut: layer4 continues on a
+                # detached leaf whose .grad the first half fills; the second half restarts from (x, that gradient).  (A non-leaf tensor in backward(inputs=...)
+                # makes autograd EXECUTE its producing node, and a second pass through it would find its saved tensors freed.)
+                leaf = x.detach().requires_grad_(True)
+                self.__dict__['_sl_cut'] = (x, leaf)
+                x = leaf
         return x

@@ -87,6 +87,31 @@ class GFSS_Model(nn.Module):
             for p in part.parameters():
                 p.requires_grad = False
 
+    # ---- two-part backward for data parallelism (bucket_step.BucketedReplica): the gradients of everything behind the cut are complete when the backward
+    # reaches the cut tensor(s), so their all-reduce can travel while the rest of the backward runs
+    bucket_cut_default = True          # BucketedReplica: cut the data-parallel backward behind layer3 (82 % of the gradient bytes travel beside the second half)
+
+    def enable_backward_cut(self, flag):
+        self.backbone.__dict__['_sl_want_cut'] = bool(flag)
+
+    def late_parameters(self):
+        bb = self.backbone
+        early = {id(p) for part in (bb.conv1, bb.bn1, bb.layer1, bb.layer2, bb.layer3) for p in part.parameters()}
+        return [p for p in self.parameters() if id(p) not in early]
+
+    def cut_tensors(self):
+        """[(tensor, detached leaf the rest of the forward continued on)] of the last forward (ResNet: the output of layer3), or None.  With the cut
+        enabled the backward MUST be run in two halves (bucket_step.BucketedReplica does): loss.backward(inputs = leaves + late_parameters()), then
+        torch.autograd.backward(tensors, [leaf.grad ...], inputs = the other parameters)."""
+        t = self.backbone.__dict__.get('_sl_cut')
+        return [t] if t is not None else None
+
+    def clear_cut(self):
+        """Drop the stashed cut tensors: they keep the step's autograd graph -- and the parameters' AccumulateGrad nodes, which are bound to the stream they were
+        created on -- alive; a HIP-graph capture on another stream would then reuse those nodes."""
+        self.backbone.__dict__['_sl_cut'] = None
+        self.__dict__['_sl_cut'] = None
+
     # ---- forward
     def forward(self, img, mask=None, img_b=None, mask_b=None):
         if self.is_ft:

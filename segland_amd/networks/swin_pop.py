@@ -142,11 +142,31 @@ class GFSS_Model(pspnet_pop.GFSS_Model):
         plan.refresh()                      # every GEMM weight whose parameter changed since the last step: one batched launch
         fs.CURRENT_PLAN[0] = plan
         try:
-            feat = self.decoder(self.backbone(img))
+            self.__dict__['_sl_cut'] = None
+            feats = self.backbone(img)
+            if self.__dict__.get('_sl_want_cut') and all(f.requires_grad for f in feats):
+                leaves = tuple(f.detach().requires_grad_(True) for f in feats)      # the graph is cut here (see resnet.py base_forward)
+                self.__dict__['_sl_cut'] = list(zip(feats, leaves))
+                feats = leaves
+            feat = self.decoder(feats)
         finally:
             fs.CURRENT_PLAN[0] = None
         flush_num_batches_tracked()
         return feat
+
+    # two-part backward (bucket_step.BucketedReplica): the cut is between the Swin backbone and the UperNet decoder -- the decoder's and the head's gradients are
+    # complete when the backward reaches the backbone's four feature maps
+    bucket_cut_default = False         # measured: the cut costs a Swin-T step 0.8 ms at world size 1 and would hide only the decoder's share of a ~0.8 ms all-reduce (SEGLAND_BUCKET_CUT=1 enables it)
+
+    def enable_backward_cut(self, flag):
+        self.__dict__['_sl_want_cut'] = bool(flag)
+
+    def late_parameters(self):
+        early = {id(p) for p in self.backbone.parameters()}
+        return [p for p in self.parameters() if id(p) not in early]
+
+    def cut_tensors(self):
+        return self.__dict__.get('_sl_cut')
 
     def _padded_cls(self, cls, P):
         d = self.d_model

@@ -115,17 +115,26 @@ class AdamW(torch.optim.Optimizer):
                                    hyp=torch.zeros(4 + 2 * len(self.param_groups), dtype=torch.float32, device=dev))
 
     def graph_prepare(self):
-        """Before every replay of a graph that holds a captured step(): advances the step counts like step() would and uploads this step's
-        bias corrections and the groups' current lr / weight_decay (stream-ordered, from a fresh pinned buffer: the host may run ahead)."""
+        """Before every replay of a graph that holds a captured step(): advances the step counts like step() would and puts this step's bias corrections and the
+        groups' current lr / weight_decay into the device vector the captured kernel reads.
+        NOT by a host-to-device copy per step: measured (profiles/r2_kernel_sequence_graph_step.txt, tools/graph_host_time.py), the 40-byte upload sat on the
+        critical path of every step with 0.3-0.5 ms of GPU idle time in front of it -- the copy engine's hand-off behind the previous graph -- although the host
+        had issued it 25 ms earlier.  The rows of the next 1024 steps (host arithmetic, same values as step() computes) live in a DEVICE table that is uploaded
+        once and refreshed when it runs out or a group's lr / weight_decay changes; per step one row moves device-to-device (a 5 us kernel on the compute queue)."""
         for slot, plist, repeat in self._graph_plan:
             t = int(self.state[plist[0]]['step']) + 1
             for p in plist:
                 self.state[p]['step'] += repeat
             b1, b2 = self.param_groups[0]['betas']
-            vals = [1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), 1.0 - b1 ** (t + 1), math.sqrt(1.0 - b2 ** (t + 1))]
-            for group in self.param_groups:
-                vals += [group['lr'], group['weight_decay']]
-            self._cap[slot]['hyp'].copy_(torch.tensor(vals, dtype=torch.float32).pin_memory(), non_blocking=True)
+            cap = self._cap[slot]
+            sig = tuple((float(g['lr']), float(g['weight_decay'])) for g in self.param_groups) + (b1, b2, repeat)
+            tab = cap.get('tab')
+            if tab is None or tab['sig'] != sig or t < tab['t0'] or t >= tab['t0'] + tab['n'] * repeat or (t - tab['t0']) % repeat:
+                n = 1024
+                tail = [v for g in self.param_groups for v in (g['lr'], g['weight_decay'])]
+                rows = [[1.0 - b1 ** tt, math.sqrt(1.0 - b2 ** tt), 1.0 - b1 ** (tt + 1), math.sqrt(1.0 - b2 ** (tt + 1))] + tail for tt in range(t, t + n * repeat, repeat)]
+                tab = cap['tab'] = dict(sig=sig, t0=t, n=n, dev=torch.tensor(rows, dtype=torch.float32).pin_memory().to(cap['hyp'].device, non_blocking=True))
+            cap['hyp'].copy_(tab['dev'][(t - tab['t0']) // repeat], non_blocking=True)
 
 
 def clip_coefficient(parameters, max_norm, grad_div=1):

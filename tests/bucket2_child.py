@@ -63,7 +63,7 @@ def main():
             vals = engine.reduce_loss_dict(d)
             losses.append([float(vals['total_loss']), float(gn)])
         if mode == 'bucket':
-            assert step.graph is not None and step.replays >= iters - 3, (step.a.failures, step.b.failures, step.replays)
+            assert step.graph is not None and step.replays >= iters - 3, (step.failures, step.replays)
         m.eval()
         with torch.no_grad():
             logits = m(fm.formula_image(2, H, W, 'b2/eval').to(dev)).float().cpu()

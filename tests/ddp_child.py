@@ -75,7 +75,7 @@ def main():
                 losses.append([float(d['total_loss'].detach()), float(gn)])
                 print('ddp_child: wrapped %s iteration %d done' % (wrapped, it), file=sys.stderr, flush=True)
             if step is not None:
-                out['bucket_replays'], out['bucket_failures'], out['buckets'] = step.replays, step.a.failures + step.b.failures, len(net.buckets)
+                out['bucket_replays'], out['bucket_failures'], out['buckets'] = step.replays, step.failures, len(net.buckets)
             if wrapped and inplace and not bucket:
                 out['inplace_writes_last_step'] = hits[0]
                 out['grads_alias_cached_views'] = sum(1 for p in m.parameters() if p.grad is not None and getattr(p, '_sl_gview', None) is not None

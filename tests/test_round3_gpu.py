@@ -63,7 +63,7 @@ def test_bucket_step_two_ranks_equals_ddp(hip, tmp_path):
     d, b = res['ddp'], res['bucket']
     print('losses ddp   :', d['losses'], '\nlosses bucket:', b['losses'], '\nbuckets', b['buckets'], 'replays', b['replays'])
     assert d['ranks_equal'] and b['ranks_equal']
-    assert b['replays'] >= 2 * 3 and b['buckets'] >= 2
+    assert b['replays'] >= 3 and b['buckets'] >= 2
     for (x, gx), (y, gy) in zip(d['losses'], b['losses']):
         assert abs(x - y) <= 1e-6 * abs(y) and abs(gx - gy) <= 1e-5 * gy
     worst, key = 0.0, ''
@@ -338,3 +338,51 @@ def test_bn3_statistics_from_the_next_blocks_data_gradient(hip):
     # not bit-equal: the column sums are added in another order, the BN-backward coefficients differ in their last fp32 bits, a few bf16 roundings of dc3 flip, and the
     # train-mode BN chain of an untrained network amplifies that ~1e3..1e4 x (measured 2.2e-3 global, 2.3e-2 on the stem's bn1.bias)
     assert (num / den) ** 0.5 <= 1e-2 and worst[0] <= 6e-2
+
+
+@pytest.mark.parametrize('family', ['pspnet', 'swin'])
+def test_bucket_step_with_backward_cut_equals_plain_step(hip, family):
+    """bucket_step.BucketedReplica without a process group (the all-reduces are no-ops): the backward run in two halves around the model's cut (ResNet: behind
+    layer3, on a detached leaf; Swin: between backbone and decoder, four leaves), gradients adopted into the buckets per half, three captured graphs replayed in
+    order -- must train exactly like train_base.train_iteration: same losses, gradient norms and parameters after six iterations on changing batches."""
+    import copy
+    from segland_amd import bucket_step
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.optim import AdamW
+    from segland_amd.train_base import train_iteration
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    if family == 'pspnet':
+        from segland_amd.networks.pspnet_pop import GFSS_Model
+        kw, (H, W) = dict(backbone='resnet50', dilated=True, os=8), (96, 128)
+    else:
+        from segland_amd.networks.swin_pop import GFSS_Model
+        kw, (H, W) = dict(backbone='swin-t'), (128, 160)
+    ref = GFSS_Model(n_base=7, criterion=OrthLoss(255), pretrained_model=None, compute_dtype=torch.float32, **kw)
+    fm.load_formula_weights(ref)
+    ref = ref.to(DEV).train()
+    if family == 'swin':
+        ref.backbone.drop_path_hook = lambda index, B, p: torch.full((B,), 1.0, device=DEV)
+        ref.decoder.dropout2d_hook = lambda B, Cn, p: torch.full((B, Cn), 1.0, device=DEV)
+    got = copy.deepcopy(ref)
+    if family == 'swin':
+        got.backbone.drop_path_hook, got.decoder.dropout2d_hook = ref.backbone.drop_path_hook, ref.decoder.dropout2d_hook
+    batches = [(fm.formula_image(2, H, W, 'cut/img%d' % k).to(DEV), fm.formula_mask(2, H, W, 8, 'cut/mask%d' % k, block=16, ignore_rows=4).to(DEV)) for k in range(6)]
+    opt_r = AdamW(get_parameters(ref, lr=1e-4), lr=1e-4, weight_decay=1e-4)
+    sc = NativeScalerWithGradNormCount()
+    log_r = []
+    for img, mask in batches:
+        d, gn = train_iteration(ref, opt_r, sc, img, mask, double_step=True)
+        log_r.append((float(d['total_loss'].detach()), float(gn)))
+    rep = bucket_step.BucketedReplica(got, cap_mb=16, cut=True)
+    assert rep.cut and 0 < rep.late_buckets < len(rep.buckets)
+    opt_g = AdamW(get_parameters(got, lr=1e-4), lr=1e-4, weight_decay=1e-4)
+    step = bucket_step.GraphedBucketStep(rep, opt_g, double_step=True, warmup=2)
+    log_g = []
+    for img, mask in batches:
+        d, gn = step(img, mask)
+        log_g.append((float(d['total_loss'].detach()), float(gn)))
+    print(log_r, log_g)
+    assert step.graph is not None and len(step.graph) == 3 and step.replays >= 3 and step.failures == 0
+    assert log_r == log_g
+    for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
+        assert torch.equal(a, b), k

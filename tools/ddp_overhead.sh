@@ -8,7 +8,7 @@ export MASTER_ADDR=127.0.0.1 RANK=0 WORLD_SIZE=1
 for rep in 1 2; do
   python3 bench.py --no-cpu-baseline --no-step-graph --steps $STEPS "$@" 2>/dev/null | line "plain, kernel by kernel"
   python3 bench.py --no-cpu-baseline --steps $STEPS "$@" 2>/dev/null | line "plain, one graph per step"
-  SEGLAND_FORCE_DDP=1 MASTER_PORT=2950$rep python3 bench.py --no-cpu-baseline --steps $STEPS "$@" 2>/dev/null | line "RCCL world 1, bucket step (2 graphs)"
+  SEGLAND_FORCE_DDP=1 MASTER_PORT=2950$rep python3 bench.py --no-cpu-baseline --steps $STEPS "$@" 2>/dev/null | line "RCCL world 1, bucket step (3 graphs) "
   SEGLAND_FORCE_DDP=1 SEGLAND_BUCKET_STEP=0 MASTER_PORT=2951$rep python3 bench.py --no-cpu-baseline --steps $STEPS "$@" 2>/dev/null | line "RCCL world 1, DDP in-place bucket grads"
   SEGLAND_FORCE_DDP=1 SEGLAND_BUCKET_STEP=0 SEGLAND_DDP_PLAIN=1 MASTER_PORT=2952$rep python3 bench.py --no-cpu-baseline --steps $STEPS "$@" 2>/dev/null | line "RCCL world 1, DDP stock copy+scale"
 done
