@@ -203,3 +203,113 @@ def test_bench_self_launch_starts_fresh_child_ranks(monkeypatch, capsys):
     r = subprocess.run([sys.executable, bench.__file__, '--gpus', '2', '--steps', '1', '--warmup', '0'], capture_output=True, text=True, timeout=600,
                        env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
     assert r.returncode == 3 and 'one rank per GPU' in r.stderr and 'usage' not in r.stderr.lower(), (r.returncode, r.stderr[-500:])
+
+
+# ------------------------------------------------------------------------------------------------ bucket step over gloo (CPU): layout, backward cut, collectives
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', init_method='env://')
+    from segland_amd import bucket_step
+    m = _small_oracle()
+    po.train_mode(m)
+    if rank == 1:
+        with torch.no_grad():
+            m.base_emb.add_(0.5)                              # the replica must take rank 0's parameters
+    rep = bucket_step.BucketedReplica(m, cap_mb=0.05, cut=False)
+    assert len(rep.buckets) >= 3 and rep.late_buckets == len(rep.buckets)
+    img = fm.formula_image(4, 64, 64, 'ddp/img'); mask = fm.formula_mask(4, 64, 64, 8, 'ddp/mask', block=16, ignore_rows=0)
+    sl = slice(rank * 2, rank * 2 + 2)
+    for p in m.parameters():
+        p.grad = None
+    d = rep(img[sl], mask[sl])
+    d['total_loss'].backward()
+    rep.adopt_gradients()
+    assert all(p.grad.data_ptr() == rep.views[id(p)].data_ptr() for p in m.parameters() if p.requires_grad)
+    works = rep.all_reduce(async_op=True)
+    for w in works:
+        w.wait()
+    grads = {k: p.grad.clone() / world for k, p in m.named_parameters() if p.grad is not None}
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in grads.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_replica_over_gloo_matches_single_process():
+    """bucket_step.BucketedReplica on two gloo ranks (CPU): parameters broadcast from rank 0, every gradient adopted into the flat buckets, one SUM all-reduce per
+    bucket; sum / world_size equals the gradient of the one-process full batch (BatchNorm in eval, as in the DDP test above)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    m = _small_oracle()
+    po.train_mode(m)
+    img = fm.formula_image(4, 64, 64, 'ddp/img'); mask = fm.formula_mask(4, 64, 64, 8, 'ddp/mask', block=16, ignore_rows=0)
+    d = m(img, mask)
+    d['total_loss'].backward()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            np.testing.assert_allclose(got[k], p.grad.numpy(), rtol=2e-4, atol=1e-6, err_msg=k)
+
+
+def test_bucket_replica_backward_cut_on_cpu():
+    """The two-part backward of bucket_step.BucketedReplica on a toy model with the cut interface of the GPU models (late_parameters / cut_tensors on a detached
+    leaf / clear_cut): gradients of both halves land in their own bucket groups and equal a plain backward."""
+    from segland_amd import bucket_step
+
+    class Toy(torch.nn.Module):
+        bucket_cut_default = True
+
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.early = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16))
+            self.late = torch.nn.Sequential(torch.nn.Tanh(), torch.nn.Linear(16, 4))
+            self._want, self._cut = False, None
+
+        def enable_backward_cut(self, flag):
+            self._want = bool(flag)
+
+        def late_parameters(self):
+            return list(self.late.parameters())
+
+        def cut_tensors(self):
+            return [self._cut] if self._cut is not None else None
+
+        def clear_cut(self):
+            self._cut = None
+
+        def forward(self, x, y):
+            self._cut = None
+            h = self.early(x)
+            if self._want and h.requires_grad:
+                leaf = h.detach().requires_grad_(True)
+                self._cut, h = (h, leaf), leaf
+            return {'total_loss': ((self.late(h) - y) ** 2).mean()}
+
+    x, y = torch.randn(5, 8), torch.randn(5, 4)
+    ref = Toy()
+    ref(x, y)['total_loss'].backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    m = Toy()
+    rep = bucket_step.BucketedReplica(m, cap_mb=0.001)
+    assert rep.cut and m._want and 0 < rep.late_buckets < len(rep.buckets)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    bwd1, bwd2, _ = rep.train_step_parts(opt)
+    bwd1(x, y)
+    assert all(p.grad is not None for p in m.late.parameters()) and all(p.grad is None for p in m.early.parameters())
+    bwd2()
+    assert m._cut is None
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, want[k], rtol=1e-6, atol=1e-7), k
+        assert p.grad.data_ptr() == rep.views[id(p)].data_ptr()
+    late_ids = {id(p) for p in m.late.parameters()}
+    n_late = sum(-(-p.numel() // 64) * 64 for p in m.parameters() if id(p) in late_ids)
+    assert sum(b.numel() for b in rep.buckets[:rep.late_buckets]) == n_late
