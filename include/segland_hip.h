@@ -362,6 +362,11 @@ int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float b
 int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
                        const float* hyper_dev, int repeat, const float* grad_scale, sl_stream_t stream);
 
+/* Many small strided fp32 copies in one launch (the zero-padded staging copies of weights / biases / BatchNorm vectors at the channel pitch, refreshed once per
+ * optimizer step).  table_dev: n entries {float* dst; const float* src; int rows, cols, dst_pitch, pad; int64 start} (40 bytes): src is [rows][cols] contiguous,
+ * row r goes to dst + r * dst_pitch; start = running count of 1024-element chunks of the preceding entries, total_chunks their grand total. */
+int sl_copy2d_multi(const void* table_dev, int n, long long total_chunks, sl_stream_t stream);
+
 /* ---- Swin-POP path ---------------------------------------------------------------------------
  * Token maps are NHWC images [B][H][W][pitch] with C real channels and a ZERO channel pad up to `pitch` (a multiple of 64 so that the
  * nn.Linear layers run on sl_conv2d_* as 1x1 convs; Swin-T/S: C = 96, pitch = 128).  Replaces, on the GPU, these call sites of the

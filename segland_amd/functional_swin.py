@@ -36,9 +36,15 @@ class _Plan:
 
     def __init__(self):
         self.items, self.table, self.total, self.sig = {}, None, 0, None
+        self.vecs, self.ctable, self.ctotal, self.cn = {}, None, 0, 0      # padded BatchNorm gamma / beta copies (_bn_padded) ride in the same copy launch
 
     def register(self, weight, bias, dtype, Kp, Np, k, col_map, L, stage):
         self.items[(id(weight), Kp, Np, dtype)] = (weight, bias, dtype, Kp, Np, k, col_map, L, stage)
+        self.sig = None
+
+    def register_vec(self, dst, src, on_refresh):
+        """dst[:len(src)] <- src (fp32 vectors) with every refresh; on_refresh() tells the owner that its copy is current."""
+        self.vecs[(dst.data_ptr(), src.data_ptr())] = (dst, src, on_refresh)
         self.sig = None
 
     def refresh(self):
@@ -50,7 +56,7 @@ class _Plan:
             return
         if len(stale) * 2 < len(self.items):             # a few trainable weights over a frozen model (ft_pop): individual launches are cheaper
             return
-        sig = tuple((id(it[0]), it[0].data_ptr(), it[3], it[4], it[2]) for it in self.items.values())
+        sig = tuple((id(it[0]), it[0].data_ptr(), it[3], it[4], it[2]) for it in self.items.values()) + tuple(self.vecs.keys())
         if sig != self.sig:
             rec, start = b'', 0
             for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
@@ -58,17 +64,41 @@ class _Plan:
                 assert Np % 64 == 0 and Kp % 32 == 0 and k * k <= 9
                 rec += struct.pack('<QQQiiiiq', src.data_ptr(), L.wf.data_ptr(), L.wb.data_ptr(), Np, Kp, k * k, ops.dt(dtype), start)
                 start += Np * Kp // 2048
-            self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(next(iter(self.items.values()))[0].device)
-            self.total, self.sig = start, sig
+            dev = next(iter(self.items.values()))[0].device
+            self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev)
+            self.total = start
+            # the strided re-fills of the padded staging buffers (weights, biases, BatchNorm vectors) as ONE launch: table of (dst, src, rows, cols, dst pitch)
+            crec, cstart, cn = b'', 0, 0
+
+            def add(dst, src, rows, cols, pitch):
+                nonlocal crec, cstart, cn
+                crec += struct.pack('<QQiiiiq', dst.data_ptr(), src.data_ptr(), rows, cols, pitch, 0, cstart)
+                cstart += (rows * cols + 1023) // 1024
+                cn += 1
+            for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
+                ok = w.dtype == torch.float32 and w.is_contiguous()
+                if stage is not None and cmap is None and ok:
+                    add(stage, w, w.shape[0], w.shape[1] * k * k, Kp * k * k)
+                if L.bias is not None and b is not None and L.bias.data_ptr() != b.data_ptr() and b.dtype == torch.float32 and b.is_contiguous():
+                    add(L.bias, b, 1, b.shape[0], L.bias.shape[0])
+            for (dst, src, _) in self.vecs.values():
+                add(dst, src, 1, src.shape[0], dst.shape[0])
+            self.ctable = torch.frombuffer(bytearray(crec), dtype=torch.uint8).to(dev) if cn else None
+            self.ctotal, self.cn, self.sig = cstart, cn, sig
+        if self.ctable is not None:
+            ops.copy2d_multi(self.ctable, self.cn, self.ctotal)
         for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
-            if stage is not None:                         # zero pad is persistent; only the real block is rewritten
+            ok = w.dtype == torch.float32 and w.is_contiguous()
+            if stage is not None and (cmap is not None or not ok):          # zero pad is persistent; only the real block is rewritten
                 w4 = w.detach().reshape(w.shape[0], w.shape[1], k, k)
                 if cmap is not None:
                     stage[:w.shape[0]].index_copy_(1, cmap, w4)
                 else:
                     stage[:w.shape[0], :w.shape[1]].copy_(w4)
-            if L.bias is not None and b is not None and L.bias.data_ptr() != b.data_ptr():
+            if L.bias is not None and b is not None and L.bias.data_ptr() != b.data_ptr() and not (b.dtype == torch.float32 and b.is_contiguous()):
                 L.bias[:b.shape[0]].copy_(b.detach())
+        for (_, _, on_refresh) in self.vecs.values():
+            on_refresh()
         ops.weight_prep_batched(self.table, len(self.items), self.total)
         for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
             w._sl_lin[(Kp, Np, dtype)] = (_lin_key(w, b, dtype), L)
@@ -366,6 +396,14 @@ def _bn_padded(bn, P):
         with torch.no_grad():
             ent['gw'][:Cn].copy_(bn.weight); ent['gb'][:Cn].copy_(bn.bias)
         ent['key'] = key
+        plan = CURRENT_PLAN[0]
+        if plan is not None and not ent.get('planned') and bn.weight.dtype == torch.float32 and bn.weight.is_contiguous() and bn.bias.is_contiguous():
+            # from the next optimizer step on these two copies ride in the plan's one copy launch (the key is then current right after refresh())
+            def current(ent=ent, bn=bn):
+                ent['key'] = (_wver(bn.weight), _wver(bn.bias), bn.weight.data_ptr())
+            plan.register_vec(ent['gw'], bn.weight.detach(), current)
+            plan.register_vec(ent['gb'], bn.bias.detach(), current)
+            ent['planned'] = True
     return ent['gw'], ent['gb'], ent['rm'], ent['rv']
 
 

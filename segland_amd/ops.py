@@ -864,3 +864,7 @@ def pop_proto_bwd(Sa, Sb, inv, G, dSa, dSb, dorth, need_a=True, need_b=False):
     dEb = torch.empty_like(Sb) if (need_b and Sb is not None) else None
     check(_lib.lib().sl_pop_proto_bwd(_p(Sa), Ka, _p(Sb), Kb, Cn, _p(inv), _p(G), _p(dSa), _p(dSb), _p(dorth), _p(dEa), _p(dEb), _s()), 'pop_proto_bwd')
     return dEa, dEb
+
+
+def copy2d_multi(table, n, total_chunks):
+    check(_lib.lib().sl_copy2d_multi(_p(table), n, int(total_chunks), _s()), 'copy2d_multi')
