@@ -488,17 +488,23 @@ template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                       int lane, int tid, unsigned char* smem);
 
-template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
+// GATE: this instantiation carries the gated-statistics store phase (MODE 3).  The two persistent 512-thread kernels are compiled once with and once without it: they sit
+// at the register limit (the half-tile kernel: 12 -> 19 spilled VGPRs with MODE 3 inlined), and every launch paid for it, gated or not: 25.98 vs 25.78 ms per ResNet-50
+// step, A/B/A/B on one box (SEGLAND_CONV_GATE_SPLIT=0 launches everything on the instantiation that carries MODE 3).
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true>
 __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
   const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2;
   // Returns the number of vector-memory instructions the wave issued (loads + stores; every path below issues the same count in every wave), or -1 when that is
   // not a compile-time fact of the path: the persistent half-tile kernel uses it to wait for loads that are OLDER than these instructions without waiting for them.
-  if (full && !shaped && !p.addend && p.gate) {
-    conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-    return SPLIT ? 49 : -1;                                             // 2 passes x 8 sweeps x (BN input + gate byte + store), + the statistic partial
-  } else if (full && !shaped && !p.addend) {
+  if constexpr (GATE) {
+    if (full && !shaped && !p.addend && p.gate) {
+      conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+      return SPLIT ? 49 : -1;                                           // 2 passes x 8 sweeps x (BN input + gate byte + store), + the statistic partial
+    }
+  }
+  if (full && !shaped && !p.addend) {
     if constexpr (SPLIT) asm volatile("; EPI_BEGIN mode1");
     conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     if constexpr (SPLIT) asm volatile("; EPI_END mode1");
@@ -1055,6 +1061,7 @@ __device__ __forceinline__ int p8_slot_a1(int par) { return (par ? 2 : 7) * P8_S
 __device__ __forceinline__ int p8_slot_b1(int par) { return (par ? 3 : 8) * P8_SLOT; }
 __device__ __forceinline__ int p8_slot_b0(int j) { return (j == 0 ? 9 : j + 3) * P8_SLOT; }
 
+template <bool GATE>
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
@@ -1221,7 +1228,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       setup(bm, bn);
       issue_first();
     }
-    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
+    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
     if (!counted) younger = 0;
     lds_barrier();                              // statistic partials are read from the staging area: the next tile's second K-tile goes to slots inside it
   }
@@ -1241,11 +1248,14 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
   static const bool persist = !(getenv("SEGLAND_P8_PERSIST") && getenv("SEGLAND_P8_PERSIST")[0] == '0');
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     attr_set = true;
   }
   const int ntiles = p.gridM * p.gridN;
-  hipLaunchKernelGGL(conv_gemm_p8_kernel, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  static const bool one_kernel = getenv("SEGLAND_CONV_GATE_SPLIT") && getenv("SEGLAND_CONV_GATE_SPLIT")[0] == '0';      // A/B: every launch on the instantiation that carries MODE 3
+  if (p.gate || one_kernel) hipLaunchKernelGGL(conv_gemm_p8_kernel<true>, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  else        hipLaunchKernelGGL(conv_gemm_p8_kernel<false>, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;
 }
@@ -1260,6 +1270,7 @@ constexpr int P9_PATCH = 576 * 128;                                     // large
 constexpr int P9_LDS = P9_PATCH + 4 * P8_SLOT;                          // + B0 / B1 of two K-tiles = 136 KiB
 constexpr int P9_PATCH1 = 42 * 1024;                                    // d = 1: 324 rows -> two patch buffers (the next chunk's patch lands under the current chunk's taps)
 constexpr int P9_LDS1 = 2 * P9_PATCH1 + 4 * P8_SLOT;                    // 148 KiB
+template <bool GATE>
 __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
@@ -1419,7 +1430,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     } else ++tap;
   }
   lds_barrier();
-  conv_epilogue_lds<T, BM, BN, 2, 4, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
 // Four-wave form of the patch kernel (experimental, SEGLAND_CONV_P9W4=1): one wave per SIMD, 128 x 128 of the tile per wave (16 accumulator blocks = 256 registers), so an A
@@ -1585,8 +1596,14 @@ int launch_p9(ConvGemmParams& p, hipStream_t st) {
   static const bool nogroup = getenv("SEGLAND_P9_NGROUP") && getenv("SEGLAND_P9_NGROUP")[0] == '0';
   if (nogroup) p.flags |= 16;
   static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS)); attr_set = true; }
-  hipLaunchKernelGGL(conv_gemm_p9_kernel, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
+    attr_set = true;
+  }
+  static const bool one_kernel = getenv("SEGLAND_CONV_GATE_SPLIT") && getenv("SEGLAND_CONV_GATE_SPLIT")[0] == '0';
+  if (p.gate || one_kernel) hipLaunchKernelGGL(conv_gemm_p9_kernel<true>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+  else        hipLaunchKernelGGL(conv_gemm_p9_kernel<false>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p9_kernel");
   return 0;
 }
