@@ -854,7 +854,7 @@ struct RingGeom {
   static constexpr int LDS_BYTES = RING_BYTES > EPI ? RING_BYTES : EPI;
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
+template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST, bool GATE = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmParams p) {
   constexpr int EPC = 16 / sizeof(T);
   constexpr int CPRW = RBYTES / 16;             // 16-byte chunks per stage row
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
     slot = nslot;
   }
   __syncthreads();
-  conv_epilogue_lds<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+  conv_epilogue_lds<T, BM, BN, WM, WN, false, GATE>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
@@ -1023,10 +1023,13 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
   const size_t lds = RG::LDS_BYTES;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  // like the half-tile and patch kernels: the gated-statistics store phase lives in an instantiation of its own
+  if (p.gate) hipLaunchKernelGGL((conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST, true>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  else        hipLaunchKernelGGL((conv_gemm_ring_kernel<T, BM, BN, WM, WN, RBYTES, NST, false>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
   SL_LAUNCH_CHECK("conv_gemm_ring_kernel");
   return 0;
 }
