@@ -262,6 +262,8 @@ class GraphedBucketStep:
                 self._invalidate()
                 return out
             except Exception as e:
+                # a part that was captured AND replayed before the failure has run once (forward + first half of the backward: this batch then updates the BatchNorm
+                # running statistics twice, the optimizer has not stepped); the step is redone kernel by kernel from zero_grad on
                 self.graphs, self.key = None, None
                 self.failures += 1
                 graph_step.STATS['failures'] += 1
