@@ -835,7 +835,12 @@ template <typename T, bool TR>
 int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
   dim3 grid(pl.gridN * pl.gridC * pl.taps * pl.splits);
   if (pl.glds) {
-    if (pl.bnn == 256 && pl.bcc == 256) return launch_wgrad_glds<T, 256, 256, 2, 4, TR>(grid, p, st);
+    if (pl.bnn == 256 && pl.bcc == 256) {
+      // SEGLAND_WGRAD_W4=1: four waves of 128 x 128 (0.5 KiB of fragment reads per MFMA instead of 0.75; one wave per SIMD)
+      static const bool w4 = getenv("SEGLAND_WGRAD_W4") && getenv("SEGLAND_WGRAD_W4")[0] == '1';
+      if (w4 && sizeof(T) == 2) return launch_wgrad_glds<T, 256, 256, 2, 2, TR>(grid, p, st);
+      return launch_wgrad_glds<T, 256, 256, 2, 4, TR>(grid, p, st);
+    }
     if (pl.bnn == 256) return launch_wgrad_glds<T, 256, 128, 4, 2, TR>(grid, p, st);
     if (pl.bcc == 256) return launch_wgrad_glds<T, 128, 256, 2, 4, TR>(grid, p, st);
     return launch_wgrad_glds<T, 128, 128, 2, 2, TR>(grid, p, st);

@@ -563,25 +563,42 @@ __global__ __launch_bounds__(256) void ppm_rows_gemm_kernel(RowsGemm p) {
 // y = sum of the K slabs (fixed order) and/or the per-(level, 128-row group) column sums  part[g][0][n] = sum y, part[g][1][n] = sum y^2.
 __global__ __launch_bounds__(256) void ppm_rows_finish_kernel(const float* slabs, int ks, long long slab_stride, float* y, int N, RowsGemm g,
                                                               float* part) {
-  __shared__ float red[2][4][64];
+  // 16 lanes x float4 cover the block's 64 columns, 16 row phases cover its <= 128 rows: 8 rows x ks 16-byte loads per thread
+  __shared__ float4 red[2][16][16];
   int l = 0;                                            // tile_off here = prefix of 128-row groups per level
   while (l + 1 < g.nl && (int)blockIdx.y >= g.tile_off[l + 1]) ++l;
   const int m0 = g.row_off[l] + ((int)blockIdx.y - g.tile_off[l]) * 128, mend = min(g.row_off[l + 1], m0 + 128);
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
-  float s = 0.f, s2 = 0.f;
-  for (int m = m0 + rq; m < mend; m += 4) {
-    float v = slabs[(size_t)m * N + n];
-    for (int k = 1; k < ks; ++k) v += slabs[(size_t)k * slab_stride + (size_t)m * N + n];
-    if (ks > 1 || y != slabs) y[(size_t)m * N + n] = v;
-    s += v; s2 += v * v;
+  const int cq = threadIdx.x & 15, rq = threadIdx.x >> 4, n = blockIdx.x * 64 + cq * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s;
+  for (int m = m0 + rq; m < mend; m += 16) {
+    const float* src = slabs + (size_t)m * N + n;
+    float4 v = *reinterpret_cast<const float4*>(src);
+    int k = 1;
+    for (; k + 4 <= ks; k += 4) {                       // four slabs in flight, summed in slab order
+      const float4 a = *reinterpret_cast<const float4*>(src + (size_t)k * slab_stride);
+      const float4 b = *reinterpret_cast<const float4*>(src + (size_t)(k + 1) * slab_stride);
+      const float4 c = *reinterpret_cast<const float4*>(src + (size_t)(k + 2) * slab_stride);
+      const float4 d = *reinterpret_cast<const float4*>(src + (size_t)(k + 3) * slab_stride);
+      v.x = (((v.x + a.x) + b.x) + c.x) + d.x; v.y = (((v.y + a.y) + b.y) + c.y) + d.y;
+      v.z = (((v.z + a.z) + b.z) + c.z) + d.z; v.w = (((v.w + a.w) + b.w) + c.w) + d.w;
+    }
+    for (; k < ks; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(src + (size_t)k * slab_stride);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    if (ks > 1 || y != slabs) *reinterpret_cast<float4*>(y + (size_t)m * N + n) = v;
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
   }
   if (!part) return;
-  red[0][rq][threadIdx.x & 63] = s; red[1][rq][threadIdx.x & 63] = s2;
+  red[0][rq][cq] = s; red[1][rq][cq] = s2;
   __syncthreads();
-  if (rq == 0) {
-    const int c = threadIdx.x;
-    part[((size_t)blockIdx.y * 2 + 0) * N + n] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
-    part[((size_t)blockIdx.y * 2 + 1) * N + n] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4;
+    float4 t = red[which][0][cq];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) { const float4 u = red[which][r][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+    *reinterpret_cast<float4*>(part + ((size_t)blockIdx.y * 2 + which) * N + n) = t;
   }
 }
 

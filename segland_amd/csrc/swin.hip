@@ -1048,6 +1048,276 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
   for (int e = tid; e < WN * WN; e += 256) dr[e] = tile[(e / WN) * 64 + e % WN];
 }
 
+// ---- MFMA backward, second form (default): same arithmetic and operand values as window_attention_bwd_mfma_kernel (bit-identical results), different data path.
+// * the 16 natural fragments of a window (q, k, v, dO x two 32-token blocks x two 16-d steps: a lane's 16 bytes of its token row) go from global memory straight to
+//   registers, all loads in flight together, and serve both layouts; nothing natural is staged in the LDS;
+// * k, q, dO are also written to the LDS as [token][32 d] tiles of 64-byte rows with 16-byte stores from those registers, and the three transposed operands
+//   (K^T, Q^T, dO^T: rows = d, k index = tokens) are ds_read_b64_tr_b16 reads of them -- no 2-byte scatter; the tokens of a 16-block sit in the order
+//   {0-3, 8-11, 4-7, 12-15} so that the hardware's k order (rows 8*half + e) is the D-layout order of the probability registers they multiply;
+// * 72 KiB of LDS per block instead of 156: two blocks per CU, i.e. a second wave on every SIMD under the first one's load / exp / LDS latencies.
+typedef __attribute__((ext_vector_type(4))) short win_s16x4_t;
+__device__ __forceinline__ uint2 win_lds_tr(const unsigned char* p) {
+  const win_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) win_s16x4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ uint4 win_trfrag(const unsigned char* tile, int lane, int blk, int s2) {     // rows = d (lane & 31), k = tokens 32*blk + 16*s2 .. +15 in D-layout order
+  const int g4 = lane >> 4, l = lane & 15;
+  const unsigned char* a = tile + (32 * blk + 16 * s2 + 8 * (g4 >> 1) + (l >> 2)) * 64 + (16 * (g4 & 1) + 4 * (l & 3)) * 2;
+  const uint2 lo = win_lds_tr(a), hi = win_lds_tr(a + 4 * 64);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+constexpr int WB2_TILE = 64 * 64;             // bytes of one [64 tokens][32 d] bf16 tile
+
+__global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+                                                                            const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
+                                                                            float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
+  float* biast = biasl + WN * BLP + 16;                     // [49][52] (+16): bias[key][query]
+  unsigned char* tbase = (unsigned char*)(biast + WN * BLP + 16);      // per wave: K, Q, dO tiles
+  float* mzbase = (float*)(tbase + 4 * 3 * WB2_TILE);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
+  for (int e = tid; e < WN * WN; e += 256) {
+    const float v = rel_bias[(size_t)head * WN * WN + e];
+    biasl[(e / WN) * BLP + e % WN] = v;
+    biast[(e % WN) * BLP + e / WN] = v;
+  }
+  __syncthreads();
+  unsigned char* tk = tbase + wave * 3 * WB2_TILE;
+  unsigned char* tq = tk + WB2_TILE;
+  unsigned char* tg = tq + WB2_TILE;
+  float* mz = mzbase + wave * 256;
+  const float scale = rsqrtf((float)HD);
+  f32x16_t dsum[2][2];
+#pragma unroll
+  for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dsum[ib][jb][r] = 0.f;
+
+  for (int t = 0; t < wpw; ++t) {
+    const int wi = (chunk * wpw + t) * 4 + wave;
+    if (wi >= nwin) break;
+    const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
+    int pixr[2];                                            // pixel of token 32*rb + l31; -1 pad token, -2 no such token
+    uint4 fq[2][2], fk[2][2], fv[2][2], fg[2][2];           // [token block][d step]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int n = 32 * rb + l31;
+      int pix = -2, reg;
+      if (n < WN) win_token(g, wy, wx, n, pix, reg);
+      pixr[rb] = pix;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int d0 = 16 * s2 + 8 * hf, col = head * HD + d0;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        fq[rb][s2] = z; fk[rb][s2] = z; fv[rb][s2] = z; fg[rb][s2] = z;
+        if (pix >= 0) {
+          const bf16_t* src = qkv + ((size_t)b * g.H * g.W + pix) * g.P3 + col;
+          fq[rb][s2] = *(const uint4*)src;
+          fk[rb][s2] = *(const uint4*)(src + g.C);
+          fv[rb][s2] = *(const uint4*)(src + 2 * g.C);
+          fg[rb][s2] = *(const uint4*)(dout + ((size_t)b * g.H * g.W + pix) * g.Cp + col);
+        } else if (pix == -1) {                             // pad token: q / k / v are the qkv bias as the GEMM would have stored it, dO is zero
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[col + e];
+          fq[rb][s2] = pack16<bf16_t>(f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[g.C + col + e];
+          fk[rb][s2] = pack16<bf16_t>(f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[2 * g.C + col + e];
+          fv[rb][s2] = pack16<bf16_t>(f);
+        }
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int n = 32 * rb + l31, row = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int o = row * 64 + (2 * s2 + hf) * 16;
+        *(uint4*)(tk + o) = fk[rb][s2];
+        *(uint4*)(tq + o) = fq[rb][s2];
+        *(uint4*)(tg + o) = fg[rb][s2];
+      }
+    }
+    unsigned pk[8];
+    win_pack_regions(g, wy, wx, lane, pk);
+    __builtin_amdgcn_wave_barrier();
+    // ---------------- T-layout, one 32-query block at a time
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x16_t st[2], dp[2];
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[ib][r] = 0.f; dp[ib][r] = 0.f; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int ib = 0; ib < 2; ++ib) {
+          st[ib] = mfma16(fk[ib][s2], fq[jb][s2], st[ib]);
+          dp[ib] = mfma16(fv[ib][s2], fg[jb][s2], dp[ib]);
+        }
+      const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
+      const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int i0 = 32 * ib + 8 * m + 4 * hf;
+          const float4 bv = *(const float4*)(biasl + jc * BLP + i0);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float sc = st[ib][4 * m + e] * scale + bb[e];
+            if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+            sc = (i0 + e) < WN ? sc : -INFINITY;
+            st[ib][4 * m + e] = sc;
+            mx = fmaxf(mx, sc);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float z = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = __expf(st[ib][r] - mx); st[ib][r] = e; z += e; }
+      z += __shfl_xor(z, 32, 64);
+      const float inv = 1.f / z;
+      float rs = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[ib][r] *= inv; rs = fmaf(st[ib][r], dp[ib][r], rs); }
+      rs += __shfl_xor(rs, 32, 64);
+      if (hf == 0) { mz[4 * j + 0] = mx; mz[4 * j + 1] = inv; mz[4 * j + 2] = rs; }
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dp[ib][r] = st[ib][r] * (dp[ib][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][r] : 0.f; }
+      // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
+      f32x16_t oq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oq[r] = 0.f;
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) oq = mfma16(win_trfrag(tk, lane, ib, s2), regs_frag(dp[ib], s2), oq);
+      if (pixr[jb] >= 0) {
+        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pixr[jb]) * g.P3;
+        store_dT(dst + head * HD, oq, hf, scale);
+        if (head == 0 && g.P3 > 3 * g.C && hf == 0)
+          for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- N-layout (lane = key), one 32-key block at a time
+    float padk[16], padv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
+    bool anypad = false;
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      f32x16_t st[2], dp[2];                              // index = query block (registers); lanes = keys 32*ib + l31
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[jb][r] = 0.f; dp[jb][r] = 0.f; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+          st[jb] = mfma16(fq[jb][s2], fk[ib][s2], st[jb]);
+          dp[jb] = mfma16(fg[jb][s2], fv[ib][s2], dp[jb]);
+        }
+      const int i = 32 * ib + l31, ic = i < WN ? i : WN - 1;
+      const unsigned regk = (pk[ic >> 3] >> (4 * (ic & 7))) & 15u;
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int j0 = 32 * jb + 8 * m + 4 * hf;
+          const float4 bv = *(const float4*)(biast + ic * BLP + j0);
+          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = j0 + e;
+            float sc = st[jb][4 * m + e] * scale + bb[e];
+            if (g.shift > 0) { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; if (rq != regk) sc += -100.f; }
+            const float4 mzv = *(const float4*)(mz + 4 * j);
+            const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
+            st[jb][4 * m + e] = pr;                                            // P[query][key]
+            dp[jb][4 * m + e] = pr * (dp[jb][4 * m + e] - mzv.z);              // dS[query][key]
+          }
+        }
+      // dK^T[d][key] = sum_query Q^T[d][query] dS[query][key];  dV^T[d][key] = sum_query dO^T[d][query] P[query][key]
+      f32x16_t ok, ov;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ok[r] = 0.f; ov[r] = 0.f; }
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          ok = mfma16(win_trfrag(tq, lane, jb, s2), regs_frag(dp[jb], s2), ok);
+          ov = mfma16(win_trfrag(tg, lane, jb, s2), regs_frag(st[jb], s2), ov);
+        }
+      if (pixr[ib] >= 0) {
+        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pixr[ib]) * g.P3 + head * HD;
+        store_dT(dst + 1 * g.C, ok, hf, scale);
+        store_dT(dst + 2 * g.C, ov, hf, 1.f);
+      } else if (pixr[ib] == -1) {
+        anypad = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { padk[r] += ok[r] * scale; padv[r] += ov[r]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
+    if (__any(anypad)) {
+      // fixed-order sum over the window's pad keys through LDS (this wave's tiles are consumed): [half][key lane][16 d-registers]
+      float* sk = (float*)tk;
+      float* sv = sk + 64 * 17;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sk[(hf * 32 + l31) * 17 + r] = padk[r]; sv[(hf * 32 + l31) * 17 + r] = padv[r]; }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < HD) {
+        const int d = lane, h2 = (d >> 2) & 1, r = 4 * (d >> 3) + (d & 3);       // d = 8*(r>>2) + 4*half + (r&3)
+        float tkk = 0.f, tvv = 0.f;
+        for (int l = 0; l < 32; ++l) { tkk += sk[(h2 * 32 + l) * 17 + r]; tvv += sv[(h2 * 32 + l) * 17 + r]; }
+        padp[d] = 0.f; padp[HD + d] = tkk; padp[2 * HD + d] = tvv;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int e = lane; e < 96; e += 64) padp[e] = 0.f;
+    }
+  }
+  // gradient of the position bias: the 4 waves' sums through LDS (the tile area is free now), then one partial row per block
+  __syncthreads();
+  float* tile = (float*)tbase;                                 // [64 queries][64 keys] floats = 16 KiB <= 48 KiB of tiles
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = 32 * jb + l31, i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (w == 0) tile[j * 64 + i] = dsum[ib][jb][r]; else tile[j * 64 + i] += dsum[ib][jb][r];
+          }
+    }
+    __syncthreads();
+  }
+  float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
+  for (int e = tid; e < WN * WN; e += 256) dr[e] = tile[(e / WN) * 64 + e % WN];
+}
+
 // backward of one (window, head); block (head, chunk) walks `wpb` windows and keeps the sum of dS (= gradient of the relative position bias)
 // in registers.  dqkv of real tokens is written in place; k / v gradients of PAD tokens belong to the qkv bias: pad_part[window][head][3*32].
 template <typename T>
@@ -1377,6 +1647,10 @@ extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
 static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && !(g_attn_valu_override >= 0 ? g_attn_valu_override : attn_valu()); }
 // MFMA backward: default for bf16 (1.57 ms per Swin-T step against 2.06 ms for the VALU kernel); SEGLAND_ATTN_BWD_MFMA=0 selects the VALU one.
 static int attn_bwd_mfma_env() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_MFMA"); v = (e && e[0] == '0') ? 0 : 1; } return v; }
+// SEGLAND_ATTN_BWD_FORM=1: the first MFMA backward (operands staged in the LDS by 2-byte scatter, one block per CU); 2 (default): registers + transpose reads, two blocks per CU
+int g_attn_bwd_form = -1;
+static int attn_bwd_form() { if (g_attn_bwd_form < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_FORM"); g_attn_bwd_form = (e && e[0] == '1') ? 1 : 2; } return g_attn_bwd_form; }
+extern "C" void sl_debug_attn_bwd_form(int v) { g_attn_bwd_form = v; }
 static bool use_attn_bwd_mfma(int dtype) {
   if (dtype != SL_BF16) return false;
   if (g_attn_valu_override >= 0) return g_attn_valu_override == 0;       // test hook: 0 = MFMA everywhere, 1 = VALU everywhere
@@ -1455,6 +1729,15 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
     const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 4 * 64 * NTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    if (attn_bwd_form() == 2) {
+      const size_t lds2 = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float);
+      static bool attr2 = false;
+      if (!attr2) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
+      hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
+                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
+      SL_LAUNCH_CHECK("window_attention_bwd_mfma2_kernel");
+      return 0;
+    }
     hipLaunchKernelGGL(window_attention_bwd_mfma_kernel, dim3(chunks * g.heads), dim3(256), lds, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
                        (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
     SL_LAUNCH_CHECK("window_attention_bwd_mfma_kernel");
