@@ -603,6 +603,7 @@ __device__ __forceinline__ f32x16_t mfma16(const uint4& first_rows_to_regs, cons
 __device__ __forceinline__ void win_pack_regions(const WinGeom& g, int wy, int wx, int lane, unsigned (&pk)[8]) {
   int pix, reg = 0;
   if (lane < WN) win_token(g, wy, wx, lane, pix, reg);
+  if (g.shift == 0) reg = 0;                  // no shift: no mask; one region, so the comparisons below need no branch on the shift
   unsigned v = (unsigned)reg << (4 * (lane & 7));
   v |= __shfl_xor(v, 1, 64); v |= __shfl_xor(v, 2, 64); v |= __shfl_xor(v, 4, 64);
 #pragma unroll
@@ -629,7 +630,7 @@ __device__ __forceinline__ void win_softmax_regs(const WinGeom& g, f32x16_t (&ac
         for (int e = 0; e < 4; ++e) {
           const int i = i0 + e;
           float sc = acc[ib][jb][4 * m + e] * scale + bb[e];
-          if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+          { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; sc += rk != regq ? -100.f : 0.f; }
           sc = i < WN ? sc : -INFINITY;
           acc[ib][jb][4 * m + e] = sc;
           mx = fmaxf(mx, sc);
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float sc = st[ib][4 * m + e] * scale + bb[e];
-            if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+            { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; sc += rk != regq ? -100.f : 0.f; }
             sc = (i0 + e) < WN ? sc : -INFINITY;
             st[ib][4 * m + e] = sc;
             mx = fmaxf(mx, sc);
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
           for (int e = 0; e < 4; ++e) {
             const int j = j0 + e;
             float sc = st[jb][4 * m + e] * scale + bb[e];
-            if (g.shift > 0) { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; if (rq != regk) sc += -100.f; }
+            { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; sc += rq != regk ? -100.f : 0.f; }
             const float4 mzv = *(const float4*)(mz + 4 * j);
             const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
             st[jb][4 * m + e] = pr;                                            // P[query][key]
@@ -1060,91 +1061,111 @@ __device__ __forceinline__ uint2 win_lds_tr(const unsigned char* p) {
   const win_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) win_s16x4_t*)(p));
   return __builtin_bit_cast(uint2, v);
 }
+// byte offset of 16-byte chunk c (8 d) of token n in a [64][32 d] tile: tokens of a 16-block in the order {0-3, 8-11, 4-7, 12-15} (see above), chunks XOR-swizzled by the
+// 4-row group so that 16-byte accesses down a column of lanes and the transpose reads are both conflict-free
+__device__ __forceinline__ int win_nat_off(int n, int c) {
+  const int row = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+  return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+}
 __device__ __forceinline__ uint4 win_trfrag(const unsigned char* tile, int lane, int blk, int s2) {     // rows = d (lane & 31), k = tokens 32*blk + 16*s2 .. +15 in D-layout order
   const int g4 = lane >> 4, l = lane & 15;
-  const unsigned char* a = tile + (32 * blk + 16 * s2 + 8 * (g4 >> 1) + (l >> 2)) * 64 + (16 * (g4 & 1) + 4 * (l & 3)) * 2;
-  const uint2 lo = win_lds_tr(a), hi = win_lds_tr(a + 4 * 64);
+  const int row = 32 * blk + 16 * s2 + 8 * (g4 >> 1) + (l >> 2), c = 2 * (g4 & 1) + ((l & 3) >> 1);     // LDS row (already in stored order), logical chunk
+  const unsigned char* a = tile + row * 64 + ((c ^ ((row >> 2) & 3)) << 4) + (l & 1) * 8;
+  const uint2 lo = win_lds_tr(a), hi = win_lds_tr(tile + (row + 4) * 64 + ((c ^ (((row + 4) >> 2) & 3)) << 4) + (l & 1) * 8);
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 constexpr int WB2_TILE = 64 * 64;             // bytes of one [64 tokens][32 d] bf16 tile
+constexpr int WB2_AP = 68;                    // float pitch of the dS accumulation tile: 272-byte rows -> conflict-free 16-byte accesses down a column of lanes
 
-__global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
+__global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                             const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                             float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
-  float* biast = biasl + WN * BLP + 16;                     // [49][52] (+16): bias[key][query]
-  unsigned char* tbase = (unsigned char*)(biast + WN * BLP + 16);      // per wave: K, Q, dO tiles
+  unsigned char* tbase = (unsigned char*)(biasl + WN * BLP + 16);      // per wave: K, Q, dO tiles
   float* mzbase = (float*)(tbase + 4 * 3 * WB2_TILE);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
+  float* dacc = mzbase + 4 * 256;                           // [49 queries][WB2_AP]: sum of dS over the block's windows (gradient of the position bias)
+  const int tid = threadIdx.x, wave = tid >> 6;
   const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
-  for (int e = tid; e < WN * WN; e += 256) {
-    const float v = rel_bias[(size_t)head * WN * WN + e];
-    biasl[(e / WN) * BLP + e % WN] = v;
-    biast[(e % WN) * BLP + e / WN] = v;
+  {
+    float bv[10];                                           // 2401 = 9.4 x 256: all loads in flight before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { const int e = tid + 256 * u; bv[u] = e < WN * WN ? rel_bias[(size_t)head * WN * WN + e] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { const int e = tid + 256 * u; if (e < WN * WN) biasl[(e / WN) * BLP + e % WN] = bv[u]; }
   }
+  for (int e = tid; e < WN * WB2_AP; e += 256) dacc[e] = 0.f;
   __syncthreads();
   unsigned char* tk = tbase + wave * 3 * WB2_TILE;
   unsigned char* tq = tk + WB2_TILE;
   unsigned char* tg = tq + WB2_TILE;
   float* mz = mzbase + wave * 256;
   const float scale = rsqrtf((float)HD);
-  f32x16_t dsum[2][2];
-#pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dsum[ib][jb][r] = 0.f;
 
   for (int t = 0; t < wpw; ++t) {
     const int wi = (chunk * wpw + t) * 4 + wave;
-    if (wi >= nwin) break;
-    const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
+    if ((chunk * wpw + t) * 4 >= nwin) break;               // block-uniform
+    // a wave past the last window runs on all-zero operands (dS = 0 exactly, nothing stored): the block barriers below stay uniform
+    const bool active = wi < nwin;
+    int lane = tid & 63;
+    asm volatile("" : "+v"(lane));                          // per-window addresses are computed per window: hoisted out of this (usually one-trip) loop they only spill
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int wic = active ? wi : nwin - 1;
+    const int wx = wic % g.nWx, wy = (wic / g.nWx) % g.nWy, b = wic / (g.nWx * g.nWy);
     int pixr[2];                                            // pixel of token 32*rb + l31; -1 pad token, -2 no such token
     uint4 fq[2][2], fk[2][2], fv[2][2], fg[2][2];           // [token block][d step]
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
       const int n = 32 * rb + l31;
       int pix = -2, reg;
-      if (n < WN) win_token(g, wy, wx, n, pix, reg);
+      if (n < WN && active) win_token(g, wy, wx, n, pix, reg);
       pixr[rb] = pix;
+      const size_t tok = (size_t)b * g.H * g.W + (pix >= 0 ? pix : 0);       // pad / absent tokens read pixel 0 and drop it: no branch around the loads
+      const bf16_t* src = qkv + tok * g.P3 + head * HD + 8 * hf;
+      const bf16_t* gsrc = dout + tok * g.Cp + head * HD + 8 * hf;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int d0 = 16 * s2 + 8 * hf, col = head * HD + d0;
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        fq[rb][s2] = z; fk[rb][s2] = z; fv[rb][s2] = z; fg[rb][s2] = z;
-        if (pix >= 0) {
-          const bf16_t* src = qkv + ((size_t)b * g.H * g.W + pix) * g.P3 + col;
-          fq[rb][s2] = *(const uint4*)src;
-          fk[rb][s2] = *(const uint4*)(src + g.C);
-          fv[rb][s2] = *(const uint4*)(src + 2 * g.C);
-          fg[rb][s2] = *(const uint4*)(dout + ((size_t)b * g.H * g.W + pix) * g.Cp + col);
-        } else if (pix == -1) {                             // pad token: q / k / v are the qkv bias as the GEMM would have stored it, dO is zero
-          float f[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[col + e];
-          fq[rb][s2] = pack16<bf16_t>(f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[g.C + col + e];
-          fk[rb][s2] = pack16<bf16_t>(f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[2 * g.C + col + e];
-          fv[rb][s2] = pack16<bf16_t>(f);
-        }
+        fq[rb][s2] = *(const uint4*)(src + 16 * s2);
+        fk[rb][s2] = *(const uint4*)(src + g.C + 16 * s2);
+        fv[rb][s2] = *(const uint4*)(src + 2 * g.C + 16 * s2);
+        fg[rb][s2] = *(const uint4*)(gsrc + 16 * s2);
       }
     }
 #pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        if (pixr[rb] < 0) { const uint4 z = make_uint4(0, 0, 0, 0); fq[rb][s2] = z; fk[rb][s2] = z; fv[rb][s2] = z; fg[rb][s2] = z; }
+    if (__any(pixr[0] == -1 || pixr[1] == -1)) {            // edge windows: pad tokens carry the qkv bias as the GEMM would have stored it (their dO is zero)
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int col = head * HD + 16 * s2 + 8 * hf;
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[col + e];
+          const uint4 bq = pack16<bf16_t>(f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[g.C + col + e];
+          const uint4 bk = pack16<bf16_t>(f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = qkv_bias[2 * g.C + col + e];
+          const uint4 bvv = pack16<bf16_t>(f);
+          if (pixr[rb] == -1) { fq[rb][s2] = bq; fk[rb][s2] = bk; fv[rb][s2] = bvv; }
+        }
+    }
+#pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      const int n = 32 * rb + l31, row = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const int o = row * 64 + (2 * s2 + hf) * 16;
+        const int o = win_nat_off(32 * rb + l31, 2 * s2 + hf);
         *(uint4*)(tk + o) = fk[rb][s2];
         *(uint4*)(tq + o) = fq[rb][s2];
         *(uint4*)(tg + o) = fg[rb][s2];
       }
     }
+    __builtin_amdgcn_sched_barrier(0);                      // q / dO live in the tiles from here on: only k (T-layout) and v stay in registers
     unsigned pk[8];
     win_pack_regions(g, wy, wx, lane, pk);
     __builtin_amdgcn_wave_barrier();
@@ -1157,12 +1178,14 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[ib][r] = 0.f; dp[ib][r] = 0.f; }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 qv = *(const uint4*)(tq + win_nat_off(32 * jb + l31, 2 * s2 + hf)), gv = *(const uint4*)(tg + win_nat_off(32 * jb + l31, 2 * s2 + hf));
 #pragma unroll
         for (int ib = 0; ib < 2; ++ib) {
-          st[ib] = mfma16(fk[ib][s2], fq[jb][s2], st[ib]);
-          dp[ib] = mfma16(fv[ib][s2], fg[jb][s2], dp[ib]);
+          st[ib] = mfma16(fk[ib][s2], qv, st[ib]);
+          dp[ib] = mfma16(fv[ib][s2], gv, dp[ib]);
         }
+      }
       const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
       const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
       float mx = -INFINITY;
@@ -1176,7 +1199,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float sc = st[ib][4 * m + e] * scale + bb[e];
-            if (g.shift > 0) { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; if (rk != regq) sc += -100.f; }
+            { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; sc += rk != regq ? -100.f : 0.f; }
             sc = (i0 + e) < WN ? sc : -INFINITY;
             st[ib][4 * m + e] = sc;
             mx = fmaxf(mx, sc);
@@ -1200,7 +1223,22 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
 #pragma unroll
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dp[ib][r] = st[ib][r] * (dp[ib][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][r] : 0.f; }
+        for (int r = 0; r < 16; ++r) dp[ib][r] = st[ib][r] * (dp[ib][r] - rs);
+      // sum of dS over the block's windows: the four waves add their registers to the shared tile one after the other (fixed order -> bit-stable)
+      for (int w = 0; w < 4; ++w) {
+        if (wave == w && j < WN) {
+#pragma unroll
+          for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              float4* a = (float4*)(dacc + j * WB2_AP + 32 * ib + 8 * m + 4 * hf);
+              float4 v = *a;
+              v.x += dp[ib][4 * m + 0]; v.y += dp[ib][4 * m + 1]; v.z += dp[ib][4 * m + 2]; v.w += dp[ib][4 * m + 3];
+              *a = v;
+            }
+        }
+        __syncthreads();
+      }
       // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
       f32x16_t oq;
 #pragma unroll
@@ -1218,10 +1256,7 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---------------- N-layout (lane = key), one 32-key block at a time
-    float padk[16], padv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
-    bool anypad = false;
+    float padk = 0.f, padv = 0.f;                          // lane (half, l31 < 16): sum over the window's pad keys of d-register l31 of that half
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib) {
       f32x16_t st[2], dp[2];                              // index = query block (registers); lanes = keys 32*ib + l31
@@ -1230,12 +1265,15 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
 #pragma unroll
         for (int r = 0; r < 16; ++r) { st[jb][r] = 0.f; dp[jb][r] = 0.f; }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 kv = *(const uint4*)(tk + win_nat_off(32 * ib + l31, 2 * s2 + hf));
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {
-          st[jb] = mfma16(fq[jb][s2], fk[ib][s2], st[jb]);
-          dp[jb] = mfma16(fg[jb][s2], fv[ib][s2], dp[jb]);
+          const int o = win_nat_off(32 * jb + l31, 2 * s2 + hf);
+          st[jb] = mfma16(*(const uint4*)(tq + o), kv, st[jb]);
+          dp[jb] = mfma16(*(const uint4*)(tg + o), fv[ib][s2], dp[jb]);
         }
+      }
       const int i = 32 * ib + l31, ic = i < WN ? i : WN - 1;
       const unsigned regk = (pk[ic >> 3] >> (4 * (ic & 7))) & 15u;
 #pragma unroll
@@ -1243,13 +1281,11 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int j0 = 32 * jb + 8 * m + 4 * hf;
-          const float4 bv = *(const float4*)(biast + ic * BLP + j0);
-          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = j0 + e;
-            float sc = st[jb][4 * m + e] * scale + bb[e];
-            if (g.shift > 0) { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; if (rq != regk) sc += -100.f; }
+            float sc = st[jb][4 * m + e] * scale + biasl[(j < WN ? j : WN - 1) * BLP + ic];
+            { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; sc += rq != regk ? -100.f : 0.f; }
             const float4 mzv = *(const float4*)(mz + 4 * j);
             const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
             st[jb][4 * m + e] = pr;                                            // P[query][key]
@@ -1271,51 +1307,29 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma2_kernel(WinGeom
         bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pixr[ib]) * g.P3 + head * HD;
         store_dT(dst + 1 * g.C, ok, hf, scale);
         store_dT(dst + 2 * g.C, ov, hf, 1.f);
-      } else if (pixr[ib] == -1) {
-        anypad = true;
+      }
+      if (__any(pixr[ib] == -1)) {                          // edge windows only: butterfly sums over the 32 key lanes of each half (fixed order)
+        const bool pad = pixr[ib] == -1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { padk[r] += ok[r] * scale; padv[r] += ov[r]; }
+        for (int r = 0; r < 16; ++r) {
+          float a = pad ? ok[r] * scale : 0.f, c = pad ? ov[r] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); c += __shfl_xor(c, o, 64); }
+          if (l31 == r) { padk += a; padv += c; }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
-    if (__any(anypad)) {
-      // fixed-order sum over the window's pad keys through LDS (this wave's tiles are consumed): [half][key lane][16 d-registers]
-      float* sk = (float*)tk;
-      float* sv = sk + 64 * 17;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sk[(hf * 32 + l31) * 17 + r] = padk[r]; sv[(hf * 32 + l31) * 17 + r] = padv[r]; }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < HD) {
-        const int d = lane, h2 = (d >> 2) & 1, r = 4 * (d >> 3) + (d & 3);       // d = 8*(r>>2) + 4*half + (r&3)
-        float tkk = 0.f, tvv = 0.f;
-        for (int l = 0; l < 32; ++l) { tkk += sk[(h2 * 32 + l) * 17 + r]; tvv += sv[(h2 * 32 + l) * 17 + r]; }
-        padp[d] = 0.f; padp[HD + d] = tkk; padp[2 * HD + d] = tvv;
-      }
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      for (int e = lane; e < 96; e += 64) padp[e] = 0.f;
+    float* padp = pad_part + ((size_t)wic * g.heads + head) * 96;
+    if (!active) continue;
+    if (l31 < 16) {
+      const int d = 8 * (l31 >> 2) + 4 * hf + (l31 & 3);    // d of register l31 in half hf
+      padp[d] = 0.f; padp[HD + d] = padk; padp[2 * HD + d] = padv;
     }
   }
-  // gradient of the position bias: the 4 waves' sums through LDS (the tile area is free now), then one partial row per block
   __syncthreads();
-  float* tile = (float*)tbase;                                 // [64 queries][64 keys] floats = 16 KiB <= 48 KiB of tiles
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = 32 * jb + l31, i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (w == 0) tile[j * 64 + i] = dsum[ib][jb][r]; else tile[j * 64 + i] += dsum[ib][jb][r];
-          }
-    }
-    __syncthreads();
-  }
   float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
-  for (int e = tid; e < WN * WN; e += 256) dr[e] = tile[(e / WN) * 64 + e % WN];
+  for (int e = tid; e < WN * WN; e += 256) dr[e] = dacc[(e / WN) * WB2_AP + e % WN];
 }
 
 // backward of one (window, head); block (head, chunk) walks `wpb` windows and keeps the sum of dS (= gradient of the relative position bias)
@@ -1730,7 +1744,7 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
     if (attn_bwd_form() == 2) {
-      const size_t lds2 = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float);
+      const size_t lds2 = (size_t)(WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float) + (size_t)WN * WB2_AP * sizeof(float);
       static bool attr2 = false;
       if (!attr2) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
       hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,

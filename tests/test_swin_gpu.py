@@ -364,8 +364,8 @@ def test_window_attention_mfma_vs_valu(hip, Cn, heads, H, W, shift):
         g1 = [t.float().cpu() for t in osw.window_attention_bwd(qg, bias.to(DEV), relb.to(DEV), dg, Cn, heads, shift)]
     finally:
         L.sl_debug_attn_valu(-1); L.sl_debug_attn_bwd_form(2)
-    for a, b_ in zip(g1, res['mfma'][1]):
-        assert torch.equal(a, b_)
+    assert torch.equal(g1[0], res['mfma'][1][0])                         # dqkv: bit-identical
+    assert l2(res['mfma'][1][1], g1[1]) <= 1e-6 and l2(res['mfma'][1][2], g1[2]) <= 1e-6      # sums over windows / pad keys: other (fixed) summation orders
     # torch evaluation on the bf16-rounded inputs (pad tokens carry the bf16-rounded bias, as the qkv GEMM would have stored it)
     qr = qg.float().cpu()[..., :3 * Cn].requires_grad_(True)
     br = bias.clone().requires_grad_(True)
