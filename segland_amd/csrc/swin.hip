@@ -651,26 +651,89 @@ __device__ __forceinline__ void win_softmax_regs(const WinGeom& g, f32x16_t (&ac
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) short win_s16x4_t;
+__device__ __forceinline__ uint2 win_lds_tr(const unsigned char* p) {
+  const win_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) win_s16x4_t*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+// byte offset of 16-byte chunk c (8 d) of token n in a [64][32 d] tile: tokens of a 16-block in the order {0-3, 8-11, 4-7, 12-15} (see above), chunks XOR-swizzled by the
+// 4-row group so that 16-byte accesses down a column of lanes and the transpose reads are both conflict-free
+__device__ __forceinline__ int win_nat_off(int n, int c) {
+  const int row = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+  return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
+}
+__device__ __forceinline__ uint4 win_trfrag(const unsigned char* tile, int lane, int blk, int s2) {     // rows = d (lane & 31), k = tokens 32*blk + 16*s2 .. +15 in D-layout order
+  const int g4 = lane >> 4, l = lane & 15;
+  const int row = 32 * blk + 16 * s2 + 8 * (g4 >> 1) + (l >> 2), c = 2 * (g4 & 1) + ((l & 3) >> 1);     // LDS row (already in stored order), logical chunk
+  const unsigned char* a = tile + row * 64 + ((c ^ ((row >> 2) & 3)) << 4) + (l & 1) * 8;
+  const uint2 lo = win_lds_tr(a), hi = win_lds_tr(tile + (row + 4) * 64 + ((c ^ (((row + 4) >> 2) & 3)) << 4) + (l & 1) * 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+constexpr int WB2_TILE = 64 * 64;             // bytes of one [64 tokens][32 d] bf16 tile
+constexpr int WB2_AP = 68;                    // float pitch of the dS accumulation tile: 272-byte rows -> conflict-free 16-byte accesses down a column of lanes
+
 __global__ __launch_bounds__(256) void window_attention_fwd_mfma_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                         const float* __restrict__ rel_bias, bf16_t* __restrict__ out, int nwin) {
   __shared__ __attribute__((aligned(16))) float biasl[WN * BLP + 16];
-  __shared__ __attribute__((aligned(16))) bf16_t vt[4][HD * VTP];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[4][WB2_TILE];       // V of the wave's window as a [token][32 d] tile (win_nat_off); V^T fragments are transpose reads of it
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
   const int head = blockIdx.x % g.heads, wi = (blockIdx.x / g.heads) * 4 + wave;
-  for (int e = tid; e < WN * WN; e += 256) biasl[(e / WN) * BLP + e % WN] = rel_bias[(size_t)head * WN * WN + e];
+  {
+    float bv[10];                                           // 2401 = 9.4 x 256: all loads in flight before the first LDS store
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { const int e = tid + 256 * u; bv[u] = e < WN * WN ? rel_bias[(size_t)head * WN * WN + e] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) { const int e = tid + 256 * u; if (e < WN * WN) biasl[(e / WN) * BLP + e % WN] = bv[u]; }
+  }
   __syncthreads();
   if (wi >= nwin) return;
   const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
-  // V^T into LDS: chunk c = (key, 8 consecutive d); key columns 49..63 zeroed (their probabilities are 0, LDS garbage could be NaN)
-  bf16_t* vtw = vt[wave];
-  for (int c = lane; c < WN * 4; c += 64) {
-    const int key = c >> 2, d0 = (c & 3) * 8;
-    const uint4 v = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 2, key, d0);
-    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+  // the 12 fragments of the window (q, k, v x two 32-token blocks x two 16-d steps: a lane's 16 bytes of its token row) straight from global memory, all loads in flight together
+  int pixr[2];                                              // pixel of token 32*rb + l31; -1 pad token, -2 no such token
+  uint4 fq[2][2], fk[2][2], fv[2][2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vtw[(d0 + e) * VTP + key] = (bf16_t)((w4[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+  for (int rb = 0; rb < 2; ++rb) {
+    const int n = 32 * rb + l31;
+    int pix = -2, reg;
+    if (n < WN) win_token(g, wy, wx, n, pix, reg);
+    pixr[rb] = pix;
+    const bf16_t* src = qkv + ((size_t)b * g.H * g.W + (pix >= 0 ? pix : 0)) * g.P3 + head * HD + 8 * hf;     // pad / absent tokens read pixel 0 and drop it
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      fq[rb][s2] = *(const uint4*)(src + 16 * s2);
+      fk[rb][s2] = *(const uint4*)(src + g.C + 16 * s2);
+      fv[rb][s2] = *(const uint4*)(src + 2 * g.C + 16 * s2);
+    }
   }
-  for (int e = lane; e < HD * (64 - WN); e += 64) vtw[(e / (64 - WN)) * VTP + WN + e % (64 - WN)] = 0;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      if (pixr[rb] < 0) { const uint4 z = make_uint4(0, 0, 0, 0); fq[rb][s2] = z; fk[rb][s2] = z; fv[rb][s2] = z; }
+  if (__any(pixr[0] == -1 || pixr[1] == -1)) {              // edge windows: pad tokens carry the qkv bias as the GEMM would have stored it
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int col = head * HD + 16 * s2 + 8 * hf;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = qkv_bias[col + e];
+        const uint4 bq = pack16<bf16_t>(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = qkv_bias[g.C + col + e];
+        const uint4 bk = pack16<bf16_t>(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = qkv_bias[2 * g.C + col + e];
+        const uint4 bvv = pack16<bf16_t>(f);
+        if (pixr[rb] == -1) { fq[rb][s2] = bq; fk[rb][s2] = bk; fv[rb][s2] = bvv; }
+      }
+  }
+  unsigned char* tv = vt[wave];
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) *(uint4*)(tv + win_nat_off(32 * rb + l31, 2 * s2 + hf)) = fv[rb][s2];      // rows of tokens 49..63 are zero (their probabilities are 0, garbage could be NaN)
   unsigned pk[8];
   win_pack_regions(g, wy, wx, lane, pk);
   // S^T = K Q^T
@@ -682,20 +745,13 @@ __global__ __launch_bounds__(256) void window_attention_fwd_mfma_kernel(WinGeom 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[ib][jb][r] = 0.f;
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    uint4 kf[2], qf[2];
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      kf[rb] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 1, 32 * rb + l31, 16 * s2 + 8 * hf);
-      qf[rb] = win_frag(g, qkv, qkv_bias, b, wy, wx, head, 0, 32 * rb + l31, 16 * s2 + 8 * hf);
-    }
+  for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
     for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-      for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = mfma16(kf[ib], qf[jb], acc[ib][jb]);
-  }
+      for (int jb = 0; jb < 2; ++jb) acc[ib][jb] = mfma16(fk[ib][s2], fq[jb][s2], acc[ib][jb]);
   win_softmax_regs(g, acc, biasl, pk, lane, rsqrtf((float)HD));
-  __builtin_amdgcn_wave_barrier();            // the wave's own LDS writes of V^T are complete before its reads (same wave: program order + lgkmcnt)
+  __builtin_amdgcn_wave_barrier();            // the wave's own LDS writes of V are complete before its reads (same wave: program order + lgkmcnt)
   // O^T = V^T P^T
   f32x16_t o[2];
 #pragma unroll
@@ -706,9 +762,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_mfma_kernel(WinGeom 
   for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const bf16_t* vr = vtw + l31 * VTP + 32 * ib + 16 * s2 + 4 * hf;
-      const uint2 lo = *(const uint2*)vr, hi = *(const uint2*)(vr + 8);
-      const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      const uint4 vf = win_trfrag(tv, lane, ib, s2);
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         float pv[8];
@@ -719,10 +773,7 @@ __global__ __launch_bounds__(256) void window_attention_fwd_mfma_kernel(WinGeom 
     }
 #pragma unroll
   for (int jb = 0; jb < 2; ++jb) {
-    const int j = 32 * jb + l31;
-    if (j >= WN) continue;
-    int pix, reg;
-    win_token(g, wy, wx, j, pix, reg);
+    const int pix = pixr[jb];
     if (pix < 0) continue;
     bf16_t* dst = out + ((size_t)b * g.H * g.W + pix) * g.Cp + head * HD + 4 * hf;
 #pragma unroll
@@ -1056,27 +1107,6 @@ __global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom 
 //   (K^T, Q^T, dO^T: rows = d, k index = tokens) are ds_read_b64_tr_b16 reads of them -- no 2-byte scatter; the tokens of a 16-block sit in the order
 //   {0-3, 8-11, 4-7, 12-15} so that the hardware's k order (rows 8*half + e) is the D-layout order of the probability registers they multiply;
 // * 72 KiB of LDS per block instead of 156: two blocks per CU, i.e. a second wave on every SIMD under the first one's load / exp / LDS latencies.
-typedef __attribute__((ext_vector_type(4))) short win_s16x4_t;
-__device__ __forceinline__ uint2 win_lds_tr(const unsigned char* p) {
-  const win_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) win_s16x4_t*)(p));
-  return __builtin_bit_cast(uint2, v);
-}
-// byte offset of 16-byte chunk c (8 d) of token n in a [64][32 d] tile: tokens of a 16-block in the order {0-3, 8-11, 4-7, 12-15} (see above), chunks XOR-swizzled by the
-// 4-row group so that 16-byte accesses down a column of lanes and the transpose reads are both conflict-free
-__device__ __forceinline__ int win_nat_off(int n, int c) {
-  const int row = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
-  return row * 64 + ((c ^ ((row >> 2) & 3)) << 4);
-}
-__device__ __forceinline__ uint4 win_trfrag(const unsigned char* tile, int lane, int blk, int s2) {     // rows = d (lane & 31), k = tokens 32*blk + 16*s2 .. +15 in D-layout order
-  const int g4 = lane >> 4, l = lane & 15;
-  const int row = 32 * blk + 16 * s2 + 8 * (g4 >> 1) + (l >> 2), c = 2 * (g4 & 1) + ((l & 3) >> 1);     // LDS row (already in stored order), logical chunk
-  const unsigned char* a = tile + row * 64 + ((c ^ ((row >> 2) & 3)) << 4) + (l & 1) * 8;
-  const uint2 lo = win_lds_tr(a), hi = win_lds_tr(tile + (row + 4) * 64 + ((c ^ (((row + 4) >> 2) & 3)) << 4) + (l & 1) * 8);
-  return make_uint4(lo.x, lo.y, hi.x, hi.y);
-}
-constexpr int WB2_TILE = 64 * 64;             // bytes of one [64 tokens][32 d] bf16 tile
-constexpr int WB2_AP = 68;                    // float pitch of the dS accumulation tile: 272-byte rows -> conflict-free 16-byte accesses down a column of lanes
-
 __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                             const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
                                                                             float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
