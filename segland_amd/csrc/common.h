@@ -52,6 +52,22 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
   return r;
 }
 
+// GELU(x) = x/2 (1 + erf(x / sqrt 2)) (torch.nn.GELU, exact form).  fp32 tensors: erff.  bf16 tensors: Abramowitz-Stegun 7.1.26 (|error of erf| < 6.1e-7 in fp32 arithmetic,
+// |error of GELU| < 3.7e-7: three orders below the bf16 rounding of the stored value) -- one v_rcp, one v_exp and six FMAs instead of erff's ~40 instructions, which were half of
+// the fc1 epilogue's time (113.7 -> 59 us is bias-only at 131 072 x 384; tools/gemm_time.py).
+__device__ __forceinline__ float sl_erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+  const float r = fmaf(-p * t, __expf(-ax * ax), 1.f);
+  return copysignf(r, x);
+}
+template <typename T> __device__ __forceinline__ float sl_gelu(float x) {
+  if constexpr (sizeof(T) == 4) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+  else return 0.5f * x * (1.f + sl_erf_as(x * 0.70710678118654752440f));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -484,6 +484,107 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   }
 }
 
+// Branch-free store phase of the affine epilogues on tiles inside M (nn.Linear over token maps, eval-mode BatchNorm folded into the conv):
+//   v = acc * scale[n] + bias[n];  GELU: out2 = gelu(round(v));  RS: v *= row_scale[image of the row];  ADD: v += addend;  relu (runtime floor);  out = round(v)
+// -- the generic store phase evaluates every optional operand per row behind run-time tests and always carries the statistic sums: 59 us against 25 us for the plain store
+// on the 131 072 x 128 -> 384 qkv GEMM of Swin-T stage 1 (tools/gemm_time.py).  Same operation order as conv_epilogue_generic (bit-identical results).
+template <typename T, int BM, int BN, int WM, int WN, bool ADD, bool RS_, bool GELU, bool SCRELU>
+__device__ __forceinline__ void conv_epilogue_affine(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
+                                                     int lane, int tid, unsigned char* smem) {
+  using G = EpiGeom<T, BM, BN, WM, WN, false>;
+  constexpr int EPC = 16 / sizeof(T), EP2 = EPC / 2;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CPR = BN / EPC;
+  constexpr int RS = NT / CPR;
+  constexpr int ROWS = BM / G::NPASS;
+  constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+  typedef __attribute__((ext_vector_type(2))) float f2_t;       // pairs: v_pk_mul_f32 / v_pk_add_f32, one v_cvt_pk_bf16_f32 per pair
+  const int cc = tid % CPR, r0 = tid / CPR;
+  const int ncol = bn * BN + cc * EPC;
+  f2_t bias[EP2], scl[EP2];
+#pragma unroll
+  for (int e = 0; e < EP2; ++e) {
+    bias[e] = p.bias ? (f2_t){p.bias[ncol + 2 * e], p.bias[ncol + 2 * e + 1]} : (f2_t){0.f, 0.f};
+    scl[e] = (SCRELU && p.scale) ? (f2_t){p.scale[ncol + 2 * e], p.scale[ncol + 2 * e + 1]} : (f2_t){1.f, 1.f};
+  }
+  const float lo = p.relu ? 0.f : -INFINITY;
+  const size_t rstep = (size_t)RS * p.N * sizeof(T);
+  const int hw = p.Hd * p.Wd;
+  auto unpack2 = [](const uint4& raw, f2_t* v) {
+    if constexpr (sizeof(T) == 2) {
+      const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (f2_t){__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+    } else {
+      v[0] = (f2_t){__uint_as_float(raw.x), __uint_as_float(raw.y)}; v[1] = (f2_t){__uint_as_float(raw.z), __uint_as_float(raw.w)};
+    }
+  };
+  auto pack2 = [](const f2_t* v) -> uint4 {
+    if constexpr (sizeof(T) == 2) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+      return make_uint4(__builtin_bit_cast(unsigned, __builtin_convertvector(v[0], bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(v[1], bf16x2_t)),
+                        __builtin_bit_cast(unsigned, __builtin_convertvector(v[2], bf16x2_t)), __builtin_bit_cast(unsigned, __builtin_convertvector(v[3], bf16x2_t)));
+    } else {
+      return make_uint4(__float_as_uint(v[0].x), __float_as_uint(v[0].y), __float_as_uint(v[1].x), __float_as_uint(v[1].y));
+    }
+  };
+#pragma unroll
+  for (int pass = 0; pass < G::NPASS; ++pass) {
+    epi_stage_acc<T, BM, BN, WM, WN, false>(acc, pass, wm, wn, lane, smem);
+    lds_barrier();
+    const int m0 = bm * BM + pass * ROWS + r0;
+    const size_t goff = ((size_t)m0 * p.N + ncol) * sizeof(T);
+    unsigned char* o = (unsigned char*)p.out + goff;
+    unsigned char* o2 = GELU ? (unsigned char*)p.out2 + goff : nullptr;
+    const unsigned char* ad = ADD ? (const unsigned char*)p.addend + goff : nullptr;
+    const unsigned char* l = smem + r0 * G::PITCH + cc * 16;
+    int img = 0, rem = 0;
+    if constexpr (RS_) { img = m0 / hw; rem = m0 - img * hw; }
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += CH) {
+      uint4 addv[CH]; float rsv[CH];
+      if constexpr (ADD) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) addv[u] = *(const uint4*)(ad + (size_t)(it0 + u) * rstep);
+      }
+      if constexpr (RS_) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { rsv[u] = p.row_scale[img]; rem += RS; while (rem >= hw) { rem -= hw; ++img; } }
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        f2_t v[EP2];
+        unpack2(*(const uint4*)(l + (it0 + u) * (RS * G::PITCH)), v);
+#pragma unroll
+        for (int e = 0; e < EP2; ++e) { if constexpr (SCRELU) v[e] = v[e] * scl[e]; v[e] = v[e] + bias[e]; }
+        if constexpr (GELU) {
+          f2_t g[EP2];
+          unpack2(pack2(v), g);
+#pragma unroll
+          for (int e = 0; e < EP2; ++e) g[e] = (f2_t){sl_gelu<T>(g[e].x), sl_gelu<T>(g[e].y)};
+          st16((T*)(o2 + (size_t)(it0 + u) * rstep), pack2(g));
+        }
+        if constexpr (RS_) {
+#pragma unroll
+          for (int e = 0; e < EP2; ++e) v[e] = v[e] * rsv[u];
+        }
+        if constexpr (ADD) {
+          f2_t a[EP2];
+          unpack2(addv[u], a);
+#pragma unroll
+          for (int e = 0; e < EP2; ++e) v[e] = v[e] + a[e];
+        }
+        if constexpr (SCRELU) {
+#pragma unroll
+          for (int e = 0; e < EP2; ++e) v[e] = (f2_t){v[e].x > lo ? v[e].x : lo, v[e].y > lo ? v[e].y : lo};
+        }
+        st16((T*)(o + (size_t)(it0 + u) * rstep), pack2(v));
+      }
+    }
+    lds_barrier();
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                       int lane, int tid, unsigned char* smem);
@@ -514,6 +615,22 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
     conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     if constexpr (SPLIT) asm volatile("; EPI_END mode2");
     return SPLIT ? (p.addend_mask ? 48 : 32) : -1;                      // per sweep: addend load (+ gate byte) + store
+  }
+  if constexpr (!SPLIT) {
+    if (full && (p.bias || p.scale) && !p.mask_src && !p.pre_addend && !p.addend_mask && !p.stat_partial && !p.tile16) {
+      const bool sr = p.scale || p.relu;              // eval-mode BatchNorm folded into the conv (+ residual + ReLU); the Swin linears have neither
+      if (p.out2) {
+        if (!p.addend && !p.row_scale && !sr) { conv_epilogue_affine<T, BM, BN, WM, WN, false, false, true, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+      } else if (p.addend) {
+        if (p.row_scale) { if (!sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, true, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; } }
+        else if (sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, true>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+        else { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+      } else if (!p.row_scale) {
+        if (sr) conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+        else conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+        return -1;
+      }
+    }
   }
   conv_epilogue_generic<T, BM, BN, WM, WN, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
   return -1;
@@ -608,7 +725,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
             float g[EPC];
             unpack16<T>(pack16<T>(v), g);
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) g[e] = 0.5f * g[e] * (1.f + erff(g[e] * 0.70710678118654752440f));
+            for (int e = 0; e < EPC; ++e) g[e] = sl_gelu<T>(g[e]);
             st16((T*)p.out2 + (size_t)m * p.N + ncol, pack16<T>(g));
           }
           if (p.row_scale) {

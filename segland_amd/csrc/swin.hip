@@ -263,7 +263,7 @@ __global__ void gelu_fwd_kernel(const T* __restrict__ h, T* __restrict__ y, long
     float t[V];
     unpack16<T>(((const uint4*)h)[i], t);
 #pragma unroll
-    for (int e = 0; e < V; ++e) t[e] = 0.5f * t[e] * (1.f + erff(t[e] * 0.70710678118654752440f));
+    for (int e = 0; e < V; ++e) t[e] = sl_gelu<T>(t[e]);
     ((uint4*)y)[i] = pack16<T>(t);
   }
 }
@@ -425,6 +425,61 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, TS* __restrict__ d
         for (int e = 0; e < V; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
       }
     }
+    TS* dst = dx + ((size_t)(b * h + ys) * w + xs) * pdx + xoff + v * V;
+    if (accumulate) {
+      float p[V];
+      ldv<TS, V>(dst, p);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += p[e];
+    }
+    stv<TS, V>(dst, acc);
+  }
+}
+
+// Few source pixels (the pyramid priors of the decoder: 1 x 1 .. 6 x 6 grids under a 16 x 16 map): the gather form above has one thread per (source pixel, 8 channels)
+// walk every destination pixel -- 128 threads x 256 dependent loads for the 1 x 1 level, 145 us.  Here a block owns one source pixel: thread = (channel vector, candidate
+// group), the groups walk the candidate destinations interleaved (fixed order) and are summed in group order through the LDS.
+template <typename T, typename TS>
+__global__ __launch_bounds__(256) void bilinear_bwd_small_kernel(const T* __restrict__ dy, TS* __restrict__ dx, int B, int h, int w, int H, int W, int C, int pdx, int xoff,
+                                                                 int pdy, int yoff, int align, int accumulate) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[256 * V];
+  const int nv = C / V, G = 256 / nv;                       // nv divides 256 (checked by the launcher)
+  const int v = threadIdx.x % nv, grp = threadIdx.x / nv;
+  const int xs = blockIdx.x % w, ys = (blockIdx.x / w) % h, b = blockIdx.x / (w * h);
+  const float sy = src_scale(h, H, align), sx = src_scale(w, W, align);
+  int Ya, Yb, Xa, Xb;
+  const float lo_y = align ? (float)ys - 1.f : (float)ys - 0.5f, hi_y = align ? (float)ys + 1.f : (float)ys + 1.5f, sh = align ? 0.f : 0.5f;
+  const float lo_x = align ? (float)xs - 1.f : (float)xs - 0.5f, hi_x = align ? (float)xs + 1.f : (float)xs + 1.5f;
+  if (sy > 0.f) { Ya = (int)floorf(lo_y / sy - sh) - 1; Yb = (int)ceilf(hi_y / sy - sh) + 1; } else { Ya = 0; Yb = H - 1; }
+  if (sx > 0.f) { Xa = (int)floorf(lo_x / sx - sh) - 1; Xb = (int)ceilf(hi_x / sx - sh) + 1; } else { Xa = 0; Xb = W - 1; }
+  if (!align && ys == 0) Ya = 0;
+  if (!align && xs == 0) Xa = 0;
+  Ya = Ya < 0 ? 0 : Ya; Xa = Xa < 0 ? 0 : Xa; Yb = Yb > H - 1 ? H - 1 : Yb; Xb = Xb > W - 1 ? W - 1 : Xb;
+  const int nx = Xb - Xa + 1, ncand = (Yb - Ya + 1) * nx;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.f;
+  const T* base = dy + (size_t)b * H * W * pdy + yoff + v * V;
+  for (int c = grp; c < ncand; c += G) {
+    const int Y = Ya + c / nx, X = Xa + c % nx;
+    int y0, y1, x0, x1; float ly0, ly1, lx0, lx1;
+    src_taps(Y, sy, h, align, y0, y1, ly0, ly1);
+    src_taps(X, sx, w, align, x0, x1, lx0, lx1);
+    const float wgt = ((y0 == ys ? ly0 : 0.f) + (y1 == ys ? ly1 : 0.f)) * ((x0 == xs ? lx0 : 0.f) + (x1 == xs ? lx1 : 0.f));
+    if (wgt == 0.f) continue;
+    float g[V];
+    unpack16<T>(*(const uint4*)(base + ((size_t)Y * W + X) * pdy), g);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = fmaf(wgt, g[e], acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[(grp * nv + v) * V + e] = acc[e];
+  __syncthreads();
+  if (grp == 0) {
+    for (int k = 1; k < G; ++k)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += red[(k * nv + v) * V + e];
     TS* dst = dx + ((size_t)(b * h + ys) * w + xs) * pdx + xoff + v * V;
     if (accumulate) {
       float p[V];
@@ -1664,6 +1719,14 @@ extern "C" int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* ds
   SL_REQUIRE(ddst && dsrc, "bilinear_bwd: null buffer");
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)d->B * d->h * d->w * d->C;
+  const int nsrc = d->B * d->h * d->w, nv = d->C / (d->dtype == SL_BF16 ? 8 : 4);
+  if (nsrc <= 2048 && (long long)d->H * d->W >= 4LL * d->h * d->w && nv <= 128 && 256 % nv == 0) {       // few source pixels under a large map: a block per source pixel
+    if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, float>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS);
+    else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, bf16_t>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS);
+    else hipLaunchKernelGGL((bilinear_bwd_small_kernel<float, float>), dim3(nsrc), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS);
+    SL_LAUNCH_CHECK("bilinear_bwd_small_kernel");
+    return 0;
+  }
   if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS);
   else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS);
   else hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS);
