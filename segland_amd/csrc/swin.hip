@@ -1601,7 +1601,7 @@ extern "C" int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   return 0;
 }
 
-constexpr int LN_BWD_BLOCKS = 512;      // partial rows of the fused column sums (grid-stride over the rows)
+constexpr int LN_BWD_BLOCKS = 2048;     // partial rows of the fused column sums (grid-stride over the rows)
 
 // fused column sums need every lane's channel vectors in registers: up to 3 per lane (C <= 3 * 64 * 8 = 1536 in bf16, 768 in fp32)
 
@@ -1793,20 +1793,24 @@ static int win_wpw(const WinGeom& g) { return (win_wpb(g) + 3) / 4; }         //
 // d relative_position_bias_table[t][h] = sum over the (query, key) pairs with relative offset t of d bias[h][pair] (swintransformer.py:128-131 backward):
 // fixed-order gather through the constant pair lists (pairs[t][j], -1 padded) -- the index_add_ of an autograd gather is atomic, this is bit-stable.
 __global__ void relpos_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ pairs, int rows, int m, int heads, int npair, float* __restrict__ dtable) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= rows * heads) return;
-  const int t = i / heads, h = i - t * heads;
+  // eight lanes per table entry: lane `sub` adds pairs sub, sub + 8, ... (up to 49 per offset: one thread walked them as a chain of dependent loads, 21 us whatever the stage),
+  // then a fixed xor tree over the eight partial sums
+  const int gi = blockIdx.x * blockDim.x + threadIdx.x, i = gi >> 3, sub = gi & 7;
+  const bool live = i < rows * heads;
+  const int ic = live ? i : 0;
+  const int t = ic / heads, h = ic - t * heads;
   float s = 0.f;
-  for (int j = 0; j < m; ++j) {
+  for (int j = sub; j < m; j += 8) {
     const int pidx = pairs[t * m + j];
     if (pidx >= 0) s += dbias[(size_t)h * npair + pidx];
   }
-  dtable[i] = s;
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  if (live && sub == 0) dtable[i] = s;
 }
 
 extern "C" int sl_relpos_table_grad(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, sl_stream_t stream) {
   SL_REQUIRE(dbias && pairs && dtable && rows > 0 && m > 0 && heads > 0 && npair > 0, "relpos_table_grad: bad args");
-  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(rows * heads, 256)), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable);
+  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(rows * heads * 8, 256)), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable);
   SL_LAUNCH_CHECK("relpos_table_grad_kernel");
   return 0;
 }
