@@ -120,6 +120,12 @@ int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, 
  * with sl_stream_join(stream, reduce_stream) before dw is consumed and before `workspace` is used by anything but the next weight gradient. */
 int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                              int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream);
+
+/* Weight gradient and the bias gradient's column-sum partials of one nn.Linear / biased conv (swintransformer.py:40-52 Mlp, :95-98 qkv / proj: the autograd of F.linear
+ * yields dW = dy^T x and db = sum_rows dy).  colsum_partial: float [sl_colsum_rows_blocks(B*Ho*Wo, Cout, dtype)][Cout]; finalize with sl_colsum_finalize(_multi).
+ * 1x1 layers carry the column sums in the slab-reduce launch of the weight gradient; other shapes run sl_colsum_rows_partial after it. */
+int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              float* colsum_partial, sl_stream_t stream);
 /* `stream` waits for everything queued on `other` so far (event record + stream wait: legal inside a stream capture) */
 int sl_stream_join(sl_stream_t stream, sl_stream_t other);
 
@@ -366,6 +372,10 @@ int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, flo
  * optimizer step).  table_dev: n entries {float* dst; const float* src; int rows, cols, dst_pitch, pad; int64 start} (40 bytes): src is [rows][cols] contiguous,
  * row r goes to dst + r * dst_pitch; start = running count of 1024-element chunks of the preceding entries, total_chunks their grand total. */
 int sl_copy2d_multi(const void* table_dev, int n, long long total_chunks, sl_stream_t stream);
+
+/* The relative-position bias tiles of n Swin blocks in one launch: out[h][p] = table[index[p]][h] (swintransformer.py:128-131, the gather + permute of
+ * WindowAttention.forward).  table_dev: device array of n entries {float* out; const float* table; const int64_t* index; int heads; int npair;} (32 bytes). */
+int sl_relpos_gather_multi(const void* table_dev, int n, sl_stream_t stream);
 
 /* ---- Swin-POP path ---------------------------------------------------------------------------
  * Token maps are NHWC images [B][H][W][pitch] with C real channels and a ZERO channel pad up to `pitch` (a multiple of 64 so that the

@@ -93,3 +93,62 @@ void sl_set_error(const char* fmt, ...);
   } while (0)
 
 __host__ __device__ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- column sums over the rows of a [rows][C] tensor (bias gradients): block `block` sums its contiguous row chunk, four rows in flight per thread, into part[block][C]
+// (fixed order).  Shared by colsum_rows_partial_kernel (pop_head.hip) and the weight-gradient slab reduce that carries the bias gradient in the same launch (conv_wgrad.hip).
+template <typename T>
+__device__ __forceinline__ void sl_colsum_rows_block(const T* __restrict__ x, long long rows, int C, long long rows_per_block, float* __restrict__ part, int block, float* red) {
+  constexpr int V = Vec16<T>::N;
+  const int nvec = C / V;
+  const int tpr = nvec < 256 ? nvec : 256, rpb = 256 / tpr;
+  const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
+  const long long r0 = (long long)block * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int vc = tc; vc < nvec; vc += tpr) {
+    float s[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = 0.f;
+    if (tr < rpb) {
+      long long r = r0 + tr;
+      for (; r + 3 * rpb < r1; r += 4 * rpb) {
+        uint4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = ((const uint4*)x)[(size_t)(r + u * rpb) * nvec + vc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float v[V];
+          unpack16<T>(q[u], v);
+#pragma unroll
+          for (int k = 0; k < V; ++k) s[k] += v[k];
+        }
+      }
+      for (; r < r1; r += rpb) {
+        float v[V];
+        unpack16<T>(((const uint4*)x)[(size_t)r * nvec + vc], v);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += v[k];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V; ++k) red[threadIdx.x * V + k] = s[k];
+    __syncthreads();
+    if (tr == 0) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        float a = 0.f;
+        for (int j = 0; j < rpb; ++j) a += red[(j * tpr + tc) * V + k];
+        part[(size_t)block * C + vc * V + k] = a;
+      }
+    }
+  }
+}
+
+
+// rows per block of the column-sum partials (the same rule for every caller: the partial buffer has ceil(rows / chunk) rows)
+inline long long sl_colsum_rows_chunk(long long rows, int C, int esize) {
+  const int nvec = C * esize / 16, tpr = nvec < 256 ? nvec : 256, rpb = 256 / tpr;
+  long long rpblk = (long long)rpb * 16;                         // >= four 4-deep iterations per thread
+  const long long cap = 2048;                                    // partial rows the finalize sums
+  if ((rows + rpblk - 1) / rpblk > cap) rpblk = ((rows + cap - 1) / cap + rpb - 1) / rpb * rpb;
+  return rpblk;
+}

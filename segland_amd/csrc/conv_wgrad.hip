@@ -480,6 +480,26 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __
   }
 }
 
+// The flat slab reduce and the column sums of dy (the bias gradient of the same nn.Linear) in ONE launch: blocks [0, nred) reduce the slabs, blocks [nred, nred + ncol) each
+// sum one row chunk of dy into colsum_part -- two ~6 us launches per linear and step otherwise (96 of the 767 launches of a Swin-T step).
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_colsum_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits, int Cin, int dw_cin_total,
+                                                                       int dw_ci_off, int nred, const T* __restrict__ dy, long long rows, int Cout, long long rows_per_block,
+                                                                       float* __restrict__ colsum_part) {
+  __shared__ float red[256 * Vec16<T>::N];
+  if ((int)blockIdx.x >= nred) { sl_colsum_rows_block<T>(dy, rows, Cout, rows_per_block, colsum_part, (int)blockIdx.x - nred, red); return; }
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)nred * blockDim.x) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += ws[(size_t)k * total + e]; s1 += ws[(size_t)(k + 1) * total + e];
+      s2 += ws[(size_t)(k + 2) * total + e]; s3 += ws[(size_t)(k + 3) * total + e];
+    }
+    for (; k < splits; ++k) s0 += ws[(size_t)k * total + e];
+    dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
+  }
+}
+
 // paired rows (plan(): 64-channel layers): slab = [2*Cout][taps][2*Cin]; the weight gradient is the sum of the two parity-diagonal blocks
 __global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits, int dw_cin_total, int dw_ci_off) {
   const long long total = (long long)Cout * Cin * taps, slab = 4 * total;
@@ -884,6 +904,7 @@ extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   return need;
 }
 
+extern "C" int sl_colsum_rows_partial(int dtype, const void* x, long long rows, int C, float* partial, sl_stream_t stream);
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
 extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
@@ -928,9 +949,30 @@ extern "C" int sl_stream_join(sl_stream_t stream, sl_stream_t other) {
 }
 
 // dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
+static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial);
+
 extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                         int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream) {
+  return bwd_weight_impl(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, stream, reduce_stream, nullptr);
+}
+
+// Weight gradient + bias gradient partials of one nn.Linear / biased conv: colsum_partial [sl_colsum_rows_blocks(B*Ho*Wo, Cout, dtype)][Cout] receives the column sums of dy
+// per row chunk (finalize: sl_colsum_finalize / _multi).  1x1 layers on the tile kernels carry them in the slab-reduce launch; other shapes run the separate kernel.
+extern "C" int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                         float* colsum_partial, sl_stream_t stream) {
+  SL_REQUIRE(colsum_partial, "conv bwd_weight_bias: null partial buffer");
+  return bwd_weight_impl(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream, nullptr, colsum_partial);
+}
+
+static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
+  // column sums of dy by the stand-alone kernel: every path below that does not carry them in its reduce launch
+  auto colsum_separately = [&]() -> int {
+    if (!colsum_partial) return 0;
+    return sl_colsum_rows_partial(d->dtype, dy, (long long)d->B * d->Ho * d->Wo, d->Cout, colsum_partial, stream);
+  };
   const bool forked = reduce_stream && reduce_stream != stream;
   if (g_fork.pending) {                          // a reduce of the previous call may still read the workspace this call overwrites
     if (hipStreamWaitEvent((hipStream_t)stream, g_fork.red_done, 0) != hipSuccess) { sl_set_error("conv bwd_weight: hipStreamWaitEvent failed"); return SL_EINVAL; }
@@ -967,7 +1009,7 @@ extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, cons
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, rs, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
     reduced();
-    return 0;
+    return colsum_separately();
   }
   if (c64p_eligible(d) && use_tr()) {
     const int nblk = c64p_blocks(d), nslab = c64p_slabs(d), ntiles = (int)((long long)d->B * d->H * d->W / CP_T);
@@ -988,7 +1030,7 @@ extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, cons
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off);
     SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
     reduced();
-    return 0;
+    return colsum_separately();
   }
   const WgradPlan pl = plan(d);
   if (workspace_bytes < pl.ws_bytes) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, pl.ws_bytes); return SL_EWORKSPACE; }
@@ -1013,11 +1055,25 @@ extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, cons
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
   } else if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off);
+    const int nred = (int)((total + 255) / 256);
+    if (colsum_partial && !forked) {
+      const long long rows = (long long)d->B * d->Ho * d->Wo, ch = sl_colsum_rows_chunk(rows, d->Cout, d->dtype == SL_BF16 ? 2 : 4);
+      const int ncol = (int)((rows + ch - 1) / ch);
+      if (d->dtype == SL_BF16)
+        hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<bf16_t>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
+                           nred, (const bf16_t*)dy, rows, d->Cout, ch, colsum_partial);
+      else
+        hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<float>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
+                           nred, (const float*)dy, rows, d->Cout, ch, colsum_partial);
+      SL_LAUNCH_CHECK("wgrad_reduce_flat_colsum_kernel");
+      reduced();
+      return 0;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)nred), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off);
   } else {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
   }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
   reduced();
-  return 0;
+  return colsum_separately();
 }

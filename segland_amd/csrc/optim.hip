@@ -115,3 +115,27 @@ extern "C" int sl_copy2d_multi(const void* table_dev, int n, long long total_chu
   SL_LAUNCH_CHECK("copy2d_multi_kernel");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The relative-position bias tiles of every Swin block in ONE launch (swintransformer.py:128-131: table[index].view(n, n, heads).permute(2, 0, 1)):
+//   out[h][p] = table[index[p]][h],  p < npair = 49 * 49.   One gather + one permute copy per block and optimizer step otherwise (24 launches of ~5 us per Swin-T step).
+// table: device array of n entries {out (float*), table (const float*), index (const int64*), heads, npair (int)} = 32 bytes; block b of the grid serves entry b / 4, quarter b % 4.
+namespace {
+struct RelGatherEntry { float* out; const float* table; const long long* index; int heads, npair; };
+static_assert(sizeof(RelGatherEntry) == 32, "table layout is part of the ABI");
+__global__ __launch_bounds__(256) void relpos_gather_multi_kernel(const RelGatherEntry* __restrict__ tab) {
+  const RelGatherEntry t = tab[blockIdx.x >> 2];
+  const int total = t.heads * t.npair;
+  for (int e = (blockIdx.x & 3) * 256 + threadIdx.x; e < total; e += 1024) {
+    const int h = e / t.npair, pp = e - h * t.npair;
+    t.out[e] = t.table[(size_t)t.index[pp] * t.heads + h];
+  }
+}
+}  // namespace
+
+extern "C" int sl_relpos_gather_multi(const void* table_dev, int n, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && n > 0, "relpos_gather_multi: bad args");
+  hipLaunchKernelGGL(relpos_gather_multi_kernel, dim3(4 * n), dim3(256), 0, (hipStream_t)stream, (const RelGatherEntry*)table_dev);
+  SL_LAUNCH_CHECK("relpos_gather_multi_kernel");
+  return 0;
+}

@@ -177,50 +177,8 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 // step, 15 % of it -- a kernel shaped for 65 536-row tensors with one row in flight per thread and rows / 64 blocks, i.e. 128 blocks for the 8 192-token stage.)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const T* __restrict__ x, long long rows, int C, long long rows_per_block, float* __restrict__ part) {
-  constexpr int V = Vec16<T>::N;
-  __shared__ float red[256 * V];
-  const int nvec = C / V;
-  const int tpr = nvec < 256 ? nvec : 256, rpb = 256 / tpr;
-  const int tr = threadIdx.x / tpr, tc = threadIdx.x % tpr;
-  const long long r0 = (long long)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  for (int vc = tc; vc < nvec; vc += tpr) {
-    float s[V];
-#pragma unroll
-    for (int k = 0; k < V; ++k) s[k] = 0.f;
-    if (tr < rpb) {
-      long long r = r0 + tr;
-      for (; r + 3 * rpb < r1; r += 4 * rpb) {
-        uint4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = ((const uint4*)x)[(size_t)(r + u * rpb) * nvec + vc];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float v[V];
-          unpack16<T>(q[u], v);
-#pragma unroll
-          for (int k = 0; k < V; ++k) s[k] += v[k];
-        }
-      }
-      for (; r < r1; r += rpb) {
-        float v[V];
-        unpack16<T>(((const uint4*)x)[(size_t)r * nvec + vc], v);
-#pragma unroll
-        for (int k = 0; k < V; ++k) s[k] += v[k];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < V; ++k) red[threadIdx.x * V + k] = s[k];
-    __syncthreads();
-    if (tr == 0) {
-#pragma unroll
-      for (int k = 0; k < V; ++k) {
-        float a = 0.f;
-        for (int j = 0; j < rpb; ++j) a += red[(j * tpr + tc) * V + k];
-        part[(size_t)blockIdx.x * C + vc * V + k] = a;
-      }
-    }
-  }
+  __shared__ float red[256 * Vec16<T>::N];
+  sl_colsum_rows_block<T>(x, rows, C, rows_per_block, part, blockIdx.x, red);
 }
 
 // The same for up to SL_COLSUM_MAX partial buffers in ONE launch (the bias / LayerNorm / attention-bias gradients of a transformer block
@@ -595,21 +553,14 @@ extern "C" int sl_rowdot_bwd(int dtype, const void* h, const float* w, const flo
 }
 
 
-static long long colsum_rows_chunk(long long rows, int C, int esize) {
-  const int nvec = C * esize / 16, tpr = nvec < 256 ? nvec : 256, rpb = 256 / tpr;
-  long long rpblk = (long long)rpb * 16;                         // >= four 4-deep iterations per thread
-  const long long cap = 2048;                                    // partial rows the finalize sums
-  if ((rows + rpblk - 1) / rpblk > cap) rpblk = ((rows + cap - 1) / cap + rpb - 1) / rpb * rpb;
-  return rpblk;
-}
 extern "C" int sl_colsum_rows_blocks(long long rows, int C, int dtype) {
   if (rows <= 0 || C <= 0) return 0;
-  const long long ch = colsum_rows_chunk(rows, C, dtype == SL_BF16 ? 2 : 4);
+  const long long ch = sl_colsum_rows_chunk(rows, C, dtype == SL_BF16 ? 2 : 4);
   return (int)((rows + ch - 1) / ch);
 }
 extern "C" int sl_colsum_rows_partial(int dtype, const void* x, long long rows, int C, float* partial, sl_stream_t stream) {
   SL_REQUIRE(x && partial && rows > 0 && C > 0 && (dtype == SL_BF16 ? C % 8 == 0 : C % 4 == 0), "colsum_rows_partial: bad args");
-  const long long ch = colsum_rows_chunk(rows, C, dtype == SL_BF16 ? 2 : 4);
+  const long long ch = sl_colsum_rows_chunk(rows, C, dtype == SL_BF16 ? 2 : 4);
   const int nblk = (int)((rows + ch - 1) / ch);
   if (dtype == SL_BF16) hipLaunchKernelGGL(colsum_rows_partial_kernel<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, C, ch, partial);
   else if (dtype == SL_F32) hipLaunchKernelGGL(colsum_rows_partial_kernel<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, C, ch, partial);

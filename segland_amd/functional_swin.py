@@ -37,6 +37,7 @@ class _Plan:
     def __init__(self):
         self.items, self.table, self.total, self.sig = {}, None, 0, None
         self.vecs, self.ctable, self.ctotal, self.cn = {}, None, 0, 0      # padded BatchNorm gamma / beta copies (_bn_padded) ride in the same copy launch
+        self.rels, self.rtable = {}, None                                  # relative-position bias tiles of the blocks: one gather launch per refresh
 
     def register(self, weight, bias, dtype, Kp, Np, k, col_map, L, stage):
         self.items[(id(weight), Kp, Np, dtype)] = (weight, bias, dtype, Kp, Np, k, col_map, L, stage)
@@ -45,6 +46,11 @@ class _Plan:
     def register_vec(self, dst, src, on_refresh):
         """dst[:len(src)] <- src (fp32 vectors) with every refresh; on_refresh() tells the owner that its copy is current."""
         self.vecs[(dst.data_ptr(), src.data_ptr())] = (dst, src, on_refresh)
+        self.sig = None
+
+    def register_rel(self, attn, out):
+        """out [heads, n, n] <- relative_position_bias_table[relative_position_index] with every refresh (see _rel_bias)."""
+        self.rels[id(attn)] = (attn, out)
         self.sig = None
 
     def refresh(self):
@@ -56,7 +62,8 @@ class _Plan:
             return
         if len(stale) * 2 < len(self.items):             # a few trainable weights over a frozen model (ft_pop): individual launches are cheaper
             return
-        sig = tuple((id(it[0]), it[0].data_ptr(), it[3], it[4], it[2]) for it in self.items.values()) + tuple(self.vecs.keys())
+        sig = tuple((id(it[0]), it[0].data_ptr(), it[3], it[4], it[2]) for it in self.items.values()) + tuple(self.vecs.keys()) + \
+            tuple((k, a.relative_position_bias_table.data_ptr(), o.data_ptr()) for k, (a, o) in self.rels.items())
         if sig != self.sig:
             rec, start = b'', 0
             for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
@@ -84,6 +91,12 @@ class _Plan:
             for (dst, src, _) in self.vecs.values():
                 add(dst, src, 1, src.shape[0], dst.shape[0])
             self.ctable = torch.frombuffer(bytearray(crec), dtype=torch.uint8).to(dev) if cn else None
+            rrec = b''
+            for (a, o) in self.rels.values():
+                t, idx = a.relative_position_bias_table, a.relative_position_index
+                assert t.dtype == torch.float32 and t.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+                rrec += struct.pack('<QQQii', o.data_ptr(), t.data_ptr(), idx.data_ptr(), t.shape[1], idx.numel())
+            self.rtable = torch.frombuffer(bytearray(rrec), dtype=torch.uint8).to(dev) if rrec else None
             self.ctotal, self.cn, self.sig = cstart, cn, sig
         if self.ctable is not None:
             ops.copy2d_multi(self.ctable, self.cn, self.ctotal)
@@ -100,6 +113,11 @@ class _Plan:
         for (_, _, on_refresh) in self.vecs.values():
             on_refresh()
         ops.weight_prep_batched(self.table, len(self.items), self.total)
+        if self.rtable is not None:
+            ops.relpos_gather_multi(self.rtable, len(self.rels))
+            for (a, o) in self.rels.values():
+                t = a.relative_position_bias_table
+                a.__dict__['_sl_rel'] = ((_wver(t), t.data_ptr()), o)
         for (w, b, dtype, Kp, Np, k, cmap, L, stage) in self.items.values():
             w._sl_lin[(Kp, Np, dtype)] = (_lin_key(w, b, dtype), L)
 
@@ -179,13 +197,15 @@ def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=No
     dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
     dw = db = None
     if need_w:
-        dwp = ops.conv2d_bwd_weight(x, dy, L.spec, x2=x2)
+        if L.bias is not None:
+            dwp, db = ops.conv2d_bwd_weight_bias(x, dy, L.spec, x2=x2, batch=batch)       # bias gradient in the weight gradient's reduce launch
+            db = db[:L.N]
+            db = db.contiguous() if batch is None else db
+        else:
+            dwp = ops.conv2d_bwd_weight(x, dy, L.spec, x2=x2)
         dw = (dwp[:L.N].index_select(1, col_map) if col_map is not None else dwp[:L.N, :L.K]).contiguous()
         if L.k == 1:
             dw = dw.view(L.N, L.K) if dw.shape[1] == L.K else dw
-        if L.bias is not None:
-            db = ops.colsum_rows(dy, batch=batch)[:L.N]
-            db = db.contiguous() if batch is None else db
     return dx, dw, db
 
 
@@ -198,6 +218,9 @@ def _rel_bias(attn):
         n = attn.relative_position_index.shape[0]
         ent = (key, t.detach()[attn.relative_position_index.view(-1)].view(n, n, -1).permute(2, 0, 1).contiguous().float())
         attn.__dict__['_sl_rel'] = ent
+        plan = CURRENT_PLAN[0]
+        if plan is not None and t.dtype == torch.float32 and t.is_contiguous() and t.is_leaf and id(attn) not in plan.rels:
+            plan.register_rel(attn, ent[1])              # from the next optimizer step on the tile is refilled in place by the plan's one gather launch
     return ent[1]
 
 

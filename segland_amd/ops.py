@@ -336,6 +336,28 @@ def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0, fork_reduce=
     return dw
 
 
+def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
+    """(dw float OIHW, db): weight and bias gradient of a biased 1x1 conv / nn.Linear; the column sums of dy ride in the weight gradient's slab-reduce launch.
+    batch (ColsumBatch): db is filled by batch.run()."""
+    B, H, W, C1 = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
+    L = _lib.lib()
+    need = L.sl_conv2d_bwd_weight_workspace(C.byref(d))
+    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
+    if cur is not None and cur.numel() < need:
+        wgrad_reduce_join()
+    ws = workspace(need, x.device, 'wgrad')
+    dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    Cn = dy.shape[-1]
+    rows = dy.numel() // Cn
+    assert Cn == spec.cout and dy.is_contiguous()
+    part = _f32((L.sl_colsum_rows_blocks(rows, Cn, dt(dy)), Cn), dy.device)
+    tok = PROFILER.begin('conv_wgrad', d)
+    check(L.sl_conv2d_bwd_weight_bias(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_bias')
+    PROFILER.end(tok)
+    return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
+
+
 def wgrad_reduce_join():
     """The current stream waits for every slab reduce issued on the second stream so far."""
     if _red_pending[0]:
@@ -868,3 +890,7 @@ def pop_proto_bwd(Sa, Sb, inv, G, dSa, dSb, dorth, need_a=True, need_b=False):
 
 def copy2d_multi(table, n, total_chunks):
     check(_lib.lib().sl_copy2d_multi(_p(table), n, int(total_chunks), _s()), 'copy2d_multi')
+
+
+def relpos_gather_multi(table, n):
+    check(_lib.lib().sl_relpos_gather_multi(_p(table), n, _s()), 'relpos_gather_multi')

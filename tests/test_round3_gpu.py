@@ -386,3 +386,63 @@ def test_bucket_step_with_backward_cut_equals_plain_step(hip, family):
     assert log_r == log_g
     for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize('tokens,cin,cout', [(8192, 384, 1152), (2048, 192, 576), (512, 64, 128), (4096, 128, 384)])
+def test_weight_gradient_carries_the_bias_gradient(hip, tokens, cin, cout):
+    """sl_conv2d_bwd_weight_bias (the slab reduce and the column sums of dy in one launch for 1x1 layers on the tile kernels, the stand-alone column-sum kernel
+    otherwise) against the two separate calls: bit-identical dW and db, and db against a float64 sum."""
+    from segland_amd import ops
+    torch.manual_seed(tokens + cin)
+    B, H, W = 2, tokens // 2 // 32, 32
+    x = torch.randn(B, H, W, cin, device=DEV).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, cout, device=DEV).to(torch.bfloat16)
+    spec = ops.ConvSpec(cin, cout, 1, 1, 0, 1)
+    dw0 = ops.conv2d_bwd_weight(x, dy, spec).clone()
+    db0 = ops.colsum_rows(dy).clone()
+    dw1, db1 = ops.conv2d_bwd_weight_bias(x, dy, spec)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1)
+    batch = ops.ColsumBatch()
+    dw2, db2 = ops.conv2d_bwd_weight_bias(x, dy, spec, batch=batch)
+    batch.run()
+    assert torch.equal(dw0, dw2) and torch.equal(db0, db2)
+    want = dy.double().sum((0, 1, 2))
+    assert float((db1.double() - want).abs().max()) <= 1e-4 * float(want.abs().max() + 1)
+
+
+def test_relpos_bias_tiles_of_all_blocks_in_one_launch(hip):
+    """sl_relpos_gather_multi against table[index].view(n, n, heads).permute(2, 0, 1) (swintransformer.py:128-131) for blocks with different head counts; and through
+    the model: after an optimizer step the plan's refresh refills the tiles the blocks hold (functional_swin._Plan.register_rel)."""
+    import struct
+    from segland_amd import ops
+    ws = 7
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1; rel[:, :, 1] += ws - 1; rel[:, :, 0] *= 2 * ws - 1
+    index = rel.sum(-1).to(DEV)
+    tabs = [torch.randn((2 * ws - 1) ** 2, h, device=DEV) for h in (3, 6, 12, 24)]
+    outs = [torch.empty(h, 49, 49, device=DEV) for h in (3, 6, 12, 24)]
+    rec = b''.join(struct.pack('<QQQii', o.data_ptr(), t.data_ptr(), index.data_ptr(), t.shape[1], index.numel()) for t, o in zip(tabs, outs))
+    ops.relpos_gather_multi(torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(DEV), len(tabs))
+    for t, o in zip(tabs, outs):
+        assert torch.equal(o, t[index.view(-1)].view(49, 49, -1).permute(2, 0, 1))
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.swin_pop import GFSS_Model
+    from segland_amd.optim import AdamW
+    from segland_amd.utils.pyt_utils import get_parameters
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), pretrained_model=None, compute_dtype=torch.bfloat16, backbone='swin-t')
+    fm.load_formula_weights(m)
+    m = m.to(DEV).train()
+    opt = AdamW(get_parameters(m, lr=1e-2), lr=1e-2, weight_decay=0.0)
+    img, mask = fm.formula_image(2, 128, 160, 'rel/img').to(DEV), fm.formula_mask(2, 128, 160, 8, 'rel/mask', block=16, ignore_rows=4).to(DEV)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        m(img, mask)['total_loss'].backward()
+        opt.step()
+    plan = m.__dict__['_sl_swin_plan']
+    assert len(plan.rels) == 12
+    m(img, mask)                                             # refresh at the top of this forward: tiles follow the stepped tables
+    for attn, tile in plan.rels.values():
+        t = attn.relative_position_bias_table.detach()
+        assert torch.equal(tile, t[attn.relative_position_index.view(-1)].view(49, 49, -1).permute(2, 0, 1))
+        assert attn.__dict__['_sl_rel'][1] is tile
