@@ -186,10 +186,26 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, Up
   }
   __syncthreads();
   // ---- pass 1: softmax - onehot of every footprint pixel, once
-  for (int pix = tid; pix < NY * NX; pix += 256) {
+  // the thread's labels first, all loads in flight (a load at the top of every iteration was a chain of ~8 memory round trips per block)
+  constexpr int TPF = 8;
+  long long tpre[TPF];
+#pragma unroll
+  for (int u = 0; u < TPF; ++u) {
+    const int pix = tid + 256 * u;
+    const int yr = pix / NX, xr = pix - yr * NX;
+    tpre[u] = pix < NY * NX ? tgt[((size_t)b * g.H + Ylo + yr) * g.W + Xlo + xr] : (long long)ignore;
+  }
+#pragma unroll 1
+  for (int u = 0; tid + 256 * u < NY * NX; ++u) {
+    const int pix = tid + 256 * u;
     const int yr = pix / NX, xr = pix - yr * NX;
     float* out = G + (size_t)pix * K;
-    const long long t = tgt[((size_t)b * g.H + Ylo + yr) * g.W + Xlo + xr];
+    long long t;
+    if (u < TPF) {
+      t = tpre[0];
+#pragma unroll
+      for (int q = 1; q < TPF; ++q) t = u == q ? tpre[q] : t;
+    } else t = tgt[((size_t)b * g.H + Ylo + yr) * g.W + Xlo + xr];
     if (t == ignore || t < 0 || t >= K) {
       for (int k = 0; k < K; ++k) out[k] = 0.f;
       continue;

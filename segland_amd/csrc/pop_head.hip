@@ -21,25 +21,49 @@ template <int LPR> __device__ __forceinline__ float across_groups(float v) {  //
   return v;
 }
 
+// prototype rows into the LDS, zero beyond the n valid floats: N floats (a multiple of 1024) as float4 loads that are all in flight before the first LDS store
+// (a scalar load -> store loop was 16 dependent memory round trips at the top of every block)
+template <int N>
+__device__ __forceinline__ void pop_fill_protos(const float* __restrict__ S, int n, float* Sl) {
+  static_assert(N % 1024 == 0, "prototype tile: whole float4 sweeps of the block");
+  constexpr int IT = N / 1024;
+  float4 v[IT];
+#pragma unroll
+  for (int u = 0; u < IT; ++u) {
+    const int e = (u * 256 + threadIdx.x) * 4;
+    v[u] = e + 3 < n ? *(const float4*)(S + e) : make_float4(e < n ? S[e] : 0.f, e + 1 < n ? S[e + 1] : 0.f, e + 2 < n ? S[e + 2] : 0.f, 0.f);
+  }
+#pragma unroll
+  for (int u = 0; u < IT; ++u) *(float4*)(Sl + (u * 256 + threadIdx.x) * 4) = v[u];
+}
+
 template <typename T, int NV, int LPR, int KM>   // NV 16-byte vectors per lane, LPR lanes per row, KM >= Kt prototypes (unrolled)
 __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restrict__ feats, const float* __restrict__ S, int Kt,
                                                                 float* __restrict__ proj, T* __restrict__ bg, long long R, int C) {
   constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Sl = sm;                       // [KM][C], rows >= Kt are zero
-  for (int e = threadIdx.x; e < KM * C; e += 256) Sl[e] = e < Kt * C ? S[e] : 0.f;
+  pop_fill_protos<KM * LPR * NV * V>(S, Kt * C, Sl);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
-  for (long long rb = (blockIdx.x * 4LL + wave) * RPW; rb < R; rb += gridDim.x * 4LL * RPW) {
+  // the next row's vectors are loaded while the current row is reduced: one row per wave and iteration was a chain load -> dot -> shuffle tree -> store per row
+  const long long rstep = gridDim.x * 4LL * RPW;
+  uint4 nxt[NV];
+  {
+    const long long r = (blockIdx.x * 4LL + wave) * RPW + grp;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) nxt[j] = r < R ? *(const uint4*)(feats + (size_t)r * C + (j * LPR + sub) * V) : make_uint4(0, 0, 0, 0);
+  }
+  for (long long rb = (blockIdx.x * 4LL + wave) * RPW; rb < R; rb += rstep) {
     const long long r = rb + grp;
     const bool live = r < R;
     float q[NV * V], o[NV * V];
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      if (live) unpack16<T>(*(const uint4*)(feats + (size_t)r * C + (j * LPR + sub) * V), &q[j * V]);
-      else
+    for (int j = 0; j < NV; ++j) unpack16<T>(nxt[j], &q[j * V]);             // rows past R were loaded as zeros
+    {
+      const long long rn = r + rstep;
 #pragma unroll
-        for (int e = 0; e < V; ++e) q[j * V + e] = 0.f;
+      for (int j = 0; j < NV; ++j) nxt[j] = (rb + rstep < R && rn < R) ? *(const uint4*)(feats + (size_t)rn * C + (j * LPR + sub) * V) : make_uint4(0, 0, 0, 0);
     }
     // all projections first (they use q, not the running residual): KM independent shuffle reductions in flight instead of a chain of Kt x log2(LPR)
     float d[KM];
@@ -300,7 +324,7 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
   constexpr int V = Vec16<T>::N, CL = NV * V, RPW = 64 / LPR;     // CL channels per lane
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* Sl = sm;                                 // [KM][C]; reused for the cross-wave reduction
-  for (int e = threadIdx.x; e < KM * C; e += 256) Sl[e] = e < Kt * C ? S[e] : 0.f;
+  pop_fill_protos<KM * LPR * NV * V>(S, Kt * C, Sl);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   float acc[KM][CL];

@@ -359,13 +359,31 @@ __global__ void ppm_fact_scatterA_kernel(PpmGeom g, int N, const T* __restrict__
     float acc[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) acc[k] = 0.f;
-    for (int x = 0; x < g.W; ++x) {
-      const float wgt = tap_weight(x + kx - 1, s, g.W, j);
-      if (wgt == 0.f) continue;
-      float d[V];
-      unpack16<T>(*(const uint4*)(dcb + (((size_t)b * g.H + y) * g.W + x) * N + v * V), d);
+    if (nv % 64 == 0) {
+      // the 64 lanes of a wavefront differ only in v: lane x evaluates the weight of column x0 + x once and the loop reads it back lane by lane -- every thread evaluated
+      // all W weights before (~40 instructions each, the kernel was bound by them), and the test for a zero weight is wave-uniform now
+      const int lane = threadIdx.x & 63;
+      for (int x0 = 0; x0 < g.W; x0 += 64) {
+        const float wl = x0 + lane < g.W ? tap_weight(x0 + lane + kx - 1, s, g.W, j) : 0.f;
+        const int xe = g.W - x0 < 64 ? g.W - x0 : 64;
+        for (int xx = 0; xx < xe; ++xx) {
+          const float wgt = __shfl(wl, xx, 64);
+          if (wgt == 0.f) continue;
+          float d[V];
+          unpack16<T>(*(const uint4*)(dcb + (((size_t)b * g.H + y) * g.W + x0 + xx) * N + v * V), d);
 #pragma unroll
-      for (int k = 0; k < V; ++k) acc[k] += wgt * d[k];
+          for (int k = 0; k < V; ++k) acc[k] += wgt * d[k];
+        }
+      }
+    } else {
+      for (int x = 0; x < g.W; ++x) {
+        const float wgt = tap_weight(x + kx - 1, s, g.W, j);
+        if (wgt == 0.f) continue;
+        float d[V];
+        unpack16<T>(*(const uint4*)(dcb + (((size_t)b * g.H + y) * g.W + x) * N + v * V), d);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += wgt * d[k];
+      }
     }
     float* o = sa + (size_t)e * V;
 #pragma unroll
@@ -387,10 +405,23 @@ __global__ void ppm_fact_scatterB_kernel(PpmGeom g, int N, const float* __restri
     const int j = rr % s; rr /= s;
     const int i = rr % s; const int b = rr / s;
     float acc = 0.f;
-    for (int y = 0; y < g.H; ++y) {
-      const float wgt = tap_weight(y + ky - 1, s, g.H, i);
-      if (wgt == 0.f) continue;
-      acc += wgt * sa[((((size_t)b * g.H + y) * 3 + kx) * nlj + ljoff + j) * N + n];
+    if (N % 64 == 0) {                                   // the wavefront shares (row, tap): weights once per wave, as in stage A
+      const int lane = threadIdx.x & 63;
+      for (int y0 = 0; y0 < g.H; y0 += 64) {
+        const float wl = y0 + lane < g.H ? tap_weight(y0 + lane + ky - 1, s, g.H, i) : 0.f;
+        const int ye = g.H - y0 < 64 ? g.H - y0 : 64;
+        for (int yy = 0; yy < ye; ++yy) {
+          const float wgt = __shfl(wl, yy, 64);
+          if (wgt == 0.f) continue;
+          acc += wgt * sa[((((size_t)b * g.H + y0 + yy) * 3 + kx) * nlj + ljoff + j) * N + n];
+        }
+      }
+    } else {
+      for (int y = 0; y < g.H; ++y) {
+        const float wgt = tap_weight(y + ky - 1, s, g.H, i);
+        if (wgt == 0.f) continue;
+        acc += wgt * sa[((((size_t)b * g.H + y) * 3 + kx) * nlj + ljoff + j) * N + n];
+      }
     }
     gq[e] = acc;
   }
