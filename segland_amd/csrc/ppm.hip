@@ -109,6 +109,30 @@ __global__ void ppm_pool_bwd_cells_kernel(PpmGeom g, const float* __restrict__ d
     const int cy = (int)(r % g.ncy); const int b = (int)(r / g.ncy);
     const int y0 = g.yb[cy], y1 = g.yb[cy + 1], x0 = g.xb[cx], x1 = g.xb[cx + 1];
     float acc = 0.f;
+    int nbins = 0;
+    for (int l = 0; l < g.nlevels; ++l) nbins += g.sizes[l] * g.sizes[l];
+    if (g.C % 64 == 0 && nbins <= 64) {
+      // a wavefront shares (b, cy, cx): lane q decides once whether bin q (levels in order, (ii, j) row-major inside a level) contains the cell and with which weight;
+      // the loop reads the 50 decisions back lane by lane -- every thread walked all bins with their integer divisions before (the launch was bound by that arithmetic)
+      const int lane = threadIdx.x & 63;
+      float wq = 0.f; int rowq = 0;
+      {
+        int q = lane, l = 0;
+        while (l < g.nlevels && q >= g.sizes[l] * g.sizes[l]) { q -= g.sizes[l] * g.sizes[l]; ++l; }
+        if (l < g.nlevels) {
+          const int s = g.sizes[l], ii = q / s, j = q - ii * s;
+          const int ys = d_bin_start(ii, g.H, s), ye = d_bin_end(ii, g.H, s), xs = d_bin_start(j, g.W, s), xe = d_bin_end(j, g.W, s);
+          if (!(y0 < ys || y1 > ye) && !(x0 < xs || x1 > xe)) { wq = 1.f / (float)((ye - ys) * (xe - xs)); rowq = g.rowoff[l] + (b * s + ii) * s + j; }
+        }
+      }
+      for (int q = 0; q < nbins; ++q) {
+        const float w = __shfl(wq, q, 64);
+        if (w == 0.f) continue;
+        acc += dpooled[(size_t)__shfl(rowq, q, 64) * g.C + c] * w;
+      }
+      gcell[i] = acc;
+      continue;
+    }
     for (int l = 0; l < g.nlevels; ++l) {
       const int s = g.sizes[l];
       for (int ii = 0; ii < s; ++ii) {
