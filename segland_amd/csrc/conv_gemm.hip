@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef SL_CH3_SPLIT
+#define SL_CH3_SPLIT 2
+#endif
 namespace {
 
 struct ConvGemmParams {
@@ -39,7 +42,7 @@ struct ConvGemmParams {
   int M;
   int gridM, gridN;
   int tile16;                           // patch kernel: row block bm is a 16 x 16-pixel tile (b, y0 / 16, x0 / 16), its 256 rows are 16 segments of 16 pixels
-  int flags;                            // p8: bit 0 = counted first wait (SEGLAND_P8_COUNTED, default on)
+  int flags;                            // p8: bit 0 = counted first wait (SEGLAND_P8_COUNTED, default on); bit 1 = generic store phase instead of conv_epilogue_affine (SEGLAND_CONV_AFFINE=0 / sl_debug_conv_affine: A/B and the bit-identity test)
   unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
 
@@ -365,7 +368,7 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
         mu[e] = (f2_t){p.bn_mean[ncol + 2 * e], p.bn_mean[ncol + 2 * e + 1]};
         is[e] = (f2_t){p.bn_invstd[ncol + 2 * e], p.bn_invstd[ncol + 2 * e + 1]};
       }
-      constexpr int CH3 = SPLIT ? 2 : CH;          // the persistent half-tile kernel is at its register limit: two rows in flight there
+      constexpr int CH3 = SPLIT ? SL_CH3_SPLIT : CH;          // the persistent half-tile kernel is at its register limit: few rows in flight there
 #pragma unroll 1
       for (int it0 = 0; it0 < NIT; it0 += CH3) {
         uint4 xv[CH3]; unsigned bits[CH3];
@@ -617,7 +620,7 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
     return SPLIT ? (p.addend_mask ? 48 : 32) : -1;                      // per sweep: addend load (+ gate byte) + store
   }
   if constexpr (!SPLIT) {
-    if (full && (p.bias || p.scale) && !p.mask_src && !p.pre_addend && !p.addend_mask && !p.stat_partial && !p.tile16) {
+    if (full && (p.bias || p.scale) && !p.mask_src && !p.pre_addend && !p.addend_mask && !p.stat_partial && !p.tile16 && !(p.flags & 2)) {
       const bool sr = p.scale || p.relu;              // eval-mode BatchNorm folded into the conv (+ residual + ReLU); the Swin linears have neither
       if (p.out2) {
         if (!p.addend && !p.row_scale && !sr) { conv_epilogue_affine<T, BM, BN, WM, WN, false, false, true, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
@@ -2230,7 +2233,10 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   return launch_glds<T, 128, 64, 2, 2>(p, st);
 }
 
+int g_conv_affine = -1;    // 1 (default): branch-free affine store phase for biased / folded-BN epilogues; 0: the generic one everywhere
 int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
+  if (g_conv_affine < 0) { const char* e = getenv("SEGLAND_CONV_AFFINE"); g_conv_affine = (e && e[0] == '0') ? 0 : 1; }
+  if (!g_conv_affine) p.flags |= 2;
   const int bke = dtype == SL_BF16 ? 64 : 32;
   SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "conv: bad dtype %d", dtype);
   SL_REQUIRE(p.C1 > 0 && p.C1 % bke == 0 && p.C2 % bke == 0, "conv: source channels (%d,%d) must be multiples of %d", p.C1, p.C2, bke);
@@ -2255,6 +2261,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
+extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
 extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; g_conv_p9w4 = (v & 2) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off (bit 0), four-wave form (bit 1)
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 

@@ -446,3 +446,45 @@ def test_relpos_bias_tiles_of_all_blocks_in_one_launch(hip):
         t = attn.relative_position_bias_table.detach()
         assert torch.equal(tile, t[attn.relative_position_index.view(-1)].view(49, 49, -1).permute(2, 0, 1))
         assert attn.__dict__['_sl_rel'][1] is tile
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('tokens,cin,cout', [(8192, 384, 1152), (32768, 128, 384), (4096 + 96, 192, 192), (2048, 768, 768)])
+def test_affine_store_phase_equals_the_generic_one(hip, tokens, cin, cout, dtype):
+    """conv_epilogue_affine (bias / DropPath row scale / residual / GELU side output / folded BatchNorm + ReLU as branch-free template specialisations) against the generic
+    store phase of the same kernels (SEGLAND_CONV_AFFINE=0): bit-identical outputs on whole and ragged tiles, and the GELU output against torch."""
+    from segland_amd import _lib, ops
+    torch.manual_seed(tokens + cin)
+    B = 4
+    H, W = tokens // B // 16, 16
+    x = torch.randn(B, H, W, cin, device=DEV).to(dtype)
+    w = torch.randn(cout, cin, 1, 1, device=DEV) * 0.05
+    wf, _ = ops.weight_prep(w, dtype)
+    spec = ops.ConvSpec(cin, cout, 1, 1, 0, 1)
+    bias, scale = torch.randn(cout, device=DEV), torch.rand(cout, device=DEV) + 0.5
+    res = torch.randn(B, H, W, cout, device=DEV).to(dtype)
+    rs = torch.tensor([0.0, 1.25, 1.25, 0.0], device=DEV)
+    L = _lib.lib()
+
+    def run():
+        return [ops.linear_fwd(x, wf, spec, bias=bias),
+                ops.linear_fwd(x, wf, spec, bias=bias, residual=res),
+                ops.linear_fwd(x, wf, spec, bias=bias, residual=res, row_scale=rs),
+                *ops.linear_fwd(x, wf, spec, bias=bias, want_gelu=True),
+                ops.conv2d_affine_fwd(x, wf, spec, scale, bias, relu=True),
+                ops.conv2d_affine_fwd(x, wf, spec, scale, bias, residual=res, relu=True),
+                ops.conv2d_fwd(x, wf, spec, bias=bias, relu=True)[0]]
+    fast = run()
+    L.sl_debug_conv_affine(0)
+    try:
+        slow = run()
+    finally:
+        L.sl_debug_conv_affine(1)
+    for i, (a, b_) in enumerate(zip(fast, slow)):
+        assert torch.equal(a, b_), i
+    y, g = fast[3], fast[4]
+    want = F.gelu(y.float())
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+    assert float((g.float() - want).abs().max()) <= tol * float(want.abs().max())
+    ref = (x.float().view(-1, cin) @ w.view(cout, cin).to(dtype).float().t() + bias).view(B, H, W, cout)
+    assert float((fast[0].float() - ref).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 2e-3) * float(ref.abs().max())
