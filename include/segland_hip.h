@@ -126,6 +126,10 @@ int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2,
  * 1x1 layers carry the column sums in the slab-reduce launch of the weight gradient; other shapes run sl_colsum_rows_partial after it. */
 int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                               float* colsum_partial, sl_stream_t stream);
+/* The same for layers computed at zero-padded channel counts (Swin-T/S carry C = 96 at pitch 128, section 10 of DESIGN.md): the GEMM runs at d->Cout x d->Cin, dw is the
+ * PARAMETER's shape [n_valid][c_valid][KH][KW] -- the slab reduce writes only the channels that exist (no slicing copy behind it).  colsum_partial may be NULL. */
+int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
+                              size_t workspace_bytes, float* colsum_partial, sl_stream_t stream);
 /* `stream` waits for everything queued on `other` so far (event record + stream wait: legal inside a stream capture) */
 int sl_stream_join(sl_stream_t stream, sl_stream_t other);
 

@@ -448,11 +448,14 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 
 // dw_oihw[n][c][t] = sum_s ws[s][n][t][c].  One block per (n, 64-channel chunk): the taps x 64 slab values are read as
 // 256-byte rows (coalesced), transposed through LDS and written as ONE contiguous run of 64*taps floats.
+// n_valid / c_valid (all reduce kernels): output / input channels that exist in dw -- a gradient computed at zero-padded channel counts (Swin: 96 -> 128) lands in the
+// parameter's own shape [n_valid][dw_cin_total][taps] without a slicing copy behind it.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits,
-                                                           int dw_cin_total, int dw_ci_off) {
+                                                           int dw_cin_total, int dw_ci_off, int n_valid, int c_valid) {
   __shared__ float tile[64 * 49];      // [c][t], taps <= 49
   const int cchunks = Cin / 64;
   const int n = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * 64;
+  if (n >= n_valid || c0 >= c_valid) return;
   const size_t slab = (size_t)Cout * taps * Cin;
   for (int e = threadIdx.x; e < taps * 64; e += 256) {
     const int t = e / 64, c = e % 64;
@@ -463,11 +466,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
   __syncthreads();
   float* o = dw + ((size_t)n * dw_cin_total + dw_ci_off + c0) * taps;
-  for (int e = threadIdx.x; e < taps * 64; e += 256) o[e] = tile[e];
+  const int lim = taps * (c_valid - c0 < 64 ? c_valid - c0 : 64);
+  for (int e = threadIdx.x; e < lim; e += 256) o[e] = tile[e];
 }
 
 // taps == 1: the slab layout already equals OIHW
-__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits, int Cin, int dw_cin_total, int dw_ci_off) {
+__global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits, int Cin, int dw_cin_total, int dw_ci_off, int n_valid, int c_valid) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
@@ -476,7 +480,7 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __
       s2 += ws[(size_t)(k + 2) * total + e]; s3 += ws[(size_t)(k + 3) * total + e];
     }
     for (; k < splits; ++k) s0 += ws[(size_t)k * total + e];
-    dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
+    if (e / Cin < n_valid && e % Cin < c_valid) dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -485,7 +489,7 @@ __global__ void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __
 template <typename T>
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_colsum_kernel(const float* __restrict__ ws, float* __restrict__ dw, long long total, int splits, int Cin, int dw_cin_total,
                                                                        int dw_ci_off, int nred, const T* __restrict__ dy, long long rows, int Cout, long long rows_per_block,
-                                                                       float* __restrict__ colsum_part) {
+                                                                       float* __restrict__ colsum_part, int n_valid, int c_valid) {
   __shared__ float red[256 * Vec16<T>::N];
   if ((int)blockIdx.x >= nred) { sl_colsum_rows_block<T>(dy, rows, Cout, rows_per_block, colsum_part, (int)blockIdx.x - nred, red); return; }
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)nred * blockDim.x) {
@@ -496,19 +500,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_colsum_kernel(const flo
       s2 += ws[(size_t)(k + 2) * total + e]; s3 += ws[(size_t)(k + 3) * total + e];
     }
     for (; k < splits; ++k) s0 += ws[(size_t)k * total + e];
-    dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
+    if (e / Cin < n_valid && e % Cin < c_valid) dw[(e / Cin) * dw_cin_total + dw_ci_off + (e % Cin)] = (s0 + s1) + (s2 + s3);
   }
 }
 
 // paired rows (plan(): 64-channel layers): slab = [2*Cout][taps][2*Cin]; the weight gradient is the sum of the two parity-diagonal blocks
-__global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits, int dw_cin_total, int dw_ci_off) {
+__global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits, int dw_cin_total, int dw_ci_off, int n_valid, int c_valid) {
   const long long total = (long long)Cout * Cin * taps, slab = 4 * total;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const int t = (int)(e % taps), c = (int)((e / taps) % Cin), n = (int)(e / ((long long)taps * Cin));
     const size_t o0 = ((size_t)n * taps + t) * (2 * Cin) + c, o1 = ((size_t)(Cout + n) * taps + t) * (2 * Cin) + Cin + c;
     float s0 = 0.f, s1 = 0.f;
     for (int k = 0; k < splits; ++k) { s0 += ws[(size_t)k * slab + o0]; s1 += ws[(size_t)k * slab + o1]; }
-    dw[((size_t)n * dw_cin_total + dw_ci_off + c) * taps + t] = s0 + s1;
+    if (n < n_valid && c < c_valid) dw[((size_t)n * dw_cin_total + dw_ci_off + c) * taps + t] = s0 + s1;
   }
 }
 
@@ -950,7 +954,7 @@ extern "C" int sl_stream_join(sl_stream_t stream, sl_stream_t other) {
 
 // dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial);
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial, int n_valid = 0, int c_valid = 0);
 
 extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                         int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream) {
@@ -965,9 +969,18 @@ extern "C" int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, con
   return bwd_weight_impl(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream, nullptr, colsum_partial);
 }
 
+// The same at zero-padded channel counts: the problem is d->Cout x d->Cin (multiples of 64), dw is the parameter's own [n_valid][c_valid][KH][KW]; colsum_partial may be null.
+extern "C" int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
+                                         size_t workspace_bytes, float* colsum_partial, sl_stream_t stream) {
+  SL_REQUIRE(d && n_valid > 0 && c_valid > 0 && n_valid <= d->Cout && c_valid <= d->Cin, "conv bwd_weight_clip: bad valid channel counts");
+  return bwd_weight_impl(d, x, x2, dy, dw, c_valid, 0, workspace, workspace_bytes, stream, nullptr, colsum_partial, n_valid, c_valid);
+}
+
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial) {
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial, int n_valid, int c_valid) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
+  const int nv = n_valid > 0 ? n_valid : d->Cout, cv = c_valid > 0 ? c_valid : d->Cin;
+  SL_REQUIRE(nv <= d->Cout && cv <= d->Cin, "conv bwd_weight: valid channel counts exceed the (padded) problem");
   // column sums of dy by the stand-alone kernel: every path below that does not carry them in its reduce launch
   auto colsum_separately = [&]() -> int {
     if (!colsum_partial) return 0;
@@ -987,14 +1000,14 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     return (hipStream_t)reduce_stream;
   };
   auto reduced = [&]() { if (forked) { (void)hipEventRecord(g_fork.red_done, (hipStream_t)reduce_stream); g_fork.pending = true; } };
-  SL_REQUIRE(dw_ci_off >= 0 && dw_ci_off + d->Cin <= dw_cin_total, "conv bwd_weight: bad dw channel window");
+  SL_REQUIRE(dw_ci_off >= 0 && dw_ci_off + cv <= dw_cin_total, "conv bwd_weight: bad dw channel window");
   const int bke = d->dtype == SL_BF16 ? 64 : 32;
   const int c2 = d->Cin - d->C1;
   SL_REQUIRE(d->dtype == SL_BF16 || d->dtype == SL_F32, "conv bwd_weight: bad dtype");
   SL_REQUIRE(d->Cout % 64 == 0 && d->C1 % 64 == 0 && c2 % 64 == 0, "conv bwd_weight: channels must be multiples of 64 (Cout %d, C1 %d, C2 %d)", d->Cout, d->C1, c2);
   (void)bke;
   SL_REQUIRE(c2 == 0 || x2, "conv bwd_weight: x2 missing");
-  if (c64k3_eligible(d, dw_cin_total, dw_ci_off) && use_tr()) {
+  if (c64k3_eligible(d, dw_cin_total, dw_ci_off) && use_tr() && nv == d->Cout && cv == d->Cin) {
     const int nblk = c64k3_blocks(d), ntiles = d->B * cdiv(d->H, C3_T) * cdiv(d->W, C3_T);
     const size_t need = (size_t)(nblk + 1) * 64 * 64 * 9 * sizeof(float);         // nblk slabs + their sum
     if (workspace_bytes < need) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
@@ -1006,7 +1019,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     float* sum = (float*)workspace + (size_t)nblk * 64 * 64 * 9;
     hipStream_t rs = fork();
     if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, (sl_stream_t)rs)) return e;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, rs, (const float*)sum, dw, 64, 64, 9, 1, 64, 0);      // [n][tap][c] -> OIHW
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, rs, (const float*)sum, dw, 64, 64, 9, 1, 64, 0, 64, 64);      // [n][tap][c] -> OIHW
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
     reduced();
     return colsum_separately();
@@ -1027,7 +1040,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     float* sum = (float*)workspace + (size_t)nslab * total;
     hipStream_t rs = fork();
     if (int e = sl_colsum_finalize((const float*)workspace, nslab, (int)total, sum, (sl_stream_t)rs)) return e;          // fixed-order column sums over the slabs (one block per 64 numbers)
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off, nv, cv);
     SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
     reduced();
     return colsum_separately();
@@ -1052,7 +1065,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   st = fork();
   if (pl.pair) {
     const long long total = (long long)d->Cout * d->Cin * pl.taps;
-    hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off, nv, cv);
   } else if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
     const int nred = (int)((total + 255) / 256);
@@ -1061,17 +1074,17 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
       const int ncol = (int)((rows + ch - 1) / ch);
       if (d->dtype == SL_BF16)
         hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<bf16_t>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
-                           nred, (const bf16_t*)dy, rows, d->Cout, ch, colsum_partial);
+                           nred, (const bf16_t*)dy, rows, d->Cout, ch, colsum_partial, nv, cv);
       else
         hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<float>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
-                           nred, (const float*)dy, rows, d->Cout, ch, colsum_partial);
+                           nred, (const float*)dy, rows, d->Cout, ch, colsum_partial, nv, cv);
       SL_LAUNCH_CHECK("wgrad_reduce_flat_colsum_kernel");
       reduced();
       return 0;
     }
-    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)nred), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off);
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)nred), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off, nv, cv);
   } else {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off, nv, cv);
   }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
   reduced();

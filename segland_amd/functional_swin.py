@@ -197,13 +197,19 @@ def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=No
     dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
     dw = db = None
     if need_w:
+        clip = col_map is None and x2 is None and L.K < L.spec.cin          # zero-padded input channels: the reduce writes the parameter's shape, no slicing copy
         if L.bias is not None:
-            dwp, db = ops.conv2d_bwd_weight_bias(x, dy, L.spec, x2=x2, batch=batch)       # bias gradient in the weight gradient's reduce launch
+            if clip:
+                dwp, db = ops.conv2d_bwd_weight_clip(x, dy, L.spec, L.N, L.K, want_bias=True, batch=batch)
+            else:
+                dwp, db = ops.conv2d_bwd_weight_bias(x, dy, L.spec, x2=x2, batch=batch)       # bias gradient in the weight gradient's reduce launch
             db = db[:L.N]
             db = db.contiguous() if batch is None else db
+        elif clip:
+            dwp = ops.conv2d_bwd_weight_clip(x, dy, L.spec, L.N, L.K)
         else:
             dwp = ops.conv2d_bwd_weight(x, dy, L.spec, x2=x2)
-        dw = (dwp[:L.N].index_select(1, col_map) if col_map is not None else dwp[:L.N, :L.K]).contiguous()
+        dw = dwp if clip else (dwp[:L.N].index_select(1, col_map) if col_map is not None else dwp[:L.N, :L.K]).contiguous()
         if L.k == 1:
             dw = dw.view(L.N, L.K) if dw.shape[1] == L.K else dw
     return dx, dw, db

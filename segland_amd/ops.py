@@ -358,6 +358,31 @@ def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
     return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
 
 
+def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=False, batch=None):
+    """dw in the PARAMETER's shape [n_valid][c_valid][k][k] of a layer computed at zero-padded channel counts (spec.cout x spec.cin): the slab reduce writes only the
+    channels that exist.  want_bias: also the bias gradient (padded length spec.cout; batch as in conv2d_bwd_weight_bias)."""
+    B, H, W, C1 = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
+    L = _lib.lib()
+    need = L.sl_conv2d_bwd_weight_workspace(C.byref(d))
+    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
+    if cur is not None and cur.numel() < need:
+        wgrad_reduce_join()
+    ws = workspace(need, x.device, 'wgrad')
+    dw = torch.empty((n_valid, c_valid, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    part = None
+    if want_bias:
+        Cn = dy.shape[-1]
+        assert Cn == spec.cout and dy.is_contiguous()
+        part = _f32((L.sl_colsum_rows_blocks(dy.numel() // Cn, Cn, dt(dy)), Cn), dy.device)
+    tok = PROFILER.begin('conv_wgrad', d)
+    check(L.sl_conv2d_bwd_weight_clip(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_clip')
+    PROFILER.end(tok)
+    if not want_bias:
+        return dw
+    return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
+
+
 def wgrad_reduce_join():
     """The current stream waits for every slab reduce issued on the second stream so far."""
     if _red_pending[0]:

@@ -488,3 +488,20 @@ def test_affine_store_phase_equals_the_generic_one(hip, tokens, cin, cout, dtype
     assert float((g.float() - want).abs().max()) <= tol * float(want.abs().max())
     ref = (x.float().view(-1, cin) @ w.view(cout, cin).to(dtype).float().t() + bias).view(B, H, W, cout)
     assert float((fast[0].float() - ref).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 2e-3) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('hw,cin,cout,k,nv,cv', [(64, 128, 128, 1, 96, 96), (128, 128, 128, 1, 96, 96), (32, 128, 384, 1, 288, 96), (32, 128, 128, 3, 96, 96), (16, 256, 128, 3, 128, 192)])
+def test_weight_gradient_in_the_parameters_shape(hip, hw, cin, cout, k, nv, cv):
+    """sl_conv2d_bwd_weight_clip (a layer computed at zero-padded channel counts; the slab reduce writes only the channels that exist) against the padded gradient sliced
+    afterwards: bit-identical, with and without the bias gradient riding along."""
+    from segland_amd import ops
+    torch.manual_seed(hw + cin + k)
+    B = 4
+    x = torch.randn(B, hw, hw, cin, device=DEV).to(torch.bfloat16)
+    dy = torch.randn(B, hw, hw, cout, device=DEV).to(torch.bfloat16)
+    spec = ops.ConvSpec(cin, cout, k, 1, k // 2, 1)
+    full = ops.conv2d_bwd_weight(x, dy, spec).clone()
+    got = ops.conv2d_bwd_weight_clip(x, dy, spec, nv, cv)
+    assert tuple(got.shape) == (nv, cv, k, k) and torch.equal(got, full[:nv, :cv])
+    got2, db = ops.conv2d_bwd_weight_clip(x, dy, spec, nv, cv, want_bias=True)
+    assert torch.equal(got2, full[:nv, :cv]) and torch.equal(db, ops.colsum_rows(dy))
