@@ -311,7 +311,7 @@ def main():
                                    '(fwd+loss+bwd+clip+AdamW x%d), %d x MI355X' % (a.backbone, a.dtype, a.batch, a.size, a.size, 2 if double else 1, world),
                        'global_batch': a.batch * world, 'parallelism': 'dp%d' % world},
             'whole_step_tflops': round(value * GFLOP_PER_TILE.get(a.backbone, 0) / 1e3, 1),
-            'step_issue': (('three HIP graph replays (forward + backward to the cut, rest of the backward, clip + AdamW) around the RCCL all-reduces of the gradient buckets (segland_amd/bucket_step.py, the train_base default at N > 1)' if replica is not None
+            'step_issue': ((('three HIP graph replays (forward + backward to the cut, rest of the backward, clip + AdamW)' if replica.cut else 'two HIP graph replays (forward + backward, clip + AdamW)') + ' around the RCCL all-reduces of the gradient buckets (segland_amd/bucket_step.py, the train_base default at N > 1)' if replica is not None
                             else 'one HIP graph replay per step (segland_amd/graph_step.py, the train_base default on one GPU)') if graphed is not None
                            else 'kernel by kernel from Python' + (' under DistributedDataParallel / RCCL' if use_ddp else '')),
         }
