@@ -21,6 +21,34 @@ template <int LPR> __device__ __forceinline__ float across_groups(float v) {  //
   return v;
 }
 
+// KM per-lane partial sums (one per prototype) -> the KM row totals, every lane of the LPR-lane row group holding all of them.  A plain tree is KM x log2(LPR) shuffles (48 at
+// KM = 8, LPR = 64 -- these kernels were bound by the LDS pipe that serves ds_bpermute).  Here each step halves the values a lane carries (the lane keeps the half chosen by its
+// lane bit and sends the other): KM / 2 + KM / 4 + ... + 1 shuffles, then plain steps on the single value left, then KM broadcasts: 10 + 8 at KM = 8, LPR = 64.
+template <int LPR, int KM>
+__device__ __forceinline__ void group_sum_multi(float (&d)[KM], int lane) {
+  static_assert((KM & (KM - 1)) == 0 && KM <= LPR, "power-of-two prototype slots, not more than lanes per row");
+  float cur[KM];
+#pragma unroll
+  for (int k = 0; k < KM; ++k) cur[k] = d[k];
+  int ofs = LPR / 2;
+#pragma unroll
+  for (int n = KM; n > 1; n >>= 1, ofs >>= 1) {          // n values -> n / 2: bit `ofs` of the lane picks the upper half
+    const bool up = (lane & ofs) != 0;
+#pragma unroll
+    for (int i = 0; i < n / 2; ++i) {
+      const float mine = up ? cur[n / 2 + i] : cur[i], send = up ? cur[i] : cur[n / 2 + i];
+      cur[i] = mine + __shfl_xor(send, ofs, 64);
+    }
+  }
+  float r = cur[0];
+#pragma unroll
+  for (; ofs > 0; ofs >>= 1) r += __shfl_xor(r, ofs, 64);
+  // lanes whose upper log2(KM) bits (inside the row group) spell k hold total k: lane index inside the group = k * (LPR / KM) + anything
+  const int base = lane & ~(LPR - 1);
+#pragma unroll
+  for (int k = 0; k < KM; ++k) d[k] = __shfl(r, base + k * (LPR / KM), 64);
+}
+
 // prototype rows into the LDS, zero beyond the n valid floats: N floats (a multiple of 1024) as float4 loads that are all in flight before the first LDS store
 // (a scalar load -> store loop was 16 dependent memory round trips at the top of every block)
 template <int N>
@@ -46,6 +74,16 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
   pop_fill_protos<KM * LPR * NV * V>(S, Kt * C, Sl);
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
+  constexpr bool SREG = KM * NV * V <= 64;               // 64 registers: 8 prototypes x 8 channels per lane (the 512-channel head), 8 x 8 at 128 channels / 16 lanes
+  float sreg[SREG ? KM : 1][NV * V];
+  if constexpr (SREG) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < V; ++e) sreg[k][j * V + e] = Sl[k * C + (j * LPR + sub) * V + e];
+  }
   // the next row's vectors are loaded while the current row is reduced: one row per wave and iteration was a chain load -> dot -> shuffle tree -> store per row
   const long long rstep = gridDim.x * 4LL * RPW;
   uint4 nxt[NV];
@@ -65,7 +103,7 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < NV; ++j) nxt[j] = (rb + rstep < R && rn < R) ? *(const uint4*)(feats + (size_t)rn * C + (j * LPR + sub) * V) : make_uint4(0, 0, 0, 0);
     }
-    // all projections first (they use q, not the running residual): KM independent shuffle reductions in flight instead of a chain of Kt x log2(LPR)
+    // all projections first (they use q, not the running residual); the lane's slice of the prototypes lives in registers when it fits (SREG)
     float d[KM];
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
@@ -73,13 +111,10 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < V; ++e) a = fmaf(q[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], a);
+        for (int e = 0; e < V; ++e) a = fmaf(q[j * V + e], SREG ? sreg[k][j * V + e] : Sl[k * C + (j * LPR + sub) * V + e], a);
       d[k] = a;
     }
-#pragma unroll
-    for (int ofs = LPR / 2; ofs > 0; ofs >>= 1)
-#pragma unroll
-      for (int k = 0; k < KM; ++k) d[k] += __shfl_xor(d[k], ofs, 64);
+    group_sum_multi<LPR, KM>(d, lane);
 #pragma unroll
     for (int e = 0; e < NV * V; ++e) o[e] = q[e];
 #pragma unroll
@@ -89,7 +124,7 @@ __global__ __launch_bounds__(256) void pop_decompose_fwd_kernel(const T* __restr
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
-          for (int e = 0; e < V; ++e) o[j * V + e] -= d[k] * Sl[k * C + (j * LPR + sub) * V + e];
+          for (int e = 0; e < V; ++e) o[j * V + e] -= d[k] * (SREG ? sreg[k][j * V + e] : Sl[k * C + (j * LPR + sub) * V + e]);
       }
     }
     if (live) {
@@ -332,6 +367,14 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
   for (int k = 0; k < KM; ++k)
 #pragma unroll
     for (int e = 0; e < CL; ++e) acc[k][e] = 0.f;
+  constexpr bool SREG = KM * CL <= 64;                    // the lane's slice of the prototypes in registers (8 prototypes x 8 channels)
+  float sreg[SREG ? KM : 1][CL];
+  if constexpr (SREG) {
+#pragma unroll
+    for (int k = 0; k < KM; ++k)
+#pragma unroll
+      for (int e = 0; e < CL; ++e) sreg[k][e] = Sl[k * C + ((e / V) * LPR + sub) * V + (e % V)];
+  }
   const long long r0 = blockIdx.x * rows_per_blk;
   long long r1 = r0 + rows_per_blk; if (r1 > R) r1 = R;
   for (long long rb = r0 + wave * RPW; rb < r1; rb += 4 * RPW) {
@@ -350,23 +393,28 @@ __global__ __launch_bounds__(256) void pop_decompose_bwd_kernel(const T* __restr
     }
 #pragma unroll
     for (int e = 0; e < CL; ++e) o[e] = g[e];
+    // all KM dot products first, one transposed reduction for them (group_sum_multi), then the updates: the chain dot -> shuffle tree -> update per prototype
+    // was KM dependent trees per row
+    float d[KM], tp[KM], pp[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < CL; ++e) a = fmaf(g[e], SREG ? sreg[k][e] : Sl[k * C + ((e / V) * LPR + sub) * V + (e % V)], a);
+      d[k] = a;
+      tp[k] = (live && k < Kt) ? dproj[(size_t)r * Kt + k] : 0.f;
+      pp[k] = (live && k < Kt) ? proj[(size_t)r * Kt + k] : 0.f;
+    }
+    group_sum_multi<LPR, KM>(d, lane);
 #pragma unroll
     for (int k = 0; k < KM; ++k) {
       if (k < Kt) {
-        float d = 0.f;
+        const float t = live ? tp[k] - d[k] : 0.f, p = pp[k];
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-          for (int e = 0; e < V; ++e) d = fmaf(g[j * V + e], Sl[k * C + (j * LPR + sub) * V + e], d);
-        d = group_sum<LPR>(d);
-        const float t = live ? dproj[(size_t)r * Kt + k] - d : 0.f, p = live ? proj[(size_t)r * Kt + k] : 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j)
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            o[j * V + e] = fmaf(t, Sl[k * C + (j * LPR + sub) * V + e], o[j * V + e]);
-            acc[k][j * V + e] += t * q[j * V + e] - p * g[j * V + e];
-          }
+        for (int e = 0; e < CL; ++e) {
+          o[e] = fmaf(t, SREG ? sreg[k][e] : Sl[k * C + ((e / V) * LPR + sub) * V + (e % V)], o[e]);
+          acc[k][e] += t * q[e] - p * g[e];
+        }
       }
     }
     if (live) {
