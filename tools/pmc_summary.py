@@ -8,7 +8,7 @@ for name, did, d, cn, cv in rows:
     n = re.sub(r'\(anonymous namespace\)::', '', name); n = re.sub(r'^void ', '', n)[:70]
     agg[n][cn].append(cv); dur[n].append(d)
 for n in agg:
-    if 'conv' not in n and 'wgrad' not in n: continue
+    if not any(k in n for k in (sys.argv[2:] or ['conv', 'wgrad'])): continue
     print('==', n)
     for cn, v in sorted(agg[n].items()):
         print('   %-28s mean %14.1f  (n=%d)' % (cn, sum(v) / len(v), len(v)))
