@@ -10,15 +10,13 @@ for r in rows:
     cur.append(r)
     if 'adamw_multi_kernel' in r[0]:
         steps.append(cur); cur = []
-# the requested step, unless the profiler stalled inside it (a trace flush shows up as millisecond gaps between graph nodes): then the neighbour with the median wall time of the
-# graph-replayed steps (the second half of the run) is shown instead and the header says so
+# the requested step, unless the profiler stalled inside it (a trace flush shows up as gaps of tens of microseconds to milliseconds between graph nodes): then the step with the
+# shortest wall time among the graph-replayed steps (the second half of the run) is shown instead and the header says so
 def wall(st): return (st[-1][2] - st[0][1]) / 1e3
-half = steps[len(steps) // 2:]
-med = sorted(wall(st) for st in half)[len(half) // 2]
+cand = min(range(len(steps) // 2, len(steps)), key=lambda i: wall(steps[i]))
 note = ''
-if wall(steps[which]) > 1.05 * med:
-    cand = min(range(len(steps) // 2, len(steps)), key=lambda i: abs(wall(steps[i]) - med))
-    note = ' (step %d had a profiler stall: wall %.1f us against a median of %.1f; showing the median step)' % (which, wall(steps[which]), med)
+if wall(steps[which]) > 1.01 * wall(steps[cand]):
+    note = ' (step %d had profiler stalls: wall %.1f us; showing the shortest replayed step of the run, %d)' % (which, wall(steps[which]), cand)
     which = cand
 seq = steps[which]
 def short(n):
