@@ -144,14 +144,40 @@ def cpu_baseline(budget_s, backbone, model='pspnet_pop'):
                       '%d threads (cgroup/affinity limit) on %s' % (backbone, size, size, t, threads, cpu)}
 
 
+def visible_gpus():
+    """GPUs a child rank would see, counted WITHOUT a HIP call in this process: the KFD topology nodes that have SIMDs, cut down by
+    ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set.  None when the topology is not readable (the pre-check is then skipped and
+    a wrong rank count fails in the children).  torch.cuda.device_count() is NOT used: on ROCm without amdsmi it calls hipGetDeviceCount, which brings the
+    HIP / HSA runtime up in the parent (round-3 advisor)."""
+    import glob
+    if not os.path.isdir('/sys/class/kfd/kfd/topology/nodes'):
+        return 0                                            # no KFD driver on this host: no AMD GPU for any child either
+    n = 0
+    try:
+        for f in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+            for line in open(f):
+                if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                    n += 1
+    except OSError:
+        return None
+    if n == 0:
+        return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def self_launch(n, argv=None):
     """`python bench.py --gpus N` as a plain command (no launcher): start the N ranks as FRESH child processes of
-    `python -m torch.distributed.run` -- before this process has made any GPU call (a process that initialised the GPU must never exec or
-    become a rank) -- and pass rank 0's JSON line through.  Returns the exit code.  torch.cuda.device_count() does not initialise the GPU."""
+    `python -m torch.distributed.run` and pass rank 0's JSON line through.  Returns the exit code.  The parent makes no GPU call at all -- a process that
+    initialised the GPU must never exec or become a rank, and it would keep a runtime handle open beside the N ranks: the devices are counted from
+    sysfs (visible_gpus)."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
-    if have < n:
+    have = visible_gpus()
+    if have is not None and have < n:
         print('bench.py --gpus %d: this node exposes %d GPU(s); one rank per GPU is required (RCCL refuses two ranks on one device). '
               'Run with --gpus %d or fewer.' % (n, have, max(have, 1)), file=sys.stderr, flush=True)
         return 3

@@ -115,12 +115,6 @@ int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, con
 /* the same, writing into a WIDER gradient tensor dw [Cout][dw_cin_total][KH][KW] at input-channel offset dw_ci_off */
 int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                             int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
-/* the same with the fixed-order slab reduce issued on `reduce_stream` (NULL or == stream: everything on `stream`).  The library orders the two streams with two
- * lazily created events (MFMA kernel -> reduce; reduce -> the next weight gradient's use of the workspace); the caller makes `stream` wait for the reduces
- * with sl_stream_join(stream, reduce_stream) before dw is consumed and before `workspace` is used by anything but the next weight gradient. */
-int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                             int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream);
-
 /* Weight gradient and the bias gradient's column-sum partials of one nn.Linear / biased conv (swintransformer.py:40-52 Mlp, :95-98 qkv / proj: the autograd of F.linear
  * yields dW = dy^T x and db = sum_rows dy).  colsum_partial: float [sl_colsum_rows_blocks(B*Ho*Wo, Cout, dtype)][Cout]; finalize with sl_colsum_finalize(_multi).
  * 1x1 layers carry the column sums in the slab-reduce launch of the weight gradient; other shapes run sl_colsum_rows_partial after it. */
@@ -130,9 +124,6 @@ int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2
  * PARAMETER's shape [n_valid][c_valid][KH][KW] -- the slab reduce writes only the channels that exist (no slicing copy behind it).  colsum_partial may be NULL. */
 int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
                               size_t workspace_bytes, float* colsum_partial, sl_stream_t stream);
-/* `stream` waits for everything queued on `other` so far (event record + stream wait: legal inside a stream capture) */
-int sl_stream_join(sl_stream_t stream, sl_stream_t other);
-
 /* OIHW float master weight -> w_fwd [Cout][KH][KW][Cin] and/or w_bwd [Cin][KH][KW][Cout] in dtype (either may be NULL) */
 int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,
                    sl_stream_t stream);
@@ -269,6 +260,9 @@ int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S, int Kt, f
  * (eps 1e-12), G [Ka][Ka+Kb] = Sa [Sa ; Sb]^T, orth[0] = mean |G[i][j]| over j > i, inv_norm [Ka+Kb] for the backward.  Kb may be 0 (base training: G = S S^T). */
 int sl_pop_proto_fwd(const float* Ea, int Ka, const float* Eb, int Kb, int C, float* Sa, float* Sb, float* inv_norm, float* G, float* orth,
                      sl_stream_t stream);
+/* 1 when sl_pop_proto_fwd AND sl_pop_proto_bwd serve (Ka, Kb, C) -- both are one-block kernels with everything in the LDS, the backward needs about twice the
+ * forward's -- else 0: the caller then evaluates pspnet_pop.py:96-99,185-186 / criterion.py:37-43 with its own tensor ops (GFSS_Model._protos). */
+int sl_pop_proto_ok(int Ka, int Kb, int C);
 /* gradients wrt Ea / Eb (either may be NULL) from dSa / dSb (may be NULL = zero) and the scalar dorth (may be NULL) */
 int sl_pop_proto_bwd(const float* Sa, int Ka, const float* Sb, int Kb, int C, const float* inv_norm, const float* G, const float* dSa,
                      const float* dSb, const float* dorth, float* dEa, float* dEb, sl_stream_t stream);

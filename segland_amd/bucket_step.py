@@ -12,8 +12,13 @@ averaged over the ranks, `module.`-prefixed state_dict) with a structure that ne
     eager     SUM all-reduce of the early buckets; the current stream then waits for all of them (RCCL over xGMI; nothing of RCCL is captured)
     graph B   gradient-norm clip + both AdamW steps of the loop body; the 1 / world_size of the mean lives in the optimizer kernel
 
-The parameter-gradient exchange is the path's only collective.  Per-GPU BatchNorm statistics only: SyncBatchNorm's per-layer
-collectives (SEGLAND_SYNC_BN=1) cannot sit inside a captured forward, `eligible()` says no and the caller keeps DistributedDataParallel.
+The parameter-gradient exchange is the path's only collective with per-GPU BatchNorm statistics (the default).  SyncBatchNorm's per-layer
+collectives (SEGLAND_SYNC_BN=1: the reference's distributed semantics, train_base.py:175-178) cannot sit inside a captured forward: the replica is used all the
+same -- same buckets, same in-place gradients, same collectives around the two backward halves -- but `GraphedBucketStep` then issues every step kernel by kernel
+(`capturable()` says why) instead of handing the job to DistributedDataParallel's reducer.
+Capturing is a COLLECTIVE decision: the three parts are captured back to back without running anything and without any collective, the ranks then agree (MIN
+all-reduce of a success flag) and either all replay or all stay kernel by kernel -- a rank whose capture failed alone would otherwise issue the step's all-reduces
+a second time while the others issue them once (round-3 advisor).
 Exposed communication: the early buckets only (34 MB for ResNet-50 against 190 MB without the cut, SEGLAND_BUCKET_CUT=0); the DistributedDataParallel wrapper
 costs 2-3 % at any world size.  SEGLAND_BUCKET_STEP=0 keeps DistributedDataParallel with the in-place bucket gradients of
 engine.enable_inplace_bucket_gradients."""
@@ -27,10 +32,17 @@ from . import graph_step
 
 
 def eligible(world_size, use_cuda):
-    """Bucketed replicas instead of DistributedDataParallel: GPU, per-GPU BatchNorm statistics, not switched off."""
+    """Bucketed replicas instead of DistributedDataParallel: GPU, not switched off.  (With SEGLAND_SYNC_BN=1 the replica's step is issued kernel by kernel.)"""
+    return use_cuda and os.environ.get('SEGLAND_BUCKET_STEP', '1') != '0' and os.environ.get('SEGLAND_STEP_GRAPH', '1') != '0'
+
+
+def capturable(module):
+    """None when the replica's step can be captured, else the reason it is issued kernel by kernel: a forward / backward that contains collectives of its own
+    (SyncBatchNorm statistics, functional.sync_world) cannot be a HIP graph on this stack -- nothing of RCCL is captured."""
     from . import functional
-    return (use_cuda and os.environ.get('SEGLAND_BUCKET_STEP', '1') != '0' and os.environ.get('SEGLAND_STEP_GRAPH', '1') != '0'
-            and functional._SYNC_BN == '0')
+    if functional._SYNC_BN != '0' and any(isinstance(m, nn.SyncBatchNorm) for m in module.modules()):
+        return 'SEGLAND_SYNC_BN=%s: SyncBatchNorm all-reduces inside the forward and the backward' % functional._SYNC_BN
+    return None
 
 
 class BucketedReplica(nn.Module):
@@ -184,18 +196,28 @@ class BucketedReplica(nn.Module):
             return norm
         return backward_late, backward_early, update_part
 
-    def _run(self, parts, img, mask, call):
-        """The step with the all-reduce of the late buckets issued between the two backward halves (travelling beside the second one)."""
+    def _run(self, parts, img, mask, call, collectives=True):
+        """The step with the all-reduce of the late buckets issued between the two backward halves (travelling beside the second one).
+        collectives=False: the parts only, in order (GraphedBucketStep captures them back to back: nothing runs, so there is nothing to exchange)."""
         bwd1, bwd2, upd = parts
         loss = call(bwd1, img, mask)
         two = self.cut and self.late_buckets < len(self.buckets)
-        works = self.all_reduce('late' if two else None, async_op=True)
+        works = self.all_reduce('late' if two else None, async_op=True) if collectives else []
         if two:
             call(bwd2)
-            works += self.all_reduce('early', async_op=True)
+            if collectives:
+                works += self.all_reduce('early', async_op=True)
         for w in works:
             w.wait()
         return loss, call(upd)
+
+    def agree(self, ok):
+        """True when EVERY rank says ok (MIN all-reduce of one flag; one host read-back, used once per capture attempt)."""
+        if not self.active:
+            return bool(ok)
+        flag = torch.full((1,), 1.0 if ok else 0.0, dtype=torch.float32, device=self.buckets[0].device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item() > 0.5)
 
     def train_iteration(self, optimizer, img, mask, double_step=True):
         """The loop body of train_base.py:250-264 issued kernel by kernel (what GraphedBucketStep replays)."""
@@ -205,7 +227,9 @@ class BucketedReplica(nn.Module):
 class GraphedBucketStep:
     """Callable with the signature and results of train_base.train_iteration for a BucketedReplica: graph A1 (forward + backward down to the cut), all-reduce of the
     late buckets (asynchronous), graph A2 (rest of the backward), all-reduce of the early buckets, graph B (clip + AdamW).  The graphs are captured together (after
-    `warmup` eager steps per input signature) and replayed in capture order from one memory pool; if any capture fails the step stays kernel by kernel."""
+    `warmup` eager steps per input signature) from one memory pool WITHOUT running and without collectives; the ranks then agree on the outcome
+    (BucketedReplica.agree) and either all replay -- the capturing step itself is the first replay -- or all issue this step and the following ones kernel by kernel
+    (two more attempts).  Every rank must see the same sequence of input signatures (DistributedSampler + drop_last, engine._loader): the attempts line up."""
 
     def __init__(self, replica, optimizer, double_step=True, warmup=3):
         self.replica, self.optimizer, self.warmup = replica, optimizer, warmup
@@ -214,6 +238,10 @@ class GraphedBucketStep:
         self.static_in, self.outs, self.static_grads = None, None, None
         self.replays, self.failures = 0, 0
         self.bn_training = True
+        self.eager_reason = capturable(replica.module)
+        if self.eager_reason is not None:
+            import logging
+            logging.getLogger('Segmentation').info('bucket_step: steps are issued kernel by kernel (%s)', self.eager_reason)
 
     def _state_key(self, tensors):
         m = self.replica
@@ -223,11 +251,11 @@ class GraphedBucketStep:
         loss, norm = self.replica._run(self.parts, img, mask, lambda f, *a: graph_step._detached(f(*a)))
         return loss, norm
 
-    def _capture(self, img, mask, key):
-        self.graphs = None
+    def _capture_graphs(self, img, mask):
+        """-> (graphs, (loss, norm)): the parts recorded in order from one pool.  Nothing executes and no collective is issued (the unit tests replace this method)."""
         self.static_in = (img.clone(), mask.clone())
         self.optimizer.capture_begin()
-        graphs, outs, pool = [], [], None
+        graphs, pool = [], None
         torch.cuda.synchronize()
 
         def call(fn, *args):
@@ -238,44 +266,53 @@ class GraphedBucketStep:
                 out = graph_step._detached(fn(*a))
             if pool is None:
                 pool = g.pool()
-            if fn is self.parts[2]:
-                self.optimizer.graph_prepare()
-            g.replay()                                # a captured part has not run: execute it before the collective / the next part that consumes it
-            graphs.append(g); outs.append(out)
+            graphs.append(g)
             return out
-        loss, norm = self.replica._run(self.parts, img, mask, call)
-        self.graphs, self.outs, self.key = graphs, (loss, norm), key
+        return graphs, self.replica._run(self.parts, img, mask, call, collectives=False)
+
+    def _capture(self, img, mask, key):
+        """One capture attempt on every rank.  True: self.graphs holds this step, not yet run."""
+        self.graphs, err = None, None
+        try:
+            graphs, outs = self._capture_graphs(img, mask)
+        except Exception as e:                            # noqa: BLE001  (whatever it was, the other ranks must hear about it)
+            graphs, outs, err = None, None, e
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        if not self.replica.agree(err is None):
+            self.graphs, self.key = None, None
+            self.failures += 1
+            graph_step.STATS['failures'] += 1
+            import logging
+            logging.getLogger('Segmentation').warning('bucket_step: capture failed on %s (%s); every rank issues this step kernel by kernel, %s',
+                                                      'this rank' if err is not None else 'another rank',
+                                                      '%s: %s' % (type(err).__name__, str(err).splitlines()[0] if str(err) else '') if err is not None else 'its log has the reason',
+                                                      'then another attempt' if self.failures < 3 else 'and all later ones')
+            if self.failures >= 3:
+                self.warmup = float('inf')
+            return False
+        self.graphs, self.outs, self.key = graphs, outs, key
         self.bn_training = any(isinstance(x, torch.nn.modules.batchnorm._BatchNorm) and x.training for x in self.replica.modules())
         self.static_grads = [(p, p.grad) for p in self.replica.parameters() if p.grad is not None]
         graph_step.STATS['captures'] += 1
-        return loss, norm
+        return True
 
     def __call__(self, img, mask):
+        if self.eager_reason is not None:
+            return self._eager(img, mask)
         key = self._state_key((img, mask))
+        fresh = False
         if key != self.key or self.graphs is None:
             n = self.seen.get(key, 0)
             if n < self.warmup:
                 self.seen[key] = n + 1
                 return self._eager(img, mask)
-            try:
-                out = self._capture(img, mask, key)
-                self._invalidate()
-                return out
-            except Exception as e:
-                # a part that was captured AND replayed before the failure has run once (forward + first half of the backward: this batch then updates the BatchNorm
-                # running statistics twice, the optimizer has not stepped); the step is redone kernel by kernel from zero_grad on
-                self.graphs, self.key = None, None
-                self.failures += 1
-                graph_step.STATS['failures'] += 1
-                torch.cuda.synchronize()
-                import logging
-                logging.getLogger('Segmentation').warning('bucket_step: capture failed (%s: %s); %s', type(e).__name__, str(e).splitlines()[0] if str(e) else '',
-                                                          'one more eager step, then another attempt' if self.failures < 3 else 'staying eager')
-                if self.failures >= 3:
-                    self.warmup = float('inf')
-                return self._eager(img, mask)
-        for dst, src in zip(self.static_in, (img, mask)):
-            dst.copy_(src, non_blocking=True)
+            if not self._capture(img, mask, key):
+                return self._eager(img, mask)             # nothing of the failed attempt has run: this is the step's one and only execution, on every rank
+            fresh = True                                  # static_in holds this batch already
+        if not fresh:
+            for dst, src in zip(self.static_in, (img, mask)):
+                dst.copy_(src, non_blocking=True)
         for p, g in self.static_grads:
             if p.grad is not g:
                 p.grad = g

@@ -42,7 +42,7 @@ struct ConvGemmParams {
   int M;
   int gridM, gridN;
   int tile16;                           // patch kernel: row block bm is a 16 x 16-pixel tile (b, y0 / 16, x0 / 16), its 256 rows are 16 segments of 16 pixels
-  int flags;                            // p8: bit 0 = counted first wait (SEGLAND_P8_COUNTED, default on); bit 1 = generic store phase instead of conv_epilogue_affine (SEGLAND_CONV_AFFINE=0 / sl_debug_conv_affine: A/B and the bit-identity test)
+  int flags;                            // p8: bit 0 = counted first wait (always set); bit 1 = generic store phase instead of conv_epilogue_affine (test hook sl_debug_conv_affine: the bit-identity test)
   unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
 
@@ -64,188 +64,6 @@ template <> struct Mma<float> {
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-template <typename T, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void conv_epilogue(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
-                                              int lane, int tid, unsigned char* smem) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  const int frow = lane & 31, fhalf = lane >> 5;
-  // ---------------------------------------------------------------- epilogue
-  // D layout (32x32): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float csum[TN], csq[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
-  T* out = (T*)p.out;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = bn * BN + wn * (BN / WN) + j * 32 + frow;
-    const float bias = p.bias ? p.bias[n] : 0.f;
-    const float scl = p.scale ? p.scale[n] : 1.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = bm * BM + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        float v = acc[i][j][r];
-        if (p.pre_addend && m < p.M) v += to_f<T>(((const T*)p.pre_addend)[(size_t)m * p.N + n]);
-        csum[j] += v; csq[j] += v * v;     // rows >= M are exact zeros (zero-filled A rows, no bias on BN convs)
-        if (m < p.M) {
-          v = v * scl + bias;
-          const size_t o = (size_t)m * p.N + n;
-          if (p.addend) {
-            float av = to_f<T>(((const T*)p.addend)[o]);
-            if (p.addend_mask) av = (p.addend_mask[o / (16 / sizeof(T))] >> (o % (16 / sizeof(T)))) & 1u ? av : 0.f;
-            v += av;
-          }
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          if (p.mask_src) v = to_f<T>(((const T*)p.mask_src)[o]) > 0.f ? v : 0.f;
-          out[o] = from_f<T>(v);
-        }
-      }
-    }
-  }
-  if (p.stat_partial) {
-    float* red = (float*)smem;   // [WM][2][BN]; tiles are dead after the final barrier of the main loop
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
-      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
-      if (fhalf == 0) {
-        const int col = wn * (BN / WN) + j * 32 + frow;
-        red[(wm * 2 + 0) * BN + col] = s;
-        red[(wm * 2 + 1) * BN + col] = q;
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < 2 * BN; e += 64 * WM * WN) {
-      const int which = e / BN, col = e % BN;
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < WM; ++w) t += red[(w * 2 + which) * BN + col];
-      p.stat_partial[((size_t)bm * 2 + which) * p.N + bn * BN + col] = t;
-    }
-  }
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmParams p) {
-  constexpr int EPC = 16 / sizeof(T);      // elements per 16-byte chunk
-  constexpr int BKE = 8 * EPC;             // elements per K-tile
-  constexpr int AR = BM / 32, BR = BN / 32;  // chunks per thread
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  static_assert(WM * WN == 4, "4 waves");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* lds_a = smem;                       // [2][BM][128]
-  unsigned char* lds_b = smem + 2 * BM * 128;        // [2][BN][128]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-
-  // XCD-aware block remap: blocks that share an A row-block run back to back on one XCD (private L2).
-  int bid = blockIdx.x;
-  {
-    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int bm = bid / p.gridN, bn = bid % p.gridN;
-
-  const int kc = tid & 7;          // chunk column handled by this thread
-  const int r0 = tid >> 3;         // first row handled (then +32, +64, ...)
-
-  // per-row destination coordinates
-  int rb[AR], ry[AR], rx[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    int m = bm * BM + r0 + 32 * i;
-    if (m < p.M) {
-      int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
-      int yd = rem / p.Wd, xd = rem - yd * p.Wd;
-      rb[i] = b;
-      if (p.mode == 0) { ry[i] = yd * p.stride - p.pad; rx[i] = xd * p.stride - p.pad; }
-      else             { ry[i] = yd + p.pad;            rx[i] = xd + p.pad; }
-    } else { rb[i] = -1; ry[i] = 0; rx[i] = 0; }
-  }
-
-  const int CT = p.C1 + p.C2;
-  const int ctiles = CT / BKE;
-  const int taps = p.KH * p.KW;
-  const int nk = taps * ctiles;
-  const T* wrow[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) wrow[i] = (const T*)p.wt + (size_t)(bn * BN + r0 + 32 * i) * taps * CT + kc * EPC;
-
-  uint4 areg[AR], breg[BR];
-  int tap = 0, ct = 0;   // K-tile counters of the NEXT tile to load
-
-  auto load_global = [&]() {
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
-    const int c0 = ct * BKE;
-    const T* base; int pitch, coff;
-    if (c0 < p.C1) { base = (const T*)p.src1; pitch = p.C1; coff = c0; }
-    else           { base = (const T*)p.src2; pitch = p.C2; coff = c0 - p.C1; }
-#pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      int ys, xs; bool ok = rb[i] >= 0;
-      if (p.mode == 0) { ys = ry[i] + ky * p.dil; xs = rx[i] + kx * p.dil; }
-      else {
-        int ty = ry[i] - ky * p.dil, tx = rx[i] - kx * p.dil;
-        ok = ok && ty >= 0 && tx >= 0;
-        if (p.stride == 1) { ys = ty; xs = tx; }
-        else { ys = ty / p.stride; xs = tx / p.stride; ok = ok && (ys * p.stride == ty) && (xs * p.stride == tx); }
-      }
-      ok = ok && (unsigned)ys < (unsigned)p.Hs && (unsigned)xs < (unsigned)p.Ws;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(base + ((size_t)(rb[i] * p.Hs + ys) * p.Ws + xs) * pitch + coff + kc * EPC);
-      areg[i] = v;
-    }
-    const size_t koff = (size_t)tap * CT + c0;
-#pragma unroll
-    for (int i = 0; i < BR; ++i) breg[i] = *(const uint4*)(wrow[i] + koff);
-    if (++ct == ctiles) { ct = 0; ++tap; }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AR; ++i) *(uint4*)(lds_a + buf * BM * 128 + lds_off(r0 + 32 * i, kc)) = areg[i];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) *(uint4*)(lds_b + buf * BN * 128 + lds_off(r0 + 32 * i, kc)) = breg[i];
-  };
-
-  f32x16_t acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  load_global();
-  store_lds(0);
-  __syncthreads();
-
-  const int frow = lane & 31, fhalf = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_global();
-    const unsigned char* la = lds_a + buf * BM * 128;
-    const unsigned char* lb = lds_b + buf * BN * 128;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *(const uint4*)(la + lds_off(wm * (BM / WM) + i * 32 + frow, 2 * s + fhalf));
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *(const uint4*)(lb + lds_off(wn * (BN / WN) + j * 32 + frow, 2 * s + fhalf));
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Mma<T>::run(af[i], bf[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) store_lds(buf ^ 1);
-    __syncthreads();
-  }
-
-  conv_epilogue<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Epilogue of the glds kernels.  The MFMAs are issued with the operand roles swapped (A = weight rows, B = pixel rows),
@@ -594,7 +412,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
 
 // GATE: this instantiation carries the gated-statistics store phase (MODE 3).  The two persistent 512-thread kernels are compiled once with and once without it: they sit
 // at the register limit (the half-tile kernel: 12 -> 19 spilled VGPRs with MODE 3 inlined), and every launch paid for it, gated or not: 25.98 vs 25.78 ms per ResNet-50
-// step, A/B/A/B on one box (SEGLAND_CONV_GATE_SPLIT=0 launches everything on the instantiation that carries MODE 3).
+// step, A/B/A/B on one box (profiles/r3_ab_gate_split.txt).
 template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true>
 __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
@@ -1366,9 +1184,7 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, 256);
   p.gridN = p.N / 256;
   p.trace = g_p8_trace;
-  static const bool counted = !(getenv("SEGLAND_P8_COUNTED") && getenv("SEGLAND_P8_COUNTED")[0] == '0');
-  p.flags = counted ? 1 : 0;
-  static const bool persist = !(getenv("SEGLAND_P8_PERSIST") && getenv("SEGLAND_P8_PERSIST")[0] == '0');
+  p.flags = 1;                                  // the next tile's first wait is counted past the epilogue's own loads and stores
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
@@ -1376,9 +1192,9 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int ntiles = p.gridM * p.gridN;
-  static const bool one_kernel = getenv("SEGLAND_CONV_GATE_SPLIT") && getenv("SEGLAND_CONV_GATE_SPLIT")[0] == '0';      // A/B: every launch on the instantiation that carries MODE 3
-  if (p.gate || one_kernel) hipLaunchKernelGGL(conv_gemm_p8_kernel<true>, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
-  else        hipLaunchKernelGGL(conv_gemm_p8_kernel<false>, dim3(persist && ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  // persistent: min(tiles, 256) blocks walk over the tiles; the instantiation with the gated-statistics store phase only where it is used
+  if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<true>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  else        hipLaunchKernelGGL(conv_gemm_p8_kernel<false>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;
 }
@@ -1431,7 +1247,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
     const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
     psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((px >> 1) & 7)) << 4) : nullptr;      // swizzle by the patch COLUMN (see ldA)
   }
-  const bool dbuf = d == 1 && !(p.flags & 8);                             // two patch buffers fit (flags bit 3: SEGLAND_P9_DBUF=0, A/B)
+  const bool dbuf = d == 1 && !(p.flags & 8);                             // two patch buffers fit (flags bit 3 forces one: unused since round 4)
   const int boff = dbuf ? 2 * P9_PATCH1 : P9_PATCH;                       // weight ring behind the patch area
   auto issue_patch = [&](int chunk) {
     const unsigned dst = lds_base + (dbuf && (chunk & 1) ? P9_PATCH1 : 0);
@@ -1556,145 +1372,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
-// Four-wave form of the patch kernel (experimental, SEGLAND_CONV_P9W4=1): one wave per SIMD, 128 x 128 of the tile per wave (16 accumulator blocks = 256 registers), so an A
-// fragment serves four column blocks and a B fragment four row blocks: 32 fragment reads per 64 MFMAs instead of 24 per 32 -- a third fewer LDS reads, the co-limiter of
-// the eight-wave loop -- at the price of no second wave on the SIMD to cover stalls: the fragments of the next k-step are loaded while the current one multiplies.
-__global__ __launch_bounds__(256) void conv_gemm_p9w4_kernel(ConvGemmParams p) {
-  using T = bf16_t;
-  constexpr int BM = 256, BN = 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  int bid = blockIdx.x;
-  {
-    const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int GN = p.gridN > 2 && p.gridN % 2 == 0 ? 2 : p.gridN;
-  const int grp = bid / (p.gridM * GN), rem = bid - grp * (p.gridM * GN);
-  const int bm = rem / GN, bn = grp * GN + rem % GN;
-  const int d = p.dil, PW = 16 + 2 * d, PP = PW * PW;
-  const int CT = p.C1, nchunk = CT / 64;
-  const int tx = p.Ws >> 4, ty = p.Hs >> 4;
-  const int bx = bm % tx, by = (bm / tx) % ty, bb = bm / (tx * ty);
-  const int y0 = by * 16 - d, x0 = bx * 16 - d;
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  const int lr = lane >> 3, lpos = lane & 7;
-  const unsigned char* zsrc = g_zero_page + lpos * 16;
-  // patch fill: instruction g = j * 4 + wave covers patch rows g * 8 .. + 7
-  constexpr int NPI = 18;
-  const unsigned char* psrc[NPI];
-#pragma unroll
-  for (int j = 0; j < NPI; ++j) {
-    const int pr = (j * 4 + wave) * 8 + lr;
-    const int py = pr / PW, px = pr - py * PW;
-    const int iy = y0 + py, ix = x0 + px;
-    const bool ok = pr < PP && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-    psrc[j] = ok ? (const unsigned char*)p.src1 + ((size_t)(bb * p.Hs + iy) * p.Ws + ix) * CT * sizeof(T) + ((lpos ^ ((px >> 1) & 7)) << 4) : nullptr;      // swizzle by the patch COLUMN (see ldA)
-  }
-  auto issue_patch = [&](int chunk) {
-#pragma unroll
-    for (int j = 0; j < NPI; ++j) {
-      if ((j * 4 + wave) * 8 < PP) glds16_asm(psrc[j] ? psrc[j] + (size_t)chunk * 128 : zsrc, lds_base + (j * 4 + wave) * 1024);
-    }
-  };
-  // weight rows of a K-tile: 256 rows x 128 B = 32 instructions, 8 per wave; row n = (j * 4 + wave) * 8 + lr at LDS offset n * 128
-  const size_t wpitch = (size_t)9 * CT * sizeof(T);
-  const unsigned char* wptr[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = (j * 4 + wave) * 8 + lr;
-    wptr[j] = (const unsigned char*)p.wt + (size_t)(bn * BN + n) * wpitch + ((lpos ^ ((n >> 1) & 7)) << 4);
-  }
-  auto issueB = [&](int tap, int chunk, int par) {
-    const size_t koff = ((size_t)tap * CT + chunk * 64) * sizeof(T);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) glds16_asm(wptr[j] + koff, lds_base + P9_PATCH + par * (2 * P8_SLOT) + (j * 4 + wave) * 1024);
-  };
-  const int l31 = lane & 31, fh = lane >> 5;
-  int prow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) prow[i] = (wm * 8 + i * 2 + (l31 >> 4)) * PW + (l31 & 15);
-  auto ldA = [&](int i, int toff, int ks) {
-    const int pr = prow[i] + (toff >> 8);                                 // toff = ((ky PW + kx) d) << 8 | kx d
-    const int px = (l31 & 15) + (toff & 255);
-    return *(const uint4*)(smem + pr * 128 + (((2 * ks + fh) ^ ((px >> 1) & 7)) << 4));
-  };
-  const unsigned char* fb = smem + P9_PATCH + (wn * 128 + l31) * 128;
-  const int bsw = (l31 >> 1) & 7;
-  auto ldB = [&](int par, int j, int ks) { return *(const uint4*)(fb + par * (2 * P8_SLOT) + j * 4096 + (((2 * ks + fh) ^ bsw) << 4)); };
-
-  f32x16_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int NK = 9 * nchunk;
-  auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((((t2 / 3) * PW + (t2 % 3)) * d) << 8) | ((t2 % 3) * d); };      // patch row offset << 8 | column offset
-  issue_patch(0);
-  issueB(0, 0, 0);
-  issueB(1, 0, 1);
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  uint4 fa[2][4], fbv[2][4];                                             // fragment sets of k-steps of alternating parity
-  {
-    const int toff = toff_of(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[0][i] = ldA(i, toff, 0); fbv[0][i] = ldB(0, i, 0); }
-  }
-  int tap = 0, chunk = 0;
-#pragma unroll 1
-  for (int k = 0; k < NK; ++k) {
-    const int par = k & 1;
-    const int toff = toff_of(tap);
-    const bool last_tap = tap == 8;
-    const int toffn = toff_of(last_tap ? 0 : tap + 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks < 3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { fa[nxt][i] = ldA(i, toff, ks + 1); fbv[nxt][i] = ldB(par, i, ks + 1); }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { fbv[nxt][i] = ldB(par ^ 1, i, 0); if (!last_tap) fa[nxt][i] = ldA(i, toffn, 0); }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Mma<T>::run(fbv[cur][j], fa[cur][i], acc[i][j]);
-      if (ks == 2) {
-        wait_vmcnt<0>();                                                  // B(k + 1)
-        __builtin_amdgcn_s_barrier();
-        if (k + 2 < NK) {
-          int t2 = tap + 2, c2 = chunk;
-          if (t2 >= 9) { t2 -= 9; ++c2; }
-          issueB(t2, c2, par);
-        }
-      }
-    }
-    if (last_tap) {
-      tap = 0; ++chunk;
-      if (chunk < nchunk) {
-        __builtin_amdgcn_s_barrier();
-        issue_patch(chunk);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = ldA(i, toffn, 0);
-      }
-    } else ++tap;
-  }
-  lds_barrier();
-  conv_epilogue_lds<T, BM, BN, 2, 2, false>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-}
-
 int g_conv_p9 = -1;      // SEGLAND_CONV_P9 / sl_debug_conv_p9
-int g_conv_p9w4 = -1;    // SEGLAND_CONV_P9W4 / sl_debug_conv_p9 bit 1: the four-wave form
 static bool p9_on() {
   if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
   return g_conv_p9 != 0;
@@ -1706,26 +1384,13 @@ static bool p9_shape(const ConvGemmParams& p) {
 }
 int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
-  if (g_conv_p9w4 < 0) g_conv_p9w4 = (getenv("SEGLAND_CONV_P9W4") && getenv("SEGLAND_CONV_P9W4")[0] == '1') ? 1 : 0;
-  if (g_conv_p9w4) {
-    static bool attr4 = false;
-    if (!attr4) { (void)hipFuncSetAttribute((const void*)conv_gemm_p9w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P9_LDS); attr4 = true; }
-    hipLaunchKernelGGL(conv_gemm_p9w4_kernel, dim3(p.gridM * p.gridN), dim3(256), P9_LDS, st, p);
-    SL_LAUNCH_CHECK("conv_gemm_p9w4_kernel");
-    return 0;
-  }
-  static const bool nodbuf = getenv("SEGLAND_P9_DBUF") && getenv("SEGLAND_P9_DBUF")[0] == '0';
-  if (nodbuf) p.flags |= 8;
-  static const bool nogroup = getenv("SEGLAND_P9_NGROUP") && getenv("SEGLAND_P9_NGROUP")[0] == '0';
-  if (nogroup) p.flags |= 16;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
     (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
     attr_set = true;
   }
-  static const bool one_kernel = getenv("SEGLAND_CONV_GATE_SPLIT") && getenv("SEGLAND_CONV_GATE_SPLIT")[0] == '0';
-  if (p.gate || one_kernel) hipLaunchKernelGGL(conv_gemm_p9_kernel<true>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+  if (p.gate) hipLaunchKernelGGL(conv_gemm_p9_kernel<true>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
   else        hipLaunchKernelGGL(conv_gemm_p9_kernel<false>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p9_kernel");
   return 0;
@@ -2122,11 +1787,10 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
   }
 }
 
-static int sk_min_n() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_CONV_SK_MINN"); v = e ? atoi(e) : 64; } return v; }
 static bool sk_shape(int dtype, int KH, int KW, int stride, int pad, int Cin, int C1, int N, long long M) {
   static const bool off = getenv("SEGLAND_CONV_SK") && getenv("SEGLAND_CONV_SK")[0] == '0';
   return !off && dtype == SL_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && C1 == Cin && (Cin == 64 || Cin == 128 || Cin == 256) &&
-         N % 64 == 0 && N >= sk_min_n() && M >= 65536 && M % 256 == 0;
+         N % 64 == 0 && M >= 65536 && M % 256 == 0;
 }
 
 template <int KS, int MODE, bool SKEW>
@@ -2146,17 +1810,11 @@ int launch_sk_k(ConvGemmParams& p, hipStream_t st) {
 int launch_sk(ConvGemmParams& p, hipStream_t st) {
   // measured (tools/sk_time.sh): half-a-step-apart wave groups pay where the store phase carries the statistics (256 -> 1024 forward: 53 -> 49 us) and cost where it is pure
   // memory traffic (data gradient 1024 -> 256: 41 -> 47 us, with addend 58 -> 67 us).  bit 0: statistics, bit 1: plain store, bit 2: addend
-  static const int skew = getenv("SEGLAND_CONV_SK_SKEW") ? atoi(getenv("SEGLAND_CONV_SK_SKEW")) : 1;
+  constexpr int skew = 1;
   p.gridM = p.M / 256; p.gridN = 1;
   if (p.gate) return launch_sk_k<5, false>(p, st);
   if (p.addend) return (skew & 4) ? launch_sk_k<2, true>(p, st) : launch_sk_k<2, false>(p, st);
   return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);
-}
-
-int g_conv_variant = -1;   // 1: register-staged 128-row tiles, 2: glds 128-row tiles, 3: glds 256-row 8-wave tiles, 4: 64-byte-row ring, 5 (default): half-tile slots with 128-byte rows where N % 256 == 0
-static int conv_variant() {
-  if (g_conv_variant < 0) { const char* e = getenv("SEGLAND_CONV_VARIANT"); g_conv_variant = (e && e[0] >= '1' && e[0] <= '5') ? e[0] - '0' : 5; }
-  return g_conv_variant;
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -2174,68 +1832,42 @@ int launch_glds(ConvGemmParams& p, hipStream_t st) {
   return 0;
 }
 
-// rows per block of the kernel that will run for an M-row problem (also the granularity of the BN partial statistics)
-static int small_k() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SEGLAND_CONV_SMALLK"); v = e ? atoi(e) : 0; }
-  return v;
-}
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int min_tiles256() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_MINTILES", 96); return v; }
-static int ring128_min() { static int v = -1; if (v < 0) v = env_int("SEGLAND_CONV_RING128_MIN", 16); return v; }      // 128-row blocks from which the 4-stage ring replaces the 2-stage kernel (512 until round 3: Swin-T stage 3 / 4 GEMMs of 8 192 / 2 048 tokens gain 4 %, ResNet-50 unchanged)
-static int block_rows(long long M, int ktot) { return (conv_variant() >= 3 && M >= 256LL * min_tiles256() && ktot > small_k()) ? 256 : 128; }
+// rows per block of the kernel that will run for an M-row problem (also the granularity of the BN partial statistics): 256-row tiles need enough row blocks
+// to fill 256 CUs; the 4-stage ring replaces the 2-stage kernel from 16 blocks of 128 rows (Swin-T stage 3 / 4 GEMMs of 8 192 / 2 048 tokens: +4 %)
+constexpr int MIN_TILES256 = 96, RING128_MIN = 16;
+static int block_rows(long long M) { return M >= 256LL * MIN_TILES256 ? 256 : 128; }
 
 template <typename T>
 int launch_gemm(ConvGemmParams& p, hipStream_t st) {
-  const int v = conv_variant();
   const bool n128 = (p.N % 128 == 0), n256 = (p.N % 256 == 0);
-  if (v == 1) {
-    p.gridM = cdiv(p.M, 128); p.gridN = p.N / (n128 ? 128 : 64);
-    const size_t lds = 2 * (128 + (n128 ? 128 : 64)) * 128;
-    if (n128) hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 128, 2, 2>), dim3(p.gridM * p.gridN), dim3(256), lds, st, p);
-    else      hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 64, 2, 2>), dim3(p.gridM * p.gridN), dim3(256), lds, st, p);
-    SL_LAUNCH_CHECK("conv_gemm_kernel");
-    return 0;
-  }
-  // 256-row tiles need enough row-blocks to fill 256 CUs; tiny problems (PPM stages, prototype rows) stay on 128-row tiles
-  const bool big = block_rows(p.M, p.KH * p.KW * (p.C1 + p.C2)) == 256;
+  // tiny problems (PPM stages, prototype rows) stay on 128-row tiles
+  const bool big = block_rows(p.M) == 256;
   if constexpr (sizeof(T) == 2) {
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
       return launch_c64k3(p, st);
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (v >= 5 && sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
+    if (sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
         (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
       return launch_sk(p, st);
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (v >= 5 && p9_shape(p)) return launch_p9(p, st);
-  }
-  if constexpr (sizeof(T) == 2) {
+    if (p9_shape(p)) return launch_p9(p, st);
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
-    if (big && v >= 5 && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
+    if (big && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
   }
-  if (big && v >= 4) {
+  if (big) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
     if (n256) return launch_ring<T, 256, 256, 2, 4, 64, 4>(p, st);
     if (n128) return launch_ring<T, 256, 128, 4, 2, 64, 4>(p, st);
     return launch_glds<T, 256, 64, 8, 1>(p, st);        // N = 64 layers: too few weight rows for a 64-byte-row ring
   }
-  if (big) {
-    if (n256) return launch_glds<T, 256, 256, 2, 4>(p, st);
-    if (n128) return launch_glds<T, 256, 128, 4, 2>(p, st);
-    return launch_glds<T, 256, 64, 8, 1>(p, st);
-  }
-  if (v >= 4 && n128 && p.M >= 128LL * ring128_min()) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
+  if (n128 && p.M >= 128LL * RING128_MIN) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
   if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
   return launch_glds<T, 128, 64, 2, 2>(p, st);
 }
 
 int g_conv_affine = -1;    // 1 (default): branch-free affine store phase for biased / folded-BN epilogues; 0: the generic one everywhere
 int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
-  if (g_conv_affine < 0) { const char* e = getenv("SEGLAND_CONV_AFFINE"); g_conv_affine = (e && e[0] == '0') ? 0 : 1; }
+  if (g_conv_affine < 0) g_conv_affine = 1;
   if (!g_conv_affine) p.flags |= 2;
   const int bke = dtype == SL_BF16 ? 64 : 32;
   SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "conv: bad dtype %d", dtype);
@@ -2260,37 +1892,32 @@ int check_desc(const SlConvDesc* d) {
 }  // namespace
 
 // test hook (not part of the public ABI)
-extern "C" void sl_debug_conv_variant(int v) { g_conv_variant = v; }
 extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
-extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; g_conv_p9w4 = (v & 2) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off (bit 0), four-wave form (bit 1)
+extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
-// Which kernel a shape runs on: 1000000*variant + 1000*BM + BN  (variant 4 = ring, 2 = two-stage glds, 1 = register staged).
-// mode 0: forward, 1: data gradient.  Used by bench.py to attribute HIP-event timings to rocprof kernel names.
+// Which kernel a shape runs on: 1000000*family + 1000*BM + BN  (family 8 = 3x3 patch, 7 = 64 -> 64 patch, 6 = pixel-stationary, 5 = half-tile, 4 = ring, 2 = two-stage glds):
+// the predicate chain of launch_gemm.  mode 0: forward, 1: data gradient.  Used by bench.py to attribute HIP-event timings to rocprof kernel names.
 extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
   if (!d) return SL_EINVAL;
   const long long M = mode == 0 ? (long long)d->B * d->Ho * d->Wo : (long long)d->B * d->H * d->W;
   const int N = mode == 0 ? d->Cout : d->Cin;
-  const int ktot = d->KH * d->KW * (mode == 0 ? d->Cin : d->Cout);
-  const int v = conv_variant();
   const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
-  if (v == 1) return 1000000 + 128000 + (n128 ? 128 : 64);
-  const bool big = block_rows(M, ktot) == 256;
-  if (v >= 2 && d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
+  const bool big = block_rows(M) == 256;
+  if (d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
   // the short-K kernel serves the unshaped epilogues (training-mode convs: raw result + statistics, or + addend); folded eval-mode convs of these shapes stay on the tile kernels
-  if (v >= 5 && sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
-  if (v >= 5 && d->dtype == SL_BF16 && n256 && p9_on() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
+  if (sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
+  if (d->dtype == SL_BF16 && n256 && p9_on() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
       d->C1 == d->Cin && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 && d->H % 16 == 0 && d->W % 16 == 0 && M >= 32768) return 8256256;      // conv_gemm_p9_kernel (unshaped epilogues)
-  if (big && v >= 5 && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
-  if (big && v >= 4) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
-  if (big) return 2000000 + 256000 + (n256 ? 256 : (n128 ? 128 : 64));
-  if (v >= 4 && n128 && M >= 128LL * ring128_min()) return 4128128;
+  if (big && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
+  if (big) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
+  if (n128 && M >= 128LL * RING128_MIN) return 4128128;
   return 2000000 + 128000 + (n128 ? 128 : 64);
 }
 
 extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
 // Rows of the BN statistic partials a forward launch writes: derived from the SAME predicate chain as launch_gemm (sl_conv2d_tile_config), so a
-// non-default tuning knob (SEGLAND_CONV_MINTILES, SEGLAND_CONV_VARIANT ...) can never make the caller allocate rows the kernel does not write.
+// change of the dispatch thresholds can never make the caller allocate rows the kernel does not write.
 extern "C" int sl_conv2d_stat_rows(const SlConvDesc* d) {
   if (!d) return SL_EINVAL;
   const long long M = (long long)d->B * d->Ho * d->Wo;
@@ -2372,7 +1999,7 @@ extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const voi
 extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
   if (!d) return 0;
   static const bool off = getenv("SEGLAND_BN_FUSE") && getenv("SEGLAND_BN_FUSE")[0] == '0';
-  if (off || conv_variant() < 2) return 0;
+  if (off) return 0;
   const int cfg = sl_conv2d_tile_config(d, 1);
   const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
   const long long M = (long long)d->B * d->H * d->W;
@@ -2401,7 +2028,7 @@ extern "C" int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d) {
   if (!d) return 0;
   static const bool off = getenv("SEGLAND_BN_FUSE_CROSS") && getenv("SEGLAND_BN_FUSE_CROSS")[0] == '0';
   const long long M = (long long)d->B * d->H * d->W;
-  if (off || conv_variant() < 5 || d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (off || d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo) return 0;
   if (!sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->Cout, d->Cout, d->Cin, M) || d->Cin % 128 != 0 || d->Cin > 1024) return 0;
   return (int)(M / 256);
 }

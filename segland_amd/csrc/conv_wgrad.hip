@@ -760,16 +760,7 @@ inline int c64p_blocks(const SlConvDesc* d) { const long long t = (long long)d->
 inline int c64p_slabs(const SlConvDesc* d) { return c64p_blocks(d) * ((d->Cout == 64 && d->Cin == 64) ? 4 : 1); }
 
 int g_use_tr = -1;
-int use_tr() {
-  if (g_use_tr < 0) { const char* e = getenv("SEGLAND_WGRAD_TR"); g_use_tr = (e && e[0] == '0') ? 0 : 1; }
-  return g_use_tr;
-}
-
-int g_wgrad_variant = -1;   // 1: register-staged 128x128 tiles, 2 (default): glds tiles up to 256x256; SEGLAND_WGRAD_VARIANT
-int wgrad_variant() {
-  if (g_wgrad_variant < 0) { const char* e = getenv("SEGLAND_WGRAD_VARIANT"); g_wgrad_variant = (e && e[0] == '1') ? 1 : 2; }
-  return g_wgrad_variant;
-}
+int use_tr() { return g_use_tr != 0; }      // bf16 fragments by ds_read_b64_tr_b16 (default) or scalar LDS reads (test hook sl_debug_wgrad_tr: the two must agree bit for bit)
 
 struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; bool glds, pair; size_t ws_bytes; };
 
@@ -784,7 +775,7 @@ WgradPlan plan(const SlConvDesc* d) {
   const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
   const bool ident = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   const long long M = (long long)d->B * d->Ho * d->Wo;
-  if (wgrad_variant() >= 2 && !all128 && c2 == 0 && d->dtype == SL_BF16 && M % 2 == 0 && d->Wo % 2 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0 &&
+  if (!all128 && c2 == 0 && d->dtype == SL_BF16 && M % 2 == 0 && d->Wo % 2 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0 &&
       ((ident && M >= (1 << 19)) || (!ident && d->Cin == 64 && d->stride == 1))) {    // measured: short 1x1 problems are faster on the 64-wide kernel
     SlConvDesc d2 = *d;
     d2.Cout = 2 * d->Cout; d2.Cin = d2.C1 = 2 * d->Cin;
@@ -801,19 +792,15 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M) {
   WgradPlan pl;
   const int c2 = d->Cin - d->C1;
   const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
-  pl.glds = wgrad_variant() >= 2 && all128;
+  pl.glds = all128;                               // 128- / 256-wide glds tiles; 64-channel sides run on the register-staged kernel
   if (pl.glds) {
     const bool wide = d->dtype == SL_BF16;          // f32 stages are twice as large: 128-wide tiles keep the ring in 128 KiB
     pl.bnn = (wide && d->Cout % 256 == 0) ? 256 : 128;
     pl.bcc = (wide && d->C1 % 256 == 0 && c2 % 256 == 0) ? 256 : 128;
-    // few output tiles (a 256 x 1024 gradient is FOUR 256 x 256 tiles: 64 splits over the pixels, 64 MB of slabs for 1 MB of gradient): tuning hook -- with at most
-    // SEGLAND_WGRAD_SMALLTILE_MAX 256 x 256 tiles (x taps) the n side drops to 128 rows, i.e. twice the tiles, half the splits and slab bytes
-    static const int small_max = getenv("SEGLAND_WGRAD_SMALLTILE_MAX") ? atoi(getenv("SEGLAND_WGRAD_SMALLTILE_MAX")) : 4;      // measured (profiles/r3_ab_wgrad_tiles.txt): 4 -> -0.16 ms per ResNet-50 step (the 1x1 256 <-> 1024 and 512 -> 512 gradients), 9 (adds the 3x3 256 -> 256 layers) +0.03, 36 +0.6
-    if (small_max > 0 && pl.bnn == 256 && pl.bcc == 256 && (long long)(d->Cout / 256) * (d->Cin / 256) * d->KH * d->KW <= small_max) {
-      static const int both = getenv("SEGLAND_WGRAD_SMALLTILE_BOTH") ? atoi(getenv("SEGLAND_WGRAD_SMALLTILE_BOTH")) : 0;
-      pl.bnn = 128;
-      if (both) pl.bcc = 128;
-    }
+    // few output tiles (a 256 x 1024 gradient is FOUR 256 x 256 tiles: 64 splits over the pixels, 64 MB of slabs for 1 MB of gradient): with at most four
+    // 256 x 256 tiles (x taps) the n side drops to 128 rows, i.e. twice the tiles, half the splits and slab bytes.  Measured (profiles/r3_ab_wgrad_tiles.txt):
+    // -0.16 ms per ResNet-50 step (the 1x1 256 <-> 1024 and 512 -> 512 gradients); with the 3x3 256 -> 256 layers included (nine tiles) +0.03, both sides at 128 slower
+    if (pl.bnn == 256 && pl.bcc == 256 && (long long)(d->Cout / 256) * (d->Cin / 256) * d->KH * d->KW <= 4) pl.bnn = 128;
   } else {
     pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
     pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;
@@ -859,12 +846,7 @@ template <typename T, bool TR>
 int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
   dim3 grid(pl.gridN * pl.gridC * pl.taps * pl.splits);
   if (pl.glds) {
-    if (pl.bnn == 256 && pl.bcc == 256) {
-      // SEGLAND_WGRAD_W4=1: four waves of 128 x 128 (0.5 KiB of fragment reads per MFMA instead of 0.75; one wave per SIMD)
-      static const bool w4 = getenv("SEGLAND_WGRAD_W4") && getenv("SEGLAND_WGRAD_W4")[0] == '1';
-      if (w4 && sizeof(T) == 2) return launch_wgrad_glds<T, 256, 256, 2, 2, TR>(grid, p, st);
-      return launch_wgrad_glds<T, 256, 256, 2, 4, TR>(grid, p, st);
-    }
+    if (pl.bnn == 256 && pl.bcc == 256) return launch_wgrad_glds<T, 256, 256, 2, 4, TR>(grid, p, st);     // (four waves of 128 x 128 measured slower: profiles/r3_ab_wgrad_w4.txt)
     if (pl.bnn == 256) return launch_wgrad_glds<T, 256, 128, 4, 2, TR>(grid, p, st);
     if (pl.bcc == 256) return launch_wgrad_glds<T, 128, 256, 2, 4, TR>(grid, p, st);
     return launch_wgrad_glds<T, 128, 128, 2, 2, TR>(grid, p, st);
@@ -885,7 +867,6 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" void sl_debug_wgrad_variant(int v) { g_wgrad_variant = v; }
 // test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 
@@ -911,54 +892,18 @@ extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
 extern "C" int sl_colsum_rows_partial(int dtype, const void* x, long long rows, int C, float* partial, sl_stream_t stream);
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
-extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream);
 
 extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw,
                                     void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   return sl_conv2d_bwd_weight_ex(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream);
 }
-extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                                       int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
-  return sl_conv2d_bwd_weight_ex2(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, stream, nullptr);
-}
-
-// Slab reduces on a second stream.  The weight gradient has no consumer until the optimizer, and its fixed-order slab reduce (0.9 ms per ResNet-50
-// step in 80 small launches) is pure HBM traffic: issued on `reduce_stream` it runs beside the MFMA-bound data-gradient kernel that follows on `stream`
-// (in a captured step: a parallel branch of the graph).  Two lazily created events order it: main -> reduce after the MFMA kernel, and reduce -> main
-// before the NEXT weight gradient touches the (shared) workspace; the caller joins with sl_stream_join(stream, reduce_stream) before dw is consumed.
-namespace {
-struct ReduceFork {
-  hipEvent_t main_done = nullptr, red_done = nullptr;
-  bool pending = false;
-  int init() {
-    if (main_done) return 0;
-    if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&red_done, hipEventDisableTiming) != hipSuccess) {
-      sl_set_error("conv bwd_weight: hipEventCreate failed"); return SL_EINVAL;
-    }
-    return 0;
-  }
-} g_fork;
-}  // namespace
-
-// stream waits for everything queued on `other` so far (event record + wait; capturable)
-extern "C" int sl_stream_join(sl_stream_t stream, sl_stream_t other) {
-  if (!other || other == stream) return 0;
-  if (int e = g_fork.init()) return e;
-  if (hipEventRecord(g_fork.red_done, (hipStream_t)other) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_fork.red_done, 0) != hipSuccess) {
-    sl_set_error("sl_stream_join: event record / wait failed"); return SL_EINVAL;
-  }
-  g_fork.pending = false;
-  return 0;
-}
-
 // dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial, int n_valid = 0, int c_valid = 0);
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid = 0, int c_valid = 0);
 
-extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream) {
-  return bwd_weight_impl(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, stream, reduce_stream, nullptr);
+extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
+                                       int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  return bwd_weight_impl(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, stream, nullptr);
 }
 
 // Weight gradient + bias gradient partials of one nn.Linear / biased conv: colsum_partial [sl_colsum_rows_blocks(B*Ho*Wo, Cout, dtype)][Cout] receives the column sums of dy
@@ -966,18 +911,18 @@ extern "C" int sl_conv2d_bwd_weight_ex2(const SlConvDesc* d, const void* x, cons
 extern "C" int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                                          float* colsum_partial, sl_stream_t stream) {
   SL_REQUIRE(colsum_partial, "conv bwd_weight_bias: null partial buffer");
-  return bwd_weight_impl(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream, nullptr, colsum_partial);
+  return bwd_weight_impl(d, x, x2, dy, dw, d ? d->Cin : 0, 0, workspace, workspace_bytes, stream, colsum_partial);
 }
 
 // The same at zero-padded channel counts: the problem is d->Cout x d->Cin (multiples of 64), dw is the parameter's own [n_valid][c_valid][KH][KW]; colsum_partial may be null.
 extern "C" int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
                                          size_t workspace_bytes, float* colsum_partial, sl_stream_t stream) {
   SL_REQUIRE(d && n_valid > 0 && c_valid > 0 && n_valid <= d->Cout && c_valid <= d->Cin, "conv bwd_weight_clip: bad valid channel counts");
-  return bwd_weight_impl(d, x, x2, dy, dw, c_valid, 0, workspace, workspace_bytes, stream, nullptr, colsum_partial, n_valid, c_valid);
+  return bwd_weight_impl(d, x, x2, dy, dw, c_valid, 0, workspace, workspace_bytes, stream, colsum_partial, n_valid, c_valid);
 }
 
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, sl_stream_t reduce_stream, float* colsum_partial, int n_valid, int c_valid) {
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
   const int nv = n_valid > 0 ? n_valid : d->Cout, cv = c_valid > 0 ? c_valid : d->Cin;
   SL_REQUIRE(nv <= d->Cout && cv <= d->Cin, "conv bwd_weight: valid channel counts exceed the (padded) problem");
@@ -986,20 +931,8 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     if (!colsum_partial) return 0;
     return sl_colsum_rows_partial(d->dtype, dy, (long long)d->B * d->Ho * d->Wo, d->Cout, colsum_partial, stream);
   };
-  const bool forked = reduce_stream && reduce_stream != stream;
-  if (g_fork.pending) {                          // a reduce of the previous call may still read the workspace this call overwrites
-    if (hipStreamWaitEvent((hipStream_t)stream, g_fork.red_done, 0) != hipSuccess) { sl_set_error("conv bwd_weight: hipStreamWaitEvent failed"); return SL_EINVAL; }
-    g_fork.pending = false;
-  }
-  if (forked) { if (int e = g_fork.init()) return e; }
-  // after the MFMA kernel: hand over to the reduce stream; after the reduce kernels: mark them for the next call / the join
-  auto fork = [&]() -> hipStream_t {
-    if (!forked) return (hipStream_t)stream;
-    (void)hipEventRecord(g_fork.main_done, (hipStream_t)stream);
-    (void)hipStreamWaitEvent((hipStream_t)reduce_stream, g_fork.main_done, 0);
-    return (hipStream_t)reduce_stream;
-  };
-  auto reduced = [&]() { if (forked) { (void)hipEventRecord(g_fork.red_done, (hipStream_t)reduce_stream); g_fork.pending = true; } };
+  // the fixed-order slab reduces follow their MFMA kernel on the same stream (on a second stream they measured slower inside the captured step:
+  // profiles/r3_ab_switches.txt, 27.10 vs 26.53 ms -- every fork / join is a pair of cross-branch dependencies in the graph)
   SL_REQUIRE(dw_ci_off >= 0 && dw_ci_off + cv <= dw_cin_total, "conv bwd_weight: bad dw channel window");
   const int bke = d->dtype == SL_BF16 ? 64 : 32;
   const int c2 = d->Cin - d->C1;
@@ -1017,11 +950,10 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     hipLaunchKernelGGL(conv_wgrad_c64k3_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, d->B, d->H, d->W, ntiles);
     SL_LAUNCH_CHECK("conv_wgrad_c64k3_kernel");
     float* sum = (float*)workspace + (size_t)nblk * 64 * 64 * 9;
-    hipStream_t rs = fork();
+    hipStream_t rs = (hipStream_t)stream;
     if (int e = sl_colsum_finalize((const float*)workspace, nblk, 64 * 64 * 9, sum, (sl_stream_t)rs)) return e;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(64), dim3(256), 0, rs, (const float*)sum, dw, 64, 64, 9, 1, 64, 0, 64, 64);      // [n][tap][c] -> OIHW
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
-    reduced();
     return colsum_separately();
   }
   if (c64p_eligible(d) && use_tr()) {
@@ -1038,11 +970,10 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     SL_LAUNCH_CHECK("conv_wgrad_c64p_kernel");
     const long long total = (long long)d->Cout * d->Cin;
     float* sum = (float*)workspace + (size_t)nslab * total;
-    hipStream_t rs = fork();
+    hipStream_t rs = (hipStream_t)stream;
     if (int e = sl_colsum_finalize((const float*)workspace, nslab, (int)total, sum, (sl_stream_t)rs)) return e;          // fixed-order column sums over the slabs (one block per 64 numbers)
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rs, (const float*)sum, dw, total, 1, d->Cin, dw_cin_total, dw_ci_off, nv, cv);
     SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
-    reduced();
     return colsum_separately();
   }
   const WgradPlan pl = plan(d);
@@ -1062,14 +993,13 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   else e = launch_wgrad<bf16_t, false>(pl, p, st);
   if (e) return e;
   SL_REQUIRE(pl.taps <= 49, "conv bwd_weight: kernel window larger than 7x7");
-  st = fork();
   if (pl.pair) {
     const long long total = (long long)d->Cout * d->Cin * pl.taps;
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off, nv, cv);
   } else if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
     const int nred = (int)((total + 255) / 256);
-    if (colsum_partial && !forked) {
+    if (colsum_partial) {
       const long long rows = (long long)d->B * d->Ho * d->Wo, ch = sl_colsum_rows_chunk(rows, d->Cout, d->dtype == SL_BF16 ? 2 : 4);
       const int ncol = (int)((rows + ch - 1) / ch);
       if (d->dtype == SL_BF16)
@@ -1079,14 +1009,12 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
         hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<float>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
                            nred, (const float*)dy, rows, d->Cout, ch, colsum_partial, nv, cv);
       SL_LAUNCH_CHECK("wgrad_reduce_flat_colsum_kernel");
-      reduced();
-      return 0;
+        return 0;
     }
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((unsigned)nred), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off, nv, cv);
   } else {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout * (d->Cin / 64)), dim3(256), 0, st, (const float*)workspace, dw, d->Cout, d->Cin, pl.taps, pl.splits, dw_cin_total, dw_ci_off, nv, cv);
   }
   SL_LAUNCH_CHECK("wgrad_reduce_kernel");
-  reduced();
   return colsum_separately();
 }

@@ -419,8 +419,7 @@ extern "C" int sl_upsample_ce_bwd(const float* logits, const int64_t* target, co
   const UpGeom g = make_up(B, K, h, w, H, W);
   const long long cells = (long long)B * h * w;
   // tiled kernel when the joint footprint of a CT x CT cell tile fits the LDS (always for an upsampling factor <= ~12 at K <= 16)
-  static const bool gather_only = getenv("SEGLAND_CE_BWD_GATHER") != nullptr;
-  if (!gather_only && g.sy > 0.f && g.sx > 0.f) {
+  if (g.sy > 0.f && g.sx > 0.f) {
     UpTile ut;
     ut.NYmax = (int)ceilf((float)(CT + 1) / g.sy) + 3; if (ut.NYmax > H) ut.NYmax = H;
     ut.NXmax = (int)ceilf((float)(CT + 1) / g.sx) + 3; if (ut.NXmax > W) ut.NXmax = W;

@@ -565,11 +565,23 @@ extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S
 }
 
 
+// One block holds everything in the LDS: the forward [Kt][C] rows + the [Ka][Kt] similarities, the backward TWO [Kt][C] matrices next to 4.2 KB of static
+// arrays (coef, dots).  Without the opt-in attribute a block gets 64 KiB, static + dynamic: the forward must refuse what the backward of the same step could not
+// run (round-3 advisor: C = 512 with 16..29 prototypes passed the forward and raised mid-step in the backward).
+static bool pp_fits(int Ka, int Kb, int C) {
+  const size_t Kt = (size_t)Ka + Kb;
+  const size_t fwd = (Kt * C + (size_t)Ka * Kt) * sizeof(float) + PP_KMAX * sizeof(float);
+  const size_t bwd = 2 * Kt * C * sizeof(float) + (PP_KMAX * PP_KMAX + PP_KMAX) * sizeof(float);
+  return Ka >= 1 && Kb >= 0 && Kt <= (size_t)PP_KMAX && C > 0 && fwd <= 64 * 1024 && bwd <= 64 * 1024;
+}
+
+extern "C" int sl_pop_proto_ok(int Ka, int Kb, int C) { return pp_fits(Ka, Kb, C) ? 1 : 0; }
+
 extern "C" int sl_pop_proto_fwd(const float* Ea, int Ka, const float* Eb, int Kb, int C, float* Sa, float* Sb, float* inv_norm, float* G, float* orth,
                                 sl_stream_t stream) {
   SL_REQUIRE(Ea && Sa && inv_norm && G && orth && Ka >= 1 && Kb >= 0 && Ka + Kb <= PP_KMAX && C > 0 && (Kb == 0 || (Eb && Sb)), "pop_proto_fwd: bad args");
   const size_t lds = ((size_t)(Ka + Kb) * C + (size_t)Ka * (Ka + Kb)) * sizeof(float);
-  SL_REQUIRE(lds <= 60 * 1024, "pop_proto_fwd: %d prototypes of %d channels do not fit one block", Ka + Kb, C);
+  SL_REQUIRE(pp_fits(Ka, Kb, C), "pop_proto_fwd: %d prototypes of %d channels do not fit one block (forward + backward; sl_pop_proto_ok)", Ka + Kb, C);
   hipLaunchKernelGGL(pop_proto_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, Ea, Ka, Eb, Kb, C, Sa, Sb, inv_norm, G, orth);
   SL_LAUNCH_CHECK("pop_proto_fwd_kernel");
   return 0;
@@ -579,7 +591,7 @@ extern "C" int sl_pop_proto_bwd(const float* Sa, int Ka, const float* Sb, int Kb
                                 const float* dSb, const float* dorth, float* dEa, float* dEb, sl_stream_t stream) {
   SL_REQUIRE(Sa && inv_norm && G && Ka >= 1 && Kb >= 0 && Ka + Kb <= PP_KMAX && C > 0 && (Kb == 0 || Sb), "pop_proto_bwd: bad args");
   const size_t lds = 2 * (size_t)(Ka + Kb) * C * sizeof(float);
-  SL_REQUIRE(lds <= 60 * 1024, "pop_proto_bwd: %d prototypes of %d channels do not fit one block", Ka + Kb, C);
+  SL_REQUIRE(pp_fits(Ka, Kb, C), "pop_proto_bwd: %d prototypes of %d channels do not fit one block (sl_pop_proto_ok)", Ka + Kb, C);
   hipLaunchKernelGGL(pop_proto_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, Sa, Ka, Sb, Kb, C, inv_norm, G, dSa, dSb, dorth, dEa, dEb);
   SL_LAUNCH_CHECK("pop_proto_bwd_kernel");
   return 0;

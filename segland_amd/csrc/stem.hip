@@ -497,8 +497,7 @@ extern "C" int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w
   SL_REQUIRE(img_nchw && w_oihw && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "stem_conv_fwd: bad args");
   const size_t lds = (NTAP * 64 + 3 * PS * PS) * sizeof(float);
   dim3 grid(stem_tiles(B, H, W));
-  static const bool valu = getenv("SEGLAND_STEM_VALU") != nullptr;              // A/B: the fp32-arithmetic VALU kernel also for bf16 outputs
-  if (dtype == SL_BF16 && !valu) {
+  if (dtype == SL_BF16) {
     SL_REQUIRE(workspace && ((size_t)workspace & 15) == 0, "stem_conv_fwd: bf16 needs the 16-byte aligned workspace of sl_stem_conv_fwd_workspace()");
     uint4* wfrag = (uint4*)workspace;                                           // the weights in MFMA fragment order, rebuilt on every call (20 KiB)
     hipLaunchKernelGGL(stem_weight_frag_kernel, dim3(cdiv(2 * KSTEPS * 64, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, wfrag);
@@ -507,8 +506,7 @@ extern "C" int sl_stem_conv_fwd(int dtype, const float* img_nchw, const float* w
     SL_LAUNCH_CHECK("stem_conv_fwd_mfma_kernel");
     return 0;
   }
-  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_conv_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (bf16_t*)y, stat_partial, B, H, W);
-  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (float*)y, stat_partial, B, H, W);
+  if (dtype == SL_F32) hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, img_nchw, w_oihw, (float*)y, stat_partial, B, H, W);
   else SL_REQUIRE(false, "stem_conv_fwd: bad dtype");
   SL_LAUNCH_CHECK("stem_conv_fwd_kernel");
   return 0;
@@ -549,13 +547,11 @@ extern "C" int sl_stem_conv_bwd_weight(int dtype, const float* img_nchw, const v
   if (workspace_bytes < (size_t)nblk * 64 * NTAP * sizeof(float)) { sl_set_error("stem_conv_bwd_weight: workspace too small"); return SL_EWORKSPACE; }
   const size_t lds = (256 * 64 + 3 * PS * PS) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  static const bool valu = getenv("SEGLAND_STEM_VALU") != nullptr;
-  if (dtype == SL_BF16 && !valu) {
+  if (dtype == SL_BF16) {
     const size_t l2 = (size_t)(3 * PS * MP + 6) * sizeof(bf16_t) + 256 * 72 * sizeof(bf16_t);
     hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(nblk), dim3(256), l2, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, ntiles);
     SL_LAUNCH_CHECK("stem_wgrad_mfma_kernel");
-  } else if (dtype == SL_BF16) hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), lds, st, img_nchw, (const bf16_t*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
-  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), lds, st, img_nchw, (const float*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
+  } else if (dtype == SL_F32) hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(nblk), dim3(256), lds, st, img_nchw, (const float*)dc0, (float*)workspace, B, H, W, tpb, ntiles);
   else SL_REQUIRE(false, "stem_conv_bwd_weight: bad dtype");
   SL_LAUNCH_CHECK("stem_wgrad_kernel");
   return sl_colsum_finalize((const float*)workspace, nblk, 64 * NTAP, dw_oihw, stream);       // fixed-order sum of the block partials (64 x 16 lanes per block of columns)

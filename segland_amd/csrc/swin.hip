@@ -924,238 +924,7 @@ __device__ __forceinline__ void store_dT(bf16_t* base, const f32x16_t& o, int hf
   }
 }
 
-__global__ __launch_bounds__(256) void window_attention_bwd_mfma_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
-                                                                        const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
-                                                                        float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
-  float* biast = biasl + WN * BLP + 16;                     // [49][52] (+16): bias[key][query]
-  bf16_t* tbase = (bf16_t*)(biast + WN * BLP + 16);         // per wave: K^T, Q^T, dO^T [32][68] each
-  bf16_t* nbase = tbase + 4 * 3 * HD * VTP;                 // per wave: K, Q, V, dO natural [64][40] each
-  float* mzbase = (float*)(nbase + 4 * 4 * 64 * NTP);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hf = lane >> 5;
-  const int head = blockIdx.x % g.heads, chunk = blockIdx.x / g.heads;
-  for (int e = tid; e < WN * WN; e += 256) {
-    const float v = rel_bias[(size_t)head * WN * WN + e];
-    biasl[(e / WN) * BLP + e % WN] = v;
-    biast[(e % WN) * BLP + e / WN] = v;
-  }
-  __syncthreads();
-  bf16_t* kt = tbase + wave * 3 * HD * VTP;
-  bf16_t* qt = kt + HD * VTP;
-  bf16_t* dot = qt + HD * VTP;
-  bf16_t* nk = nbase + wave * 4 * 64 * NTP;
-  bf16_t* nq = nk + 64 * NTP;
-  bf16_t* nv = nq + 64 * NTP;
-  bf16_t* ng = nv + 64 * NTP;
-  float* mz = mzbase + wave * 256;
-  // token rows / columns 49..63 are never written afterwards: zero them once (their probabilities are 0, LDS garbage could be NaN)
-  for (int e = lane; e < 3 * HD * (64 - WN); e += 64) { const int tI = e / (HD * (64 - WN)), r = e % (HD * (64 - WN)); kt[tI * HD * VTP + (r / (64 - WN)) * VTP + WN + r % (64 - WN)] = 0; }
-  for (int e = lane; e < 4 * (64 - WN) * NTP; e += 64) { const int tI = e / ((64 - WN) * NTP), r = e % ((64 - WN) * NTP); nk[tI * 64 * NTP + WN * NTP + r] = 0; }
-  const float scale = rsqrtf((float)HD);
-  f32x16_t dsum[2][2];
-#pragma unroll
-  for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dsum[ib][jb][r] = 0.f;
-
-  for (int t = 0; t < wpw; ++t) {
-    const int wi = (chunk * wpw + t) * 4 + wave;
-    if (wi >= nwin) break;
-    const int wx = wi % g.nWx, wy = (wi / g.nWx) % g.nWy, b = wi / (g.nWx * g.nWy);
-    lds_fill(g, qkv, g.P3, 1 * g.C + head * HD, qkv_bias, 1 * g.C + head * HD, b, wy, wx, lane, nk, kt);
-    lds_fill(g, qkv, g.P3, 0 * g.C + head * HD, qkv_bias, 0 * g.C + head * HD, b, wy, wx, lane, nq, qt);
-    lds_fill(g, qkv, g.P3, 2 * g.C + head * HD, qkv_bias, 2 * g.C + head * HD, b, wy, wx, lane, nv, nullptr);
-    lds_fill(g, dout, g.Cp, head * HD, qkv_bias, -1, b, wy, wx, lane, ng, dot);       // dO of pad queries is zero: their outputs are cropped
-    unsigned pk[8];
-    win_pack_regions(g, wy, wx, lane, pk);
-    // natural-layout fragments (token row n, 8 consecutive d per lane) from LDS
-    auto frag = [&](int which, int n, int s2) { return *(const uint4*)((which == 0 ? nq : (which == 1 ? nk : nv)) + n * NTP + 16 * s2 + 8 * hf); };
-    auto gfrag = [&](int n, int s2) { return *(const uint4*)(ng + n * NTP + 16 * s2 + 8 * hf); };
-    // ---------------- T-layout, one 32-query block at a time (registers: 2 x 2 accumulators instead of 2 x 4)
-#pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-      f32x16_t st[2], dp[2];
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[ib][r] = 0.f; dp[ib][r] = 0.f; }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 qv = frag(0, 32 * jb + l31, s2), gv = gfrag(32 * jb + l31, s2);
-#pragma unroll
-        for (int ib = 0; ib < 2; ++ib) {
-          st[ib] = mfma16(frag(1, 32 * ib + l31, s2), qv, st[ib]);
-          dp[ib] = mfma16(frag(2, 32 * ib + l31, s2), gv, dp[ib]);
-        }
-      }
-      const int j = 32 * jb + l31, jc = j < WN ? j : WN - 1;
-      const unsigned regq = (pk[jc >> 3] >> (4 * (jc & 7))) & 15u;
-      float mx = -INFINITY;
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int i0 = 32 * ib + 8 * m + 4 * hf;
-          const float4 bv = *(const float4*)(biasl + jc * BLP + i0);
-          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sc = st[ib][4 * m + e] * scale + bb[e];
-            { const unsigned rk = (pk[4 * ib + m] >> (16 * hf + 4 * e)) & 15u; sc += rk != regq ? -100.f : 0.f; }
-            sc = (i0 + e) < WN ? sc : -INFINITY;
-            st[ib][4 * m + e] = sc;
-            mx = fmaxf(mx, sc);
-          }
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      float z = 0.f;
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { const float e = __expf(st[ib][r] - mx); st[ib][r] = e; z += e; }
-      z += __shfl_xor(z, 32, 64);
-      const float inv = 1.f / z;
-      float rs = 0.f;
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[ib][r] *= inv; rs = fmaf(st[ib][r], dp[ib][r], rs); }
-      rs += __shfl_xor(rs, 32, 64);
-      if (hf == 0) { mz[4 * j + 0] = mx; mz[4 * j + 1] = inv; mz[4 * j + 2] = rs; }
-      // dS^T in place of dP^T; pad / nonexistent queries have dO = 0 -> dP = 0, rs = 0 -> dS = 0
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dp[ib][r] = st[ib][r] * (dp[ib][r] - rs); dsum[ib][jb][r] += j < WN ? dp[ib][r] : 0.f; }
-      // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
-      f32x16_t oq;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oq[r] = 0.f;
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) oq = mfma16(lds_tfrag(kt, l31, hf, ib, s2), regs_frag(dp[ib], s2), oq);
-      if (j < WN) {
-        int pix, reg;
-        win_token(g, wy, wx, j, pix, reg);
-        if (pix >= 0) {
-          bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3;
-          store_dT(dst + head * HD, oq, hf, scale);
-          if (head == 0 && g.P3 > 3 * g.C && hf == 0)
-            for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---------------- N-layout (lane = key), one 32-key block at a time
-    float padk[16], padv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { padk[r] = 0.f; padv[r] = 0.f; }
-    bool anypad = false;
-#pragma unroll
-    for (int ib = 0; ib < 2; ++ib) {
-      f32x16_t st[2], dp[2];                              // index = query block (registers); lanes = keys 32*ib + l31
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { st[jb][r] = 0.f; dp[jb][r] = 0.f; }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 kv = frag(1, 32 * ib + l31, s2), vv = frag(2, 32 * ib + l31, s2);
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-          st[jb] = mfma16(frag(0, 32 * jb + l31, s2), kv, st[jb]);
-          dp[jb] = mfma16(gfrag(32 * jb + l31, s2), vv, dp[jb]);
-        }
-      }
-      const int i = 32 * ib + l31, ic = i < WN ? i : WN - 1;
-      const unsigned regk = (pk[ic >> 3] >> (4 * (ic & 7))) & 15u;
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const int j0 = 32 * jb + 8 * m + 4 * hf;
-          const float4 bv = *(const float4*)(biast + ic * BLP + j0);
-          const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int j = j0 + e;
-            float sc = st[jb][4 * m + e] * scale + bb[e];
-            { const unsigned rq = (pk[4 * jb + m] >> (16 * hf + 4 * e)) & 15u; sc += rq != regk ? -100.f : 0.f; }
-            const float4 mzv = *(const float4*)(mz + 4 * j);
-            const float pr = (i < WN && j < WN) ? __expf(sc - mzv.x) * mzv.y : 0.f;
-            st[jb][4 * m + e] = pr;                                            // P[query][key]
-            dp[jb][4 * m + e] = pr * (dp[jb][4 * m + e] - mzv.z);              // dS[query][key]
-          }
-        }
-      // dK^T[d][key] = sum_query Q^T[d][query] dS[query][key];  dV^T[d][key] = sum_query dO^T[d][query] P[query][key]
-      f32x16_t ok, ov;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { ok[r] = 0.f; ov[r] = 0.f; }
-#pragma unroll
-      for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          ok = mfma16(lds_tfrag(qt, l31, hf, jb, s2), regs_frag(dp[jb], s2), ok);
-          ov = mfma16(lds_tfrag(dot, l31, hf, jb, s2), regs_frag(st[jb], s2), ov);
-        }
-      int pix = -2, reg;
-      if (i < WN) win_token(g, wy, wx, i, pix, reg);
-      if (pix >= 0) {
-        bf16_t* dst = dqkv + ((size_t)b * g.H * g.W + pix) * g.P3 + head * HD;
-        store_dT(dst + 1 * g.C, ok, hf, scale);
-        store_dT(dst + 2 * g.C, ov, hf, 1.f);
-      } else if (pix == -1) {
-        anypad = true;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { padk[r] += ok[r] * scale; padv[r] += ov[r]; }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float* padp = pad_part + ((size_t)wi * g.heads + head) * 96;
-    if (__any(anypad)) {
-      // fixed-order sum over the window's pad keys through LDS (the Q^T / dO^T tiles of this wave are consumed): [half][key lane][16 d-registers]
-      float* sk = (float*)qt;
-      float* sv = (float*)dot;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { sk[(hf * 32 + l31) * 17 + r] = padk[r]; sv[(hf * 32 + l31) * 17 + r] = padv[r]; }
-      if (lane < HD) {
-        const int d = lane, h2 = (d >> 2) & 1, r = 4 * (d >> 3) + (d & 3);       // d = 8*(r>>2) + 4*half + (r&3)
-        float tk = 0.f, tv = 0.f;
-        for (int l = 0; l < 32; ++l) { tk += sk[(h2 * 32 + l) * 17 + r]; tv += sv[(h2 * 32 + l) * 17 + r]; }
-        padp[d] = 0.f; padp[HD + d] = tk; padp[2 * HD + d] = tv;
-      }
-      // the scratch overwrote token columns 49..63 of Q^T / dO^T, which must read as zero for the next window
-      for (int e = lane; e < 2 * HD * (64 - WN); e += 64) { const int tI = e / (HD * (64 - WN)), r = e % (HD * (64 - WN)); qt[tI * HD * VTP + (r / (64 - WN)) * VTP + WN + r % (64 - WN)] = 0; }
-    } else {
-      for (int e = lane; e < 96; e += 64) padp[e] = 0.f;
-    }
-  }
-  // gradient of the position bias: the 4 waves' sums through LDS (the K^T / Q^T / dO^T area is free now), then one partial row per block
-  __syncthreads();
-  float* tile = (float*)tbase;                                 // [64 queries][64 keys] floats = 16 KiB <= 4 * 3 * 32 * 68 * 2 bytes
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib)
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int j = 32 * jb + l31, i = 32 * ib + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (w == 0) tile[j * 64 + i] = dsum[ib][jb][r]; else tile[j * 64 + i] += dsum[ib][jb][r];
-          }
-    }
-    __syncthreads();
-  }
-  float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
-  for (int e = tid; e < WN * WN; e += 256) dr[e] = tile[(e / WN) * 64 + e % WN];
-}
-
-// ---- MFMA backward, second form (default): same arithmetic and operand values as window_attention_bwd_mfma_kernel (bit-identical results), different data path.
+// ---- MFMA backward (round 3; the first form -- operands staged in the LDS by 2-byte scatter, 156 KiB, one block per CU -- ran 130 us per launch against 65.6 and was removed in round 4).
 // * the 16 natural fragments of a window (q, k, v, dO x two 32-token blocks x two 16-d steps: a lane's 16 bytes of its token row) go from global memory straight to
 //   registers, all loads in flight together, and serve both layouts; nothing natural is staged in the LDS;
 // * k, q, dO are also written to the LDS as [token][32 d] tiles of 64-byte rows with 16-byte stores from those registers, and the three transposed operands
@@ -1747,22 +1516,11 @@ extern "C" int sl_scale_add(int dtype, const void* x, const float* scale, const 
   return 0;
 }
 
-static int attn_valu() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_VALU"); v = (e && e[0] == '1') ? 1 : 0; } return v; }
-extern "C" void sl_debug_attn_valu(int v);
+// test hook (not part of the public ABI): 1 = the fp32-arithmetic VALU kernels (what float32 tensors always run on) also for bf16, 0 / -1 = MFMA kernels for bf16
 static int g_attn_valu_override = -1;
 extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
-static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && !(g_attn_valu_override >= 0 ? g_attn_valu_override : attn_valu()); }
-// MFMA backward: default for bf16 (1.57 ms per Swin-T step against 2.06 ms for the VALU kernel); SEGLAND_ATTN_BWD_MFMA=0 selects the VALU one.
-static int attn_bwd_mfma_env() { static int v = -1; if (v < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_MFMA"); v = (e && e[0] == '0') ? 0 : 1; } return v; }
-// SEGLAND_ATTN_BWD_FORM=1: the first MFMA backward (operands staged in the LDS by 2-byte scatter, one block per CU); 2 (default): registers + transpose reads, two blocks per CU
-int g_attn_bwd_form = -1;
-static int attn_bwd_form() { if (g_attn_bwd_form < 0) { const char* e = getenv("SEGLAND_ATTN_BWD_FORM"); g_attn_bwd_form = (e && e[0] == '1') ? 1 : 2; } return g_attn_bwd_form; }
-extern "C" void sl_debug_attn_bwd_form(int v) { g_attn_bwd_form = v; }
-static bool use_attn_bwd_mfma(int dtype) {
-  if (dtype != SL_BF16) return false;
-  if (g_attn_valu_override >= 0) return g_attn_valu_override == 0;       // test hook: 0 = MFMA everywhere, 1 = VALU everywhere
-  return !attn_valu() && attn_bwd_mfma_env();
-}
+static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && g_attn_valu_override != 1; }
+static bool use_attn_bwd_mfma(int dtype) { return use_attn_mfma(dtype); }
 
 extern "C" int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out, sl_stream_t stream) {
   WinGeom g;
@@ -1837,21 +1595,12 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
   const int nwin = g.B * g.nWy * g.nWx;
   if (use_attn_bwd_mfma(d->dtype)) {
     const int wpw = win_wpw(g), chunks = cdiv(nwin, 4 * wpw);
-    const size_t lds = (size_t)2 * (WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * HD * VTP * sizeof(bf16_t) + (size_t)4 * 4 * 64 * NTP * sizeof(bf16_t) + (size_t)4 * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
-    if (attn_bwd_form() == 2) {
-      const size_t lds2 = (size_t)(WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float) + (size_t)WN * WB2_AP * sizeof(float);
-      static bool attr2 = false;
-      if (!attr2) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
-      hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
-                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
-      SL_LAUNCH_CHECK("window_attention_bwd_mfma2_kernel");
-      return 0;
-    }
-    hipLaunchKernelGGL(window_attention_bwd_mfma_kernel, dim3(chunks * g.heads), dim3(256), lds, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
+    const size_t lds2 = (size_t)(WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float) + (size_t)WN * WB2_AP * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
+    hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
                        (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
-    SL_LAUNCH_CHECK("window_attention_bwd_mfma_kernel");
+    SL_LAUNCH_CHECK("window_attention_bwd_mfma2_kernel");
     return 0;
   }
   const int wpb = win_wpb(g);

@@ -251,9 +251,8 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
         dgamma, dbeta = grad_alias(dgamma, gg), grad_alias(dbeta, gb)
     spec = spec_of(conv)
     dx = dw = part_below = None
-    late = _WGRAD_STREAM and os.environ.get('SEGLAND_WGRAD_LATE', '1') == '1'
-    if need_dw and not late:
-        dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
+    if need_dw:
+        dw = grad_alias(ops.conv2d_bwd_weight(x, dc, spec, x2=x2, out=gw), gw)
     if need_dx:
         _, wb = prepared(conv.weight, c.dtype)
         if below is not None and _BN_FUSE and addend is None and x2 is None and dx_out is None:
@@ -267,47 +266,7 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
         if dx is None:
             dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
                                      C1=(x.shape[3] if x2 is not None else None), out=dx_out)
-    if need_dw and late:
-        # side stream, released only AFTER the data gradient: the MFMA-bound wgrad then runs beside the HBM-bound BN backward of the
-        # previous layer (its waves fit next to the wgrad block on a CU) instead of time-slicing the CUs with the dgrad kernel
-        dw = grad_alias(wgrad_async(x, dc, spec, x2=x2, out=gw), gw)
     return dx, dw, dgamma, dbeta, dres, part_below
-
-
-# Weight gradients have no consumer until the optimizer: they run on a second HIP stream so that their MFMA-bound
-# kernels fill the matrix pipes while the main stream is in HBM-bound phases (BN backward, conv epilogues).
-_SIDE = {}
-_WGRAD_STREAM = os.environ.get('SEGLAND_WGRAD_STREAM', '0') == '1'     # measured: +1 % with the v4 conv kernel, 0 with v5 -> opt-in
-
-
-def wgrad_async(x, dy, spec, x2=None, out=None, out_ci_off=0):
-    if not _WGRAD_STREAM or (ops.PROFILER.on and ops.PROFILER.only is None):
-        # default: MFMA kernel on the main stream, its slab reduce on the second stream (joined by wgrad_join at the end of the block backward)
-        return ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=out, out_ci_off=out_ci_off, fork_reduce=True)
-    main = torch.cuda.current_stream()
-    ent = _SIDE.get(x.device)
-    if ent is None:
-        ent = _SIDE[x.device] = [torch.cuda.Stream(device=x.device), False]
-    side = ent[0]
-    # the result is allocated on the main stream (its consumers live there); inputs are pinned to the side stream's timeline
-    dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        ops.conv2d_bwd_weight(x, dy, spec, x2=x2, out=dw, out_ci_off=out_ci_off)
-    for t in (x, dy, x2):
-        if t is not None:
-            t.record_stream(side)
-    ent[1] = True
-    return dw
-
-
-def wgrad_join():
-    """Make every weight gradient launched so far visible to the current stream (called before gradients leave a backward)."""
-    ops.wgrad_reduce_join()
-    for dev, ent in _SIDE.items():
-        if ent[1]:
-            torch.cuda.current_stream(dev).wait_stream(ent[0])
-            ent[1] = False
 
 
 # ------------------------------------------------------------------------------------------------ stem
@@ -337,12 +296,30 @@ class StemFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ bottleneck
+class _BlockLink:
+    """What two consecutive bottlenecks of ONE forward pass hand each other for the cross-block bn3 fusion (_BN_CROSS).  The producer's forward makes it
+    (bn3: ReLU bits, c3, mean, invstd of its output BatchNorm; out_ptr / out_shape: the tensor it returned), the consumer's forward picks it up from the
+    producer module -- checked against its own input -- and keeps it in its ctx; the consumer's backward leaves the column sums its conv1 data-gradient
+    epilogue produced in pre3 (with the address of the gradient tensor they belong to), the producer's backward takes them.  Nothing is read from module
+    state at backward time."""
+    __slots__ = ('bn3', 'pre3', 'out_ptr', 'out_shape')
+
+    def __init__(self):
+        self.bn3 = self.pre3 = self.out_ptr = self.out_shape = None
+
+
 class BottleneckFn(torch.autograd.Function):
     """networks/backbones/resnet.py:57-78 as one kernel chain; x and the result are NHWC."""
 
     @staticmethod
     def forward(ctx, x, blk, *params):
         bns = [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else [])
+        # the hand-over record of the block that produced x IN THIS FORWARD PASS (a second forward before the first backward makes new records:
+        # a backward never sees another pass's ReLU bits or column sums)
+        pm = blk.__dict__.get('_sl_prev')
+        plink = pm.__dict__.get('_sl_link') if pm is not None else None
+        ctx.prev_link = plink if (plink is not None and plink.out_ptr == x.data_ptr() and plink.out_shape == tuple(x.shape)) else None
+        blk.__dict__['_sl_link'] = None
         if _frozen(ctx, *bns):
             a1 = conv_bn_infer(x, blk.conv1, blk.bn1, relu=True)
             a2 = conv_bn_infer(a1, blk.conv2, blk.bn2, relu=True)
@@ -358,8 +335,9 @@ class BottleneckFn(torch.autograd.Function):
         ctx.blk = blk
         ctx.has_ds = blk.downsample is not None
         # the next bottleneck's backward produces this block's incoming gradient: it may gate it and reduce it against c3 right there (_BN_CROSS)
-        blk.__dict__['_sl_bn3'] = (k3, c3, m3, i3) if (_BN_CROSS and k3 is not None and blk.bn3.training and not ctx.has_ds and any(ctx.needs_input_grad)) else None
-        blk.__dict__['_sl_pre3'] = None
+        link = ctx.link = blk.__dict__['_sl_link'] = _BlockLink()
+        link.bn3 = (k3, c3, m3, i3) if (_BN_CROSS and k3 is not None and blk.bn3.training and not ctx.has_ds and any(ctx.needs_input_grad)) else None
+        link.out_ptr, link.out_shape = out.data_ptr(), tuple(out.shape)
         saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3]
         if ctx.has_ds:
             saved += [cd, md, idd]
@@ -382,9 +360,8 @@ class BottleneckFn(torch.autograd.Function):
         # (where the kernel has the staged store phase: layer3 / layer4 at the bench shapes): that layer's reduce pass over (g, c) disappears
         # this block's incoming gradient may have been gated and reduced against c3 by the block behind it (its conv1 data gradient epilogue): the tensor
         # autograd hands over must be exactly the one that epilogue wrote (a second consumer of this block's output would have made autograd sum into a new one)
-        pre3 = blk.__dict__.get('_sl_pre3')
-        blk.__dict__['_sl_pre3'] = None
-        blk.__dict__['_sl_bn3'] = None
+        link = ctx.link
+        pre3, link.pre3, link.bn3 = link.pre3, None, None
         p3 = None
         if pre3 is not None and pre3[0] == dout.data_ptr() and pre3[1] == tuple(dout.shape) and not ctx.has_ds:
             p3, k3 = pre3[2], None                   # dout is gated already: no bits for bn3, none for the identity shortcut
@@ -400,8 +377,8 @@ class BottleneckFn(torch.autograd.Function):
         # the block in front of this one can take its bn3 column sums from this block's conv1 data gradient only if the shortcut gradient enters that epilogue
         # gated already: either dout arrived gated (p3), or the shortcut is a downsample branch, or -- the start of a chain inside a stage -- bn3's apply pass
         # also writes the gated gradient (one extra write of dout's size, repaid by every block further up the stage)
-        prev = blk.__dict__.get('_sl_prev')
-        prev3 = prev.__dict__.get('_sl_bn3') if (prev is not None and need_x and _BN_CROSS) else None
+        plink = ctx.prev_link
+        prev3 = plink.bn3 if (plink is not None and need_x and _BN_CROSS) else None
         if prev3 is not None and (prev3[1].shape != x.shape or prev3[1].dtype != x.dtype or not ops.conv2d_bwd_data_addend_bnstat_ok(x, spec_of(blk.conv1))):
             prev3 = None
         want_dres = prev3 is not None and not ctx.has_ds and k3 is not None and p3 is None and done3 is None
@@ -425,8 +402,7 @@ class BottleneckFn(torch.autograd.Function):
                                                addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1,
                                                prev3=prev3)
         if pp is not None and prev3 is not None:
-            prev.__dict__['_sl_pre3'] = (dx.data_ptr(), tuple(dx.shape), pp)
-        wgrad_join()
+            plink.pre3 = (dx.data_ptr(), tuple(dx.shape), pp)
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds
 
 
@@ -513,7 +489,7 @@ class PPMFn(torch.autograd.Function):
         _, wbf = prepared(bt[3].weight, x4.dtype)
         dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
         gwf = grad_dst(bt[3].weight) if need_w else None
-        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf, fork_reduce=True), gwf) if need_w else None
+        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf), gwf) if need_w else None
         dbias = ops.colsum_rows(dfeat) if need_w else None
         if ctx.fact:
             N = bt[0].out_channels
@@ -557,7 +533,6 @@ class PPMFn(torch.autograd.Function):
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None
         dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None
-        wgrad_join()
         return (dx4, None, *gstage, dwb, dgb, dbb, dwf, dbias)
 
 
@@ -639,7 +614,7 @@ def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x, big=0):
         ops.conv2d_bwd_data(dh2[a:b].view(1, 1, b - a, Cn), w2b, spec_of(cls[2]), (1, b - a), mask_src=h1r[a:b].view(1, 1, b - a, Cn), out=dh1[a:b].view(1, 1, b - a, Cn))
     dh2, dh1 = dh2.view(1, 1, R, Cn), dh1.view(1, 1, R, Cn)
     g2 = grad_dst(cls[2].weight) if need_w else None
-    dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2, fork_reduce=True), g2) if need_w else None
+    dw2 = grad_alias(ops.conv2d_bwd_weight(h1, dh2, spec_of(cls[2]), out=g2), g2) if need_w else None
     dX = None
     if need_x:
         _, w1b = prepared(cls[0].weight, X.dtype)
@@ -647,8 +622,7 @@ def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x, big=0):
         for a, b in parts:
             ops.conv2d_bwd_data(dh1[0, 0, a:b].view(1, 1, b - a, Cn), w1b, spec_of(cls[0]), (1, b - a), out=dX[a:b].view(1, 1, b - a, Cn))
     g1 = grad_dst(cls[0].weight) if need_w else None
-    dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1, fork_reduce=True), g1) if need_w else None
-    ops.wgrad_reduce_join()
+    dw1 = grad_alias(ops.conv2d_bwd_weight(X.view(1, 1, R, Cn), dh1, spec_of(cls[0]), out=g1), g1) if need_w else None
     return dX, dw1, dw2, (dw3.view_as(cls[4].weight) if need_w else None)
 
 

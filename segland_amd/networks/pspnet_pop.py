@@ -180,7 +180,9 @@ class GFSS_Model(nn.Module):
     def _protos(self):
         """(sb, sn | None, orth term): normalised prototypes + the orthogonality term of this mode's similarity matrix (base: sb sb^T, :185-186;
         ft: sn [sn ; sb]^T, :236-239), one kernel (functional.ProtoFn).  SEGLAND_PROTO_FUSED=0: the torch ops."""
-        if not _PROTO_FUSED or not self.base_emb.is_cuda:
+        ka, kb = (self.novel_emb.shape[0], self.base_emb.shape[0]) if self.is_ft else (self.base_emb.shape[0], 0)
+        if not _PROTO_FUSED or not self.base_emb.is_cuda or not ops.proto_fused_ok(ka, kb, self.base_emb.shape[1]):
+            # torch ops: switched off, or more prototypes than the one-block kernels hold (--base-classes > 15 at 512 channels)
             sb = F.normalize(self.base_emb.float(), p=2, dim=-1)
             return sb, (F.normalize(self.novel_emb.float(), p=2, dim=-1) if self.is_ft else None), None
         if self.is_ft:

@@ -63,8 +63,7 @@ class _Profiler:
 
     def family(self, kind, d):
         if kind == 'conv_wgrad':
-            # the kernel rocprofv3 names.  Its deterministic slab reduce (a separate small launch) is inside the span in the instrumented per-shape
-            # pass and beside it, on the second stream, in the timed regions (conv2d_bwd_weight fork_reduce)
+            # the kernel rocprofv3 names.  Its deterministic slab reduce (a separate small launch behind it on the same stream) is inside the span
             cfg = _lib.lib().sl_conv2d_wgrad_config(C.byref(d))
             dts = 'bf16' if d.dtype == SL_BF16 else 'f32'
             if cfg == 1:
@@ -284,8 +283,8 @@ _ws_cache = {}
 
 
 def workspace(nbytes, dev, tag=None):
-    """Grow-only scratch buffer per device (stream-ordered reuse: all our launches are on the current stream).  `tag`: a separate buffer
-    (the weight-gradient slabs, which a reduce on the second stream may still be reading when the next op on this stream starts)."""
+    """Grow-only scratch buffer per device and stream (stream-ordered reuse: all our launches are on the current stream).  `tag`: a separate buffer (the
+    weight-gradient slabs keep theirs: up to 1 GiB, and the small users do not grow with them)."""
     key = (dev, _s(), tag)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
@@ -294,44 +293,16 @@ def workspace(nbytes, dev, tag=None):
     return w
 
 
-# Slab reduces of the weight gradients on a second stream (csrc/conv_wgrad.hip: sl_conv2d_bwd_weight_ex2): the reduce of layer k runs beside the
-# MFMA-bound data gradient of layer k that follows on the main stream.  Only callers that join before the gradient leaves their backward
-# (wgrad_reduce_join) may ask for it.  MEASURED NEGATIVE (same box, A/B/A/B, profiles/r3_ab_switches.txt): 27.10 ms per step with the fork,
-# 26.53 without -- every fork / join is a pair of cross-branch dependencies in the captured graph, which cost more than the 9 us reduce they
-# hide.  Off by default; SEGLAND_WGRAD_REDUCE_STREAM=1 switches it on.
-import os as _os
-_RED_FORK = _os.environ.get('SEGLAND_WGRAD_REDUCE_STREAM', '0') == '1'
-_red_streams = {}
-_red_pending = [False]
-
-
-def _reduce_stream(dev):
-    st = _red_streams.get(dev)
-    if st is None:
-        st = _red_streams[dev] = torch.cuda.Stream(device=dev)
-    return st
-
-
-def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0, fork_reduce=False):
-    """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off.
-    fork_reduce: the slab reduce goes to the second stream; the caller MUST call wgrad_reduce_join() before dw is read or handed to autograd."""
+def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0):
+    """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off.  The fixed-order slab
+    reduce follows the MFMA kernel on the same stream."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
-    need = _lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d))
-    fork = fork_reduce and _RED_FORK and not (PROFILER.on and PROFILER.only is None)     # the instrumented per-shape pass times kernel + reduce on one stream
-    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
-    if cur is not None and cur.numel() < need:
-        wgrad_reduce_join()                       # the buffer is about to be replaced: no reduce on the second stream may still be reading the old one
-    ws = workspace(need, x.device, 'wgrad')
+    ws = workspace(_lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
     dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
     tot = dw.shape[1]
     tok = PROFILER.begin('conv_wgrad', d)
-    red = None
-    if fork:
-        rs = _reduce_stream(x.device)
-        red = rs.cuda_stream
-        _red_pending[0] = True
-    check(_lib.lib().sl_conv2d_bwd_weight_ex2(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s(), red), 'conv2d_bwd_weight')
+    check(_lib.lib().sl_conv2d_bwd_weight_ex(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
     PROFILER.end(tok)
     return dw
 
@@ -342,11 +313,7 @@ def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     L = _lib.lib()
-    need = L.sl_conv2d_bwd_weight_workspace(C.byref(d))
-    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
-    if cur is not None and cur.numel() < need:
-        wgrad_reduce_join()
-    ws = workspace(need, x.device, 'wgrad')
+    ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
     dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
     Cn = dy.shape[-1]
     rows = dy.numel() // Cn
@@ -364,11 +331,7 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     L = _lib.lib()
-    need = L.sl_conv2d_bwd_weight_workspace(C.byref(d))
-    cur = _ws_cache.get((x.device, _s(), 'wgrad'))
-    if cur is not None and cur.numel() < need:
-        wgrad_reduce_join()
-    ws = workspace(need, x.device, 'wgrad')
+    ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
     dw = torch.empty((n_valid, c_valid, spec.k, spec.k), dtype=torch.float32, device=x.device)
     part = None
     if want_bias:
@@ -381,18 +344,6 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
     if not want_bias:
         return dw
     return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
-
-
-def wgrad_reduce_join():
-    """The current stream waits for every slab reduce issued on the second stream so far."""
-    if _red_pending[0]:
-        dev = torch.cuda.current_device()
-        rs = _red_streams.get(torch.device('cuda', dev))
-        if rs is None and _red_streams:
-            rs = list(_red_streams.values())[0]
-        if rs is not None:
-            check(_lib.lib().sl_stream_join(_s(), rs.cuda_stream), 'stream_join')
-        _red_pending[0] = False
 
 
 # --------------------------------------------------------------------------------------------- batch norm
@@ -893,6 +844,11 @@ def nchw_f32_to_nhwc(x, dtype):
 
 
 # --------------------------------------------------------------------------------------------- prototype preparation
+def proto_fused_ok(Ka, Kb, Cn):
+    """Do the one-block prototype kernels (forward AND backward) hold Ka + Kb prototypes of Cn channels?"""
+    return bool(_lib.lib().sl_pop_proto_ok(int(Ka), int(Kb), int(Cn)))
+
+
 def pop_proto_fwd(Ea, Eb=None):
     """(Sa, Sb, inv_norm, G, orth): L2-normalised prototypes, G = Sa [Sa ; Sb]^T and mean |G[i][j]|, j > i, in one launch."""
     Ka, Cn = Ea.shape

@@ -188,11 +188,11 @@ def test_bench_self_launch_starts_fresh_child_ranks(monkeypatch, capsys):
     spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: 1)
     assert bench.self_launch(2, ['--gpus', '2']) == 3
     assert 'exposes 1 GPU' in capsys.readouterr().err
     calls = []
-    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda: 8)
     monkeypatch.setattr(subprocess, 'call', lambda cmd, env=None: calls.append((cmd, env)) or 0)
     assert bench.self_launch(4, ['--gpus', '4', '--steps', '5']) == 0
     cmd, env = calls[0]
@@ -264,36 +264,7 @@ def test_bucket_replica_backward_cut_on_cpu():
     leaf / clear_cut): gradients of both halves land in their own bucket groups and equal a plain backward."""
     from segland_amd import bucket_step
 
-    class Toy(torch.nn.Module):
-        bucket_cut_default = True
-
-        def __init__(self):
-            super().__init__()
-            torch.manual_seed(0)
-            self.early = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16))
-            self.late = torch.nn.Sequential(torch.nn.Tanh(), torch.nn.Linear(16, 4))
-            self._want, self._cut = False, None
-
-        def enable_backward_cut(self, flag):
-            self._want = bool(flag)
-
-        def late_parameters(self):
-            return list(self.late.parameters())
-
-        def cut_tensors(self):
-            return [self._cut] if self._cut is not None else None
-
-        def clear_cut(self):
-            self._cut = None
-
-        def forward(self, x, y):
-            self._cut = None
-            h = self.early(x)
-            if self._want and h.requires_grad:
-                leaf = h.detach().requires_grad_(True)
-                self._cut, h = (h, leaf), leaf
-            return {'total_loss': ((self.late(h) - y) ** 2).mean()}
-
+    Toy = _CutToy
     x, y = torch.randn(5, 8), torch.randn(5, 4)
     ref = Toy()
     ref(x, y)['total_loss'].backward()
@@ -313,3 +284,134 @@ def test_bucket_replica_backward_cut_on_cpu():
     late_ids = {id(p) for p in m.late.parameters()}
     n_late = sum(-(-p.numel() // 64) * 64 for p in m.parameters() if id(p) in late_ids)
     assert sum(b.numel() for b in rep.buckets[:rep.late_buckets]) == n_late
+
+
+# ------------------------------------------------------------------------------------------------ the capture decision of GraphedBucketStep is collective
+class _CutToy(torch.nn.Module):
+    """The cut interface of the GPU models (late_parameters / cut_tensors on a detached leaf / clear_cut) on two small MLP halves."""
+    bucket_cut_default = True
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.early = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16))
+        self.late = torch.nn.Sequential(torch.nn.Tanh(), torch.nn.Linear(16, 4))
+        self._want, self._cut = False, None
+
+    def enable_backward_cut(self, flag):
+        self._want = bool(flag)
+
+    def late_parameters(self):
+        return list(self.late.parameters())
+
+    def cut_tensors(self):
+        return [self._cut] if self._cut is not None else None
+
+    def clear_cut(self):
+        self._cut = None
+
+    def forward(self, x, y):
+        self._cut = None
+        h = self.early(x)
+        if self._want and h.requires_grad:
+            leaf = h.detach().requires_grad_(True)
+            self._cut, h = (h, leaf), leaf
+        return {'total_loss': ((self.late(h) - y) ** 2).mean()}
+
+
+class _ToyOpt(torch.optim.SGD):
+    """segland_amd.optim.AdamW's extra surface (step(repeat, grad_scale), capture_begin, graph_prepare) on plain SGD."""
+
+    def step(self, closure=None, repeat=1, grad_scale=None):
+        for _ in range(repeat):
+            for g in self.param_groups:
+                for p in g['params']:
+                    if p.grad is not None:
+                        p.data.add_(p.grad * (grad_scale if grad_scale is not None else 1.0), alpha=-g['lr'])
+
+    def capture_begin(self):
+        pass
+
+    def graph_prepare(self):
+        pass
+
+
+def _fallback_worker(rank, world, port, q, fail_rank):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', init_method='env://')
+    from segland_amd import bucket_step
+
+    class Recorded:
+        """Stands in for a captured HIP graph on the CPU: recording does not run the part, replay() does."""
+
+        def __init__(self, fn, args, slot):
+            self.fn, self.args, self.slot = fn, args, slot
+
+        def replay(self):
+            out = self.fn(*self.args)
+            if isinstance(out, dict):
+                self.slot.update({k: v.detach() for k, v in out.items()})
+            elif out is not None:
+                self.slot['norm'] = out.detach()
+
+    class Step(bucket_step.GraphedBucketStep):
+        attempts = 0
+
+        def _capture_graphs(self, img, mask):
+            Step.attempts += 1
+            graphs, loss, norm = [], {}, {}
+            self.static_in = (img.clone(), mask.clone())
+
+            def call(fn, *args):
+                if rank == fail_rank and Step.attempts == 1 and len(graphs) == 1:
+                    raise RuntimeError('injected: the second part fails to capture on rank %d only' % rank)
+                graphs.append(Recorded(fn, self.static_in if args else (), loss if not graphs else norm))
+                return loss if len(graphs) == 1 else norm
+            self.replica._run(self.parts, img, mask, call, collectives=False)
+            return graphs, (loss, norm)
+
+    torch.manual_seed(100 + rank)
+    data = [(torch.randn(5, 8), torch.randn(5, 4)) for _ in range(5)]
+
+    def run(graphed):
+        m = _CutToy()
+        rep = bucket_step.BucketedReplica(m, cap_mb=0.001)
+        opt = _ToyOpt(m.parameters(), lr=0.05)
+        step = Step(rep, opt, double_step=True, warmup=1) if graphed else None
+        for x, y in data:
+            step(x, y) if graphed else rep.train_iteration(opt, x, y, double_step=True)
+        return [p.detach().clone() for p in m.parameters()], step
+
+    want, _ = run(False)
+    got, step = run(True)
+    same = all(torch.equal(a, b) for a, b in zip(want, got))
+    # the ranks hold the same parameters after every step (same averaged gradient): compare rank 1's with rank 0's
+    flat = torch.cat([p.reshape(-1) for p in got])
+    ref0 = flat.clone()
+    dist.broadcast(ref0, 0)
+    q.put((rank, same, bool(torch.equal(flat, ref0)), step.failures, step.replays, Step.attempts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('fail_rank', [1, 0])
+def test_bucket_step_capture_failure_on_one_rank_is_a_collective_decision(fail_rank):
+    """Round-3 advisor: a capture that fails on ONE rank (out of memory on one GPU) must not leave that rank issuing the step's all-reduces twice while the other issues
+    them once.  GraphedBucketStep captures without running or exchanging anything, the ranks agree, and the step runs once everywhere: kernel by kernel after a failed
+    attempt (on either rank), as three replays after a good one.  Two gloo ranks, recorded parts standing in for HIP graphs; parameters equal the plain
+    train_iteration run bit for bit and equal across ranks; both ranks count one failure and the same number of replays (no hang = the collectives lined up)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, fail_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, same, same_as_rank0, failures, replays, attempts in res:
+        assert same, 'rank %d: parameters differ from the kernel-by-kernel run' % rank
+        assert same_as_rank0, 'rank %d: parameters differ from rank 0' % rank
+        assert (failures, attempts, replays) == (1, 2, 3), (rank, failures, attempts, replays)      # step 0 warm-up, 1 failed attempt -> eager, 2 capture + replay, 3-4 replays

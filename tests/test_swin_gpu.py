@@ -358,14 +358,6 @@ def test_window_attention_mfma_vs_valu(hip, Cn, heads, H, W, shift):
         finally:
             L.sl_debug_attn_valu(-1)
         res[name] = (out.float().cpu(), [t.float().cpu() for t in grads])
-    # the two data paths of the MFMA backward (LDS-staged operands / registers + transpose reads) feed the same operand values to the same MFMA sequence
-    L.sl_debug_attn_valu(0); L.sl_debug_attn_bwd_form(1)
-    try:
-        g1 = [t.float().cpu() for t in osw.window_attention_bwd(qg, bias.to(DEV), relb.to(DEV), dg, Cn, heads, shift)]
-    finally:
-        L.sl_debug_attn_valu(-1); L.sl_debug_attn_bwd_form(2)
-    assert torch.equal(g1[0], res['mfma'][1][0])                         # dqkv: bit-identical
-    assert l2(res['mfma'][1][1], g1[1]) <= 1e-6 and l2(res['mfma'][1][2], g1[2]) <= 1e-6      # sums over windows / pad keys: other (fixed) summation orders
     # torch evaluation on the bf16-rounded inputs (pad tokens carry the bf16-rounded bias, as the qkv GEMM would have stored it)
     qr = qg.float().cpu()[..., :3 * Cn].requires_grad_(True)
     br = bias.clone().requires_grad_(True)
