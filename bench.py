@@ -53,6 +53,8 @@ def parse():
     p.add_argument('--no-step-graph', action='store_true', help='issue the timed steps kernel by kernel (default on one GPU: they replay the step as ONE HIP graph, segland_amd/graph_step.py, '
                    'like train_base does).  Either way a second region of instrumented kernel-by-kernel steps carries the roofline events')
     p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
+    p.add_argument('--no-other-configs', action='store_true', help='skip the short measurements of BASELINE configs 3 (ResNet-101 shard), 4 (fine-tune pair) and 5 (Swin-T shard) '
+                   'that ride on the default N = 1 run (`other_configs` in the JSON line); profiling runs pass this so that the trace holds the headline workload only')
     return p.parse_args()
 
 
@@ -167,6 +169,93 @@ def visible_gpus():
         if v is not None:
             n = min(n, len([x for x in v.split(',') if x.strip() != '']))
     return n
+
+
+def _dominant(table, peak):
+    """(kernel family with the most time in an instrumented step, its fraction of `peak` TFLOP/s, its ms per step)."""
+    if not table:
+        return None, None, None
+    e = max(table.values(), key=lambda t: t['ms_total'])
+    return e['family'], round(e['gflop'] / max(e['ms_total'], 1e-9) / peak, 4), round(e['ms_total'], 3)
+
+
+def short_config(kind, dev, steps=10):
+    """One of BASELINE.json's other single-GPU workloads, measured briefly in this process after the headline region so that the driver's N = 1 line shows them:
+    'c3' = config 3's per-GPU shard (PSPNet-POP ResNet-101, bf16, 16 tiles), 'c5' = config 5's (Swin-T POP, bf16, 8 tiles), both the train_base.py loop body
+    replayed as one HIP graph; 'c4' = config 4 (ft_pop.py:233-269: one novel + one base tile per step, frozen backbone + decoder, SGD on the novel head).
+    3 eager warm-up steps (the last one instrumented: dominant conv kernel family and its fraction of the 2 500 TFLOP/s peak), graph capture, `steps` timed replays."""
+    from segland_amd import graph_step, networks, ops
+    from segland_amd.loss.criterion import OrthLoss
+    torch.manual_seed(0)
+    dt = torch.bfloat16
+    if kind in ('c3', 'c5'):
+        name, backbone, batch = ('pspnet_pop', 'resnet101', 16) if kind == 'c3' else ('swin_pop', 'swin-t', 8)
+        kw = dict(dilated=True, os=8) if name == 'pspnet_pop' else {}
+        with contextlib.redirect_stdout(sys.stderr):
+            model = getattr(networks, name).GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone=backbone, pretrained_model=None, compute_dtype=dt, **kw).to(dev).train()
+        opt = make_optimizer(model)
+        params = [p for p in model.parameters() if p.requires_grad]
+        batches = [synthetic_batch(batch, 512, dev, seed=100 + k) for k in range(2)]
+        for i in range(3):
+            if i == 2:
+                ops.PROFILER.start()
+            train_step(model, opt, *batches[i % 2], params, True)
+        torch.cuda.synchronize()
+        table = ops.PROFILER.stop(); ops.PROFILER.stop_bytes()
+        fn = lambda m_, o_, s_, im_, mk_, double_step=True: (train_step(m_, o_, im_, mk_, params, double_step), None)      # noqa: E731
+        graphed = graph_step.GraphedTrainStep(fn, model, opt, None, double_step=True, warmup=0)
+        for k in range(3):
+            graphed(*batches[k % 2])
+        step = (lambda k: graphed(*batches[k % 2])) if graphed.graph is not None else (lambda k: train_step(model, opt, *batches[k % 2], params, True))
+        units, unit, gflop = batch, 'tiles/s', GFLOP_PER_TILE[backbone]
+        issue = 'one HIP graph replay per step' if graphed.graph is not None else 'kernel by kernel'
+        what = '%s %s bf16, batch %d, 512x512, train_base.py loop body (BASELINE config %s per GPU)' % ('PSPNet-POP' if kind == 'c3' else 'Swin-POP', backbone, batch, kind[1])
+    else:
+        from segland_amd.ft_pop import ft_graph_body, ft_iteration, ft_iteration_graphed
+        from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+        with contextlib.redirect_stdout(sys.stderr):
+            model = networks.pspnet_pop.GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, compute_dtype=dt,
+                                                   dilated=True, os=8).to(dev)
+        model.init_cls_n()
+        opt = torch.optim.SGD(get_parameters(model, lr=1e-3, freeze_backbone=True), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        g = torch.Generator(device='cpu').manual_seed(7)
+        img, img_b = torch.randn(1, 3, 512, 512, generator=g).to(dev), torch.randn(1, 3, 512, 512, generator=g).to(dev)
+        mask = torch.randint(8, 12, (1, 512, 512), generator=g).to(dev); mask[:, :40] = 255
+        mask_b = torch.randint(0, 8, (1, 512, 512), generator=g).to(dev)
+        model.train_mode()
+        sc = NativeScalerWithGradNormCount()
+        from segland_amd.networks import pspnet_pop as _pp
+        fg = _pp._FEATURE_GRAPH
+        for i in range(3):
+            if i == 2:
+                ops.PROFILER.start()
+                _pp._FEATURE_GRAPH = False                  # the instrumented step issues the frozen feature extractor kernel by kernel (a graph replay cannot carry event pairs)
+            try:
+                ft_iteration(model, opt, sc, (img, mask, img_b, mask_b.clone()), dev)
+            finally:
+                _pp._FEATURE_GRAPH = fg
+        torch.cuda.synchronize()
+        table = ops.PROFILER.stop(); ops.PROFILER.stop_bytes()
+        graphed = graph_step.GraphedStep(ft_graph_body(model), model) if graph_step.eligible(model, opt, dev, need_adamw=False) else None
+        if graphed is not None:
+            for k in range(5):
+                ft_iteration_graphed(graphed, opt, (img, mask, img_b, mask_b), dev)
+        replayed = graphed is not None and graphed.graph is not None
+        step = (lambda k: ft_iteration_graphed(graphed, opt, (img, mask, img_b, mask_b), dev)) if replayed else (lambda k: ft_iteration(model, opt, sc, (img, mask, img_b, mask_b.clone()), dev))
+        units, unit, gflop = 1, 'pairs/s', 901.7                                      # SURVEY 8d: the pair as the reference executes it
+        issue = 'forward + backward + clip replayed as one HIP graph, SGD step behind it' if replayed else 'kernel by kernel'
+        what = 'ft_pop.py novel-class update: 1 novel + 1 base 512x512 tile per step, PSPNet-POP ResNet-50 bf16, frozen backbone + decoder (BASELINE config 4)'
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    value = units * steps / dt_s
+    fam, frac, fam_ms = _dominant(table, PEAK_BF16_TFLOPS)
+    return {'workload': what, 'value': round(value, 2), 'unit': unit, 'ms_per_step': round(1e3 * dt_s / steps, 3), 'steps': steps, 'step_issue': issue,
+            'whole_step_frac_of_peak': round(value * gflop / 1e3 / PEAK_BF16_TFLOPS, 4), 'reference_gflop_per_unit': gflop,
+            'dominant_kernel': fam, 'dominant_kernel_frac_of_peak': frac, 'dominant_kernel_ms_per_step': fam_ms}
 
 
 def self_launch(n, argv=None):
@@ -384,6 +473,18 @@ def main():
                                        + ' (every shape it serves; a weight-gradient span includes the small fixed-order slab reduce launched behind the kernel); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
                                        + 'peak is the 2.4 GHz figure: on these N(0,1) operands the chip sustains ~1.65 GHz under this kernel (the same binary on all-zero operands runs '
                                        + '+26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
+        if world == 1 and not a.no_other_configs and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.dtype == 'bf16' and a.batch == 16 and a.size == 512:
+            # the other BASELINE configurations that fit one GPU, ~5 s each (the headline model is released first)
+            model = opt = net = params = batches = graphed = eager_fn = fn = img = mask = replica = None      # noqa: F841
+            import gc
+            others = {}
+            for kind, key in (('c3', 'config3_resnet101_shard'), ('c4', 'config4_ft_pair'), ('c5', 'config5_swin_t_shard')):
+                gc.collect(); torch.cuda.empty_cache()
+                try:
+                    others[key] = short_config(kind, dev)
+                except Exception as e:                  # noqa: BLE001  (the headline line must not be lost to a side measurement)
+                    others[key] = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
+            out['other_configs'] = others
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(a.cpu_budget, a.backbone, a.model)
         print(json.dumps(out), flush=True)

@@ -82,6 +82,13 @@ int sl_linear_fwd(const SlConvDesc* d, const void* x, const void* w, const float
  * BatchNorm (running statistics), the shortcut add and the ReLU of resnet.py:60-76 folded into the conv epilogue. */
 int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
                          const float* shift, const void* residual, int relu, void* y, sl_stream_t stream);
+/* The same with (a) `pre_addend` [M][Cout] added to the conv result BEFORE scale / shift (the factorised pyramid priors of pspnet_pop.py:31-35 in a frozen forward: the
+ * prior half of the 3x3 bottleneck conv contracted on the pooled grids, see sl_ppm_fact_gather) and (b) an optional split-K workspace: layers with too few 256 x 256 tiles
+ * for the chip (the fine-tune pair of ft_pop.py:233-269 is 8 192 pixel rows) are cut along K, the parts' fp32 tiles go through `workspace` and are summed in a fixed
+ * order before the epilogue.  sl_conv2d_affine_fwd_workspace: bytes that would be used (0 = the layer is not split); workspace may be NULL (no split). */
+size_t sl_conv2d_affine_fwd_workspace(const SlConvDesc* d);
+int sl_conv2d_affine_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend, const float* scale,
+                            const float* shift, const void* residual, int relu, void* y, void* workspace, size_t workspace_bytes, sl_stream_t stream);
 
 /* dx = conv_transpose(dy, w) (+addend [* relu bit of addend_mask]) (masked by mask_src > 0).
  * wt: [Cin][KH][KW][Cout] dtype (sl_weight_prep).  dx: [B][H][W][Cin] (all Cin channels, also for a virtual concat).

@@ -61,86 +61,6 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_finalize_train_kernel(cons
   }
 }
 
-// Round 4: the same sums on 1024 threads per 32 channels with every load of a thread in flight at once.  The 32 x 32 form above reads 4 bytes per lane and walks
-// rows / 32 rows per thread in batches of eight: 5-8 us per launch for 0.5-4 MB of partials that sit in the L2 / Infinity Cache (profiles/r3_kernel_sequence_graph_step.txt),
-// 116 such launches per ResNet-50 step.  Here a thread owns FOUR channels (16-byte loads) of the row lane rl = tid / 8 (128 row lanes): rows / 128 row pairs per thread -- two
-// for the 256-row partials of the 64 x 64 maps, eight for layer1's 1024 -- then the eight row lanes of a wavefront by shuffles, the 16 wavefronts through the LDS in a fixed
-// order (bit-stable; double accumulation as before).  C % 4 == 0 and a 16-byte aligned buffer; anything else keeps the form above.
-constexpr int FQ = 8, FRL = 128;
-__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
-  return __hiloint2double(hi, lo);
-}
-// -> s[k], q[k] (k = threadIdx.x % 32... valid in threads < 32: channel blockIdx.x * 32 + threadIdx.x)
-__device__ __forceinline__ void colsum2_quads(const float* __restrict__ part, int rows, int C, double& s, double& q, double (*red)[2][4 * FQ]) {
-  const int tid = threadIdx.x, cq = tid & (FQ - 1), rl = tid / FQ;
-  const int c0 = blockIdx.x * 4 * FQ + 4 * cq;
-  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
-  if (c0 < C) {
-    const float4* p4 = (const float4*)(part + c0);
-    const size_t pitch = (size_t)C / 4;                      // float4 per [row][stat] line
-    // four row pairs in flight per thread, every load unconditional (a row past the end re-reads this thread's first row and is dropped by a select: loads under a
-    // branch would make the compiler wait for all of them before the first add)
-    for (int r = rl; r < rows; r += 4 * FRL) {
-      float4 v0[4], v1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rr = r + u * FRL < rows ? r + u * FRL : rl;
-        v0[u] = p4[((size_t)rr * 2 + 0) * pitch]; v1[u] = p4[((size_t)rr * 2 + 1) * pitch];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = r + u * FRL < rows;
-        a0[0] += ok ? (double)v0[u].x : 0.0; a0[1] += ok ? (double)v0[u].y : 0.0; a0[2] += ok ? (double)v0[u].z : 0.0; a0[3] += ok ? (double)v0[u].w : 0.0;
-        a1[0] += ok ? (double)v1[u].x : 0.0; a1[1] += ok ? (double)v1[u].y : 0.0; a1[2] += ok ? (double)v1[u].z : 0.0; a1[3] += ok ? (double)v1[u].w : 0.0;
-      }
-    }
-  }
-  // the eight row lanes of a wavefront (lane bits 3..5), fixed xor tree
-#pragma unroll
-  for (int m = FQ; m < 64; m <<= 1) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a0[k] += shfl_xor_f64(a0[k], m); a1[k] += shfl_xor_f64(a1[k], m); }
-  }
-  const int wave = tid >> 6, lane = tid & 63;
-  if (lane < FQ) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[wave][0][4 * lane + k] = a0[k]; red[wave][1][4 * lane + k] = a1[k]; }
-  }
-  __syncthreads();
-  s = 0.0; q = 0.0;
-  if (tid < 4 * FQ) {
-#pragma unroll
-    for (int w = 0; w < FQ * FRL / 64; ++w) { s += red[w][0][tid]; q += red[w][1][tid]; }
-  }
-}
-
-__global__ __launch_bounds__(FQ * FRL) void bn_finalize_train_q_kernel(const float* __restrict__ part, int rows, int C, double count,
-                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                         float* rmean, float* rvar, float momentum, float eps,
-                                         float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[FQ * FRL / 64][2][4 * FQ];
-  double s, q;
-  colsum2_quads(part, rows, C, s, q, red);
-  const int c = blockIdx.x * 4 * FQ + threadIdx.x;
-  if (threadIdx.x >= 4 * FQ || c >= C) return;
-  const double mu = s / count;
-  double var = q / count - mu * mu;
-  if (var < 0.0) var = 0.0;
-  const double is = 1.0 / sqrt(var + (double)eps);
-  mean[c] = (float)mu;
-  invstd[c] = (float)is;
-  const double g = gamma ? (double)gamma[c] : 1.0, b = beta ? (double)beta[c] : 0.0;
-  scale[c] = (float)(g * is);
-  shift[c] = (float)(b - mu * g * is);
-  if (rmean) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
-    rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unbiased);
-  }
-}
-
 __global__ void bn_finalize_eval_kernel(int C, const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                         float eps, float* mean, float* invstd, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,26 +228,6 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_bwd_finalize_kernel(const 
   }
 }
 
-__global__ __launch_bounds__(FQ * FRL) void bn_bwd_finalize_q_kernel(const float* __restrict__ part, int nblk, int C, double count, const float* gamma,
-                                       const float* mean, const float* invstd, int train, float* dgamma, float* dbeta,
-                                       float* cA, float* cB, float* cC) {
-  __shared__ double red[FQ * FRL / 64][2][4 * FQ];
-  double s1, s2;
-  colsum2_quads(part, nblk, C, s1, s2, red);
-  const int c = blockIdx.x * 4 * FQ + threadIdx.x;
-  if (threadIdx.x >= 4 * FQ || c >= C) return;
-  if (dgamma) dgamma[c] = (float)s2;
-  if (dbeta) dbeta[c] = (float)s1;
-  const double g = gamma ? (double)gamma[c] : 1.0, is = (double)invstd[c];
-  cA[c] = (float)(g * is);
-  if (train) {
-    cB[c] = (float)(-g * is * is * s2 / count);
-    cC[c] = (float)(-g * is * s1 / count);
-  } else {
-    cB[c] = 0.f; cC[c] = 0.f;
-  }
-}
-
 template <typename T, bool FIXEDC, bool DUAL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const uint8_t* __restrict__ mask, const T* __restrict__ x,
                                     const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC,
@@ -390,28 +290,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-static int g_bn_fin_quads = 1;      // test hook sl_debug_bn_finalize_form: 0 = the 32 x 32 form everywhere
-inline bool fin_quads(const float* part, int C) { return g_bn_fin_quads && C % 4 == 0 && ((size_t)part & 15) == 0; }
+// Block shape of the two finalize kernels: 32 channels x 32 row lanes (measured against 64 x 16 and 16 x 64 in round 2: -0.26 ms per ResNet-50 step).  Round 4 tried 1024 threads
+// per 32 channels with 16-byte loads, every load of a thread in flight at once and a shuffle + 16-wave LDS reduction: 7.7 / 7.2 us per launch against 5.9 / 6.0 for this form
+// (gpurun r4c: rocprofv3 --stats of bench.py) -- removed.
 
 inline int ew_blocks(long long nvec) { long long b = (nvec + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 inline int reduce_blocks(long long rows) { long long b = (rows + 63) / 64; return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b)); }
 
 }  // namespace
 
-// test hook (not part of the public ABI): 1 (default) = 16-byte-load finalize kernels where the buffer allows, 0 = the 32 x 32 form
-extern "C" void sl_debug_bn_finalize_form(int v) { g_bn_fin_quads = v ? 1 : 0; }
-
 extern "C" int sl_bn_finalize_train(const float* stat_partial, int stat_rows, int C, long long count, const float* gamma,
                                     const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                     float* mean, float* invstd, float* scale, float* shift, sl_stream_t stream) {
   SL_REQUIRE(stat_partial && mean && invstd && scale && shift && C > 0 && stat_rows > 0 && count > 0, "bn_finalize_train: bad args");
   SL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running stats must come in pairs");
-  if (fin_quads(stat_partial, C))
-    hipLaunchKernelGGL(bn_finalize_train_q_kernel, dim3(cdiv(C, 4 * FQ)), dim3(FQ * FRL), 0, (hipStream_t)stream, stat_partial, stat_rows, C, (double)count, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
-  else
-    hipLaunchKernelGGL((bn_finalize_train_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partial, stat_rows, C, (double)count, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  hipLaunchKernelGGL((bn_finalize_train_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partial, stat_rows, C, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   SL_LAUNCH_CHECK("bn_finalize_train_kernel");
   return 0;
 }
@@ -469,12 +363,8 @@ extern "C" int sl_bn_bwd_finalize(const float* partial, int nblk, int C, long lo
                                   const float* mean, const float* invstd, int train, float* dgamma, float* dbeta,
                                   float* cA, float* cB, float* cC, sl_stream_t stream) {
   SL_REQUIRE(partial && invstd && cA && cB && cC && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
-  if (fin_quads(partial, C))
-    hipLaunchKernelGGL(bn_bwd_finalize_q_kernel, dim3(cdiv(C, 4 * FQ)), dim3(FQ * FRL), 0, (hipStream_t)stream, partial, nblk, C, (double)count, gamma, mean, invstd, train,
-                       dgamma, dbeta, cA, cB, cC);
-  else
-    hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, (double)count, gamma, mean, invstd, train,
-                       dgamma, dbeta, cA, cB, cC);
+  hipLaunchKernelGGL((bn_bwd_finalize_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, (double)count, gamma, mean, invstd, train,
+                     dgamma, dbeta, cA, cB, cC);
   SL_LAUNCH_CHECK("bn_bwd_finalize_kernel");
   return 0;
 }

@@ -43,6 +43,9 @@ struct ConvGemmParams {
   int gridM, gridN;
   int tile16;                           // patch kernel: row block bm is a 16 x 16-pixel tile (b, y0 / 16, x0 / 16), its 256 rows are 16 segments of 16 pixels
   int flags;                            // p8: bit 0 = counted first wait (always set); bit 1 = generic store phase instead of conv_epilogue_affine (test hook sl_debug_conv_affine: the bit-identity test)
+  // split-K (inference convs on few row tiles: the fine-tune pair's 8 192-row layers): the K range is cut into `ksplit` parts, block (tile, part) writes its raw fp32
+  // accumulators to ws [part][M][N] and conv_splitk_finish_kernel sums the parts in a fixed order and applies pre_addend / scale / bias / addend / ReLU
+  float* ws; int ksplit;
   unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
 
@@ -984,6 +987,72 @@ int launch_ring(ConvGemmParams& p, hipStream_t st) {
 // next K-tile's A0 during P3); B fragments stream through a 4-deep register ring, three k-steps ahead (P3 re-uses the B0 fragments
 // and P2 the B1 fragments of P1 from registers: 24 LDS fragment reads per 32 MFMAs).  Two counted waits and two barriers per K-tile.
 // Wave (wm, wn) of the 2 x 4 grid owns rows {h*128 + wm*64 ..+63} and columns {h*128 + wn*32 ..+31} of both halves h.
+// split-K: the wave's accumulators (half-tile layout: tile row = half*128 + wm*64 + i2*32 + lane&31, column = j*128 + wn*32 + 8q + 4*(lane>>5) .. +3) as fp32 to
+// ws [part][M][N]; 32 16-byte stores per lane.  tile16: row block bm is a 16 x 16-pixel tile.
+__device__ __forceinline__ void conv_store_partial(const ConvGemmParams& p, f32x16_t (&acc)[4][2], int part, int bm, int bn, int wm, int wn, int lane) {
+  const int l31 = lane & 31, fh = lane >> 5;
+  float* base = p.ws + (size_t)part * p.M * p.N + bn * 256 + wn * 32 + 4 * fh;
+  int tbase = 0;
+  if (p.tile16) { const int tx = p.Wd >> 4, ty = p.Hd >> 4; tbase = ((bm / (tx * ty)) * p.Hd + ((bm / tx) % ty) * 16) * p.Wd + (bm % tx) * 16; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int R = (i >> 1) * 128 + wm * 64 + (i & 1) * 32 + l31;
+    const int m = p.tile16 ? tbase + (R >> 4) * p.Wd + (R & 15) : bm * 256 + R;
+    if (m < p.M) {
+      float* row = base + (size_t)m * p.N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(float4*)(row + j * 128 + 8 * q) = make_float4(acc[i][j][4 * q + 0], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+    }
+  }
+}
+
+// out = act((sum over parts + pre_addend) * scale + bias + addend): the epilogue of the generic store phase (same operation order) behind a split-K launch
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvGemmParams p) {
+  constexpr int EPC = 16 / sizeof(T);
+  const size_t nvec = (size_t)p.M * p.N / EPC, slab = (size_t)p.M * p.N;
+  const int nvc = p.N / EPC;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+    float a[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) a[e] = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) {
+      const float4* src = (const float4*)(p.ws + s * slab + v * EPC);
+#pragma unroll
+      for (int h = 0; h < EPC / 4; ++h) { const float4 t = src[h]; a[4 * h + 0] += t.x; a[4 * h + 1] += t.y; a[4 * h + 2] += t.z; a[4 * h + 3] += t.w; }
+    }
+    // the tile kernels round the accumulators to T when they stage the tile and apply the epilogue to the rounded values: the same here, so that a layer gives the
+    // same result whichever way it is dispatched (up to the order of the K sum)
+    float r[EPC];
+    unpack16<T>(pack16<T>(a), r);
+    const int c = (int)(v % nvc) * EPC;
+    if (p.pre_addend) {
+      float t[EPC];
+      unpack16<T>(((const uint4*)p.pre_addend)[v], t);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) r[e] += t[e];
+    }
+    if (p.bias || p.scale) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) r[e] = r[e] * (p.scale ? p.scale[c + e] : 1.f) + (p.bias ? p.bias[c + e] : 0.f);
+    }
+    if (p.addend) {
+      float t[EPC];
+      unpack16<T>(((const uint4*)p.addend)[v], t);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) r[e] += t[e];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) r[e] = r[e] > 0.f ? r[e] : 0.f;
+    }
+    ((uint4*)p.out)[v] = pack16<T>(r);
+  }
+}
+
 constexpr int P8_SLOT = 128 * 128;
 constexpr int P8_RING = 10 * P8_SLOT;         // A0 x3, A1 x2, B1 x2, B0 x3 = the whole 160 KiB
 constexpr int P8_LDS = P8_RING;
@@ -1002,8 +1071,9 @@ __device__ __forceinline__ int p8_slot_a1(int par) { return (par ? 2 : 7) * P8_S
 __device__ __forceinline__ int p8_slot_b1(int par) { return (par ? 3 : 8) * P8_SLOT; }
 __device__ __forceinline__ int p8_slot_b0(int j) { return (j == 0 ? 9 : j + 3) * P8_SLOT; }
 
-template <bool GATE>
+template <int EPI>       // 0: the store phases without MODE 3, 1: with the gated-statistics store phase (MODE 3)
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
+  constexpr bool GATE = EPI == 1;
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1030,6 +1100,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
     const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     bm = bid / p.gridN; bn = bid % p.gridN;
   };
+
   auto setup = [&](int bm, int bn) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -1179,6 +1250,14 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
   }
 }
 
+int launch_splitk_finish(ConvGemmParams& p, hipStream_t st) {
+  const size_t nvec = (size_t)p.M * p.N / 8;
+  const int blocks = (int)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096);
+  hipLaunchKernelGGL(conv_splitk_finish_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+  SL_LAUNCH_CHECK("conv_splitk_finish_kernel");
+  return 0;
+}
+
 unsigned long long* g_p8_trace = nullptr;
 int launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, 256);
@@ -1187,14 +1266,14 @@ int launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.flags = 1;                                  // the next tile's first wait is counted past the epilogue's own loads and stores
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
-    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     attr_set = true;
   }
   const int ntiles = p.gridM * p.gridN;
   // persistent: min(tiles, 256) blocks walk over the tiles; the instantiation with the gated-statistics store phase only where it is used
-  if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<true>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
-  else        hipLaunchKernelGGL(conv_gemm_p8_kernel<false>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<1>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  else        hipLaunchKernelGGL(conv_gemm_p8_kernel<0>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;
 }
@@ -1209,15 +1288,18 @@ constexpr int P9_PATCH = 576 * 128;                                     // large
 constexpr int P9_LDS = P9_PATCH + 4 * P8_SLOT;                          // + B0 / B1 of two K-tiles = 136 KiB
 constexpr int P9_PATCH1 = 42 * 1024;                                    // d = 1: 324 rows -> two patch buffers (the next chunk's patch lands under the current chunk's taps)
 constexpr int P9_LDS1 = 2 * P9_PATCH1 + 4 * P8_SLOT;                    // 148 KiB
-template <bool GATE>
+template <int EPI>       // 0 / 1 / 2 as in conv_gemm_p8_kernel; split-K parts are ranges of 64-channel chunks (all nine taps of a chunk stay together: one patch per chunk)
 __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
+  constexpr bool GATE = EPI == 1, SPLITK = EPI == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  int bid = blockIdx.x;
+  const int KS = SPLITK ? p.ksplit : 1;
+  const int part = SPLITK ? (int)(blockIdx.x % KS) : 0;               // neighbouring blocks share the tile: the same patch rows and weight rows pass through the L2 together
+  int bid = blockIdx.x / KS;
   {
     const int nwg = p.gridM * p.gridN, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -1228,7 +1310,8 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   const int grp = bid / (p.gridM * GN), rem = bid - grp * (p.gridM * GN);
   const int bm = rem / GN, bn = grp * GN + rem % GN;
   const int d = p.dil, PW = 16 + 2 * d, PP = PW * PW;
-  const int CT = p.C1, nchunk = CT / 64;
+  const int CT = p.C1;
+  const int cbeg = SPLITK ? (CT / 64) * part / KS : 0, nchunk = SPLITK ? (CT / 64) * (part + 1) / KS : CT / 64;      // chunks [cbeg, nchunk)
   const int tx = p.Ws >> 4, ty = p.Hs >> 4;
   const int bx = bm % tx, by = (bm / tx) % ty, bb = bm / (tx * ty);
   const int y0 = by * 16 - d, x0 = bx * 16 - d;                          // image position of patch pixel (0, 0)
@@ -1310,20 +1393,20 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
   // K-tile k = (chunk, tap), weight slot pair k & 1.  One barrier per K-tile, at the end of P2: by then every wave has read both halves of slot pair k & 1 (B0(k) in P3 of
   // K-tile k - 1, B1(k) in P0), so B(k + 2) is issued into it right there and has a whole K-tile to land; B(k + 1) is waited for at the same point and P3 already loads the next
   // K-tile's first fragments (B0 from the other slot pair, the first eight image rows of the patch at the next tap's offset), so no K-tile starts with an empty pipeline.
-  const int NK = 9 * nchunk;
+  const int NK = 9 * (nchunk - cbeg);
   auto toff_of = [&](int tap) { const int t2 = p.mode ? 8 - tap : tap; return ((((t2 / 3) * PW + (t2 % 3)) * d) << 8) | ((t2 % 3) * d); };      // patch row offset << 8 | column offset      // data gradient: the correlation with the flipped window
-  issue_patch(0);
-  issueB(0, 0, 0);
-  issueB(1, 0, 1);
+  issue_patch(cbeg);
+  issueB(0, cbeg, 0);
+  issueB(1, cbeg, 1);
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   uint4 a[4][2], b0k[4], b1k[4];
   {
-    const int toff = toff_of(0);
+    const int toff = toff_of(0), pb0 = dbuf && (cbeg & 1) ? P9_PATCH1 : 0;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toff, ks); a[ks][1] = ldA(0, 1, toff, ks); b0k[ks] = ldB(0, ks); }
+    for (int ks = 0; ks < 4; ++ks) { a[ks][0] = ldA(0, 0, toff, ks, pb0); a[ks][1] = ldA(0, 1, toff, ks, pb0); b0k[ks] = ldB(0, ks); }
   }
-  int tap = 0, chunk = 0;
+  int tap = 0, chunk = cbeg;
 #pragma unroll 1
   for (int k = 0; k < NK; ++k) {
     const int par = k & 1;
@@ -1368,6 +1451,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
       }
     } else ++tap;
   }
+  if constexpr (SPLITK) { conv_store_partial(p, acc, part, bm, bn, wm, wn, lane); return; }
   lds_barrier();
   conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
@@ -1379,19 +1463,25 @@ static bool p9_on() {
 }
 static bool p9_shape(const ConvGemmParams& p) {
   return p9_on() && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
-         p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && (long long)p.M >= 32768 &&
+         p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && ((long long)p.M >= 32768 || p.ksplit > 1) &&
          !(p.out2 || p.row_scale);                                       // every epilogue with the tile16 row map (fast: store / statistics / gated addend; generic: bias, folded BN, ReLU, pre-addend)
 }
 int launch_p9(ConvGemmParams& p, hipStream_t st) {
   p.gridM = p.M / 256; p.gridN = p.N / 256; p.tile16 = 1;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
-    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(P9_LDS1 > P9_LDS ? P9_LDS1 : P9_LDS));
     attr_set = true;
   }
-  if (p.gate) hipLaunchKernelGGL(conv_gemm_p9_kernel<true>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
-  else        hipLaunchKernelGGL(conv_gemm_p9_kernel<false>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+  if (p.ksplit > 1) {
+    hipLaunchKernelGGL(conv_gemm_p9_kernel<2>, dim3(p.gridM * p.gridN * p.ksplit), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+    SL_LAUNCH_CHECK("conv_gemm_p9_kernel (split-K)");
+    return launch_splitk_finish(p, st);
+  }
+  if (p.gate) hipLaunchKernelGGL(conv_gemm_p9_kernel<1>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
+  else        hipLaunchKernelGGL(conv_gemm_p9_kernel<0>, dim3(p.gridM * p.gridN), dim3(512), p.dil == 1 ? P9_LDS1 : P9_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p9_kernel");
   return 0;
 }
@@ -1836,6 +1926,24 @@ int launch_glds(ConvGemmParams& p, hipStream_t st) {
 // to fill 256 CUs; the 4-stage ring replaces the 2-stage kernel from 16 blocks of 128 rows (Swin-T stage 3 / 4 GEMMs of 8 192 / 2 048 tokens: +4 %)
 constexpr int MIN_TILES256 = 96, RING128_MIN = 16;
 static int block_rows(long long M) { return M >= 256LL * MIN_TILES256 ? 256 : 128; }
+// (Measured and dropped, tools/ft_shapes.py: 256 x 256 tiles by TILE count on short M -- 8 192 rows x 1024 / 2048 channels are 128 / 256 tiles -- lose to the 128 x 128
+// ring kernel with two blocks per CU on three of four shapes: 256 -> 1024 25.0 vs 11.2 us, 512 -> 1024 29.4 vs 16.3, 512 -> 2048 35.1 vs 32.7, 1024 -> 2048 44.9 vs 51.0.)
+
+// Split-K plan of an inference conv (ConvGemmParams::ksplit): parts > 1 for a 3x3 layer of the patch kernel's kind with too few 16 x 16-pixel tiles for the chip and at least
+// 1024 input channels to cut by 64-channel chunks: the pyramid conv of a fine-tune pair (8 192 rows, 2048 -> 512: 64 tiles) runs in 152 instead of 251 us on the 128 x 128
+// ring kernel.  Measured and left unsplit (tools/ft_shapes.py, us split / unsplit): 3x3 512 -> 512 d4 68.4 / 67.1, 3x3 256 -> 256 d2 44.8 / 36.8, and every 1x1 layer
+// (half-tile kernel by K-tiles: 2048 -> 512 52 / 33, 1024 -> 256 35 / 19) -- the partial tiles' round trip costs what the extra blocks gain.
+static int splitk_parts(const ConvGemmParams& p, int dtype) {
+  if (dtype != SL_BF16 || p.stat_partial || p.gate || p.mask_src || p.addend_mask || p.out2 || p.row_scale || p.C2 || p.N % 256 || p.M % 256 || p.C1 % 64) return 1;
+  const long long tiles = (long long)(p.M / 256) * (p.N / 256);
+  if (tiles >= 128 || p.M >= 32768 || p.C1 < 1024) return 1;
+  if (!(p9_on() && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0))
+    return 1;
+  const int units = p.C1 / 64;
+  int s = 1;
+  while (s < 8 && units / (2 * s) >= 4 && tiles * 2 * s <= 256) s *= 2;
+  return s;
+}
 
 template <typename T>
 int launch_gemm(ConvGemmParams& p, hipStream_t st) {
@@ -1843,6 +1951,7 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   // tiny problems (PPM stages, prototype rows) stay on 128-row tiles
   const bool big = block_rows(p.M) == 256;
   if constexpr (sizeof(T) == 2) {
+    if (p.ksplit > 1) return launch_p9(p, st);                                        // planned by splitk_parts: the shape is served
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
       return launch_c64k3(p, st);
@@ -1860,7 +1969,10 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
     if (n128) return launch_ring<T, 256, 128, 4, 2, 64, 4>(p, st);
     return launch_glds<T, 256, 64, 8, 1>(p, st);        // N = 64 layers: too few weight rows for a 64-byte-row ring
   }
-  if (n128 && p.M >= 128LL * RING128_MIN) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);   // small-K problems: 64 KiB LDS, 2 blocks/CU
+  // 128 x 128 tiles (few rows: Swin stage 3 / 4 token maps, the fine-tune pair's 8 192-row layers): 64-byte rows, 4 stages, 64 KiB, two blocks per CU.  Round 4 measured
+  // the other stage geometries of this template end to end (Swin-T POP tiles/s / fine-tune pairs/s, one box): 128-byte rows x 3 stages (96 KiB, one block per CU)
+  // 696.6 / 379.5, x 4 stages 712.3 / 408.1, 128-byte rows x 3 stages on eight waves of 64 x 32 705.7 / 392.0 -- against 720.2 / 419.1 for this one
+  if (n128 && p.M >= 128LL * RING128_MIN) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);
   if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
   return launch_glds<T, 128, 64, 2, 2>(p, st);
 }
@@ -1966,17 +2078,41 @@ extern "C" int sl_linear_fwd(const SlConvDesc* d, const void* x, const void* w, 
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }
 
+static void affine_params(ConvGemmParams& p, const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend, const float* scale,
+                          const float* shift, const void* residual, int relu, void* y) {
+  p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.wt = w; p.out = y;
+  p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
+  p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
+  p.scale = scale; p.bias = shift; p.relu = relu; p.addend = residual; p.pre_addend = pre_addend;
+  p.M = d->B * d->Ho * d->Wo;
+}
+
+extern "C" int sl_conv2d_affine_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend, const float* scale,
+                                       const float* shift, const void* residual, int relu, void* y, void* workspace, size_t workspace_bytes, sl_stream_t stream);
+
 extern "C" int sl_conv2d_affine_fwd(const SlConvDesc* d, const void* x, const void* x2, const void* w, const float* scale,
                                     const float* shift, const void* residual, int relu, void* y, sl_stream_t stream) {
+  return sl_conv2d_affine_fwd_ex(d, x, x2, w, nullptr, scale, shift, residual, relu, y, nullptr, 0, stream);
+}
+
+// bytes of split-K workspace sl_conv2d_affine_fwd_ex can use for this layer (0: the layer is not split)
+extern "C" size_t sl_conv2d_affine_fwd_workspace(const SlConvDesc* d) {
+  if (!d || check_desc(d)) return 0;
+  ConvGemmParams p{};
+  affine_params(p, d, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+  const int parts = splitk_parts(p, d->dtype);
+  return parts > 1 ? (size_t)parts * p.M * p.N * sizeof(float) : 0;
+}
+
+extern "C" int sl_conv2d_affine_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, const void* w, const void* pre_addend, const float* scale,
+                                       const float* shift, const void* residual, int relu, void* y, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   if (int e = check_desc(d)) return e;
   SL_REQUIRE(x && w && y && scale && shift, "conv affine fwd: null buffer");
   SL_REQUIRE(d->C1 == d->Cin || x2, "conv affine fwd: x2 missing for a concat input");
   ConvGemmParams p{};
-  p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.wt = w; p.out = y;
-  p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo;
-  p.N = d->Cout; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 0;
-  p.scale = scale; p.bias = shift; p.relu = relu; p.addend = residual;
-  p.M = d->B * d->Ho * d->Wo;
+  affine_params(p, d, x, x2, w, pre_addend, scale, shift, residual, relu, y);
+  const int parts = workspace ? splitk_parts(p, d->dtype) : 1;
+  if (parts > 1 && workspace_bytes >= (size_t)parts * p.M * p.N * sizeof(float) && ((size_t)workspace & 15) == 0) { p.ws = (float*)workspace; p.ksplit = parts; }
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }
 

@@ -19,7 +19,7 @@ from collections import defaultdict
 import numpy as np
 
 from .augment import TileAugmenter, draw_train_params
-from .oem import BASE_CLASSES, NOVEL_CLASSES, NUM_CLASSES, _Raw, _rasterio, _read
+from .oem import BASE_CLASSES, NOVEL_CLASSES, NUM_CLASSES, PackedTiles, _Raw, _decoder, _read, crop_rows
 
 MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)               # base_dataset.py:9 (not overridden by oem_ft.py)
 
@@ -31,14 +31,34 @@ class PairAugmenter:
         self.aug = TileAugmenter(crop_size, mean, std, ignore_label, lut=None, device=device)
 
     def prepare(self, pairs, params):
-        B = len(pairs)
-        img, lab = self.aug.prepare([p[0] for p in pairs] + [p[1] for p in pairs], [q[0] for q in params] + [q[1] for q in params])
+        """pairs: PackedTiles from PairCollate (2B tiles, novel / base alternating) or a list of ((novel image, label), (base image, label))."""
+        B = len(params)
+        prm = [q[0] for q in params] + [q[1] for q in params]
+        if isinstance(pairs, PackedTiles):
+            img, lab = self.aug.prepare(pairs, prm, order=list(range(0, 2 * B, 2)) + list(range(1, 2 * B, 2)))
+        else:
+            img, lab = self.aug.prepare([p[0] for p in pairs] + [p[1] for p in pairs], prm)
         return img[:B], lab[:B], img[B:], lab[B:]
 
 
-def pair_collate(batch):
-    """Raw pairs stay lists (tiles differ in size): ([(novel tile, base tile)], [(novel draws, base draws)], [ids])."""
-    return [b[0] for b in batch], [b[1] for b in batch], [b[2] for b in batch]
+class PairCollate:
+    """(PackedTiles of the 2B tiles in the order novel_0, base_0, novel_1, base_1, ..., [(novel draws, base draws)], [ids]): like oem.RawCollate the tiles are cut
+    down to the rows their crops read and leave the worker as one shared-memory buffer.  `pairs[2 * i]` / `pairs[2 * i + 1]` are pair i's novel / base tile."""
+
+    def __init__(self, crop_h=None):
+        self.crop_h = crop_h
+
+    def __call__(self, batch):
+        tiles, params = [], []
+        for (nov, base), (pn, pb), _ in batch:
+            ni, nl, pn = crop_rows(nov[0], nov[1], pn, self.crop_h)
+            bi, bl, pb = crop_rows(base[0], base[1], pb, self.crop_h)
+            tiles += [(ni, nl), (bi, bl)]
+            params.append((pn, pb))
+        return PackedTiles(tiles), params, [b[2] for b in batch]
+
+
+pair_collate = PairCollate()
 
 
 class PairReader(_Raw):
@@ -52,6 +72,7 @@ class PairReader(_Raw):
                                'it is not on the ft_pop path and is not built')
         assert mode == 'train'
         self.list_path, self.shot, self.mode, self.crop_size, self.ignore_label, self.use_base = list_path, shot, mode, tuple(crop_size), ignore_label, use_base
+        self.collate_fn = PairCollate(self.crop_size[0])
         self.base_classes, self.novel_classes = set(BASE_CLASSES), set(NOVEL_CLASSES)
         filter_flag = bool(filter)
         list_dir = os.path.dirname(list_path) + ('_filter' if filter_flag else '')
@@ -123,7 +144,7 @@ class GFSSegTrain(PairReader):
 
     def __init__(self, root, list_path, fold, shot=1, mode='train', crop_size=(512, 512), ignore_label=255, base_size=(1024, 1024),
                  resize_label=False, seed=123, filter=False, use_base=True):
-        _rasterio()
+        _decoder()
         self.root = root
         self._init_lists(list_path, shot, mode, crop_size, ignore_label, seed, filter, use_base)
 

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from .augment import TileAugmenter, draw_train_params, remap_lut
-from .oem import MEAN, STD, _Raw, raw_collate  # noqa: F401
+from .oem import MEAN, STD, RawCollate, _Raw, raw_collate  # noqa: F401
 
 
 class _Base(_Raw):
@@ -32,6 +32,7 @@ class GFSSegTrain(_Base):
                  length=64, seed=0, **kw):
         super().__init__(length, (crop_size[0] + 96, crop_size[1] + 64), seed)
         self.crop_size = tuple(crop_size)
+        self.collate_fn = RawCollate(self.crop_size[0])
 
     def __getitem__(self, i):
         img, lab = self._tile(i, 8)

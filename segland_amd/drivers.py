@@ -187,5 +187,5 @@ def resolve(dataset_pkg, name):
     mod = getattr(dataset_pkg, name, None)
     if mod is None:
         have = sorted(k for k, v in vars(dataset_pkg).items() if hasattr(v, 'GFSSegTrain'))
-        raise RuntimeError("unknown dataset '%s' (available: %s; 'oem' / 'oem_ft' decode GeoTIFF tiles with rasterio)" % (name, ', '.join(have)))
+        raise RuntimeError("unknown dataset '%s' (available: %s; 'oem' / 'oem_ft' decode GeoTIFF tiles with rasterio or Pillow)" % (name, ', '.join(have)))
     return mod

@@ -434,9 +434,19 @@ class PPMFn(torch.autograd.Function):
                 _, _, scale, shift = _bn_eval_coeffs(st[2])
                 ops.bn_act(call[off:off + n], scale, shift, relu=True, out=stage_act[off:off + n])
                 off += n
-            priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
             bt = dec.bottleneck
-            ab = conv_bn_infer(priors, bt[0], bt[1], relu=True, x2=x4)
+            if _PPM_FACTORISED:
+                # as in the training branch: the prior half of the 3x3 conv contracted on the s x s grids (exact), the x4 half on the MFMA kernel with the
+                # gathered prior term entering before the folded BatchNorm -- half the FLOPs of the virtual-concat conv, and a shape the patch kernel serves
+                N = bt[0].out_channels
+                wq_f, _, wf4, _ = _ppm_weights(bt[0].weight, Cs, len(sizes), x4.dtype)
+                q, _ = ops.ppm_rows_gemm(stage_act, wq_f, B, sizes)
+                gpri = ops.ppm_fact_gather(q, x4.shape, sizes, N, x4.dtype)
+                _, _, scale, shift = _bn_eval_coeffs(bt[1])
+                ab = ops.conv2d_affine_fwd(x4, wf4, ConvSpec(Cf, N, 3, 1, 1, 1), scale, shift, relu=True, pre_addend=gpri)
+            else:
+                priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
+                ab = conv_bn_infer(priors, bt[0], bt[1], relu=True, x2=x4)
             wf, _ = prepared(bt[3].weight, x4.dtype)
             return ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())[0]
         # the four stage convs as ONE grouped skinny GEMM over the pyramid rows (16..576 rows per level)

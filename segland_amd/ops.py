@@ -208,13 +208,18 @@ def linear_fwd(x, wf, spec, bias=None, row_scale=None, residual=None, want_gelu=
     return (y, g) if want_gelu else y
 
 
-def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=True, out=None):
-    """y = act(conv(x|x2) * scale + shift (+ residual)): eval-mode BN folded into the conv epilogue."""
+def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=True, out=None, pre_addend=None):
+    """y = act((conv(x|x2) + pre_addend) * scale + shift (+ residual)): eval-mode BN folded into the conv epilogue.  Layers with too few 256-row tiles for the chip
+    (a fine-tune pair: 8 192 pixel rows) run split along K through a workspace (sl_conv2d_affine_fwd_workspace says when)."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     y = out if out is not None else torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
+    L = _lib.lib()
+    need = L.sl_conv2d_affine_fwd_workspace(C.byref(d)) if x2 is None else 0
+    ws = workspace(need, x.device, 'splitk') if need else None
     tok = PROFILER.begin('conv_fwd', d)
-    check(_lib.lib().sl_conv2d_affine_fwd(C.byref(d), _p(x), _p(x2), _p(wf), _p(scale), _p(shift), _p(residual), int(relu), _p(y), _s()), 'conv2d_affine_fwd')
+    check(L.sl_conv2d_affine_fwd_ex(C.byref(d), _p(x), _p(x2), _p(wf), _p(pre_addend), _p(scale), _p(shift), _p(residual), int(relu), _p(y),
+                                    _p(ws), ws.numel() if ws is not None else 0, _s()), 'conv2d_affine_fwd')
     PROFILER.end(tok)
     return y
 

@@ -26,3 +26,17 @@ def hip():
     assert torch.cuda.is_available(), 'gpu-marked test needs a GPU'
     from segland_amd import _lib
     return _lib.lib()
+
+
+@pytest.fixture(autouse=True)
+def _parity_log(request):
+    """SEGLAND_PARITY_LOG=<file>: what the tests print (differing-pixel counts, cosines, relative errors: the numbers behind the tolerance gates) is appended to that file,
+    one section per test -- `pytest -q` drops it otherwise.  profiles/r4_parity_log.txt is such a file from one MI355X box."""
+    path = os.environ.get('SEGLAND_PARITY_LOG')
+    capsys = request.getfixturevalue('capsys') if path else None      # without the variable nothing about the capture changes
+    yield
+    if path:
+        out = capsys.readouterr().out
+        if out.strip():
+            with open(path, 'a') as f:
+                f.write('## %s\n%s\n' % (request.node.nodeid, out.rstrip()))

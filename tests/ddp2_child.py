@@ -2,9 +2,10 @@
 
 SURVEY.md 8(e) "equivalence test": a 2-rank data-parallel step on a split batch equals the 1-process step on the full batch.  Both ranks
 run on the ONE GPU of the test box (RCCL refuses two ranks per device, so the group is gloo, which moves CUDA tensors through the host);
-everything else is the product path: segland_amd.GFSS_Model on the HIP kernels under Engine.data_parallel (DistributedDataParallel,
-gradient_as_bucket_view, the sum-only comm hook with gradients written into the bucket views), nn.SyncBatchNorm with SEGLAND_SYNC_BN=1
-(global batch statistics: per-rank partial sums all-reduced in fp64), segland_amd.optim.AdamW with the 1 / world_size in its kernel.
+everything else is the product path: segland_amd.GFSS_Model on the HIP kernels under Engine.data_parallel -- since round 4 the build's own
+bucket_step.BucketedReplica also with SyncBatchNorm (flat gradient buckets written in place, one SUM all-reduce per bucket around the two backward halves, the step
+issued kernel by kernel because SyncBatchNorm's collectives sit inside it) --, nn.SyncBatchNorm with SEGLAND_SYNC_BN=1 (global batch statistics: per-rank partial
+sums all-reduced in fp64), segland_amd.optim.AdamW with the 1 / world_size in its kernel.
 
     python tests/ddp2_child.py <rank> <port> <out.pt>        rank 0/1: the 2-rank run;   rank -1: the single-process full-batch run
 """
@@ -52,22 +53,37 @@ def main():
         fm.load_formula_weights(m)
         m = m.to(dev).train()
         opt = AdamW(get_parameters(m, lr=1e-4), lr=1e-4, weight_decay=1e-4)
-        net = engine.data_parallel(m, sum_gradients=two)
+        net = engine.data_parallel(m, sum_gradients=two, graphable=two)
         scaler = NativeScalerWithGradNormCount(engine.grad_div)
+        step = None
         if two:
-            assert isinstance(net, nn.parallel.DistributedDataParallel) and engine.grad_div == 2
+            from segland_amd import bucket_step
+            assert isinstance(net, bucket_step.BucketedReplica) and engine.grad_div == 2
+            step = bucket_step.GraphedBucketStep(net, opt, double_step=True)
+            assert step.eager_reason is not None and 'SyncBatchNorm' in step.eager_reason
         # gradients of ONE backward before any optimizer step: the quantity the equivalence is exact for (up to the order of the sums);
         # Adam's first steps are ~ lr * sign(g), which turns last-bit differences of near-zero gradient entries into O(lr) parameter differences
         opt.zero_grad()
-        d0 = net(img, mask)
-        d0['total_loss'].backward()
+        if two:                                  # one forward / backward of the replica's step, cut at the all-reduces like BucketedReplica._run, without the update
+            parts = net.train_step_parts(opt, True)
+            d0 = parts[0](img, mask)
+            halves = net.cut and net.late_buckets < len(net.buckets)
+            works = net.all_reduce('late' if halves else None, async_op=True)
+            if halves:
+                parts[1]()
+                works += net.all_reduce('early', async_op=True)
+            for w in works:
+                w.wait()
+        else:
+            d0 = net(img, mask)
+            d0['total_loss'].backward()
         grads0 = {n: p.grad.detach().float().cpu() / engine.grad_div for n, p in m.named_parameters() if p.grad is not None}
         loss0 = float(engine.reduce_loss_dict(d0)['total_loss']) if two else float(d0['total_loss'].detach())
         stats0 = {k: v.detach().float().cpu() for k, v in m.state_dict().items() if 'running_' in k}
         del d0
         losses = []
         for it in range(3):
-            d, gn = train_iteration(net, opt, scaler, img, mask, double_step=True)
+            d, gn = step(img, mask) if step is not None else train_iteration(net, opt, scaler, img, mask, double_step=True)
             vals = engine.reduce_loss_dict(d) if two else {k: float(v) for k, v in d.items()}
             losses.append([float(vals['total_loss']), float(gn)])
         m.eval()

@@ -5,7 +5,8 @@ world_size-1 RCCL run of the PRODUCT: segland_amd.GFSS_Model on the HIP kernels,
 train_base.py:250-264 loop body.  The process group is created before any GPU work of this process.  Prints one JSON line.
 
     python tests/ddp_child.py <mode: 0 | force (SyncBN semantics) | inplace (sum-only all-reduce + gradients written into the bucket views)
-                               | bucket (bucket_step.BucketedReplica: two HIP graphs around RCCL all-reduces of the build's own buckets)> <port>
+                               | bucket (bucket_step.BucketedReplica: two HIP graphs around RCCL all-reduces of the build's own buckets)
+                               | bucket_force (the same replica with SyncBatchNorm semantics: its step is issued kernel by kernel)> <port>
 """
 import json
 import os
@@ -40,8 +41,8 @@ def main():
         img = fm.formula_image(4, 128, 128, 'ddp1/img').to(dev)
         mask = fm.formula_mask(4, 128, 128, 8, 'ddp1/mask', block=16, ignore_rows=6).to(dev)
 
-        inplace = sync in ('inplace', 'bucket')
-        bucket = sync == 'bucket'
+        inplace = sync in ('inplace', 'bucket', 'bucket_force')
+        bucket = sync in ('bucket', 'bucket_force')
         hits = [0]
         if inplace:
             real = sf.grad_dst
@@ -75,7 +76,7 @@ def main():
                 losses.append([float(d['total_loss'].detach()), float(gn)])
                 print('ddp_child: wrapped %s iteration %d done' % (wrapped, it), file=sys.stderr, flush=True)
             if step is not None:
-                out['bucket_replays'], out['bucket_failures'], out['buckets'] = step.replays, step.failures, len(net.buckets)
+                out['bucket_replays'], out['bucket_failures'], out['buckets'], out['eager_reason'] = step.replays, step.failures, len(net.buckets), step.eager_reason
             if wrapped and inplace and not bucket:
                 out['inplace_writes_last_step'] = hits[0]
                 out['grads_alias_cached_views'] = sum(1 for p in m.parameters() if p.grad is not None and getattr(p, '_sl_gview', None) is not None
@@ -94,8 +95,8 @@ def main():
 
         sf.set_sync_bn('0')
         ref_sd, ref_losses, ref_logits = run(False, nn.BatchNorm2d)
-        sf.set_sync_bn(sync if sync in ('0', 'force') else '0')
-        sd, losses, logits = run(True, nn.SyncBatchNorm if sync == 'force' else nn.BatchNorm2d)
+        sf.set_sync_bn('force' if sync in ('force', 'bucket_force') else '0')
+        sd, losses, logits = run(True, nn.SyncBatchNorm if sync in ('force', 'bucket_force') else nn.BatchNorm2d)
         sf.set_sync_bn('0')
         worst, worst_key = 0.0, ''
         for k in ref_sd:

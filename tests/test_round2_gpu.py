@@ -370,8 +370,8 @@ def test_hip_model_under_rccl_ddp(hip, sync):
 @pytest.mark.timeout(900)
 def test_two_ranks_equal_one_full_batch(hip, tmp_path):
     """a 2-rank data-parallel step on a split batch == the 1-process step on the full batch.  Two processes share the one
-    GPU of the box (gloo group: RCCL refuses two ranks per device); the product path is otherwise complete -- DDP with the sum-only hook and
-    gradients written into the bucket views, nn.SyncBatchNorm with global statistics (fp64 all-reduce of the partial sums, PPM level 1
+    GPU of the box (gloo group: RCCL refuses two ranks per device); the product path is otherwise complete -- bucket_step.BucketedReplica (flat buckets,
+    gradients written in place, one SUM all-reduce per bucket; issued kernel by kernel because of SyncBatchNorm), nn.SyncBatchNorm with global statistics (fp64 all-reduce of the partial sums, PPM level 1
     with ONE value per channel per rank included), AdamW with 1 / world_size in its kernel.  One backward: loss, all gradients and the running
     statistics agree to reduction-order tolerance; three train_base.py iterations on top stay together."""
     port = str(_free_port())
@@ -543,24 +543,14 @@ def test_g17_tile_preparation_gpu(hip):
     assert l3 is None and np.array_equal(o3[0].cpu().numpy(), g['norm_img'])
 
 
-def test_oem_reader_needs_rasterio(hip):
-    from segland_amd.dataset import oem
-    try:
-        import rasterio  # noqa: F401
-        pytest.skip('rasterio is installed here')
-    except ImportError:
-        pass
-    with pytest.raises(RuntimeError, match='rasterio'):
-        oem.GFSSegVal('/data', '/data/val.txt', 0)
-
-
 def test_train_base_on_raw_tiles_with_workers(hip, tmp_path):
-    """Row f-2 through the driver: DataLoader workers hand over raw uint8 tiles + the reference's random draws (synthetic_raw mirrors the OEM
-    reader's sample format), one augment launch per batch on the GPU, training and the end-of-run validation on whole tiles."""
+    """Row f-2 through the driver: DataLoader workers DECODE TIFF files (`synthetic_tiff`: the real dataset/oem.py readers on a generated OpenEarthMap-shaped
+    directory, dataset/tiff.py) and hand over the raw uint8 tiles as shared-memory tensors + the reference's random draws, one augment launch per batch on the GPU,
+    training and the end-of-run validation on whole tiles."""
     import glob
     from segland_amd import train_base
     snap = str(tmp_path / 'snap_raw')
-    train_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_raw', '--batch-size', '4', '--input-size', '128,128',
+    train_base.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_tiff', '--batch-size', '4', '--input-size', '128,128',
                      '--base-size', '160,160', '--num-epoch', '36', '--start-epoch', '35', '--learning-rate', '1e-4', '--print-frequency', '8', '--snapshot-dir', snap,
                      '--num-workers', '2', '--restore-from', '/nonexistent', '--allow-random-init', '--fp16'])
     assert glob.glob(os.path.join(snap, 'epoch_36.pth')) and glob.glob(os.path.join(snap, 'best.pth'))
@@ -602,13 +592,14 @@ def test_g19_pair_reader_gpu(hip, tmp_path):
 
 
 def test_ft_pop_on_raw_pairs_with_workers(hip, tmp_path):
-    """ft_pop end to end on the raw pair format (`--dataset synthetic_raw`: synthetic_raw_ft pairs for training, synthetic_raw tiles for the
-    validation): DataLoader workers decode + draw, pair_collate, one augment launch per batch, the graphed fine-tune step, validation."""
+    """ft_pop end to end on the raw pair format read from TIFF files (`--dataset synthetic_tiff`: the real dataset/oem_ft.py pair reader for training -- class lists
+    built by decoding every label file -- and dataset/oem.py tiles for the validation): DataLoader workers decode + draw, PairCollate, one augment launch per batch, the
+    graphed fine-tune step, validation."""
     import glob
     from segland_amd import ft_pop, graph_step
     before = dict(graph_step.STATS)
     snap = str(tmp_path / 'snap_ft_raw')
-    ft_pop.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_raw', '--batch-size', '2', '--input-size', '128,128',
+    ft_pop.main(['--model', 'pspnet_pop', '--backbone', 'resnet50', '--dataset', 'synthetic_tiff', '--batch-size', '2', '--input-size', '128,128',
                  '--base-size', '128,128', '--num-epoch', '2', '--learning-rate', '1e-3', '--print-frequency', '4', '--snapshot-dir', snap, '--shot', '2',
                  '--num-workers', '2', '--restore-from', '/nonexistent', '--allow-random-init', '--random-seed', '123', '--freeze-backbone', '--update-base'])
     d = {k: graph_step.STATS[k] - before[k] for k in before}

@@ -27,23 +27,32 @@ def _free_port():
 
 # --------------------------------------------------------------------------------------------- N > 1 without DistributedDataParallel
 @pytest.mark.timeout(600)
-def test_bucket_step_under_rccl_world1(hip):
+@pytest.mark.parametrize('mode', ['bucket', 'bucket_force'])
+def test_bucket_step_under_rccl_world1(hip, mode):
     """A fresh child process, world_size-1 RCCL group: Engine.data_parallel(graphable=True) returns a BucketedReplica, GraphedBucketStep replays
     graph A (forward + backward into the build's gradient buckets) / RCCL all-reduce per bucket / graph B (clip + AdamW) -- five iterations
-    must leave parameters, buffers, AdamW-driven losses and eval logits identical to the unwrapped kernel-by-kernel run."""
+    must leave parameters, buffers, AdamW-driven losses and eval logits identical to the unwrapped kernel-by-kernel run.
+    mode 'bucket_force' (round 4): nn.SyncBatchNorm with SEGLAND_SYNC_BN semantics (train_base.py:175-178) ON THE REPLICA -- its per-layer all-reduces cannot sit in a
+    captured forward, so the same buckets / in-place gradients / collectives are issued kernel by kernel instead of handing the job to DistributedDataParallel."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_child.py'), 'bucket', str(_free_port())], env=env, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_child.py'), mode, str(_free_port())], env=env, capture_output=True,
                        text=True, timeout=540)
     line = [l for l in r.stdout.splitlines() if l.startswith('DDP_CHILD ')]
     assert r.returncode == 0 and line, 'child failed (rc %d):\n%s\n%s' % (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     out = json.loads(line[-1][len('DDP_CHILD '):])
     print(out)
-    assert out['bucket_failures'] == 0 and out['bucket_replays'] >= 3 and out['buckets'] >= 2, out
+    assert out['bucket_failures'] == 0 and out['buckets'] >= 2, out
     assert out['grads_alias_cached_views'] >= 175, out               # every gradient lives in a bucket after the step
     assert out['bn1_tracked'] == out['ref_bn1_tracked'] == 5
-    assert out['worst_param_rel'] <= 1e-6 and out['logits_rel'] <= 1e-6, out
+    if mode == 'bucket':
+        assert out['bucket_replays'] >= 3 and out['eager_reason'] is None, out
+        tol_p, tol_l, tol_loss = 1e-6, 1e-6, 1e-6
+    else:
+        assert out['bucket_replays'] == 0 and 'SyncBatchNorm' in out['eager_reason'], out
+        tol_p, tol_l, tol_loss = 2e-4, 1e-3, 1e-4              # statistics through the fp64 all-reduce path (world 1: the identity): the tolerances of the DDP 'force' test
+    assert out['worst_param_rel'] <= tol_p and out['logits_rel'] <= tol_l, out
     for (a, ga), (b, gb) in zip(out['losses'], out['ref_losses']):
-        assert abs(a - b) <= 1e-6 * abs(b) and abs(ga - gb) <= 1e-5 * gb
+        assert abs(a - b) <= tol_loss * abs(b) + (1e-4 if mode != 'bucket' else 0) and abs(ga - gb) <= (1e-5 if mode == 'bucket' else 1e-3) * gb
 
 
 @pytest.mark.timeout(1500)

@@ -56,3 +56,135 @@ def test_two_live_forward_passes_keep_their_own_bn3_handover(hip):
                 assert not bad, 'pass %d (backward order %s): %d gradients differ from the pass run alone, e.g. %s' % (i, order, len(bad), bad[:3])
     finally:
         ops.conv2d_bwd_data_addend_bnstat = real
+
+
+def test_prototype_kernels_refuse_what_their_backward_cannot_hold(hip):
+    """Advisor (round 3, low): sl_pop_proto_fwd accepted (Ka + Kb) * C * 4 bytes up to 60 KB while the backward needs twice that: C = 512 with 16..29 prototypes passed the
+    forward and raised mid-step.  sl_pop_proto_ok carries the backward's requirement; GFSS_Model._protos falls back to the torch ops, so --base-classes 15 trains."""
+    from segland_amd import ops
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    assert ops.proto_fused_ok(7, 0, 512) and ops.proto_fused_ok(4, 7, 512) and ops.proto_fused_ok(14, 0, 512)
+    assert not ops.proto_fused_ok(15, 0, 512) and not ops.proto_fused_ok(20, 9, 512) and ops.proto_fused_ok(20, 9, 128)
+    E = torch.randn(15, 512, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.pop_proto_fwd(E)
+    torch.manual_seed(2)
+    m = GFSS_Model(n_base=15, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=torch.float32).to(DEV).train()
+    img = fm.formula_image(2, 64, 64, 'p15/img').to(DEV)
+    mask = fm.formula_mask(2, 64, 64, 16, 'p15/mask', block=8, ignore_rows=4).to(DEV)
+    d = m(img, mask)
+    d['total_loss'].backward()
+    assert torch.isfinite(d['total_loss']) and m.base_emb.grad is not None and torch.isfinite(m.base_emb.grad).all() and float(d['orth_loss']) >= 0.0
+
+
+# --------------------------------------------------------------------------------------------- config 4: inference convs on 8 192 pixel rows
+SPLIT_CASES = [
+    # Cin, Cout, k, dil, pre_addend, residual      (B = 2, 64 x 64: 8 192 rows.  Only long 3x3 layers are split -- the pyramid conv of pspnet_pop.py:23-29 on a pair)
+    (2048, 512, 3, 1, True, False),
+    (1024, 256, 3, 2, False, True),
+    (2048, 256, 3, 4, False, False),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,dil,pre,res', SPLIT_CASES)
+def test_split_k_inference_conv(hip, cin, cout, k, dil, pre, res):
+    """Frozen 3x3 conv + folded BatchNorm (+ residual) + ReLU on 8 192 rows: 32-64 tiles of 16 x 16 pixels x 256 channels cannot fill 256 CUs, so a layer with >= 1024
+    input channels is cut along K by 64-channel chunks (patch kernel), fp32 partial tiles go through a workspace and one finishing launch sums them in a fixed order and
+    applies the epilogue (ft_pop.py:233-269: the frozen pyramid conv of a fine-tune pair, 251 -> 152 us).  Against fp32 torch on the bf16-rounded operands, against the
+    unsplit dispatch (no workspace), and run to run bit for bit; shorter 3x3 layers and every 1x1 layer stay unsplit (measured slower split: tools/ft_shapes.py)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from segland_amd import _lib, ops
+    B, H, W = 2, 64, 64
+    g = torch.Generator(device='cpu').manual_seed(cin + cout + k)
+    dt = torch.bfloat16
+    x = torch.randn(B, H, W, cin, generator=g).to(dt).to(DEV)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dt).float().to(DEV)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    pa = torch.randn(B, H, W, cout, generator=g).to(dt).to(DEV) if pre else None
+    rs = torch.randn(B, H, W, cout, generator=g).to(dt).to(DEV) if res else None
+    spec = ops.ConvSpec(cin, cout, k, 1, dil * (k // 2), dil)
+    wf, _ = ops.weight_prep(w, dt)
+    L = _lib.lib()
+    d = ops.conv_desc(dt, B, H, W, spec)
+    need = L.sl_conv2d_affine_fwd_workspace(C.byref(d))
+    assert need >= 2 * B * H * W * cout * 4, 'the layer is not split (%d bytes)' % need
+    y = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True, pre_addend=pa)
+    y2 = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True, pre_addend=pa)
+    assert torch.equal(y, y2), 'split-K sums must be bit-stable'
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, dil * (k // 2), dil).permute(0, 2, 3, 1)
+    ref = ref.to(dt).float()                                     # the kernels round the conv result before the epilogue
+    if pre:
+        ref = ref + pa.float()
+    ref = ref * scale + shift
+    if res:
+        ref = ref + rs.float()
+    ref = torch.relu(ref)
+    err = float((y.float() - ref).abs().max())
+    assert err <= 2e-2 * float(ref.abs().max()), (err, float(ref.abs().max()))
+    # the unsplit dispatch of the same layer (no workspace handed in)
+    y0 = torch.empty_like(y)
+    _lib.check(L.sl_conv2d_affine_fwd_ex(C.byref(d), ops._p(x), None, ops._p(wf), ops._p(pa), ops._p(scale), ops._p(shift), ops._p(rs), 1, ops._p(y0), None, 0, ops._s()), 'unsplit')
+    e0 = float((y.float() - y0.float()).abs().max())
+    assert e0 <= 1.6e-2 * float(ref.abs().max()), e0            # two bf16 roundings of different K orders
+    # not split: ragged row count, enough tiles, short K, 1x1
+    assert L.sl_conv2d_affine_fwd_workspace(C.byref(ops.conv_desc(dt, 2, 60, 64, spec))) == 0
+    assert L.sl_conv2d_affine_fwd_workspace(C.byref(ops.conv_desc(dt, 16, 64, 64, spec))) == 0
+    assert L.sl_conv2d_affine_fwd_workspace(C.byref(ops.conv_desc(dt, 2, 64, 64, ops.ConvSpec(512, 512, 3, 1, 4, 4)))) == 0
+    assert L.sl_conv2d_affine_fwd_workspace(C.byref(ops.conv_desc(dt, 2, 64, 64, ops.ConvSpec(2048, 512, 1, 1, 0, 1)))) == 0
+
+
+def test_ft_pair_forward_bf16_matches_fp32_mode(hip):
+    """Config 4 end to end: forward_all's frozen feature extractor on ONE tile pair (8 192 rows per layer from layer2 on) in bf16 -- the pyramid conv split along K, its prior
+    term factorised as in training -- against the exact-fp32 mode of the same model (which takes none of the bf16-only routes)."""
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(4)
+        m = GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=dt).to(DEV)
+        m.init_cls_n()
+        m.eval()
+        with torch.no_grad():
+            outs[dt] = m(torch.cat([fm.formula_image(1, 512, 512, 'ftp/a'), fm.formula_image(1, 512, 512, 'ftp/b')]).to(DEV)).float()
+    a, b = outs[torch.bfloat16], outs[torch.float32]
+    rel = float((a - b).norm() / b.norm())
+    agree = float((a.argmax(1) == b.argmax(1)).float().mean())
+    print('ft pair forward, bf16 vs fp32 mode: rel L2 %.4f, argmax agreement %.4f' % (rel, agree))
+    assert rel <= 5e-2 and agree >= 0.97
+
+
+# --------------------------------------------------------------------------------------------- f-2: what crosses the process boundary and the bus
+def test_packed_row_cropped_tiles_prepare_identically(hip):
+    """dataset/oem.py RawCollate / oem_ft.py PairCollate (they run in the DataLoader workers) cut a tile down to the rows its crop reads and pack the batch into ONE
+    shared-memory buffer; TileAugmenter then makes one host -> device copy.  The prepared tensors equal those of the plain list-of-arrays path (the one goldens
+    G17 / G19 pin bit for bit against dataset/base_dataset.py:29-175 of the reference) -- tiles larger, equal to and SMALLER than the crop, all flips / rotations."""
+    from segland_amd.dataset.augment import TileAugmenter
+    from segland_amd.dataset.oem import PackedTiles, RawCollate
+    from segland_amd.dataset.oem_ft import PairAugmenter, PairCollate
+    rng = np.random.RandomState(3)
+    ch = cw = 64
+    sizes = [(96, 80), (64, 64), (40, 100), (130, 64), (64, 50), (200, 72), (70, 70), (33, 21)]
+    tiles = [(rng.randint(0, 256, (h, w, 3)).astype(np.uint8), rng.randint(0, 12, (h, w)).astype(np.uint8)) for h, w in sizes]
+    prm = [(int(rng.randint(0, max(h - ch, 0) + 1)), int(rng.randint(0, max(w - cw, 0) + 1)), bool(i % 2), i % 4) for i, (h, w) in enumerate(sizes)]
+    aug = TileAugmenter((ch, cw), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 255, device=DEV)
+    want_i, want_l = aug.prepare(tiles, prm)
+    batch = [(t[0], t[1], p, 'id%d' % i) for i, (t, p) in enumerate(zip(tiles, prm))]
+    for crop_h in (None, ch):
+        packed, params, ids = RawCollate(crop_h)(batch)
+        assert isinstance(packed, PackedTiles) and len(packed) == len(tiles) and ids[3] == 'id3'
+        if crop_h:
+            assert packed[0][0].shape[0] == ch and params[0][0] == 0 and packed[2][0].shape[0] == 40      # cut to the crop's rows; a smaller tile stays whole
+        got_i, got_l = aug.prepare(packed, params)
+        assert torch.equal(got_i, want_i) and torch.equal(got_l, want_l)
+    # pairs: (novel, base) = (tile 2i, tile 2i + 1)
+    pb = [(((tiles[2 * i]), (tiles[2 * i + 1])), (prm[2 * i], prm[2 * i + 1]), 'n%d' % i) for i in range(4)]
+    pa = PairAugmenter((ch, cw), (0.5, 0.5, 0.5), (0.5, 0.5, 0.5), 255, device=DEV)
+    w = pa.prepare([b[0] for b in pb], [b[1] for b in pb])
+    for crop_h in (None, ch):
+        packed, params, _ = PairCollate(crop_h)(pb)
+        g = pa.prepare(packed, params)
+        assert all(torch.equal(a, b) for a, b in zip(g, w))
+    assert torch.equal(w[0], want_i[0::2]) and torch.equal(w[2], want_i[1::2])
