@@ -454,7 +454,7 @@ def main():
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
             traffic, tsrc = None, None
-            for tname in ('r3_traffic.json', 'r3_traffic_wgrad.json', 'r3_traffic_p8.json', 'r2_traffic.json'):      # PMC passes (tools/collect_traffic.py), bytes per launch
+            for tname in ('r4_traffic.json', 'r4_traffic_wgrad.json', 'r4_traffic_p8.json', 'r3_traffic.json', 'r3_traffic_wgrad.json', 'r3_traffic_p8.json'):      # PMC passes (tools/collect_traffic.py), bytes per launch
                 tpath = os.path.join(ROOT, 'profiles', tname)
                 if traffic is None and os.path.exists(tpath):
                     try:
@@ -465,14 +465,29 @@ def main():
                                     '(tools/collect_traffic.py)' % tname)
                     except Exception:
                         pass
+            clock, mfma_busy, csrc = None, None, None
+            cpath = os.path.join(ROOT, 'profiles', 'r4_pmc_families.json')
+            if os.path.exists(cpath):
+                try:
+                    base, dims = e['family'].split('<')[0], e['family'].split('<')[1].rstrip('>').split(', ')[1:] if '<' in e['family'] else []
+                    cands = [(v['ms_per_step'], v) for k_, v in json.load(open(cpath)).items()
+                             if k_.split('<')[0] == base and (not base.startswith('conv_wgrad') or all(d_ in k_ for d_ in dims))]
+                    if cands:
+                        v = max(cands, key=lambda t: t[0])[1]
+                        clock, mfma_busy = v.get('clock_ghz'), v.get('mfma_busy_over_sq_busy')
+                        csrc = ('NOT measured in this run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of this command (kernel by kernel), committed as '
+                                'profiles/r4_pmc_families.json (tools/r4_pmc.sh): clock = GRBM_GUI_ACTIVE / kernel duration, mfma_busy = MFMA_BUSY / (32 x SQ_BUSY_CYCLES)')
+                except Exception:
+                    pass
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                               'traffic': traffic, 'traffic_source': tsrc, 'kernel': e['family'], 'launches': e['calls'],
+                               'traffic': traffic, 'traffic_source': tsrc, 'clock_ghz_measured': clock, 'mfma_busy_measured': mfma_busy, 'clock_source': csrc,
+                               'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
                                'note': 'all launches of this kernel in the %d instrumented kernel-by-kernel steps run right after the %d timed ones' % (a.steps, a.steps)
                                        + ' (every shape it serves; a weight-gradient span includes the small fixed-order slab reduce launched behind the kernel); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
-                                       + 'peak is the 2.4 GHz figure: on these N(0,1) operands the chip sustains ~1.65 GHz under this kernel (the same binary on all-zero operands runs '
-                                       + '+26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
+                                       + 'peak is the 2.4 GHz figure: clock_ghz_measured is what the chip sustained under this kernel on N(0,1) operands in the counter pass (the same binary on '
+                                       + 'all-zero operands runs +26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
         if world == 1 and not a.no_other_configs and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.dtype == 'bf16' and a.batch == 16 and a.size == 512:
             # the other BASELINE configurations that fit one GPU, ~5 s each (the headline model is released first)
             model = opt = net = params = batches = graphed = eager_fn = fn = img = mask = replica = None      # noqa: F841

@@ -31,9 +31,10 @@ def tile_arrays(k, tile, seed, novel):
     return np.ascontiguousarray(img), lab
 
 
-def make_dataset(root=None, n=24, tile=(608, 576), seed=123, shot=5, compression=None, n_val=8):
-    """Writes the directory (once per parameter set in this process) and returns its root."""
-    key = (root, n, tuple(tile), seed, shot, compression, n_val)
+def make_dataset(root=None, n=24, tile=(608, 576), seed=123, shot=5, compression=None, n_val=8, repeat=1):
+    """Writes the directory (once per parameter set in this process) and returns its root.  repeat: train.txt lists every tile that many times (a longer epoch over
+    the same files: tools/feed_rate.py)."""
+    key = (root, n, tuple(tile), seed, shot, compression, n_val, repeat)
     if key in _MADE and os.path.isdir(_MADE[key]):
         return _MADE[key]
     root = root or tempfile.mkdtemp(prefix='segland_synth_tiff_')
@@ -45,7 +46,7 @@ def make_dataset(root=None, n=24, tile=(608, 576), seed=123, shot=5, compression
         img, lab = tile_arrays(j, tile, seed, novel=(j % 3 == 2))
         tiff.write_tiff(os.path.join(root, 'images', id_ + '.tif'), img, compression)
         tiff.write_tiff(os.path.join(root, 'labels', id_ + '.tif'), lab, compression)
-    open(os.path.join(root, 'list', 'train.txt'), 'w').write(''.join(i + '\n' for i in ids))
+    open(os.path.join(root, 'list', 'train.txt'), 'w').write(''.join(i + '\n' for i in ids * repeat))
     open(os.path.join(root, 'list', 'val.txt'), 'w').write(''.join(i + '\n' for i in val))
     novel = [i for k, i in enumerate(ids) if k % 3 == 2]
     open(os.path.join(root, 'list', 'all_%sshot_seed%s.txt' % (shot, seed)), 'w').write(''.join(i + '\n' for i in novel[:4 * shot]))

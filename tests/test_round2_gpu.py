@@ -105,7 +105,9 @@ def test_argmax_and_pseudo_labels_vs_same_box_oracle(hip):
     print('argmax vs same-box oracle: %d / %d pixels differ, %d outside the 1e-5 margin; logits max err %.2e of scale'
           % (diff.sum(), diff.size, n_clear, float((lg.cpu() - lo).abs().max()) / scale))
     assert n_clear == 0
-    assert diff.sum() <= 64, 'more tied pixels than rounding can explain: %d' % diff.sum()
+    # bit-exact label map against the oracle evaluated on this machine: 0 of 524 288 pixels in every run of rounds 2-4 (profiles/r4_parity_log.txt); a pixel inside the
+    # 1e-5 margin could in principle flip with another host's summation order -- the message then says how many and how close
+    assert diff.sum() == 0, '%d argmax pixels differ from the same-box oracle (all within the 1e-5 top-2 margin)' % diff.sum()
     # the train-mode argmax of golden G6 (cross-machine): count and bound
     g = golden('g6_full_r50')
     mt = _model(dtype=torch.float32, criterion=False)
@@ -154,7 +156,8 @@ def test_argmax_and_pseudo_labels_vs_same_box_oracle(hip):
     s2 = float(p2.abs().max())
     print('pseudo-labels vs same-box oracle: %d pixels differ, %d outside the 1e-5 margin'
           % (dd.sum(), int((dd & (mg2 > 1e-5 * s2)).sum())))
-    assert int((dd & (mg2 > 1e-5 * s2)).sum()) == 0 and dd.sum() <= 16
+    assert int((dd & (mg2 > 1e-5 * s2)).sum()) == 0
+    assert dd.sum() == 0, '%d pseudo-label pixels differ from the same-box oracle (all within the 1e-5 top-2 margin)' % dd.sum()
     g7 = golden('g7_ft')
     n7 = int((mb_gpu.cpu().numpy().astype(np.uint8) != g7['mask_b_new']).sum())
     print('pseudo-labels vs golden G7 (cross-machine): %d pixels differ' % n7)
@@ -190,8 +193,8 @@ def _structured_batch(B, size, seed):
     return img, mask
 
 
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize('size', [256, 512])
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('size', [512])            # the bench shape itself (round 3 also ran 256 x 256: the same gates on a quarter of the pixels, 30 s of the suite)
 def test_c2_train_mode_bf16_gate(hip, size):
     """Config C2 (the bench configuration: R50, bf16, batch 16, TRAIN-mode BatchNorm) against the fp32 CPU oracle on this machine.
 
@@ -339,7 +342,7 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize('sync', ['0', 'force', 'inplace'])
+@pytest.mark.parametrize('sync', ['force', 'inplace'])       # ('0', stock DistributedDataParallel with its copy + scale hook, ran here until round 3: the same reducer as 'inplace' minus the build's part)
 def test_hip_model_under_rccl_ddp(hip, sync):
     """engine.py:71 / train_base.py:175-178 on the product: a fresh child process creates a world_size-1 RCCL group, wraps the HIP model
     with Engine.data_parallel (DDP bucket hooks x once_differentiable block Functions, gradient_as_bucket_view x the AdamW pointer table,

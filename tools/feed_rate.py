@@ -37,6 +37,7 @@ def main():
     p.add_argument('--source', default='tiff', choices=['tiff', 'randint'])
     p.add_argument('--compression', default=None, help='tiff_lzw | tiff_adobe_deflate | packbits (default: uncompressed)')
     p.add_argument('--files', type=int, default=96, help='tiff: tiles written to disk')
+    p.add_argument('--repeat', type=int, default=8, help='tiff, base tiles: how often train.txt lists each file (epoch = files x repeat samples: a 96-sample epoch is six batches of 16,\n                   each made by ONE worker -- the loader then measures epoch restarts, not the feed)')
     a = p.parse_args()
     dev = torch.device('cuda', 0)
     decode = 'torch.randint stand-in'
@@ -46,7 +47,7 @@ def main():
         from segland_amd.dataset import oem, oem_ft
         t0 = time.perf_counter()
         root = synthetic_tiff.make_dataset(tempfile.mkdtemp(prefix='feed_tiff_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None), n=a.files, tile=(a.tile, a.tile),
-                                           seed=123, shot=a.shot, compression=a.compression, n_val=1)
+                                           seed=123, shot=a.shot, compression=a.compression, n_val=1, repeat=1 if a.pairs else a.repeat)
         lst = os.path.join(root, 'list', 'train.txt')
         nbytes = sum(os.path.getsize(os.path.join(root, 'images', f)) for f in os.listdir(os.path.join(root, 'images')))
         t0 = time.perf_counter()
