@@ -488,7 +488,7 @@ def main():
                                        + ' (every shape it serves; a weight-gradient span includes the small fixed-order slab reduce launched behind the kernel); achieved = sum of algorithmic FLOPs / sum of HIP-event time; '
                                        + 'peak is the 2.4 GHz figure: clock_ghz_measured is what the chip sustained under this kernel on N(0,1) operands in the counter pass (the same binary on '
                                        + 'all-zero operands runs +26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
-        if world == 1 and not a.no_other_configs and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.dtype == 'bf16' and a.batch == 16 and a.size == 512:
+        if world == 1 and not use_ddp and not a.no_other_configs and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.dtype == 'bf16' and a.batch == 16 and a.size == 512:
             # the other BASELINE configurations that fit one GPU, ~5 s each (the headline model is released first)
             model = opt = net = params = batches = graphed = eager_fn = fn = img = mask = replica = None      # noqa: F841
             import gc

@@ -65,10 +65,12 @@ class BucketedReplica(nn.Module):
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, 0, group=process_group)
         if cut is None:
-            # measured at world size 1 (profiles/r3_ddp_overhead*.txt): the third graph and the second round of collectives cost 0.4 ms per ResNet-50 step and 0.8 ms per
-            # Swin-T step; what the cut hides at 8 GPUs is ~0.85 ms (156 of 190 MB) for ResNet-50 but only the decoder's share for Swin-T -- the model says which way it goes
+            # The cut buys overlap of the late buckets' all-reduce with the second half of the backward and costs a third graph and a second round of collectives:
+            # measured at world size 1 (profiles/r3_ddp_overhead*.txt) 0.4 ms per ResNet-50 step and 0.8 ms per Swin-T step with nothing to hide.  So: off at world
+            # size 1; at N > 1 the model says which way it goes (ResNet: on -- 156 of 190 MB travel beside layer1-3's backward; Swin-T: off).  What it hides at 8 GPUs
+            # is an ESTIMATE (~0.85 ms for ResNet-50 at ~300 GB/s of bus bandwidth): no multi-GPU node was available to measure it.  SEGLAND_BUCKET_CUT=1 / 0 overrides.
             env = os.environ.get('SEGLAND_BUCKET_CUT')
-            cut = (env != '0') if env is not None else bool(getattr(module, 'bucket_cut_default', False))
+            cut = (env != '0') if env is not None else (bool(getattr(module, 'bucket_cut_default', False)) and self.world > 1)
         self.cut = bool(cut) and hasattr(module, 'late_parameters') and hasattr(module, 'cut_tensors')
         self.cap = int(cap_mb * (1 << 20)) // 4
         self.buckets, self.late_buckets, self.views, self.layout = [], 0, {}, None

@@ -270,7 +270,7 @@ def test_bucket_replica_backward_cut_on_cpu():
     ref(x, y)['total_loss'].backward()
     want = {k: p.grad.clone() for k, p in ref.named_parameters()}
     m = Toy()
-    rep = bucket_step.BucketedReplica(m, cap_mb=0.001)
+    rep = bucket_step.BucketedReplica(m, cap_mb=0.001, cut=True)          # (the default cuts only at world size > 1)
     assert rep.cut and m._want and 0 < rep.late_buckets < len(rep.buckets)
     opt = torch.optim.SGD(m.parameters(), lr=0.1)
     bwd1, bwd2, _ = rep.train_step_parts(opt)
