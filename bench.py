@@ -217,7 +217,8 @@ def short_config(kind, dev, steps=10):
             model = networks.pspnet_pop.GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, compute_dtype=dt,
                                                    dilated=True, os=8).to(dev)
         model.init_cls_n()
-        opt = torch.optim.SGD(get_parameters(model, lr=1e-3, freeze_backbone=True), lr=1e-3, momentum=0.9, weight_decay=5e-4)
+        from segland_amd.optim import SGD                 # torch.optim.SGD semantics, one capturable launch (what ft_pop uses on the GPU)
+        opt = SGD(get_parameters(model, lr=1e-3, freeze_backbone=True), lr=1e-3, momentum=0.9, weight_decay=5e-4)
         g = torch.Generator(device='cpu').manual_seed(7)
         img, img_b = torch.randn(1, 3, 512, 512, generator=g).to(dev), torch.randn(1, 3, 512, 512, generator=g).to(dev)
         mask = torch.randint(8, 12, (1, 512, 512), generator=g).to(dev); mask[:, :40] = 255
@@ -236,14 +237,14 @@ def short_config(kind, dev, steps=10):
                 _pp._FEATURE_GRAPH = fg
         torch.cuda.synchronize()
         table = ops.PROFILER.stop(); ops.PROFILER.stop_bytes()
-        graphed = graph_step.GraphedStep(ft_graph_body(model), model) if graph_step.eligible(model, opt, dev, need_adamw=False) else None
+        graphed = graph_step.GraphedStep(ft_graph_body(model, optimizer=opt), model, opt) if graph_step.eligible(model, opt, dev, need_adamw=False) else None
         if graphed is not None:
             for k in range(5):
                 ft_iteration_graphed(graphed, opt, (img, mask, img_b, mask_b), dev)
         replayed = graphed is not None and graphed.graph is not None
         step = (lambda k: ft_iteration_graphed(graphed, opt, (img, mask, img_b, mask_b), dev)) if replayed else (lambda k: ft_iteration(model, opt, sc, (img, mask, img_b, mask_b.clone()), dev))
         units, unit, gflop = 1, 'pairs/s', 901.7                                      # the pair as the reference executes it
-        issue = 'forward + backward + clip replayed as one HIP graph, SGD step behind it' if replayed else 'kernel by kernel'
+        issue = 'forward + backward + clip + SGD step replayed as one HIP graph' if replayed else 'kernel by kernel'
         what = 'ft_pop.py novel-class update: 1 novel + 1 base 512x512 tile per step, PSPNet-POP ResNet-50 bf16, frozen backbone + decoder (BASELINE config 4)'
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -467,7 +468,7 @@ def main():
                         pass
             clock, mfma_busy, csrc = None, None, None
             cpath = os.path.join(ROOT, 'profiles', 'r4_pmc_families.json')
-            if os.path.exists(cpath):
+            if os.path.exists(cpath) and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.batch == 16 and a.size == 512 and a.dtype == 'bf16':      # the counter passes are of this workload
                 try:
                     base, dims = e['family'].split('<')[0], e['family'].split('<')[1].rstrip('>').split(', ')[1:] if '<' in e['family'] else []
                     cands = [(v['ms_per_step'], v) for k_, v in json.load(open(cpath)).items()

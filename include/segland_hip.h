@@ -372,6 +372,13 @@ int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float b
  * parameter group }; a record's `group` selects its pair and the record's own lr / wd are ignored. */
 int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
                        const float* hyper_dev, int repeat, const float* grad_scale, sl_stream_t stream);
+/* torch.optim.SGD (momentum, weight decay; dampening 0, nesterov off) over all parameters in one launch: ft_pop.py:205-209,252.  Table records as for sl_adamw_multi
+ * (64 bytes: p, g, momentum buffer or NULL, unused, numel, lr, weight_decay, chunk start, group, pad); hyper_dev = (lr, weight_decay) per parameter group in device
+ * memory or NULL (the records' own values): with it the launch is capturable while the driver changes the learning rate every iteration.  grad_scale: optional
+ * 1-element device float multiplied into every gradient. */
+int sl_sgd_multi(const void* table_dev, int n, long long total_chunks, float momentum, const float* hyper_dev, const float* grad_scale, sl_stream_t stream);
+/* n <= 16 host floats -> device memory as kernel arguments (stream-ordered, no host -> device copy) */
+int sl_store_floats(float* dst_dev, int n, const float* values_host, sl_stream_t stream);
 
 /* Many small strided fp32 copies in one launch (the zero-padded staging copies of weights / biases / BatchNorm vectors at the channel pitch, refreshed once per
  * optimizer step).  table_dev: n entries {float* dst; const float* src; int rows, cols, dst_pitch, pad; int64 start} (40 bytes): src is [rows][cols] contiguous,

@@ -770,13 +770,22 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M);
 // ~75 TFLOP/s.  Reading two consecutive pixels as ONE row doubles both channel counts ([M][64] is bit-identical to [M/2][128]):
 // the paired problem runs on the glds kernel and the true gradient is the sum of the two parity-diagonal blocks of its result
 // (half of the MFMA work is discarded -- still 2-3x faster).  3x3 layers gather the pair per lane, so they need Cin == 64 (one tile).
+// From how many rows a 1x1 layer with a 64-multiple (not 128-multiple) channel count runs as pixel pairs.  64-channel layers: 2^19 (round 1: shorter ones are faster on the
+// 64-wide register-staged kernel; ResNet's layer1 has kernels of its own anyway).  Layers with >= 192 channels on both sides -- Swin stage 2: 192 <-> 576 / 768 on 32 768
+// tokens -- from 16 384 rows (round 4, tools/gemm_time.py: 192 -> 576 66.2 -> 37.4 us, 192 -> 768 53.1 -> 38.3, 768 -> 192 54.3 -> 39.5, 192 -> 192 27.8 -> 24.8;
+// Swin-T POP 717.3 -> 733.7 tiles/s on one box).  g_pair_min_rows > 0: tuning hook sl_debug_wgrad_pair_min overrides both.
+long long g_pair_min_rows = 0;
+static long long pair_min_rows(const SlConvDesc* d) {
+  if (g_pair_min_rows > 0) return g_pair_min_rows;
+  return (d->Cin >= 192 && d->Cout >= 192) ? 16384 : (1 << 19);
+}
 WgradPlan plan(const SlConvDesc* d) {
   const int c2 = d->Cin - d->C1;
   const bool all128 = d->Cout % 128 == 0 && d->C1 % 128 == 0 && c2 % 128 == 0;
   const bool ident = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   const long long M = (long long)d->B * d->Ho * d->Wo;
   if (!all128 && c2 == 0 && d->dtype == SL_BF16 && M % 2 == 0 && d->Wo % 2 == 0 && d->Cout % 64 == 0 && d->Cin % 64 == 0 &&
-      ((ident && M >= (1 << 19)) || (!ident && d->Cin == 64 && d->stride == 1))) {    // measured: short 1x1 problems are faster on the 64-wide kernel
+      ((ident && M >= pair_min_rows(d)) || (!ident && d->Cin == 64 && d->stride == 1))) {
     SlConvDesc d2 = *d;
     d2.Cout = 2 * d->Cout; d2.Cin = d2.C1 = 2 * d->Cin;
     WgradPlan pl = plan_shape(&d2, M / 2);
@@ -867,6 +876,7 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" void sl_debug_wgrad_pair_min(int rows) { g_pair_min_rows = rows; }      // tuning hook: 1x1 layers with a 64-multiple (not 128-multiple) channel count run as pixel pairs from this many rows
 // test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
 

@@ -87,6 +87,56 @@ extern "C" int sl_adamw_multi_dev(const void* table_dev, int n, long long total_
 
 
 // ------------------------------------------------------------------------------------------------------------------------------------------
+// Momentum SGD over all trainable parameters in one launch (ft_pop.py:205-209 builds torch.optim.SGD(momentum 0.9, weight_decay); its loop body steps it once per
+// iteration, ft_pop.py:252).  Arithmetic = torch/optim/sgd.py (dampening 0, nesterov off, maximize off): d = g + wd p;  buf = momentum buf + d  (the first step's
+// buf = d is the same with a zero-initialised buffer);  p -= lr buf.  Same table records as AdamW (`m` = momentum buffer, `v` unused).  hyp != NULL: (lr, wd) per
+// parameter group from device memory, so that the launch can sit in a captured HIP graph while the driver changes the learning rate every iteration.
+namespace {
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const AdamEntry* __restrict__ tab, int n, long long total_chunks, float momentum, const float* __restrict__ gscale,
+                                                        const float* __restrict__ hyp) {
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long chunk = blockIdx.x; chunk < total_chunks; chunk += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].start <= chunk) lo = mid; else hi = mid - 1; }
+    AdamEntry t = tab[lo];
+    if (hyp) { t.lr = hyp[2 * t.group]; t.wd = hyp[2 * t.group + 1]; }
+    const long long base = (chunk - t.start) * AD_CHUNK;
+    for (int k = threadIdx.x; k < AD_CHUNK; k += 256) {
+      const long long e = base + k;
+      if (e >= t.numel) break;
+      float d = t.g[e] * gs + t.wd * t.p[e];
+      if (t.m) { d = momentum * t.m[e] + d; t.m[e] = d; }
+      t.p[e] -= t.lr * d;
+    }
+  }
+}
+
+struct FloatPack { float v[16]; };
+__global__ void store_floats_kernel(float* __restrict__ dst, int n, FloatPack pk) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = pk.v[threadIdx.x];
+}
+}  // namespace
+
+extern "C" int sl_sgd_multi(const void* table_dev, int n, long long total_chunks, float momentum, const float* hyper_dev, const float* grad_scale, sl_stream_t stream) {
+  SL_REQUIRE(table_dev && n > 0 && total_chunks > 0 && momentum >= 0.f, "sgd_multi: bad args");
+  const int blocks = (int)(total_chunks < 4096 ? total_chunks : 4096);
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamEntry*)table_dev, n, total_chunks, momentum, grad_scale, hyper_dev);
+  SL_LAUNCH_CHECK("sgd_multi_kernel");
+  return 0;
+}
+
+// up to 16 floats into device memory as KERNEL ARGUMENTS (no host -> device copy: a small upload in front of a graph launch sat on the critical path of every step,
+// DESIGN.md / optim.py graph_prepare): the per-group (lr, weight_decay) of a captured optimizer step whose learning rate the driver sets every iteration
+extern "C" int sl_store_floats(float* dst_dev, int n, const float* values_host, sl_stream_t stream) {
+  SL_REQUIRE(dst_dev && values_host && n >= 1 && n <= 16, "store_floats: 1..16 values");
+  FloatPack pk;
+  for (int i = 0; i < 16; ++i) pk.v[i] = i < n ? values_host[i] : 0.f;
+  hipLaunchKernelGGL(store_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dst_dev, n, pk);
+  SL_LAUNCH_CHECK("store_floats_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
 // Many small strided fp32 copies in ONE launch: src [rows][cols] contiguous -> dst rows of pitch dst_pitch (the zero-padded staging copies of a model's
 // weights / biases / BatchNorm vectors at the channel pitch, re-filled once per optimizer step: ~55 launches of 4.4 us per Swin-T step otherwise).
 // table: device array of n entries {dst, src (float*), rows, cols, dst_pitch (int), pad, start (int64)} = 40 bytes; start = running count of 1024-element chunks.

@@ -553,7 +553,9 @@ extern "C" int sl_pop_decompose_fwd(int dtype, const void* feats, const float* S
                                     int C, sl_stream_t stream) {
   SL_REQUIRE(feats && S && proj && bg && R > 0 && Kt >= 1 && Kt <= KMAXP, "pop_decompose_fwd: bad args");
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = row_blocks(R * 16, 2048);
+  // 16 rows per block (four per wave) until 2048 blocks: every block first brings the prototypes (up to 32 KB) into the LDS and its registers, which four rows per block
+  // (2048 blocks for the fine-tune pair's 8 192 rows: 60 us) do not repay; from 32 768 rows on the cap binds and nothing changes
+  const int blocks = row_blocks(R * 4, 2048);
   const size_t lds = (size_t)KMAXP * C * sizeof(float);
   if (int e = pop_dispatch(dtype, C, [&](auto t, auto nv, auto lpr) {
         using T = decltype(t);
@@ -714,14 +716,18 @@ extern "C" int sl_pop_combine_bwd(const float* dpreds, const float* proj, const 
 }
 
 static int dec_bwd_cap() { return 1024; }     // measured 180 / 160 / 161 us for 512 / 1024 / 2048 blocks at 65 536 rows
-extern "C" int sl_pop_decompose_bwd_rows(long long R) { return row_blocks(R, dec_bwd_cap()); }
+// 16 rows per block until the cap binds (from 16 384 rows on: 64 rows per block and more, as before).  A wave walks its rows one after the other and every row is a chain of
+// dependent loads and shuffles, so the launch time is (rows per wave) x (row latency) whenever there are too few blocks to hide it: the fine-tune pair's 8 192 rows took
+// 120 us on 128 blocks of 64 rows -- as long as 65 536 rows on 1 024 blocks.
+static int dec_bwd_blocks(long long R) { return row_blocks(R * 4, dec_bwd_cap()); }
+extern "C" int sl_pop_decompose_bwd_rows(long long R) { return dec_bwd_blocks(R); }
 
 extern "C" int sl_pop_decompose_bwd(int dtype, const void* dg, const void* feats, const float* S, const float* proj,
                                     const float* dproj, int Kt, void* dq, float* dS_partial, long long R, int C,
                                     sl_stream_t stream) {
   SL_REQUIRE(dg && feats && S && proj && dproj && dq && dS_partial && R > 0 && Kt >= 1 && Kt <= KMAXP, "pop_decompose_bwd: bad args");
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = row_blocks(R, dec_bwd_cap());
+  const int nblk = dec_bwd_blocks(R);
   const long long rpb = (R + nblk - 1) / nblk;
   if (Kt <= 8) {
     const size_t lds = 8 * (size_t)C * sizeof(float);

@@ -27,14 +27,18 @@ def ft_iteration(model, optimizer, loss_scaler, batch, device, dataset=None):
     return loss_dict, grad_norm
 
 
-def ft_graph_body(model, clip_grad=5.0):
-    """forward + backward + clip_grad_norm_ of ft_iteration as a function of the four batch tensors, for graph_step.GraphedStep (the SGD
-    step stays outside the graph: torch.optim.SGD bakes the learning rate, which changes every iteration here, into its launches)."""
+def ft_graph_body(model, clip_grad=5.0, optimizer=None):
+    """forward + backward + clip_grad_norm_ (+ the optimizer step) of ft_iteration as a function of the four batch tensors, for graph_step.GraphedStep.
+    optimizer: a segland_amd.optim.SGD -- its one-launch step reads the learning rate from device memory, so it sits inside the graph although ft_pop changes the
+    learning rate every iteration; with torch.optim.SGD (which bakes lr into its four launches) pass None and step behind the replay."""
     def body(img, mask, img_b, mask_b):
         loss_dict = model(img, mask, img_b, mask_b)
         loss_dict['total_loss'].backward()
         params = [p for p in model.parameters() if p.grad is not None]
-        return loss_dict, torch.nn.utils.clip_grad_norm_(params, clip_grad)
+        norm = torch.nn.utils.clip_grad_norm_(params, clip_grad)
+        if optimizer is not None:
+            optimizer.step()
+        return loss_dict, norm
     return body
 
 
@@ -42,7 +46,8 @@ def ft_iteration_graphed(graphed, optimizer, batch, device, dataset=None):
     """ft_iteration with the model part replayed from one HIP graph."""
     img, mask, img_b, mask_b = ft_batch_to_device(batch, dataset, device)
     loss_dict, grad_norm = graphed(img, mask, img_b, mask_b.contiguous())
-    optimizer.step()
+    if graphed.optimizer is None:                                 # torch.optim.SGD: not part of the body (with segland_amd.optim.SGD the body has stepped, eagerly or in the replay)
+        optimizer.step()
     optimizer.zero_grad()
     return loss_dict, grad_norm
 
@@ -76,13 +81,18 @@ def main(argv=None):
             seg_model.init_cls_n()
             params = my_utils.get_parameters(seg_model, lr=args.learning_rate, freeze_backbone=args.freeze_backbone)
             split = -1 if args.freeze_backbone else 0
-            optimizer = optim.SGD(params, lr=args.learning_rate, momentum=args.momentum, weight_decay=args.weight_decay)
+            if engine.use_cuda:
+                from .optim import SGD                                  # torch.optim.SGD semantics / state_dict, one capturable kernel launch per step
+                optimizer = SGD(params, lr=args.learning_rate, momentum=args.momentum, weight_decay=args.weight_decay)
+            else:
+                optimizer = optim.SGD(params, lr=args.learning_rate, momentum=args.momentum, weight_decay=args.weight_decay)
             optimizer.zero_grad()
             model = engine.data_parallel(seg_model)
             loss_scaler = my_utils.NativeScalerWithGradNormCount()
             graphed = None
             if not args.no_step_graph and graph_step.eligible(model, optimizer, engine.device, need_adamw=False):
-                graphed = graph_step.GraphedStep(ft_graph_body(model), model)
+                in_graph = optimizer if hasattr(optimizer, 'graph_prepare') else None
+                graphed = graph_step.GraphedStep(ft_graph_body(model, optimizer=in_graph), model, in_graph)
             if engine.is_main:
                 os.makedirs(args.snapshot_dir, exist_ok=True)
             it, max_it = args.start_epoch * len(train_loader), args.num_epoch * len(train_loader)

@@ -819,6 +819,16 @@ def adamw_multi_dev(table, n, total_chunks, b1, b2, eps, hyper, repeat, grad_sca
     check(_lib.lib().sl_adamw_multi_dev(_p(table), n, int(total_chunks), b1, b2, eps, _p(hyper), int(repeat), _p(grad_scale), _s()), 'adamw_multi_dev')
 
 
+def sgd_multi(table, n, total_chunks, momentum, hyper=None, grad_scale=None):
+    check(_lib.lib().sl_sgd_multi(_p(table), n, int(total_chunks), float(momentum), _p(hyper), _p(grad_scale), _s()), 'sgd_multi')
+
+
+def store_floats(dst, values):
+    """values (<= 16 python floats) -> the first len(values) elements of the float32 GPU tensor dst, as kernel arguments (no host -> device copy)."""
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    check(_lib.lib().sl_store_floats(_p(dst), len(values), arr, _s()), 'store_floats')
+
+
 def confusion_matrix(pred_u8, target, K, ignore_index):
     """[K][K] int64 counts, rows = ground truth, columns = prediction, pixels with target == ignore_index dropped."""
     cm = torch.zeros((K, K), dtype=torch.int64, device=target.device)

@@ -137,6 +137,100 @@ class AdamW(torch.optim.Optimizer):
             cap['hyp'].copy_(tab['dev'][(t - tab['t0']) // repeat], non_blocking=True)
 
 
+class SGD(torch.optim.Optimizer):
+    """torch.optim.SGD (momentum, weight decay; the reference's fine-tuning optimizer, ft_pop.py:205-209) with torch's interface and state_dict layout
+    (`momentum_buffer`), stepped by ONE kernel launch over all parameters (csrc/optim.hip sl_sgd_multi) and capturable: inside a HIP graph the kernel reads each
+    group's (lr, weight_decay) from device memory, which graph_prepare() refreshes before every replay -- ft_pop changes the learning rate every iteration
+    (ft_pop.py:246-249), which is what kept torch's SGD (it bakes lr into its launches: four small launches per step) outside the captured step until round 4.
+    dampening / nesterov / maximize are not implemented (the reference uses none of them)."""
+
+    def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, maximize=False, **unused):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError('SGD: invalid hyper-parameter')
+        if dampening or nesterov or maximize:
+            raise NotImplementedError('segland_amd.optim.SGD: dampening / nesterov / maximize are not implemented in the HIP kernel (use torch.optim.SGD)')
+        bad = [k for k, v in unused.items() if k not in ('foreach', 'fused', 'differentiable') or k == 'differentiable' and v]
+        if bad:
+            raise TypeError('segland_amd.optim.SGD: unsupported argument(s) %s' % ', '.join(bad))
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=0.0, weight_decay=weight_decay, nesterov=False))
+        self._table = None            # (record bytes, device table) of the last eager launch
+        self._cap = None              # HIP-graph capture: persistent {pinned table, device table, device (lr, wd) vector}
+        self._captured = False
+
+    def _records(self):
+        rec, n, chunks, mom, dev = bytearray(), 0, 0, None, None
+        for gi, group in enumerate(self.param_groups):
+            if mom is not None and group['momentum'] != mom:
+                raise RuntimeError('segland_amd.optim.SGD: momentum must be equal across parameter groups')
+            mom = group['momentum']
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    raise RuntimeError('segland_amd.optim.SGD: contiguous float32 GPU parameters and gradients only')
+                dev = p.device
+                buf = 0
+                if mom:
+                    st = self.state[p]
+                    if 'momentum_buffer' not in st or st['momentum_buffer'] is None:
+                        st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # torch: buf = clone(d) on the first step == 0 * momentum + d
+                    buf = st['momentum_buffer'].data_ptr()
+                rec += struct.pack('<QQQQqffqii', p.data_ptr(), p.grad.data_ptr(), buf, 0, p.numel(), group['lr'], group['weight_decay'], chunks, gi, 0)
+                chunks += (p.numel() + 4095) // 4096
+                n += 1
+        return rec, n, chunks, mom or 0.0, dev
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing and self._cap is None:
+            raise RuntimeError('segland_amd.optim.SGD: call capture_begin() before capturing step() into a graph (segland_amd.graph_step does)')
+        rec, n, chunks, mom, dev = self._records()
+        if n == 0:
+            return loss
+        if capturing:
+            cap = self._cap
+            if len(rec) > cap['pinned'].numel():
+                raise RuntimeError('segland_amd.optim.SGD: the captured step touches more parameters than capture_begin() saw')
+            cap['pinned'][:len(rec)] = torch.frombuffer(rec, dtype=torch.uint8)          # host write now; the H2D copy below is a graph node
+            cap['dev'].copy_(cap['pinned'], non_blocking=True)
+            ops.sgd_multi(cap['dev'], n, chunks, mom, hyper=cap['hyp'], grad_scale=grad_scale)
+            self._captured = True
+            return loss
+        ent = self._table
+        if ent is None or ent[0] != rec:
+            ent = self._table = (bytes(rec), torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True))
+        ops.sgd_multi(ent[1], n, chunks, mom, grad_scale=grad_scale)
+        return loss
+
+    # ---- whole-step HIP graphs (segland_amd/graph_step.py): same protocol as AdamW
+    def capture_begin(self):
+        dev, n = None, 0
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.requires_grad and p.is_cuda:
+                    dev, n = p.device, n + 1
+                    if group['momentum'] and self.state[p].get('momentum_buffer') is None:
+                        self.state[p]['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # not inside the capture: a replay would zero it again
+        if dev is None:
+            raise RuntimeError('segland_amd.optim.SGD.capture_begin: no GPU parameters')
+        if 2 * len(self.param_groups) > 16:
+            raise RuntimeError('segland_amd.optim.SGD: at most 8 parameter groups in a captured step')
+        self._cap = dict(pinned=torch.zeros(64 * n, dtype=torch.uint8).pin_memory(), dev=torch.zeros(64 * n, dtype=torch.uint8, device=dev),
+                         hyp=torch.zeros(16, dtype=torch.float32, device=dev))
+        self._captured = False
+
+    def graph_prepare(self):
+        """Before every replay of a graph that holds a captured step(): this iteration's (lr, weight_decay) per group -> the device vector the kernel reads, as
+        kernel arguments of a one-block launch (no host -> device copy in front of the graph)."""
+        if self._cap is not None and self._captured:
+            ops.store_floats(self._cap['hyp'], [v for g in self.param_groups for v in (g['lr'], g['weight_decay'])])
+
+
 def clip_coefficient(parameters, max_norm, grad_div=1):
     """(total_norm, coefficient) of torch.nn.utils.clip_grad_norm_(parameters, max_norm) WITHOUT scaling the gradients: the coefficient
     min(1, max_norm / (total_norm + 1e-6)) is handed to AdamW.step(grad_scale=...) and applied inside the optimizer kernel.

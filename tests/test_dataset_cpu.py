@@ -72,3 +72,43 @@ def test_synthetic_tiff_datasets_resolve_for_the_drivers():
     assert len(ds) == 6 and ds[0][0].shape == (160, 128, 3) and ds.raw_tiles
     f = synthetic_tiff_ft.GFSSegTrain(crop_size=(64, 64), length=12, shot=1)
     assert len(f) == 7 and f.pair_tiles
+
+
+def test_collates_pack_and_crop_rows():
+    """RawCollate / PairCollate (they run in the DataLoader workers): tiles cut down to the rows their crops read, the batch in ONE uint8 buffer; PackedTiles hands back
+    views that equal the arrays that went in, and the draws' h_off becomes 0 exactly where rows were dropped."""
+    import torch
+    from segland_amd.dataset.oem import PackedTiles, RawCollate, crop_rows
+    from segland_amd.dataset.oem_ft import PairCollate
+    rng = np.random.RandomState(0)
+    tiles = [(rng.randint(0, 256, (h, w, 3)).astype(np.uint8), rng.randint(0, 12, (h, w)).astype(np.uint8)) for h, w in ((96, 80), (64, 70), (40, 33), (65, 64))]
+    prm = [(17, 5, True, 1), (0, 3, False, 0), (0, 0, True, 2), (1, 0, False, 3)]
+    img, lab, p = crop_rows(tiles[0][0], tiles[0][1], prm[0], 64)
+    assert img.shape == (64, 80, 3) and p == (0, 5, True, 1) and np.array_equal(img, tiles[0][0][17:81]) and np.array_equal(lab, tiles[0][1][17:81])
+    assert crop_rows(tiles[2][0], tiles[2][1], prm[2], 64)[0].shape[0] == 40                    # smaller than the crop: padded later on the GPU, nothing dropped here
+    assert crop_rows(tiles[1][0], None, prm[1], 64)[1] is None
+    batch = [(t[0], t[1], q, 'id%d' % i) for i, (t, q) in enumerate(zip(tiles, prm))]
+    packed, params, ids = RawCollate(64)(batch)
+    assert isinstance(packed, PackedTiles) and len(packed) == 4 and ids == ['id0', 'id1', 'id2', 'id3'] and packed.buf.dtype == torch.uint8
+    assert [q[0] for q in params] == [0, 0, 0, 0] and params[0][1:] == prm[0][1:]
+    want = [tiles[0][0][17:81], tiles[1][0], tiles[2][0], tiles[3][0][1:65]]
+    for (im, lb), w in zip(packed, want):
+        assert np.array_equal(im.numpy(), w) and lb.shape == w.shape[:2]
+    assert all(m[0] % 16 == 0 and m[3] % 16 == 0 for m in packed.meta)                          # 16-byte aligned tiles inside the buffer
+    full, params_full, _ = RawCollate()(batch)                                                  # validation readers: whole tiles
+    assert np.array_equal(full[0][0].numpy(), tiles[0][0]) and params_full[0] == prm[0]
+    unl, _, _ = RawCollate()([(tiles[0][0], None, prm[1], 'u')])                                # unlabeled test tile
+    assert unl[0][1] is None and unl.meta[0][3] == -1
+    pairs, pp, pid = PairCollate(64)([(((tiles[0]), (tiles[3])), (prm[0], prm[3]), 'n0'), (((tiles[1]), (tiles[2])), (prm[1], prm[2]), 'n1')])
+    assert len(pairs) == 4 and pid == ['n0', 'n1'] and pp[0] == ((0, 5, True, 1), (0, 0, False, 3))
+    assert np.array_equal(pairs[1][0].numpy(), tiles[3][0][1:65]) and np.array_equal(pairs[2][1].numpy(), tiles[1][1])
+    import pickle
+    p2 = pickle.loads(pickle.dumps(packed))                                                     # what crosses the process boundary
+    assert np.array_equal(p2[3][0].numpy(), want[3]) and p2.meta == packed.meta
+
+
+def test_loader_workers_context():
+    from segland_amd.engine import worker_context
+    assert worker_context(0, True) is None and worker_context(4, False) is None
+    ctx = worker_context(2, True)
+    assert ctx.get_start_method() == 'forkserver' and worker_context(3, True) is ctx

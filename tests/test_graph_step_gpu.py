@@ -140,10 +140,13 @@ def test_graphed_step_draws_fresh_stochastic_depth(hip):
     assert step.replays >= 3 and len(set(losses[2:])) > 1
 
 
-@pytest.mark.parametrize('family', ['pspnet', 'swin'])
-def test_graphed_ft_step_equals_eager(hip, family):
-    """ft_pop loop body (ft_pop.py:243-256): forward_novel + forward_all on a (novel, base) pair with in-place pseudo-labels, backward and
-    clip_grad_norm_ replayed from a graph, torch SGD outside it with a learning rate that changes every iteration."""
+@pytest.mark.parametrize('family,sgd', [('pspnet', 'hip'), ('swin', 'hip'), ('pspnet', 'torch')])
+def test_graphed_ft_step_equals_eager(hip, family, sgd):
+    """ft_pop loop body (ft_pop.py:243-256): forward_novel + forward_all on a (novel, base) pair with in-place pseudo-labels, backward,
+    clip_grad_norm_ and the SGD step replayed from ONE graph with a learning rate that changes every iteration (segland_amd.optim.SGD reads it from device
+    memory) -- against the kernel-by-kernel loop body: losses, gradient norms and parameters bit for bit.  (segland_amd.optim.SGD against torch.optim.SGD, the
+    reference's optimizer: test_sgd_kernel_equals_torch_sgd.)  sgd='torch': torch's SGD behind the replay (round 3's arrangement, still what a caller-supplied torch
+    optimizer gets)."""
     from segland_amd import graph_step
     from segland_amd.ft_pop import ft_graph_body, ft_iteration, ft_iteration_graphed
     from segland_amd.loss.criterion import OrthLoss
@@ -168,12 +171,15 @@ def test_graphed_ft_step_equals_eager(hip, family):
         mask_b = fm.formula_mask(2, H, W, 8, 'gf/maskb%d' % k, block=16, ignore_rows=0)
         data.append((img, mask.to(DEV), img_b, mask_b.to(DEV)))
 
+    from segland_amd.optim import SGD
+
     def run(model, graphed):
         model.train_mode()
-        opt = torch.optim.SGD(get_parameters(model, lr=1e-2, freeze_backbone=True), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+        ours = sgd == 'hip'                                  # the same optimizer on both sides: its eager launch and its captured launch are one kernel
+        opt = (SGD if ours else torch.optim.SGD)(get_parameters(model, lr=1e-2, freeze_backbone=True), lr=1e-2, momentum=0.9, weight_decay=5e-4)
         opt.zero_grad()
         sc = NativeScalerWithGradNormCount()
-        g = graph_step.GraphedStep(ft_graph_body(model), model, warmup=2) if graphed else None
+        g = graph_step.GraphedStep(ft_graph_body(model, optimizer=opt if ours else None), model, opt if ours else None, warmup=2) if graphed else None
         log = []
         for k, (img, mask, img_b, mask_b) in enumerate(data):
             for grp in opt.param_groups:

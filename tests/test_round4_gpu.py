@@ -188,3 +188,43 @@ def test_packed_row_cropped_tiles_prepare_identically(hip):
         g = pa.prepare(packed, params)
         assert all(torch.equal(a, b) for a, b in zip(g, w))
     assert torch.equal(w[0], want_i[0::2]) and torch.equal(w[2], want_i[1::2])
+
+
+# --------------------------------------------------------------------------------------------- config 4: the optimizer of ft_pop as one capturable launch
+def test_sgd_kernel_equals_torch_sgd(hip):
+    """segland_amd.optim.SGD (csrc/optim.hip sl_sgd_multi: every parameter in one launch) against torch.optim.SGD, the reference's fine-tuning optimizer
+    (ft_pop.py:205-209: momentum 0.9, weight decay, two parameter groups with their own lr): parameters and momentum buffers to 1e-6 over five steps (torch's
+    multi-tensor kernels may contract g + wd p into one fused multiply-add; this build compiles with -ffp-contract=off) with a changing learning rate, a parameter
+    whose first gradient arrives late, odd sizes, and a state_dict round trip from torch's optimizer into this one."""
+    from segland_amd.optim import SGD
+    torch.manual_seed(1)
+    shapes = [(33, 7), (513,), (64, 16, 3, 3), (4, 512), (1,)]
+    mine = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    groups = lambda ps: [dict(params=ps[:3], lr=1e-2), dict(params=ps[3:], lr=1e-1, weight_decay=0.0)]
+    a = SGD(groups(mine), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    b = torch.optim.SGD(groups(ref), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+    for it in range(5):
+        for o in (a, b):
+            for gi, g in enumerate(o.param_groups):
+                g['lr'] = (1e-2 if gi == 0 else 1e-1) * (1 - it / 8.0)
+        for k, (p, q) in enumerate(zip(mine, ref)):
+            if k == 4 and it < 2:
+                p.grad = q.grad = None                      # first gradient at iteration 2
+                continue
+            gr = torch.randn_like(p)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        a.step(); b.step()
+        for k, (p, q) in enumerate(zip(mine, ref)):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7), (it, k, float((p - q).abs().max()))
+        if it == 2:                                         # resume: torch's state_dict layout in, torch's out
+            import copy
+            sd = copy.deepcopy(b.state_dict())              # load_state_dict keeps the tensors it is given: without the copy both optimizers would share their momentum buffers
+            a2 = SGD(groups(mine), lr=1e-2, momentum=0.9, weight_decay=5e-4)
+            a2.load_state_dict(sd)
+            a = a2
+    for p, q in zip(mine, ref):
+        ba, bb = a.state[p].get('momentum_buffer'), b.state[q].get('momentum_buffer')
+        assert (ba is None) == (bb is None) and (ba is None or torch.allclose(ba, bb, rtol=1e-6, atol=1e-7))
+    with pytest.raises(NotImplementedError):
+        SGD(mine, lr=0.1, momentum=0.9, nesterov=True)

@@ -7,9 +7,12 @@ import torch
 from segland_amd import ops
 p = argparse.ArgumentParser()
 p.add_argument('--tokens', type=int, default=8192); p.add_argument('--cin', type=int, default=384); p.add_argument('--cout', type=int, default=1536)
-p.add_argument('--gelu', action='store_true'); p.add_argument('--res', action='store_true'); p.add_argument('--reps', type=int, default=20)
+p.add_argument('--pair-min', type=int, default=0, help='sl_debug_wgrad_pair_min'); p.add_argument('--gelu', action='store_true'); p.add_argument('--res', action='store_true'); p.add_argument('--reps', type=int, default=20)
 a = p.parse_args()
 dt = torch.bfloat16
+if a.pair_min:
+    from segland_amd import _lib
+    _lib.lib().sl_debug_wgrad_pair_min(a.pair_min)
 B, H, W = 8, a.tokens // 8 // 32, 32
 assert B * H * W == a.tokens
 spec = ops.ConvSpec(a.cin, a.cout, 1, 1, 0, 1)
