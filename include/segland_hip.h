@@ -35,6 +35,8 @@ typedef void* sl_stream_t;
 
 int sl_version(void);
 const char* sl_last_error_string(void);
+/* reads and resets the HIP runtime's sticky last error of the calling thread (returns its code): the step drivers call it after a failed graph capture */
+int sl_hip_clear_error(void);
 
 /* ------------------------------------------------------------------------------------------------ convolution
  * nn.Conv2d call sites: networks/backbones/resnet.py:44-49,109-110 (Bottleneck 1x1/3x3, stride 1/2, dilation 1/2/4),

@@ -258,6 +258,8 @@ class GraphedBucketStep:
         self.static_in = (img.clone(), mask.clone())
         self.optimizer.capture_begin()
         graphs, pool = [], None
+        from . import functional
+        functional.flush_num_batches_tracked()
         torch.cuda.synchronize()
 
         def call(fn, *args):
@@ -280,7 +282,8 @@ class GraphedBucketStep:
         except Exception as e:                            # noqa: BLE001  (whatever it was, the other ranks must hear about it)
             graphs, outs, err = None, None, e
             if torch.cuda.is_available():
-                torch.cuda.synchronize()
+                from . import ops
+                ops.after_failed_capture()
         if not self.replica.agree(err is None):
             self.graphs, self.key = None, None
             self.failures += 1

@@ -138,6 +138,10 @@ def grad_alias(t, dst):
 
 
 def flush_num_batches_tracked():
+    """One launch for the counters of every train-mode BatchNorm that ran since the last flush (the models call it at the end of their feature extractor).
+    The step drivers also call it right BEFORE they start a graph capture: an entry left behind by code that ran BatchNorm layers outside a model's forward (unit
+    tests of single blocks) would otherwise be bumped by a node of the new graph -- on every replay, for as long as the graph lives, whatever has become of the
+    module that owned the counter."""
     if _nbt_pending:
         torch._foreach_add_(_nbt_pending, 1)
         _nbt_pending.clear()

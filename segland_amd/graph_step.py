@@ -60,6 +60,8 @@ class GraphedStep:
         self.static_in = tuple(t.clone() for t in tensors)
         if self.optimizer is not None:
             self.optimizer.capture_begin()
+        from . import functional
+        functional.flush_num_batches_tracked()
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
@@ -83,7 +85,8 @@ class GraphedStep:
                 self.graph, self.key = None, None
                 self.failures += 1
                 STATS['failures'] += 1
-                torch.cuda.synchronize()
+                from . import ops
+                ops.after_failed_capture()
                 import logging
                 logging.getLogger('Segmentation').warning('graph_step: capture failed (%s: %s); %s', type(e).__name__, str(e).splitlines()[0] if str(e) else '',
                                                           'one more eager step, then another attempt' if self.failures < 3 else 'staying eager')

@@ -167,7 +167,7 @@ class GFSS_Model(nn.Module):
             except Exception as e:                            # stay on the eager HIP path
                 import logging
                 logging.warning('segland_amd: HIP graph capture of the frozen feature extractor failed (%s); running eagerly', e)
-                torch.cuda.synchronize()                      # a failed capture leaves work queued on the side stream: drain before the eager path
+                ops.after_failed_capture()                    # a failed capture leaves work queued on the side stream (and the runtime's sticky error): drain before the eager path
                 self.__dict__['_sl_graph'] = (sig, None, None, None)
                 return None
         _, graph, static_in, static_out = ent

@@ -287,9 +287,23 @@ def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean,
 _ws_cache = {}
 
 
+def after_failed_capture():
+    """Drain the device and reset the runtime's sticky last error (csrc/api.cpp sl_hip_clear_error): the kernel-by-kernel step that follows a failed graph capture
+    must not have its first launch check report the capture's error."""
+    torch.cuda.synchronize()
+    _lib.lib().sl_hip_clear_error()
+
+
 def workspace(nbytes, dev, tag=None):
-    """Grow-only scratch buffer per device and stream (stream-ordered reuse: all our launches are on the current stream).  `tag`: a separate buffer (the
-    weight-gradient slabs keep theirs: up to 1 GiB, and the small users do not grow with them)."""
+    """Scratch buffer for ONE call (nothing in it outlives the call's kernels).  Eager: grow-only per device and stream (stream-ordered reuse: all our launches are
+    on the current stream); `tag`: a separate buffer (the weight-gradient slabs keep theirs: up to 1 GiB, and the small users do not grow with them).
+    While the stream is CAPTURING the cache is not used at all: the buffer comes from the capturing graph's own memory pool and goes back to it when the call returns
+    (the pool hands the same block to the next call; kernels of one graph run in capture order).  A cached buffer is not the graph's to keep: every capture of the
+    process runs on torch's one capture stream, so the cache entry of that stream was shared by all graphs, and when it grew in the middle of a capture the nodes
+    recorded before kept the address of the tensor that was dropped -- memory of an older, already destroyed graph's pool in gpurun r4k..r4m: a GPU memory fault at
+    the first replay (tests/test_round4_gpu.py::test_workspace_of_a_captured_call_belongs_to_its_graph)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
     key = (dev, _s(), tag)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:

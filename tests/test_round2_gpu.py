@@ -351,7 +351,7 @@ def test_hip_model_under_rccl_ddp(hip, sync):
     sync='inplace': Engine.data_parallel(sum_gradients=True) -- sum-only all-reduce hook, block backwards writing parameter gradients straight
     into DDP's bucket views (functional.grad_dst), the 1 / world_size inside the AdamW kernel: three iterations, identical parameters, and
     the third backward must have written >= 170 of the 180 gradients in place."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='16')      # two or three children next to pytest: 256 OpenMP threads each oversubscribe the host
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_child.py'), sync, str(_free_port())], env=env, capture_output=True,
                        text=True, timeout=540)
     line = [l for l in r.stdout.splitlines() if l.startswith('DDP_CHILD ')]
@@ -378,7 +378,7 @@ def test_two_ranks_equal_one_full_batch(hip, tmp_path):
     with ONE value per channel per rank included), AdamW with 1 / world_size in its kernel.  One backward: loss, all gradients and the running
     statistics agree to reduction-order tolerance; three train_base.py iterations on top stay together."""
     port = str(_free_port())
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='16')      # two or three children next to pytest: 256 OpenMP threads each oversubscribe the host
     child = os.path.join(ROOT, 'tests', 'ddp2_child.py')
     outs = [str(tmp_path / 'two.pt'), str(tmp_path / 'one.pt')]
     procs = [subprocess.Popen([sys.executable, child, str(r), port, outs[0]], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (0, 1)]

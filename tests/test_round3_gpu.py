@@ -34,7 +34,7 @@ def test_bucket_step_under_rccl_world1(hip, mode):
     must leave parameters, buffers, AdamW-driven losses and eval logits identical to the unwrapped kernel-by-kernel run.
     mode 'bucket_force' (round 4): nn.SyncBatchNorm with SEGLAND_SYNC_BN semantics (train_base.py:175-178) ON THE REPLICA -- its per-layer all-reduces cannot sit in a
     captured forward, so the same buckets / in-place gradients / collectives are issued kernel by kernel instead of handing the job to DistributedDataParallel."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='16')      # two or three children next to pytest: 256 OpenMP threads each oversubscribe the host
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'ddp_child.py'), mode, str(_free_port())], env=env, capture_output=True,
                        text=True, timeout=540)
     line = [l for l in r.stdout.splitlines() if l.startswith('DDP_CHILD ')]
@@ -60,7 +60,7 @@ def test_bucket_step_two_ranks_equals_ddp(hip, tmp_path):
     """Two ranks on the one GPU of the box (gloo), a different half-batch per rank and iteration, per-GPU BatchNorm statistics: the two-graph
     bucket step must train exactly like DistributedDataParallel with in-place bucket gradients (round 2's path, itself pinned against the
     one-process full batch by test_two_ranks_equal_one_full_batch): same losses, same parameters on both ranks and in both modes."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='16')      # two or three children next to pytest: 256 OpenMP threads each oversubscribe the host
     child = os.path.join(ROOT, 'tests', 'bucket2_child.py')
     res = {}
     for mode in ('ddp', 'bucket'):              # one 2-rank job after the other (side by side the four processes took 329 s instead of 62: gpurun r4g)

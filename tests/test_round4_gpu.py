@@ -228,3 +228,38 @@ def test_sgd_kernel_equals_torch_sgd(hip):
         assert (ba is None) == (bb is None) and (ba is None or torch.allclose(ba, bb, rtol=1e-6, atol=1e-7))
     with pytest.raises(NotImplementedError):
         SGD(mine, lr=0.1, momentum=0.9, nesterov=True)
+
+
+# --------------------------------------------------------------------------------------------- scratch buffers of captured calls
+def test_workspace_of_a_captured_call_belongs_to_its_graph(hip):
+    """ops.workspace while the stream is capturing: memory of the capturing graph's pool, never the process-wide cache entry (all captures run on torch's one
+    capture stream, so that entry was shared by every graph; when it grew in the middle of a capture the nodes recorded before kept the address of the dropped
+    tensor -- a block of an older, destroyed graph's pool: GPU memory fault at the first replay, gpurun r4k..r4m).  The sequence that faulted: a first graph with a
+    small weight gradient dies; a second graph records a small and then a large weight gradient; its replays equal the eager results."""
+    import gc
+    from segland_amd import ops
+    torch.manual_seed(5)
+    small = (torch.randn(2, 12, 16, 64, device=DEV).to(torch.bfloat16), torch.randn(2, 12, 16, 64, device=DEV).to(torch.bfloat16), ops.ConvSpec(64, 64, 3, 1, 1, 1))
+    big = (torch.randn(2, 96, 128, 64, device=DEV).to(torch.bfloat16), torch.randn(2, 96, 128, 256, device=DEV).to(torch.bfloat16), ops.ConvSpec(64, 256, 1, 1, 0, 1))
+    want_s, want_b = ops.conv2d_bwd_weight(*small).clone(), ops.conv2d_bwd_weight(*big).clone()
+    keys_before = set(ops._ws_cache)
+    g1 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g1):
+        w = ops.workspace(1 << 20, torch.device(DEV, 0), 'wgrad')
+        assert all(w.data_ptr() != c.data_ptr() for c in ops._ws_cache.values())
+        o1 = ops.conv2d_bwd_weight(*small)
+    g1.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o1, want_s)
+    del g1, o1, w
+    gc.collect()
+    torch.cuda.empty_cache()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        o_s = ops.conv2d_bwd_weight(*small)
+        o_b = ops.conv2d_bwd_weight(*big)
+    assert set(ops._ws_cache) == keys_before, 'a capture left an entry in the eager workspace cache'
+    for _ in range(3):
+        g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(o_s, want_s) and torch.equal(o_b, want_b)
