@@ -1945,6 +1945,7 @@ static int splitk_parts(const ConvGemmParams& p, int dtype) {
   return s;
 }
 
+long long g_ring64_max_tiles = 160;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
 template <typename T>
 int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   const bool n128 = (p.N % 128 == 0), n256 = (p.N % 256 == 0);
@@ -1972,6 +1973,15 @@ int launch_gemm(ConvGemmParams& p, hipStream_t st) {
   // 128 x 128 tiles (few rows: Swin stage 3 / 4 token maps, the fine-tune pair's 8 192-row layers): 64-byte rows, 4 stages, 64 KiB, two blocks per CU.  Round 4 measured
   // the other stage geometries of this template end to end (Swin-T POP tiles/s / fine-tune pairs/s, one box): 128-byte rows x 3 stages (96 KiB, one block per CU)
   // 696.6 / 379.5, x 4 stages 712.3 / 408.1, 128-byte rows x 3 stages on eight waves of 64 x 32 705.7 / 392.0 -- against 720.2 / 419.1 for this one
+  if constexpr (sizeof(T) == 2) {
+    // few 128 x 128 tiles (the fine-tune pair's 8 192-row layers with 128 / 256 output channels: 64 / 128 tiles on 256 CUs; Swin stage 4 projections): 64-row tiles, bit-identical
+    // results.  tools/ring64_check.py (us, 128 x 128 -> 64 x 128): 1024 -> 256 19.0 -> 15.4, 3x3 256 -> 256 d2 37.4 -> 30.0, 512 -> 128 11.6 -> 9.3, 3x3 128 -> 128 21.5 -> 16.7;
+    // from 256 tiles on the smaller tile loses (2048 -> 512 36.1 -> 38.9, 256 -> 1024 11.1 -> 13.3).  End to end, one box: 440.9 -> 454.3 pairs/s (ResNet-50), 389 -> 406 (Swin-T),
+    // Swin-T training step 733.9 -> 736.8 tiles/s; a limit of 200 / 300 tiles: 453.1 / 447.5 pairs/s.  Launches without BN statistic partials only (a training conv's
+    // partials keep the 128-row granularity sl_conv2d_stat_rows promises).
+    if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_ring64_max_tiles)
+      return launch_ring<T, 64, 128, 2, 2, 64, 4>(p, st);
+  }
   if (n128 && p.M >= 128LL * RING128_MIN) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);
   if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
   return launch_glds<T, 128, 64, 2, 2>(p, st);
@@ -2005,6 +2015,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
+extern "C" void sl_debug_ring64_max_tiles(int v) { g_ring64_max_tiles = v; }      // tuning hook: see launch_gemm
 extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 

@@ -263,3 +263,32 @@ def test_workspace_of_a_captured_call_belongs_to_its_graph(hip):
         g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(o_s, want_s) and torch.equal(o_b, want_b)
+
+
+# --------------------------------------------------------------------------------------------- config 4: few-tile inference convs on 64-row tiles
+@pytest.mark.parametrize('cin,cout,k,dil', [(1024, 256, 1, 1), (256, 256, 3, 2), (512, 128, 1, 1), (128, 128, 3, 1)])
+def test_few_tile_inference_convs_on_64_row_tiles(hip, cin, cout, k, dil):
+    """A frozen conv + folded BatchNorm of a fine-tune pair (8 192 rows, 128 / 256 output channels) has 64 / 128 tiles of 128 x 128 for 256 CUs; launch_gemm gives such
+    launches 64 x 128 tiles (conv_gemm_ring_kernel<64, 128>: 1024 -> 256 19.0 -> 15.4 us, 3x3 256 -> 256 d2 37.4 -> 30.0; 441 -> 454 pairs/s, tools/ring64_check.py).
+    Same K order per output element: bit-identical to the 128 x 128 tiles (hook sl_debug_ring64_max_tiles(0)), incl. a ragged last row block, and close to fp32 torch."""
+    import torch.nn.functional as F
+    from segland_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator(device='cpu').manual_seed(cin + cout + k)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(dt).float().to(DEV)
+    wf, _ = ops.weight_prep(w, dt)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    spec = ops.ConvSpec(cin, cout, k, 1, dil * (k // 2), dil)
+    for B, H, W in ((2, 64, 64), (1, 50, 52)):           # 8 192 rows; 2 600 rows: a ragged last row block (from 2 048 rows on, like the 128 x 128 ring tiles)
+        x = torch.randn(B, H, W, cin, generator=g).to(dt).to(DEV)
+        rs = torch.randn(B, H, W, cout, generator=g).to(dt).to(DEV)
+        try:
+            hip.sl_debug_ring64_max_tiles(0)
+            y128 = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True).clone()
+        finally:
+            hip.sl_debug_ring64_max_tiles(160)
+        y64 = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True)
+        assert torch.equal(y64, y128)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, dil * (k // 2), dil).permute(0, 2, 3, 1).to(dt).float()
+        ref = torch.relu(ref * scale + shift + rs.float())
+        assert float((y64.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
