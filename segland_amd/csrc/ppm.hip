@@ -74,6 +74,46 @@ __global__ void ppm_cells_kernel(PpmGeom g, const T* __restrict__ x, float* __re
   }
 }
 
+// The same sums for small batches (a fine-tune pair: 2 x 8 x 8 cells x 256 channel vectors = 128 blocks of threads that each walk ~100 pixels one dependent load after the
+// other: 51 us whatever the batch).  A block owns one cell x 32 channel vectors; its 8 row lanes take the cell's rows y0 + lane, + 8, ... and the lane sums are added in
+// lane order through the LDS (fixed order: bit-stable; another order than ppm_cells_kernel's row-major walk, so the two kernels agree to fp32 rounding only).
+template <typename T>
+__global__ __launch_bounds__(256) void ppm_cells_rows_kernel(PpmGeom g, const T* __restrict__ x, float* __restrict__ cells) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[8][32][V + 1];
+  const int nv = g.C / V, vblocks = (nv + 31) / 32;
+  int bid = blockIdx.x;
+  const int vb = bid % vblocks; bid /= vblocks;
+  const int cx = bid % g.ncx; bid /= g.ncx;
+  const int cy = bid % g.ncy; const int b = bid / g.ncy;
+  const int lv = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int v = vb * 32 + lv;
+  float s[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) s[k] = 0.f;
+  if (v < nv)
+    for (int y = g.yb[cy] + rl; y < g.yb[cy + 1]; y += 8)
+      for (int xx = g.xb[cx]; xx < g.xb[cx + 1]; ++xx) {
+        float t[V];
+        unpack16<T>(*(const uint4*)(x + ((size_t)(b * g.H + y) * g.W + xx) * g.C + v * V), t);
+#pragma unroll
+        for (int k = 0; k < V; ++k) s[k] += t[k];
+      }
+#pragma unroll
+  for (int k = 0; k < V; ++k) red[rl][lv][k] = s[k];
+  __syncthreads();
+  if (rl == 0 && v < nv) {
+    float* o = cells + ((((size_t)b * g.ncy + cy) * g.ncx + cx) * nv + v) * V;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float a = red[0][lv][k];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) a += red[r][lv][k];
+      o[k] = a;
+    }
+  }
+}
+
 // pooled[level rows][C] = (sum of the cells inside the bin) / bin area
 __global__ void ppm_bins_kernel(PpmGeom g, const float* __restrict__ cells, float* __restrict__ pooled) {
   const long long total = (long long)g.rowoff[4] * g.C;
@@ -474,7 +514,11 @@ extern "C" int sl_ppm_pool_fwd(const SlPpmDesc* d, const void* x, float* pooled,
   hipStream_t st = (hipStream_t)stream;
   float* cells = (float*)workspace;
   if (d->dtype == SL_BF16) {
-    hipLaunchKernelGGL(ppm_cells_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.ncy * g.ncx * g.C / 8)), dim3(256), 0, st, g, (const bf16_t*)x, cells);
+    const long long cell_vecs = (long long)g.B * g.ncy * g.ncx * (g.C / 8);
+    if (cell_vecs < 256 * 1024)      // fewer than 1024 blocks of the one-thread-per-cell kernel (batch < 16 at 64 x 64 x 2048): rows of a cell in parallel
+      hipLaunchKernelGGL(ppm_cells_rows_kernel<bf16_t>, dim3((unsigned)(g.B * g.ncy * g.ncx * ((g.C / 8 + 31) / 32))), dim3(256), 0, st, g, (const bf16_t*)x, cells);
+    else
+      hipLaunchKernelGGL(ppm_cells_kernel<bf16_t>, dim3(gs_blocks(cell_vecs)), dim3(256), 0, st, g, (const bf16_t*)x, cells);
     hipLaunchKernelGGL(ppm_bins_kernel, dim3(gs_blocks((long long)g.rowoff[4] * g.C)), dim3(256), 0, st, g, cells, (float*)pooled);
   } else if (d->dtype == SL_F32) {
     hipLaunchKernelGGL(ppm_cells_kernel<float>, dim3(gs_blocks((long long)g.B * g.ncy * g.ncx * g.C / 4)), dim3(256), 0, st, g, (const float*)x, cells);
