@@ -286,6 +286,8 @@ class GraphedBucketStep:
                 ops.after_failed_capture()
         if not self.replica.agree(err is None):
             self.graphs, self.key = None, None
+            from . import functional
+            functional.discard_pending_counters()            # queued by the attempt (here or on the rank that did capture): nothing of it runs
             self.failures += 1
             graph_step.STATS['failures'] += 1
             import logging

@@ -147,6 +147,12 @@ def flush_num_batches_tracked():
         _nbt_pending.clear()
 
 
+def discard_pending_counters():
+    """After a FAILED graph capture: the BatchNorm layers of the attempt queued their counters, but nothing of the attempt ran (the step is about to be issued again,
+    kernel by kernel, and queues them again)."""
+    _nbt_pending.clear()
+
+
 def spec_of(conv):
     return ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
 

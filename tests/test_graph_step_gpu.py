@@ -217,3 +217,44 @@ def test_train_base_replays_the_step_with_loader_workers(hip, tmp_path):
     sd = torch.load(glob.glob(os.path.join(snap, 'epoch_2.pth'))[0], map_location='cpu')
     assert int(sd['module.backbone.bn1.num_batches_tracked']) == 32
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+def test_failed_capture_falls_back_to_the_eager_step_and_recovers(hip):
+    """A step whose body needs the host while it is being captured (a `.item()` read-back: hipErrorStreamCaptureUnsupported, the capture is invalidated) must run
+    kernel by kernel as if nothing had happened -- graph_step clears the runtime's sticky error (csrc/api.cpp sl_hip_clear_error) so that the first launch check of
+    the eager step does not report the capture's failure -- and the next attempt, with a well-behaved body, captures and replays.  Losses, gradient norms and
+    parameters equal the plain eager run throughout."""
+    from segland_amd import graph_step
+    from segland_amd.optim import AdamW
+    from segland_amd.train_base import train_iteration
+    from segland_amd.utils.pyt_utils import NativeScalerWithGradNormCount, get_parameters
+    batches = _batches(7, 2, 64, 96)
+    ref = _pspnet(torch.float32)
+    got = copy.deepcopy(ref)
+    opt_r = AdamW(get_parameters(ref, lr=1e-4), lr=1e-4, weight_decay=1e-4)
+    sc = NativeScalerWithGradNormCount()
+    log_r = []
+    for img, mask in batches:
+        d, gn = train_iteration(ref, opt_r, sc, img, mask, double_step=True)
+        log_r.append((float(d['total_loss'].detach()), float(gn)))
+    opt_g = AdamW(get_parameters(got, lr=1e-4), lr=1e-4, weight_decay=1e-4)
+    poison = [True]
+
+    def body(model, optimizer, scaler, img, mask, double_step=True):
+        if poison[0] and torch.cuda.is_current_stream_capturing():
+            img.sum().item()                                  # host read-back inside the capture
+        return train_iteration(model, optimizer, scaler, img, mask, double_step=double_step)
+    step = graph_step.GraphedTrainStep(body, got, opt_g, NativeScalerWithGradNormCount(), double_step=True, warmup=2)
+    log_g = []
+    for k, (img, mask) in enumerate(batches):
+        if k == 4:
+            poison[0] = False
+        d, gn = step(img, mask)
+        log_g.append((float(d['total_loss'].detach()), float(gn)))
+        if k == 2:
+            assert step.failures == 1 and step.graph is None, 'the poisoned capture did not fail'
+    print(log_r, log_g, step.failures, step.replays)
+    assert step.failures == 2 and step.graph is not None and step.replays >= 2          # attempts at iterations 2 and 3 fail, iteration 4 captures
+    assert log_r == log_g
+    for (k, a), (_, b) in zip(ref.state_dict().items(), got.state_dict().items()):
+        assert torch.equal(a, b), k
