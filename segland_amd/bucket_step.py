@@ -287,7 +287,7 @@ class GraphedBucketStep:
         if not self.replica.agree(err is None):
             self.graphs, self.key = None, None
             from . import functional
-            functional.discard_pending_counters()            # queued by the attempt (here or on the rank that did capture): nothing of it runs
+            functional.after_failed_capture()                # counters queued and caches filled by the attempt (here or on the rank that did capture): nothing of it ran
             self.failures += 1
             graph_step.STATS['failures'] += 1
             import logging

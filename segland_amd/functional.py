@@ -153,6 +153,14 @@ def discard_pending_counters():
     _nbt_pending.clear()
 
 
+def after_failed_capture():
+    """Host-side state a failed capture attempt leaves behind: queued BatchNorm counters (nothing of the attempt ran) and cache entries whose CONTENT was to be produced
+    by captured launches -- prepared weight copies, BN evaluation coefficients -- under keys that would still match in the eager step that follows."""
+    discard_pending_counters()
+    weights_changed()
+    running_stats_changed()
+
+
 def spec_of(conv):
     return ConvSpec(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
 

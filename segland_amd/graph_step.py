@@ -87,7 +87,7 @@ class GraphedStep:
                 STATS['failures'] += 1
                 from . import functional, ops
                 ops.after_failed_capture()
-                functional.discard_pending_counters()
+                functional.after_failed_capture()
                 import logging
                 logging.getLogger('Segmentation').warning('graph_step: capture failed (%s: %s); %s', type(e).__name__, str(e).splitlines()[0] if str(e) else '',
                                                           'one more eager step, then another attempt' if self.failures < 3 else 'staying eager')

@@ -222,7 +222,8 @@ def test_train_base_replays_the_step_with_loader_workers(hip, tmp_path):
 def test_failed_capture_falls_back_to_the_eager_step_and_recovers(hip):
     """A step whose body needs the host while it is being captured (a `.item()` read-back: hipErrorStreamCaptureUnsupported, the capture is invalidated) must run
     kernel by kernel as if nothing had happened -- graph_step clears the runtime's sticky error (csrc/api.cpp sl_hip_clear_error) so that the first launch check of
-    the eager step does not report the capture's failure -- and the next attempt, with a well-behaved body, captures and replays.  Losses, gradient norms and
+    the eager step does not report the capture's failure, and invalidates what the attempt left in host-side caches (functional.after_failed_capture: the attempt
+    at iteration 3 fails AFTER the whole step was recorded) -- and the next attempt, with a well-behaved body, captures and replays.  Losses, gradient norms and
     parameters equal the plain eager run throughout."""
     from segland_amd import graph_step
     from segland_amd.optim import AdamW
@@ -238,17 +239,23 @@ def test_failed_capture_falls_back_to_the_eager_step_and_recovers(hip):
         d, gn = train_iteration(ref, opt_r, sc, img, mask, double_step=True)
         log_r.append((float(d['total_loss'].detach()), float(gn)))
     opt_g = AdamW(get_parameters(got, lr=1e-4), lr=1e-4, weight_decay=1e-4)
-    poison = [True]
+    poison = ['early']
 
     def body(model, optimizer, scaler, img, mask, double_step=True):
-        if poison[0] and torch.cuda.is_current_stream_capturing():
-            img.sum().item()                                  # host read-back inside the capture
-        return train_iteration(model, optimizer, scaler, img, mask, double_step=double_step)
+        cap = torch.cuda.is_current_stream_capturing()
+        if cap and poison[0] == 'early':
+            img.sum().item()                                  # host read-back inside the capture, before anything of the step is recorded
+        out = train_iteration(model, optimizer, scaler, img, mask, double_step=double_step)
+        if cap and poison[0] == 'late':
+            img.sum().item()                                  # ... and after ALL of it was recorded: weight copies, BN coefficients and counters of the attempt must not survive
+        return out
     step = graph_step.GraphedTrainStep(body, got, opt_g, NativeScalerWithGradNormCount(), double_step=True, warmup=2)
     log_g = []
     for k, (img, mask) in enumerate(batches):
+        if k == 3:
+            poison[0] = 'late'
         if k == 4:
-            poison[0] = False
+            poison[0] = None
         d, gn = step(img, mask)
         log_g.append((float(d['total_loss'].detach()), float(gn)))
         if k == 2:
