@@ -9,7 +9,7 @@
   pass B  SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
   pass C / D  FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE doubled: MI355X_MICROARCH.md)   -> HBM-side bytes per launch and TB/s
 
-usage: pmc_families.py <out.txt> <out.json> <steps> <dirA> [<dirB> [<dirC> <dirD>]]"""
+usage: pmc_families.py [--min-ms 0.25] [--cmd '<profiled command>'] <out.txt> <out.json> <steps> <dirA> [<dirB> [<dirC> <dirD>]]"""
 import glob, json, re, sqlite3, sys
 from collections import defaultdict
 
@@ -23,19 +23,25 @@ def load(path):
     return per, dur
 
 
-out_txt, out_json, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
-dirs = sys.argv[4:]
+min_ms, cmd = 0.25, 'python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph --no-other-configs'
+args = sys.argv[1:]
+while args and args[0].startswith('--'):              # --min-ms X: families below X ms per step are left out;  --cmd '...': the profiled command, for the header
+    if args[0] == '--min-ms': min_ms = float(args[1])
+    elif args[0] == '--cmd': cmd = args[1]
+    args = args[2:]
+out_txt, out_json, steps = args[0], args[1], int(args[2])
+dirs = args[3:]
 A, durA = load(dirs[0])
 B, durB = load(dirs[1]) if len(dirs) > 1 else ({}, {})
 C, durC = load(dirs[2]) if len(dirs) > 3 else ({}, {})
 D, durD = load(dirs[3]) if len(dirs) > 3 else ({}, {})
-lines = ['# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-step-graph --no-other-configs (one pass per counter set);',
+lines = ['# rocprofv3 --kernel-trace --pmc <counters> -- %s (one pass per counter set);' % cmd,
          '# per kernel name over all its launches in the run; ms/step from the counter pass itself (PMC passes serialise kernels: durations are close to, not equal to, the un-profiled ones)',
          '%-62s %6s %8s %9s %9s %8s %9s %9s %8s %8s %9s' % ('kernel', 'calls', 'ms/step', 'mfma/busy', 'mfma/all', 'clk GHz', 'lds confl', 'wait_inst', 'active', 'MB/launch', 'TB/s')]
 js = {}
 for n in sorted(A, key=lambda k: -sum(durA[k].values())):
     calls = len(durA[n]); ms_step = sum(durA[n].values()) / 1e6 / steps
-    if ms_step < 0.25:
+    if ms_step < min_ms:
         continue
     a = A[n]
     busy, mf, gui = a.get('SQ_BUSY_CYCLES', 0), a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0), a.get('GRBM_GUI_ACTIVE', 0)
