@@ -465,9 +465,6 @@ def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, ou
     return dx1, res[0][0], res[0][1], dx2, res[1][0], res[1][1]
 
 
-_zeros_cache = {}
-
-
 def colsum_rows(t, batch=None):
     """Per-channel sum over all rows of an NHWC tensor (nn.Linear / conv bias gradient): csrc/pop_head.hip colsum_rows_partial + a fixed-order finalize
     (batch: an ops.ColsumBatch whose run() finalizes several of them in one launch)."""
