@@ -93,31 +93,50 @@ def compute_dtype(args):
     return torch.bfloat16 if args.fp16 else torch.float32
 
 
-def batch_to_device(batch, dataset, device, cache={}):
+_AUGMENTERS = None
+
+
+def _augmenters_of(dataset):
+    global _AUGMENTERS
+    if _AUGMENTERS is None:
+        import weakref
+        _AUGMENTERS = weakref.WeakKeyDictionary()
+    d = _AUGMENTERS.get(dataset)
+    if d is None:
+        d = _AUGMENTERS[dataset] = {}
+    return d
+
+
+def batch_to_device(batch, dataset, device):
     """(img, mask) on the device from a loader batch: ready tensors (synthetic), or raw uint8 tiles + the reference's random draws that the GPU
-    crops / pads / flips / rotates / normalises / re-indexes in one launch (dataset/augment.py)."""
+    crops / pads / flips / rotates / normalises / re-indexes in one launch (dataset/augment.py).  The augmenters (device-side lookup
+    tables, ctypes staging) are cached per LIVE dataset object (_AUGMENTERS, weak keys): a cache keyed by id(dataset) would hand a later dataset that happens
+    to get the same id the augmenter of a dead one (other crop size, statistics, label map); stored on the dataset itself they would be pickled into every
+    DataLoader worker (the loaders are re-created every epoch; ctypes arrays do not pickle)."""
     if not getattr(dataset, 'raw_tiles', False):
         return batch[0].to(device, non_blocking=True), batch[1].to(device, non_blocking=True)
     tiles, params, _ = batch
+    cache = _augmenters_of(dataset)
     if hasattr(dataset, 'crop_size'):
-        key, make = (id(dataset), 'train'), lambda: dataset.augmenter(device)
+        key, make = ('train', str(device)), lambda: dataset.augmenter(device)
     else:                                  # validation: whole tiles, one augmenter per tile size
         size = tuple(tiles[0][0].shape[:2])
-        key, make = (id(dataset), size), lambda: dataset.augmenter(device, size)
+        key, make = (size, str(device)), lambda: dataset.augmenter(device, size)
     aug = cache.get(key)
     if aug is None:
         aug = cache[key] = make()
     return aug.prepare(tiles, params)
 
 
-def ft_batch_to_device(batch, dataset, device, cache={}):
+def ft_batch_to_device(batch, dataset, device):
     """(img, mask, img_b, mask_b) on the device from a fine-tune loader batch: ready tensors (synthetic_ft), or raw (novel, base) tile pairs +
     their draws (dataset/oem_ft.py, synthetic_raw_ft.py), whose 2B tiles are prepared by ONE GPU launch."""
     if not getattr(dataset, 'pair_tiles', False):
         return tuple(t.to(device, non_blocking=True) for t in batch[:4])
-    aug = cache.get(id(dataset))
+    cache = _augmenters_of(dataset)
+    aug = cache.get(('pairs', str(device)))
     if aug is None:
-        aug = cache[id(dataset)] = dataset.augmenter(device)
+        aug = cache[('pairs', str(device))] = dataset.augmenter(device)
     return aug.prepare(batch[0], batch[1])
 
 
