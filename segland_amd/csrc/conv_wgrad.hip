@@ -12,6 +12,11 @@
 #include <stdlib.h>
 #include "common.h"
 
+// conv_wgrad3.hip
+bool sl_wgrad3_eligible(const SlConvDesc* d, size_t* ws_bytes);
+int sl_wgrad3_run(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total, int dw_ci_off, void* workspace, size_t workspace_bytes,
+                  hipStream_t st);
+
 namespace {
 
 struct WgradParams {
@@ -24,6 +29,7 @@ struct WgradParams {
   int rows_per_split;  // multiple of 32
   int gridN, gridC, taps, splits;
   int pair;          // 1: a row is a PAIR of consecutive pixels (64-channel layers, see plan()); Cout, C1, M are the paired sizes
+  unsigned long long* trace;   // debug (tools/wgrad_trace.py, conv_wgrad_glds_kernel only): per block {s_memtime at entry, ring primed, main loop done, slab stored, HW_ID, XCC_ID, stages}; null in production
 };
 
 constexpr int KM = 32;  // reduction rows per LDS stage
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WCC, wn = wave % WCC;
+  unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+  if (p.trace) tr0 = __builtin_amdgcn_s_memtime();
 
   int bid = blockIdx.x;
   if (p.gridC * p.gridN * p.taps <= 64) {   // XCD-aware remap: consecutive logical blocks (same dy tile, neighbouring c tiles / taps) share
@@ -409,6 +417,7 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
     if (st < nit) issue(st, st);
   if (nit >= 3) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  if (p.trace) tr1 = __builtin_amdgcn_s_memtime();
   ldfrag(afA, bfA, 0, 0);
   int slot = 0;
   // the two waves of a SIMD (w, w + NW/2 in an 8-wave block) place their address/issue section one MFMA cluster apart, so one
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
     __builtin_amdgcn_s_barrier();
     slot = nslot;
   }
+  if (p.trace) tr2 = __builtin_amdgcn_s_memtime();
 
   float* ws = p.ws + (size_t)split * p.Cout * p.taps * CT;
 #pragma unroll
@@ -444,6 +454,13 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
         ws[((size_t)n * p.taps + tap) * CT + c] = acc[i][j][r];
       }
     }
+  if (p.trace && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stamp counts the slab stores of this wave as issued AND accepted
+    unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memtime();
+    t[4] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); t[5] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));
+    t[6] = (unsigned long long)nit; t[7] = (unsigned long long)bid;
+  }
 }
 
 // dw_oihw[n][c][t] = sum_s ws[s][n][t][c].  One block per (n, 64-channel chunk): the taps x 64 slab values are read as
@@ -759,6 +776,7 @@ inline bool c64p_eligible(const SlConvDesc* d) {
 inline int c64p_blocks(const SlConvDesc* d) { const long long t = (long long)d->B * d->H * d->W / CP_T; return t < 256 ? (int)t : 256; }
 inline int c64p_slabs(const SlConvDesc* d) { return c64p_blocks(d) * ((d->Cout == 64 && d->Cin == 64) ? 4 : 1); }
 
+unsigned long long* g_wgrad_trace = nullptr;
 int g_use_tr = -1;
 int use_tr() { return g_use_tr != 0; }      // bf16 fragments by ds_read_b64_tr_b16 (default) or scalar LDS reads (test hook sl_debug_wgrad_tr: the two must agree bit for bit)
 
@@ -876,6 +894,7 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" void sl_debug_wgrad_trace(void* buf) { g_wgrad_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see WgradParams::trace
 extern "C" void sl_debug_wgrad_pair_min(int rows) { g_pair_min_rows = rows; }      // tuning hook: 1x1 layers with a 64-multiple (not 128-multiple) channel count run as pixel pairs from this many rows
 // test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
@@ -887,6 +906,7 @@ extern "C" int sl_conv2d_wgrad_config(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 64) return SL_EINVAL;
   if (c64k3_eligible(d, d->Cin, 0) && use_tr()) return 1;
   if (c64p_eligible(d) && use_tr()) return 2;
+  if (use_tr() && sl_wgrad3_eligible(d, nullptr)) return 3;
   const WgradPlan pl = plan(d);
   return (pl.glds ? 10000000 : 20000000) + (pl.pair ? 500000 : 0) + 1000 * pl.bnn + pl.bcc;
 }
@@ -894,6 +914,7 @@ extern "C" int sl_conv2d_wgrad_config(const SlConvDesc* d) {
 extern "C" size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d) {
   if (!d || d->Cout % 64 || d->Cin % 32) return 0;
   size_t need = plan(d).ws_bytes;
+  { size_t n3 = 0; if (sl_wgrad3_eligible(d, &n3) && n3 > need) need = n3; }
   if (c64k3_eligible(d, 64, 0)) { const size_t n2 = (size_t)(c64k3_blocks(d) + 1) * 64 * 64 * 9 * sizeof(float); if (n2 > need) need = n2; }
   if (c64p_eligible(d)) { const size_t n2 = (size_t)(c64p_slabs(d) + 1) * d->Cout * d->Cin * sizeof(float); if (n2 > need) need = n2; }
   return need;
@@ -986,6 +1007,11 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     SL_LAUNCH_CHECK("wgrad_reduce_flat_kernel");
     return colsum_separately();
   }
+  // 3x3 stride-1 layers with >= 128 x 64 channels: all nine taps from one pass over dy and x (conv_wgrad3.hip)
+  if (use_tr() && nv == d->Cout && cv == d->Cin && sl_wgrad3_eligible(d, nullptr)) {
+    if (int e = sl_wgrad3_run(d, x, x2, dy, dw, dw_cin_total, dw_ci_off, workspace, workspace_bytes, (hipStream_t)stream)) return e;
+    return colsum_separately();
+  }
   const WgradPlan pl = plan(d);
   if (workspace_bytes < pl.ws_bytes) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, pl.ws_bytes); return SL_EWORKSPACE; }
   WgradParams p{};
@@ -995,6 +1021,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   p.M = d->B * d->Ho * d->Wo; p.rows_per_split = pl.rows_per_split;
   p.gridN = pl.gridN; p.gridC = pl.gridC; p.taps = pl.taps; p.splits = pl.splits;
   p.pair = pl.pair ? 1 : 0;
+  p.trace = g_wgrad_trace;
   if (pl.pair) { p.Cout = 2 * d->Cout; p.C1 = 2 * d->Cin; p.M /= 2; }
   hipStream_t st = (hipStream_t)stream;
   int e;
