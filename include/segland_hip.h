@@ -56,7 +56,7 @@ typedef struct SlConvDesc {
 /* which tile kernel a shape is dispatched to (1000000*variant + 1000*BM + BN; variant 4 = 4-stage LDS ring, 2 = two-stage);
  * mode 0 = forward, 1 = data gradient.  Lets a profiler attribute launches to kernel names. */
 int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
-/* the same for the weight gradient: 1 = conv_wgrad_c64k3_kernel, 2 = conv_wgrad_c64p_kernel, 10000000 + 1000*BN + BC = conv_wgrad_glds_kernel,
+/* the same for the weight gradient: 1 = conv_wgrad_c64k3_kernel, 2 = conv_wgrad_c64p_kernel, 3 = conv_wgrad3_kernel (3x3 stride 1, nine taps per block), 10000000 + 1000*BN + BC = conv_wgrad_glds_kernel,
  * 20000000 + ... = conv_wgrad_kernel (+ 500000: rows are pixel pairs); every one is followed by its fixed-order slab reduce. */
 int sl_conv2d_wgrad_config(const SlConvDesc* d);
 
@@ -201,6 +201,11 @@ int sl_stem_bn_relu_pool_fwd(int dtype, const void* c0, const float* scale, cons
 /* g0 = maxpool_bwd(dpooled) masked by relu'(bn(c0)) */
 int sl_stem_pool_relu_bwd(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale,
                           const float* shift, void* g0, int B, int Hc, int Wc, sl_stream_t stream);
+/* The same + the reduce pass of bn1's backward (resnet.py:124-125 backward) in the same sweep: stat_partial [sl_stem_pool_relu_bwd_bnstat_rows][2][64] receives the
+ * per-block column sums (sum g0, sum g0 * (c0 - mean) * invstd) of the stored gradient; sl_bn_bwd_finalize / sl_bn_bwd_apply(relu_mask = NULL, y = NULL) consume them. */
+int sl_stem_pool_relu_bwd_bnstat_rows(int B, int Hc, int Wc);
+int sl_stem_pool_relu_bwd_bnstat(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, void* g0, float* stat_partial, int B, int Hc, int Wc, sl_stream_t stream);
 /* im2col of the 7x7 s2 p3 receptive fields: col [B*H/2*W/2][192] dtype, column t = c*49 + ky*7 + kx (t >= 147: zero).
  * The stem weight gradient is then sl_conv2d_bwd_weight on (col as a 192-channel 1x1 input, dc0) -- an MFMA reduction. */
 int sl_stem_im2col(int dtype, const float* img_nchw, void* col, int B, int H, int W, sl_stream_t stream);
@@ -231,6 +236,12 @@ int sl_ppm_pool_bwd(const SlPpmDesc* d, const float* dpooled, const void* dcat, 
 int sl_ppm_upsample_fwd(const SlPpmDesc* d, int Cs, const float* stage, void* priors, sl_stream_t stream);
 int sl_ppm_upsample_bwd(const SlPpmDesc* d, int Cs, const void* dcat, int cat_pitch, float* dstage, void* workspace,
                         size_t workspace_bytes, sl_stream_t stream);
+/* BatchNorm + ReLU backward of ALL pyramid stages (pspnet_pop.py:12-16 backward: four nn.BatchNorm2d over B*s*s samples each) in one launch.  dy / y / x / dx:
+ * float [rows][C] in the row order above (dy: gradient wrt relu(bn(x)), y = relu(bn(x)) as the gate, x: the stage conv's output); the arrays have d->nlevels entries:
+ * mean / invstd / gamma (gamma[l] may be NULL = 1), train[l] (0: running statistics, dx = gamma * invstd * g), dgamma[l] / dbeta[l] (float [C] each, may be NULL). */
+#define SL_PPM_MAX_LEVELS 4
+int sl_ppm_stage_bn_bwd(const SlPpmDesc* d, int C, const float* dy, const float* y, const float* x, const float* const* mean, const float* const* invstd,
+                        const float* const* gamma, const int* train, float* const* dgamma, float* const* dbeta, float* dx, sl_stream_t stream);
 
 /* Grouped skinny 1x1 convolution over the pyramid rows (the four stage convs pspnet_pop.py:12-16 in one launch, and the per-level
  * GEMMs of the factorised prior path):  y[r][n] = sum_k x[r][k] * w[l(r)][n][k]  with x [rows][K], w [nlevels][N][K], y [rows][N], all

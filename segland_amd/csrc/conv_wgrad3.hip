@@ -16,6 +16,7 @@
 //   * the accumulators leave as 36 x 1 KiB float4 stores per wave in REGISTER order (slab [split][tile][wave][q][tap][lane][4]); wgrad3_reduce_kernel sums the
 //     slabs in a fixed order and writes OIHW rows of 288 contiguous floats -- bit-stable run to run.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -49,6 +50,12 @@ __device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_addr) {   
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+// the same under a lane mask (exec is set inside the statement: no divergent branch around it, the caller's basic block stays whole); LDS address = M0 + 16 * lane id
+__device__ __forceinline__ void w3_glds16_masked(const void* g, unsigned lds_addr, unsigned long long mask) {
+  unsigned keep; unsigned long long ex;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %3\n\ts_mov_b64 exec, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep), "=&s"(ex) : "v"(g), "s"(lds_addr), "s"(mask) : "memory");
 }
 template <int N> __device__ __forceinline__ void w3_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wg3Params p) {
     }
     tbl[i] = e;
   }
+  if (tid == 0) tbl[p.ppb] = make_int2(-1, 0);            // sentinel: rows behind the last piece
   __syncthreads();
   const int nst = (p.ppb * p.SP + 3) >> 2;                 // stages of four steps
 
@@ -97,50 +105,55 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wg3Params p) {
   // SOURCE side: dy chunk ^ ((pixel&3)<<2), x chunk ^ (((pixel>>1)&1)<<2) -- the LDS image of an instruction stays lane-linear.
   const unsigned lds_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)smem));
   const unsigned char* zsrc = g_w3zero + (lane & 15) * 16;
+  // The fill code is BRANCH-FREE (invalid rows select the zero page, the piece table has a sentinel entry, the partial instruction sets exec inside its asm
+  // statement) and is placed in four parts behind the MFMAs of the four steps of a stage: one basic block per stage, so its ~150 VALU instructions issue in the
+  // shadow of the matrix pipe instead of in front of it (first version: 800 ticks per step against 576 MFMA-issue cycles, profiles/r5_wgrad_trace.txt).
   int dy_t = wave >> 1, dy_pc = 0;
-  int2 dy_e = tbl[0];
   const int dy_col = 8 * (wave & 1) + (lane >> 4);
   const int dy_ch = ((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8;
   const int xq = 8 * wave + (lane >> 3);
   int x_t = xq / 18, x_pc = 0;
-  int2 x_e = tbl[0];
   const int x_pcol = xq - 18 * (xq / 18);
   const int x_ch = ((lane & 7) ^ ((((lane >> 3) >> 1) & 1) << 2)) * 8;
   int xp_t = 3, xp_pc = 0;
-  int2 xp_e = tbl[0];
   const int xp_pcol = 10 + wave;
-  const bool xp_on = (lane >> 3) == wave;
-  const int invalid_x = -1;
-  auto advance = [&](int& t, int& pc, int2& e) {
+  const unsigned long long xp_mask = 0xffull << (8 * wave);
+  auto advance = [&](int& t, int& pc) {
     t += 4;
-    if (t >= p.SP) { t -= p.SP; ++pc; e = pc < p.ppb ? tbl[pc] : make_int2(invalid_x, 0); }
+    const bool wrap = t >= p.SP;
+    t = wrap ? t - p.SP : t;
+    pc = wrap ? pc + 1 : pc;
+    pc = pc < p.ppb ? pc : p.ppb;                 // tbl[ppb] is the sentinel (no such piece)
   };
-  auto xsrc = [&](int t, const int2& e, int pcol) -> const void* {
+  auto xsrc = [&](int t, int pc, int pcol) -> const void* {
+    const int2 e = tbl[pc];
     const int y0 = e.y & 0xffff, xs = e.y >> 16;
     const int row = y0 + t - 1, col = xs + pcol - 1;
-    if (e.x >= 0 && (unsigned)row < (unsigned)p.Hs && (unsigned)col < (unsigned)p.Ws)
-      return (const void*)(xb + (size_t)(e.x + ((t - 1) * p.W + pcol - 1) * p.d) * xpitch + x_ch);
-    return (const void*)zsrc;
+    const bool ok = (e.x >= 0) & ((unsigned)row < (unsigned)p.Hs) & ((unsigned)col < (unsigned)p.Ws);
+    const unsigned char* q = (const unsigned char*)(xb + (size_t)(unsigned)(e.x + ((t - 1) * p.W + pcol - 1) * p.d) * (unsigned)xpitch + x_ch);
+    return (const void*)(ok ? q : zsrc);
   };
-  auto issue = [&](int slot) {
+  auto issue_dy = [&](int slot) {
     const unsigned sb = lds_base + slot * W3_STAGE;
-    {
-      const void* s0 = (const void*)zsrc; const void* s1 = (const void*)zsrc;
-      const int y0 = dy_e.y & 0xffff;
-      if (dy_e.x >= 0 && dy_t < p.L && y0 + dy_t < p.Hs) {
-        const bf16_t* q = dyb + (size_t)(dy_e.x + (dy_t * p.W + dy_col) * p.d) * p.Cout + dy_ch;
-        s0 = (const void*)q; s1 = (const void*)(q + (size_t)4 * p.d * p.Cout);
-      }
-      w3_glds16(s0, sb + (2 * wave) * 1024);
-      w3_glds16(s1, sb + (2 * wave + 1) * 1024);
-    }
-    w3_glds16(xsrc(x_t, x_e, x_pcol), sb + W3_DYB + wave * 1024);
-    {
-      const void* s = xsrc(xp_t, xp_e, xp_pcol);
-      if (xp_on) w3_glds16(s, sb + W3_DYB + 8 * 1024);
-    }
-    advance(dy_t, dy_pc, dy_e); advance(x_t, x_pc, x_e); advance(xp_t, xp_pc, xp_e);
+    const int2 e = tbl[dy_pc];
+    const int y0 = e.y & 0xffff;
+    const bool ok = (e.x >= 0) & (dy_t < p.L) & (y0 + dy_t < p.Hs);
+    const unsigned char* q = (const unsigned char*)(dyb + (size_t)(unsigned)(e.x + (dy_t * p.W + dy_col) * p.d) * (unsigned)p.Cout + dy_ch);
+    const unsigned char* s0 = ok ? q : zsrc;
+    const unsigned char* s1 = ok ? q + (size_t)(8 * p.d) * p.Cout : zsrc;          // 4 pixels to the right, bytes
+    w3_glds16((const void*)s0, sb + (2 * wave) * 1024);
+    w3_glds16((const void*)s1, sb + (2 * wave + 1) * 1024);
+    advance(dy_t, dy_pc);
   };
+  auto issue_x = [&](int slot) {
+    w3_glds16(xsrc(x_t, x_pc, x_pcol), lds_base + slot * W3_STAGE + W3_DYB + wave * 1024);
+    advance(x_t, x_pc);
+  };
+  auto issue_xp = [&](int slot) {
+    w3_glds16_masked(xsrc(xp_t, xp_pc, xp_pcol), lds_base + slot * W3_STAGE + W3_DYB + 8 * 1024, xp_mask);
+    advance(xp_t, xp_pc);
+  };
+  auto issue = [&](int slot) { issue_dy(slot); issue_x(slot); issue_xp(slot); };
 
   // ---- multiply side
   f32x16_t acc[3][3];
@@ -185,9 +198,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wg3Params p) {
   uint4 A1 = make_uint4(0, 0, 0, 0), A2 = make_uint4(0, 0, 0, 0);
   uint4 An = ldA(smem, 0), Bn0 = ldB(smem, 0, 0), Bn1 = ldB(smem, 0, 1), Bn2 = ldB(smem, 0, 2);
   int slot = 0;
-  for (int it = 0; it < nst; ++it) {
+  // MORE (compile time): stage it+4 exists and its fill code rides behind the MFMAs of steps 0, 1, 2 -- no branch inside the stage body
+  auto stage = [&](auto MORE, int it) {
     int s4 = slot + 4; if (s4 >= W3_NST) s4 -= W3_NST;
-    if (it + 4 < nst) issue(s4);
     int nslot = slot + 1; if (nslot == W3_NST) nslot = 0;
     const unsigned char* st = smem + slot * W3_STAGE;
     const unsigned char* stn = smem + nslot * W3_STAGE;
@@ -200,13 +213,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(Wg3Params p) {
       mm(acc[0][1], A0, B1); mm(acc[1][1], A1, B1); mm(acc[2][1], A2, B1);
       mm(acc[0][2], A0, B2); mm(acc[1][2], A1, B2); mm(acc[2][2], A2, B2);
       A2 = A1; A1 = A0;
+      if constexpr (decltype(MORE)::value) { if (i == 0) issue_dy(s4); else if (i == 1) issue_x(s4); else if (i == 2) issue_xp(s4); }
     }
     // stage it+2 complete before the next iteration: younger stages (it+3, it+4) may stay in flight
     const int younger = (it + 4 < nst ? it + 4 : nst - 1) - (it + 2);
     if (younger >= 2) w3_wait_vmcnt<8>(); else if (younger == 1) w3_wait_vmcnt<4>(); else w3_wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     slot = nslot;
-  }
+  };
+  int it = 0;
+  for (; it + 4 < nst; ++it) stage(std::true_type{}, it);
+  for (; it < nst; ++it) stage(std::false_type{}, it);
   if (p.trace) tr2 = __builtin_amdgcn_s_memtime();
 
   // slab [split][tile][wave][q][tap][lane][4]: acc[ky][kx][4q + j] = dw[n0 + 32 wn + 8q + 4(lane>>5) + j][tap][c0 + 32 wc + (lane&31)]
@@ -333,7 +350,7 @@ int sl_wgrad3_run(const SlConvDesc* d, const void* x, const void* x2, const void
   p.L = pl.L; p.SP = pl.SP; p.ppu = pl.ppu; p.pieces = pl.pieces; p.ppb = pl.ppb; p.tilesN = pl.tilesN; p.tilesC = pl.tilesC;
   p.trace = g_w3_trace;
   const int tiles = pl.tilesN * pl.tilesC;
-  const size_t lds = (size_t)W3_NST * W3_STAGE + (size_t)pl.ppb * sizeof(int2);
+  const size_t lds = (size_t)W3_NST * W3_STAGE + (size_t)(pl.ppb + 1) * sizeof(int2);
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   hipLaunchKernelGGL(conv_wgrad3_kernel, dim3(tiles * pl.splits), dim3(512), lds, st, p);

@@ -787,3 +787,64 @@ extern "C" int sl_ppm_fact_scatter(const SlPpmDesc* d, int N, const void* dcb, f
   SL_LAUNCH_CHECK("ppm_fact_scatter");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward of ALL pyramid stages (pspnet_pop.py:12-16 backward) in one launch.  The stage tensors are [rows = B * sum s^2][C] float (16 .. 576 rows per
+// level at the bench shape): the general path ran reduce / finalize / apply per level -- twelve latency-bound launches, 137 us per step (profiles/r4_kernel_sequence).
+// Here a block owns (level, 32 channels): eight row lanes sum (g, g * xhat) over the level's rows (g = dy gated by y > 0), the block combines them in fp64 in a fixed
+// order, forms the coefficients exactly as bn_bwd_finalize_kernel does and applies dx = cA g + cB (x - mean) + cC in a second sweep over the same (cache-resident) rows.
+struct PpmStageBn {
+  const float* mean[SL_PPM_MAX_LEVELS]; const float* invstd[SL_PPM_MAX_LEVELS]; const float* gamma[SL_PPM_MAX_LEVELS];
+  float* dgamma[SL_PPM_MAX_LEVELS]; float* dbeta[SL_PPM_MAX_LEVELS];
+  int row0[SL_PPM_MAX_LEVELS + 1]; int train[SL_PPM_MAX_LEVELS];
+};
+__global__ __launch_bounds__(256) void ppm_stage_bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ dx,
+                                                               int C, PpmStageBn q) {
+  __shared__ double red[2][8][32];
+  __shared__ float co[3][32];
+  const int cg = C / 32, lvl = blockIdx.x / cg, c = (blockIdx.x % cg) * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  const int r0 = q.row0[lvl], r1 = q.row0[lvl + 1];
+  const float mu = q.mean[lvl][c], is = q.invstd[lvl][c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = r0 + rl; r < r1; r += 8) {
+    const size_t o = (size_t)r * C + c;
+    const float g = y[o] > 0.f ? dy[o] : 0.f;
+    s1 += g; s2 += g * ((x[o] - mu) * is);
+  }
+  red[0][rl][threadIdx.x & 31] = (double)s1; red[1][rl][threadIdx.x & 31] = (double)s2;
+  __syncthreads();
+  if (rl == 0) {
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < 8; ++j) { a += red[0][j][threadIdx.x]; b += red[1][j][threadIdx.x]; }
+    if (q.dgamma[lvl]) q.dgamma[lvl][c] = (float)b;
+    if (q.dbeta[lvl]) q.dbeta[lvl][c] = (float)a;
+    const double gm = q.gamma[lvl] ? (double)q.gamma[lvl][c] : 1.0, isd = (double)is, count = (double)(r1 - r0);
+    co[0][threadIdx.x] = (float)(gm * isd);
+    co[1][threadIdx.x] = q.train[lvl] ? (float)(-gm * isd * isd * b / count) : 0.f;
+    co[2][threadIdx.x] = q.train[lvl] ? (float)(-gm * isd * a / count) : 0.f;
+  }
+  __syncthreads();
+  const float cA = co[0][threadIdx.x & 31], cB = co[1][threadIdx.x & 31], cC = co[2][threadIdx.x & 31];
+  for (int r = r0 + rl; r < r1; r += 8) {
+    const size_t o = (size_t)r * C + c;
+    const float g = y[o] > 0.f ? dy[o] : 0.f;
+    dx[o] = cA * g + cB * (x[o] - mu) + cC;
+  }
+}
+
+extern "C" int sl_ppm_stage_bn_bwd(const SlPpmDesc* d, int C, const float* dy, const float* y, const float* x, const float* const* mean, const float* const* invstd,
+                                   const float* const* gamma, const int* train, float* const* dgamma, float* const* dbeta, float* dx, sl_stream_t stream) {
+  SL_REQUIRE(d && dy && y && x && dx && mean && invstd && gamma && train && dgamma && dbeta, "ppm_stage_bn_bwd: null argument");
+  SL_REQUIRE(d->nlevels >= 1 && d->nlevels <= SL_PPM_MAX_LEVELS && C > 0 && C % 32 == 0, "ppm_stage_bn_bwd: bad level count / channel count");
+  PpmStageBn q{};
+  int row = 0;
+  for (int l = 0; l < d->nlevels; ++l) {
+    SL_REQUIRE(mean[l] && invstd[l], "ppm_stage_bn_bwd: null statistics");
+    q.mean[l] = mean[l]; q.invstd[l] = invstd[l]; q.gamma[l] = gamma[l]; q.dgamma[l] = dgamma[l]; q.dbeta[l] = dbeta[l]; q.train[l] = train[l];
+    q.row0[l] = row; row += d->B * d->sizes[l] * d->sizes[l];
+  }
+  q.row0[d->nlevels] = row;
+  hipLaunchKernelGGL(ppm_stage_bn_bwd_kernel, dim3(d->nlevels * (C / 32)), dim3(256), 0, (hipStream_t)stream, dy, y, x, dx, C, q);
+  SL_LAUNCH_CHECK("ppm_stage_bn_bwd_kernel");
+  return 0;
+}

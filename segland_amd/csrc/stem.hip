@@ -261,13 +261,22 @@ __global__ void stem_bn_relu_pool_fwd_kernel(const T* __restrict__ c0, const flo
 }
 
 // g0[b][y][x][c] = relu'(a0) * sum over windows whose first max sits at (y,x) of dpooled
-template <typename T>
-__global__ void stem_pool_relu_bwd_kernel(const T* __restrict__ dp, const uint8_t* __restrict__ idx, const T* __restrict__ c0,
+// STAT: also the reduce pass of bn1's backward (resnet.py:124 backward): the kernel reads c0 anyway, so the column sums (sum g0, sum g0 * xhat) of each block's
+// elements leave with it as part[block][2][64] (fixed order; the same partial format as bn_bwd_reduce_kernel) -- bn_bwd_reduce's sweep over g0 and c0 (268 MB at the
+// bench shape, 48 us) disappears.  A thread's channel vector is the same in every iteration (the grid stride is a multiple of the vectors per pixel).
+template <typename T, bool STAT>
+__global__ __launch_bounds__(256) void stem_pool_relu_bwd_kernel(const T* __restrict__ dp, const uint8_t* __restrict__ idx, const T* __restrict__ c0,
                                           const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ g0,
-                                          int B, int Hc, int Wc) {
+                                          int B, int Hc, int Wc, const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ part) {
   constexpr int V = Vec16<T>::N, NV = 64 / V;
   const int Hp = Hc / 2, Wp = Wc / 2;
   const long long total = (long long)B * Hc * Wc * NV;
+  float s1[V], s2[V], mu[V], is[V];
+  if (STAT) {
+    const int v0 = threadIdx.x % NV;
+#pragma unroll
+    for (int k = 0; k < V; ++k) { s1[k] = 0.f; s2[k] = 0.f; mu[k] = mean[v0 * V + k]; is[k] = invstd[v0 * V + k]; }
+  }
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(i % NV); long long r = i / NV;
     const int x = (int)(r % Wc); r /= Wc;
@@ -295,7 +304,26 @@ __global__ void stem_pool_relu_bwd_kernel(const T* __restrict__ dp, const uint8_
     unpack16<T>(*(const uint4*)(c0 + oc), xv);
 #pragma unroll
     for (int k = 0; k < V; ++k) g[k] = (xv[k] * scale[v * V + k] + shift[v * V + k]) > 0.f ? g[k] : 0.f;
-    *(uint4*)(g0 + oc) = pack16<T>(g);
+    const uint4 q = pack16<T>(g);
+    *(uint4*)(g0 + oc) = q;
+    if (STAT) {
+      float gr[V];
+      unpack16<T>(q, gr);                       // the sums are over the STORED (rounded) gradient, like the stand-alone reduce pass
+#pragma unroll
+      for (int k = 0; k < V; ++k) { s1[k] += gr[k]; s2[k] += gr[k] * ((xv[k] - mu[k]) * is[k]); }
+    }
+  }
+  if (STAT) {
+    __shared__ float red[256 * 2 * V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { red[threadIdx.x * 2 * V + k] = s1[k]; red[threadIdx.x * 2 * V + V + k] = s2[k]; }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int which = threadIdx.x >> 6, c = threadIdx.x & 63, v = c / V, k = c % V;
+      float a = 0.f;
+      for (int j = 0; j < 256 / NV; ++j) a += red[(j * NV + v) * 2 * V + which * V + k];
+      part[((size_t)blockIdx.x * 2 + which) * 64 + c] = a;
+    }
   }
 }
 
@@ -529,9 +557,27 @@ extern "C" int sl_stem_pool_relu_bwd(int dtype, const void* dpooled, const uint8
   SL_REQUIRE(dpooled && argmax && c0 && scale && shift && g0 && B > 0 && Hc % 2 == 0 && Wc % 2 == 0, "stem_pool_relu_bwd: bad args");
   const long long total = (long long)B * Hc * Wc * (dtype == SL_BF16 ? 8 : 16);
   const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  if (dtype == SL_BF16) hipLaunchKernelGGL(stem_pool_relu_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpooled, argmax, (const bf16_t*)c0, scale, shift, (bf16_t*)g0, B, Hc, Wc);
-  else if (dtype == SL_F32) hipLaunchKernelGGL(stem_pool_relu_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dpooled, argmax, (const float*)c0, scale, shift, (float*)g0, B, Hc, Wc);
+  if (dtype == SL_BF16) hipLaunchKernelGGL((stem_pool_relu_bwd_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpooled, argmax, (const bf16_t*)c0, scale, shift, (bf16_t*)g0, B, Hc, Wc, nullptr, nullptr, nullptr);
+  else if (dtype == SL_F32) hipLaunchKernelGGL((stem_pool_relu_bwd_kernel<float, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dpooled, argmax, (const float*)c0, scale, shift, (float*)g0, B, Hc, Wc, nullptr, nullptr, nullptr);
   else SL_REQUIRE(false, "stem_pool_relu_bwd: bad dtype");
+  SL_LAUNCH_CHECK("stem_pool_relu_bwd_kernel");
+  return 0;
+}
+
+// The same + the column sums of bn1's backward: stat_partial [sl_stem_pool_relu_bwd_bnstat_rows(B, Hc, Wc)][2][64] (consumed by sl_bn_bwd_finalize like bn_bwd_reduce's)
+extern "C" int sl_stem_pool_relu_bwd_bnstat_rows(int B, int Hc, int Wc) {
+  const long long px = (long long)B * Hc * Wc;
+  if (B <= 0 || Hc <= 0 || Wc <= 0) return 0;
+  const long long blocks = (px * 8 + 255) / 256;           // at least one 16-byte vector per thread in either dtype
+  return (int)(blocks < 2048 ? blocks : 2048);
+}
+extern "C" int sl_stem_pool_relu_bwd_bnstat(int dtype, const void* dpooled, const uint8_t* argmax, const void* c0, const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, void* g0, float* stat_partial, int B, int Hc, int Wc, sl_stream_t stream) {
+  SL_REQUIRE(dpooled && argmax && c0 && scale && shift && mean && invstd && g0 && stat_partial && B > 0 && Hc % 2 == 0 && Wc % 2 == 0, "stem_pool_relu_bwd_bnstat: bad args");
+  const int blocks = sl_stem_pool_relu_bwd_bnstat_rows(B, Hc, Wc);
+  if (dtype == SL_BF16) hipLaunchKernelGGL((stem_pool_relu_bwd_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dpooled, argmax, (const bf16_t*)c0, scale, shift, (bf16_t*)g0, B, Hc, Wc, mean, invstd, stat_partial);
+  else if (dtype == SL_F32) hipLaunchKernelGGL((stem_pool_relu_bwd_kernel<float, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dpooled, argmax, (const float*)c0, scale, shift, (float*)g0, B, Hc, Wc, mean, invstd, stat_partial);
+  else SL_REQUIRE(false, "stem_pool_relu_bwd_bnstat: bad dtype");
   SL_LAUNCH_CHECK("stem_pool_relu_bwd_kernel");
   return 0;
 }

@@ -306,9 +306,12 @@ class StemFn(torch.autograd.Function):
     def backward(ctx, dp):
         img, c0, idx, mean, invstd, scale, shift = ctx.saved_tensors
         bn = ctx.net.bn1
-        g0 = ops.stem_pool_relu_bwd(dp.contiguous(), idx, c0, scale, shift)
         gg, gb = grad_dst(bn.weight), grad_dst(bn.bias)
-        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb)
+        if _BN_FUSE:          # bn1's reduce pass rides in the pool / ReLU backward, which reads c0 anyway (round 5)
+            g0, pp = ops.stem_pool_relu_bwd_bnstat(dp.contiguous(), idx, c0, scale, shift, mean, invstd)
+        else:
+            g0, pp = ops.stem_pool_relu_bwd(dp.contiguous(), idx, c0, scale, shift), None
+        dc0, _, dgamma, dbeta = ops.bn_bwd(g0, None, c0, mean, invstd, bn.weight, train=bn.training, sync_world=sync_world(bn), dgamma_out=gg, dbeta_out=gb, pre_partial=pp)
         dw = ops.stem_conv_bwd_weight(img, dc0) if ctx.needs_input_grad[1] else None
         return None, dw, grad_alias(dgamma, gg), grad_alias(dbeta, gb), None, None
 
@@ -488,15 +491,16 @@ class PPMFn(torch.autograd.Function):
             spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
             cb, part = ops.conv2d_fwd(x4, wf4, spec4, pre_addend=gpri, want_stats=bt[1].training)
             mb, ib, scale, shift = _bn_coeffs(bt[1], part, cb.numel() // N)
-            ab = ops.bn_act(cb, scale, shift, relu=True)
+            ab, kb = ops.bn_act(cb, scale, shift, relu=True, want_mask=True)
             priors = cb.new_empty(0)
         else:
             priors = ops.ppm_upsample_fwd(stage_act, x4.shape, sizes, x4.dtype)
             cb, ab, mb, ib = conv_bn_fwd(priors, bt[0], bt[1], relu=True, x2=x4)
+            kb = cb.new_empty(0, dtype=torch.uint8)
         wf, _ = prepared(bt[3].weight, x4.dtype)
         feat, _ = ops.conv2d_fwd(ab, wf, spec_of(bt[3]), bias=bt[3].bias.detach())
         ctx.dec = dec
-        ctx.save_for_backward(x4, pooled, stage_act, priors, cb, ab, mb, ib, *cl, *ml, *il)
+        ctx.save_for_backward(x4, pooled, stage_act, priors, cb, ab, mb, ib, *cl, *ml, *il, kb, call)
         return feat
 
     @staticmethod
@@ -507,6 +511,7 @@ class PPMFn(torch.autograd.Function):
         sv = ctx.saved_tensors
         x4, pooled, stage_act, priors, cb, ab, mb, ib = sv[:8]
         cl, ml, il = sv[8:8 + nl], sv[8 + nl:8 + 2 * nl], sv[8 + 2 * nl:8 + 3 * nl]
+        kb = sv[8 + 3 * nl]                          # ReLU bits of the bottleneck BatchNorm (factorised path)
         B, H, W, Cf = x4.shape
         Cs = stage_act.shape[1]
         bt = dec.bottleneck
@@ -515,7 +520,15 @@ class PPMFn(torch.autograd.Function):
         need_x = ctx.needs_input_grad[0]
         spec_f = spec_of(bt[3])
         _, wbf = prepared(bt[3].weight, x4.dtype)
-        dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
+        # the classifier conv's data gradient gates its result with the bottleneck ReLU's bits and emits the bottleneck BatchNorm's backward column sums
+        # in its epilogue where the kernel serves the shape (round 5: one 36 us reduce pass less per step)
+        dab = ppart = None
+        if ctx.fact and _BN_FUSE and bt[1].training and kb.numel():
+            r = ops.conv2d_bwd_data_bnstat(dfeat, wbf, spec_f, (H, W), kb, cb, mb, ib)
+            if r is not None:
+                dab, ppart = r
+        if dab is None:
+            dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
         gwf = grad_dst(bt[3].weight) if need_w else None
         dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf), gwf) if need_w else None
         dbias = ops.colsum_rows(dfeat) if need_w else None
@@ -523,7 +536,8 @@ class PPMFn(torch.autograd.Function):
             N = bt[0].out_channels
             wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, nl, x4.dtype)
             ggb, gbb = (grad_dst(bt[1].weight), grad_dst(bt[1].bias)) if need_w else (None, None)
-            dcb, _, dgb, dbb = ops.bn_bwd(dab, ab, cb, mb, ib, bt[1].weight, train=bt[1].training, sync_world=sync_world(bt[1]), dgamma_out=ggb, dbeta_out=gbb)
+            dcb, _, dgb, dbb = ops.bn_bwd(dab, None, cb, mb, ib, bt[1].weight, train=bt[1].training, sync_world=sync_world(bt[1]), dgamma_out=ggb, dbeta_out=gbb,
+                                          mask=None if ppart is not None else kb, pre_partial=ppart)
             dgb, dbb = grad_alias(dgb, ggb), grad_alias(dbb, gbb)
             spec4 = ConvSpec(Cf, N, 3, 1, 1, 1)
             dcat = ops.conv2d_bwd_data(dcb, wb4, spec4, (H, W))                     # gradient of the x4 half only: [B,H,W,Cf]
@@ -551,12 +565,25 @@ class PPMFn(torch.autograd.Function):
             cat_off = len(sizes) * Cs
         dc_all = torch.empty_like(stage_act)
         gstage, off = [], 0
+        grouped = None
+        call = sv[9 + 3 * nl]
+        if _BN_FUSE and call.numel() and not any(sync_world(st[2]) for st in dec.stages):
+            # all levels' BatchNorm + ReLU backward in ONE launch (round 5): twelve latency-bound launches less per step
+            dsts = [(grad_dst(st[2].weight), grad_dst(st[2].bias)) if need_w else (None, None) for st in dec.stages]
+            tmp = torch.empty((nl, 2, Cs), dtype=torch.float32, device=x4.device)
+            dgl = [d_[0] if d_[0] is not None else tmp[k, 0] for k, d_ in enumerate(dsts)]
+            dbl = [d_[1] if d_[1] is not None else tmp[k, 1] for k, d_ in enumerate(dsts)]
+            ops.ppm_stage_bn_bwd(dstage, stage_act, call, B, sizes, ml, il, [st[2].weight for st in dec.stages], [st[2].training for st in dec.stages], dgl, dbl, out=dc_all)
+            grouped = [(grad_alias(dgl[k], dsts[k][0]), grad_alias(dbl[k], dsts[k][1])) for k in range(nl)]
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
             ggs, gbs, gws = (grad_dst(st[2].weight), grad_dst(st[2].bias), grad_dst(st[1].weight)) if need_w else (None, None, None)
-            _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
-                                        out=dc_all[off:off + n], sync_world=sync_world(st[2]), dgamma_out=ggs, dbeta_out=gbs)
-            dgs, dbs = grad_alias(dgs, ggs), grad_alias(dbs, gbs)
+            if grouped is not None:
+                dgs, dbs = grouped[k]
+            else:
+                _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
+                                            out=dc_all[off:off + n], sync_world=sync_world(st[2]), dgamma_out=ggs, dbeta_out=gbs)
+                dgs, dbs = grad_alias(dgs, ggs), grad_alias(dbs, gbs)
             dws = grad_alias(ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1]), out=gws), gws) if need_w else None
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None

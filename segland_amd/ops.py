@@ -70,6 +70,8 @@ class _Profiler:
                 return 'conv_wgrad_c64k3_kernel'
             if cfg == 2:
                 return 'conv_wgrad_c64p_kernel'
+            if cfg == 3:
+                return 'conv_wgrad3_kernel'
             name = 'conv_wgrad_glds_kernel' if cfg // 10000000 == 1 else 'conv_wgrad_kernel'
             return '%s<%s, %d, %d>%s' % (name, dts, (cfg % 500000) // 1000, cfg % 1000, ' pixel pairs' if (cfg // 500000) % 2 else '')
         cfg = _lib.lib().sl_conv2d_tile_config(C.byref(d), 0 if kind == 'conv_fwd' else 1)
@@ -506,6 +508,20 @@ def stem_pool_relu_bwd(dpooled, idx, c0, scale, shift):
     return g0
 
 
+def stem_pool_relu_bwd_bnstat(dpooled, idx, c0, scale, shift, mean, invstd):
+    """stem_pool_relu_bwd + bn1's backward column sums in the same sweep -> (g0, partial [rows][2][64]) (bn_bwd(pre_partial=...))."""
+    B, Hc, Wc, _ = c0.shape
+    L = _lib.lib()
+    g0 = torch.empty_like(c0)
+    part = _f32((L.sl_stem_pool_relu_bwd_bnstat_rows(B, Hc, Wc), 2, 64), c0.device)
+    nb = c0.numel() * c0.element_size()
+    tok = PROFILER.begin_bytes('stem_pool_relu_bwd', 2 * nb + nb // 4 + dpooled.numel())
+    check(L.sl_stem_pool_relu_bwd_bnstat(dt(c0), _p(dpooled), _p(idx), _p(c0), _p(scale), _p(shift), _p(mean), _p(invstd), _p(g0), _p(part), B, Hc, Wc, _s()),
+          'stem_pool_relu_bwd_bnstat')
+    PROFILER.end_bytes(tok)
+    return g0, part
+
+
 def stem_conv_bwd_weight(img, dc0):
     """7x7 stem weight gradient.  bf16: one MFMA kernel that gathers the im2col view from the image patch in the LDS (+ the fixed-order block
     reduce); fp32: im2col + the exact-fp32 MFMA wgrad kernel."""
@@ -561,6 +577,20 @@ def ppm_pool_bwd(dpooled, x_shape, dtype, sizes, dcat=None, cat_off=0):
     L = _lib.lib()
     ws = workspace(L.sl_ppm_workspace(C.byref(d)), dpooled.device)
     check(L.sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _p(ws), ws.numel(), _s()), 'ppm_pool_bwd')
+    return dx
+
+
+def ppm_stage_bn_bwd(dy, y, x, B, sizes, means, invstds, gammas, trains, dgammas, dbetas, out=None):
+    """BatchNorm + ReLU backward of all pyramid stages in one launch (csrc/ppm.hip ppm_stage_bn_bwd_kernel).  dy / y / x: float [rows][C]; per level lists of
+    mean / invstd / gamma / train flag and of the destinations dgamma / dbeta (float [C] tensors).  -> dx [rows][C]."""
+    n = len(sizes)
+    Cn = x.shape[1]
+    assert dy.dtype == y.dtype == x.dtype == torch.float32 and dy.is_contiguous() and y.is_contiguous() and x.is_contiguous() and x.shape[0] == ppm_rows(B, sizes)
+    d = SlPpmDesc(SL_F32, B, 0, 0, Cn, n, (C.c_int * 4)(*(list(sizes) + [0] * (4 - n))))
+    arr = lambda ts: (C.c_void_p * n)(*[_p(t) for t in ts])
+    dx = out if out is not None else torch.empty_like(x)
+    check(_lib.lib().sl_ppm_stage_bn_bwd(C.byref(d), Cn, _p(dy), _p(y), _p(x), arr(means), arr(invstds), arr(gammas), (C.c_int * n)(*[int(t) for t in trains]),
+                                         arr(dgammas), arr(dbetas), _p(dx), _s()), 'ppm_stage_bn_bwd')
     return dx
 
 

@@ -86,3 +86,62 @@ def test_wgrad_nine_tap_kernel_virtual_concat(hip):
     spec = ops.ConvSpec(C1 + C2, Cout, 3, 1, 1, 1)
     dw = ops.conv2d_bwd_weight(nhwc(x[:, :C1], dtype), nhwc(gy, dtype), spec, x2=nhwc(x[:, C1:], dtype))
     close(dw, w.grad, 'nine-tap wgrad, virtual concat')
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_stem_pool_backward_emits_bn_backward_statistics(hip, dtype):
+    """sl_stem_pool_relu_bwd_bnstat (maxpool + ReLU backward of resnet.py:124-125 with bn1's reduce pass in the same sweep): the gradient is bit-identical to the plain
+    kernel's, the column sums equal the sums over that stored gradient (fp64 reference) to 1e-5, and bn_bwd on them equals bn_bwd with its own reduce pass."""
+    from segland_amd import ops
+    B, Hc, Wc = 3, 64, 96
+    c0 = (torch.randn(B, Hc, Wc, 64, device=DEV) * 1.5).to(dtype)
+    mean = torch.randn(64, device=DEV) * 0.2
+    invstd = torch.rand(64, device=DEV) + 0.5
+    gamma = torch.rand(64, device=DEV) + 0.5
+    beta = torch.randn(64, device=DEV) * 0.3
+    scale, shift = gamma * invstd, beta - mean * gamma * invstd
+    pooled, idx = ops.stem_bn_relu_pool(c0, scale, shift, want_idx=True)
+    dp = torch.randn_like(pooled.float()).to(dtype)
+    g_plain = ops.stem_pool_relu_bwd(dp, idx, c0, scale, shift)
+    g, part = ops.stem_pool_relu_bwd_bnstat(dp, idx, c0, scale, shift, mean, invstd)
+    assert torch.equal(g, g_plain)
+    g64, x64 = g.double().reshape(-1, 64), c0.double().reshape(-1, 64)
+    ref = torch.stack([g64.sum(0), (g64 * ((x64 - mean.double()) * invstd.double())).sum(0)])
+    got = part.double().sum(0)
+    err = float(((got - ref).abs() / (g64.abs().sum(0) + 1e-9)).max())
+    print('stem bnstat column sums: max err relative to sum |g| %.2e' % err)
+    assert err < 1e-5
+    a = ops.bn_bwd(g, None, c0, mean, invstd, gamma, train=True)
+    b = ops.bn_bwd(g, None, c0, mean, invstd, gamma, train=True, pre_partial=part)
+    for u, v, what in ((a[0], b[0], 'dx'), (a[2], b[2], 'dgamma'), (a[3], b[3], 'dbeta')):
+        close(v, u, 'stem bn1 backward from fused partials: %s' % what, tol=2e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_pyramid_stage_batchnorm_backward_in_one_launch(hip):
+    """sl_ppm_stage_bn_bwd (BatchNorm + ReLU backward of the four pyramid stages, pspnet_pop.py:12-16, one launch) against ops.bn_bwd level by level (reduce / finalize /
+    apply per level): dx, dgamma, dbeta to 1e-5; one level in eval mode (running statistics)."""
+    from segland_amd import ops
+    B, sizes, Cs = 3, (1, 2, 3, 6), 128
+    rows = B * sum(s * s for s in sizes)
+    x = torch.randn(rows, Cs, device=DEV)
+    dy = torch.randn(rows, Cs, device=DEV)
+    means, invs, gammas, ys, off = [], [], [], torch.empty_like(x), 0
+    for s in sizes:
+        n = B * s * s
+        m, v = x[off:off + n].mean(0), x[off:off + n].var(0, unbiased=False)
+        i = (v + 1e-5).rsqrt()
+        g = torch.rand(Cs, device=DEV) + 0.5
+        ys[off:off + n] = torch.relu((x[off:off + n] - m) * i * g + 0.1)
+        means.append(m.contiguous()); invs.append(i.contiguous()); gammas.append(g); off += n
+    trains = [True, True, False, True]
+    dg = [torch.empty(Cs, device=DEV) for _ in sizes]
+    db = [torch.empty(Cs, device=DEV) for _ in sizes]
+    dx = ops.ppm_stage_bn_bwd(dy, ys, x, B, sizes, means, invs, gammas, trains, dg, db)
+    off = 0
+    for k, s in enumerate(sizes):
+        n = B * s * s
+        rdx, _, rdg, rdb = ops.bn_bwd(dy[off:off + n], ys[off:off + n], x[off:off + n], means[k], invs[k], gammas[k], train=trains[k])
+        close(dx[off:off + n], rdx, 'level %d dx' % k, tol=1e-5)
+        close(dg[k], rdg, 'level %d dgamma' % k, tol=1e-5)
+        close(db[k], rdb, 'level %d dbeta' % k, tol=1e-5)
+        off += n
