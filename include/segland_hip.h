@@ -56,6 +56,16 @@ typedef struct SlConvDesc {
 /* which tile kernel a shape is dispatched to (1000000*variant + 1000*BM + BN; variant 4 = 4-stage LDS ring, 2 = two-stage);
  * mode 0 = forward, 1 = data gradient.  Lets a profiler attribute launches to kernel names. */
 int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
+/* the same for a launch with the given epilogue (bit set of SL_EPI_*): what sl_conv2d_fwd(stat_partial) / sl_conv2d_affine_fwd(_ex) / sl_conv2d_bwd_data(addend, bits) /
+ * sl_conv2d_bwd_data_bnstat run on.  family 9 = conv_gemm_sk512_kernel, 8 = conv_gemm_p9_kernel (+ 10000000: split-K), 7 = conv_c64k3_kernel, 6 = conv_gemm_sk_kernel,
+ * 5 = conv_gemm_p8_kernel, 4 = conv_gemm_ring_kernel (BM = 64: the few-tile form), 2 = conv_gemm_glds_kernel. */
+#define SL_EPI_STATS 1
+#define SL_EPI_AFFINE 2
+#define SL_EPI_ADDEND 4
+#define SL_EPI_ADDEND_BITS 8
+#define SL_EPI_GATE 16
+#define SL_EPI_SPLITK 32
+int sl_conv2d_tile_config_ex(const SlConvDesc* d, int mode, int epi);
 /* the same for the weight gradient: 1 = conv_wgrad_c64k3_kernel, 2 = conv_wgrad_c64p_kernel, 3 = conv_wgrad3_kernel (3x3 stride 1, nine taps per block), 10000000 + 1000*BN + BC = conv_wgrad_glds_kernel,
  * 20000000 + ... = conv_wgrad_kernel (+ 500000: rows are pixel pairs); every one is followed by its fixed-order slab reduce. */
 int sl_conv2d_wgrad_config(const SlConvDesc* d);

@@ -305,6 +305,10 @@ class OrthLossOracle(nn.Module):
         up = F.interpolate(preds, size=target.shape[1:], mode='bilinear', align_corners=True)   # criterion.py:51
         seg = F.cross_entropy(up, target, ignore_index=self.ignore_index, reduction='mean')      # criterion.py:52
         orth = self.get_orth_loss(proto_sim)
+        if aux_preds is not None:                                                                # criterion.py:56-60 (an auxiliary head's logits, weight 0.4)
+            up_aux = F.interpolate(aux_preds, size=target.shape[1:], mode='bilinear', align_corners=True)
+            aux = F.cross_entropy(up_aux, target, ignore_index=self.ignore_index, reduction='mean')
+            return {'total_loss': seg + orth * self.w + 0.4 * aux, 'seg_loss': seg, 'aux_loss': aux, 'orth_loss': orth}
         return {'total_loss': seg + orth * self.w, 'seg_loss': seg, 'orth_loss': orth}           # criterion.py:61-63
 
 

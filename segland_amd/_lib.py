@@ -11,7 +11,7 @@ import torch  # noqa: F401  -- must be imported BEFORE libsegland_hip.so so both
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libsegland_hip.so')
+LIB_PATH = os.environ.get('SEGLAND_LIB_PATH') or os.path.join(CSRC, 'libsegland_hip.so')      # SEGLAND_LIB_PATH: a differently built library (kernel A/B from one checkout)
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'segland_hip.h')
 
 SL_F32, SL_BF16 = 0, 1

@@ -11,6 +11,9 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef SL_SK512_PF
+#define SL_SK512_PF 4
+#endif
 #ifndef SL_CH3_SPLIT
 #define SL_CH3_SPLIT 2
 #endif
@@ -1907,6 +1910,237 @@ int launch_sk(ConvGemmParams& p, hipStream_t st) {
   return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K = 512 1x1 convs at >= 65 536 pixels (layer4 conv3 forward 512 -> 2048, the data gradient of layer4 conv1 2048 <- 512 with its shortcut addend, 512 -> 1024 / 512 -> 256):
+// on the half-tile kernel a 256 x 256 tile of these layers is 8 K-tiles of main loop between a prologue and a store phase that nothing overlaps (tools/p8_trace.py: 15 / 61 / 24 %
+// and 15 / 46 / 40 %; 600-700 TFLOP/s), and BOTH operands pass the LDS-DMA path at 32 B per clock and CU.  The pixel-stationary form of conv_gemm_sk_kernel at K = 512:
+//   * each wave keeps its 32 pixel rows x 512 channels in 128 registers as MFMA fragments (read once from HBM); only the WEIGHT rows stream (from the L2): 16 B per clock
+//     and CU at the MFMA rate; a step's 64 x 32 x 32 result tile is stored (full 128-byte lines, + addend / gate bits / statistics) while the next step multiplies;
+//   * the weight rows of a step (64 rows x 1 KiB) arrive as two halves of 32 rows through a ring of THREE 32 KiB slots, each half issued a full step before its first
+//     read: half 2s+3 right behind the barrier that ends the reads of half 2s (its slot), half 2s+4 behind the step's second barrier;
+//   * counted vmcnt waits (a wave's VMEM order per step: addend (+ gate byte) loads, 4 LDS-DMA, 4 stores, 4 LDS-DMA), vmcnt(0) on the last two steps.
+struct Sk5Geom {
+  static constexpr int KS = 32, RB = 1024;                             // k-steps, operand row bytes
+  static constexpr int HSLOT = 32 * RB;                                // half a step of weight rows
+  static constexpr int OFF_STG = 3 * HSLOT;
+  static constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;
+  static constexpr int OFF_RED = OFF_STG + 8 * STG_WAVE;
+  static constexpr int LDS = OFF_RED + 2 * 8 * 2 * 64 * (int)sizeof(float);
+};
+template <int MODE>       // 1: store (+ statistics), 2: + addend, gated by the bits of addend_mask when given
+__global__ __launch_bounds__(512, 2) void conv_gemm_sk512_kernel(ConvGemmParams p) {
+  using G = Sk5Geom;
+  using T = bf16_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, fh = lane >> 5;
+  const int bm = blockIdx.x;
+  const int NS = p.N / 64, NH = 2 * NS;
+  const unsigned long long tr_entry = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // half-step H = weight rows 32 H .. 32 H + 31, one KiB instruction per row, four rows per wave; source-side swizzle: chunk ^ (row & 31)
+  const unsigned char* bsrc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = wave * 4 + j;
+    bsrc[j] = (const unsigned char*)p.wt + (size_t)row * G::RB + ((lane ^ (row & 31)) << 4);
+  }
+  auto issueH = [&](int H, int slot) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16_asm(bsrc[j] + (size_t)H * G::HSLOT, lds_base + slot * G::HSLOT + (wave * 4 + j) * 1024);
+  };
+  issueH(0, 0);
+  issueH(1, 1);
+  uint4 a[G::KS];
+  {
+    const unsigned char* arow = (const unsigned char*)p.src1 + ((size_t)bm * 256 + wave * 32 + l31) * G::RB + fh * 16;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) a[ks] = *(const uint4*)(arow + ks * 32);
+  }
+  const int fbase = l31 * G::RB, fx = l31;                              // fragment chunk (2 ks + fh) ^ (row & 31) of weight row l31 of the half
+  unsigned char* stg = smem + G::OFF_STG + wave * G::STG_WAVE;
+  float* red = (float*)(smem + G::OFF_RED);
+  const int srow = lane >> 3, sch = lane & 7;
+  const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
+  const bool gated = MODE == 2 && p.addend_mask != nullptr;
+  uint4 addv[4];
+  unsigned gbyte[4];
+
+  // weight fragments are read PF k-steps ahead of their MFMA (the compiler's own schedule keeps ONE ds_read_b128 in flight: a wave alone on its SIMD then issues an
+  // MFMA every ~86 clocks instead of every 32 -- tools/sk512_trace.py)
+  auto half = [&](const unsigned char* bb, f32x16_t& acc) {
+    constexpr int PF = SL_SK512_PF;
+    const unsigned char* rowp = bb + fbase;
+    uint4 bq[PF];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) bq[u] = *(const uint4*)(rowp + (((2 * u + fh) ^ fx) << 4));
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const uint4 b = bq[ks % PF];
+      if (ks + PF < G::KS) bq[ks % PF] = *(const uint4*)(rowp + (((2 * (ks + PF) + fh) ^ fx) << 4));
+      Mma<T>::run(b, a[ks], acc);
+    }
+    // pin the order the source has (hipcc would sink every read to just in front of its MFMA): PF reads, then MFMA / read pairs, then the last PF MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+    for (int ks = 0; ks < G::KS - PF; ++ks) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+  };
+  auto stage = [&](const f32x16_t& acc, int j) {                      // D layout: lane = pixel (l31), register r = column (r & 3) + 8 (r >> 2) + 4 fh of column half j
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint2 v;
+      v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[4 * q + 0], acc[4 * q + 1]}, bf16x2_t));
+      v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[4 * q + 2], acc[4 * q + 3]}, bf16x2_t));
+      *(uint2*)(stg + l31 * G::STG_PITCH + 64 * j + 16 * q + 8 * fh) = v;
+    }
+  };
+  auto store = [&](int s) {
+    const int cur = s & 1;
+    const int ncol = s * 64 + sch * 8;
+    float sa[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const uint4 raw = *(const uint4*)(stg + (it * 8 + srow) * G::STG_PITCH + sch * 16);
+      T* o = (T*)p.out + (orow + it * 8) * p.N + ncol;
+      if constexpr (MODE == 1) {
+        st16(o, raw);
+        if (p.stat_partial) {
+          const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float lo = __uint_as_float(w[c] << 16), hi = __uint_as_float(w[c] & 0xffff0000u);
+            sa[2 * c] += lo; sq[2 * c] += lo * lo; sa[2 * c + 1] += hi; sq[2 * c + 1] += hi * hi;
+          }
+        }
+      } else {
+        uint4 ad = addv[it];
+        if (gated) {
+          const unsigned b = gbyte[it];
+          ad.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
+          ad.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
+          ad.z &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
+          ad.w &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
+        }
+        const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w}, aw[4] = {ad.x, ad.y, ad.z, ad.w};
+        unsigned ow[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x2_t v = (f32x2_t){__uint_as_float(rw[c] << 16) + __uint_as_float(aw[c] << 16), __uint_as_float(rw[c] & 0xffff0000u) + __uint_as_float(aw[c] & 0xffff0000u)};
+          ow[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+        }
+        st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
+      }
+    }
+    if (MODE == 1 && p.stat_partial) {                                 // lanes 8 apart share the column octet
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sa[e] = sk_sum_8_16_32(sa[e]); sq[e] = sk_sum_8_16_32(sq[e]); }
+      if (lane < 8) {
+        float* r0 = red + ((cur * 8 + wave) * 2) * 64 + sch * 8;
+        *(float4*)(r0) = make_float4(sa[0], sa[1], sa[2], sa[3]); *(float4*)(r0 + 4) = make_float4(sa[4], sa[5], sa[6], sa[7]);
+        *(float4*)(r0 + 64) = make_float4(sq[0], sq[1], sq[2], sq[3]); *(float4*)(r0 + 68) = make_float4(sq[4], sq[5], sq[6], sq[7]);
+      }
+    }
+  };
+  auto finalize = [&](int s) {                                         // 128 threads, behind the barrier that follows the store phase of step s
+    if (MODE == 1 && p.stat_partial && tid < 128) {
+      const int which = (tid >> 6) & 1, col = tid & 63;
+      const float* r0 = red + ((s & 1) * 16 + which) * 64 + col;
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += r0[k * 128];
+      p.stat_partial[((size_t)bm * 2 + which) * p.N + s * 64 + col] = t;
+    }
+  };
+  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  wait_vmcnt<0>();
+  bar();
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;        // debug (tools/sk512_trace.py): [0] entry -> ring primed, then per-phase sums over the steps
+  const bool tron = p.trace != nullptr;
+  if (tron) { tl = __builtin_amdgcn_s_memtime(); tr[0] = tl - tr_entry; }
+  auto lap = [&](int k) { if (tron) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr[k] += t - tl; tl = t; } };
+  // SKEW BY ONE HALF: the two waves of a SIMD (w in group 0, w + 4 in group 1) must not store at the same time, and the one that does not store must have MFMAs to
+  // issue meanwhile.  In interval k (one barrier per interval) group g multiplies half H = k - g; a group stores step s at the START of the interval that follows its
+  // second half (group 0: interval 2s+2, group 1: 2s+3) -- while the other group's wave of the SIMD runs its half at the full rate of the matrix pipe.  Half H is read
+  // in intervals H and H+1, its slot is refilled with half H+3 behind the barrier that ends interval H+1, one interval (~2 000 clocks; the weights are L2-resident)
+  // before its first read.  Every interval ends with vmcnt(0) (the stores were issued at its start, the LDS-DMA behind them) + the barrier.
+  // First version (both groups in lockstep, store phase behind the second half): 7 000 ticks per step against 4 096 MFMA-issue cycles (tools/sk512_trace.py).
+  const int grp = wave >> 2;
+  auto load_addend = [&](int s) {
+    if constexpr (MODE == 2) {
+      const int ncol = s * 64 + sch * 8;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
+      if (gated) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) gbyte[it] = p.addend_mask[(orow + it * 8) * (size_t)(p.N / 8) + s * 8 + sch];
+      }
+    }
+  };
+  int hslot = 0;                                                       // slot of this group's half H = k - grp (advanced from H = 0 on)
+  int islot = 2;                                                       // slot of the half issued in interval k: H = k + 1
+#pragma unroll 1
+  for (int k = 0; k <= NH + 1; ++k) {
+    const int H = k - grp;
+    if (H >= 2 && !(H & 1)) { store((H >> 1) - 1); lap(5); }
+    if (k >= 1 && k + 1 < NH) issueH(k + 1, islot);
+    if (H >= 0 && H < NH) {
+      if (H & 1) load_addend(H >> 1);
+      f32x16_t acc;
+      half(smem + hslot * G::HSLOT, acc);
+      stage(acc, H & 1);
+      lap(1);
+    }
+    wait_vmcnt<0>();
+    lap(2);
+    bar();
+    lap(3);
+    if (k >= 3 && (k & 1)) finalize((k - 3) >> 1);
+    if (H >= 0) { if (++hslot == 3) hslot = 0; }
+    if (k >= 1) { if (++islot == 3) islot = 0; }
+  }
+  if (tron && lane == 0) {
+    unsigned long long* t = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;          // per WAVE (tools/sk512_trace.py)
+    tr[7] = __builtin_amdgcn_s_memtime() - tr_entry;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t[k] = tr[k];
+  }
+}
+
+int g_conv_sk512 = -1;      // SEGLAND_CONV_SK512=1 / sl_debug_conv_sk512(1): default OFF -- faster in isolation, equal inside the step (profiles/r5_ab_sk512.txt)
+static bool sk512_shape(const ConvGemmParams& p) {
+  static const bool on = getenv("SEGLAND_CONV_SK512") && getenv("SEGLAND_CONV_SK512")[0] == '1';
+  if (g_conv_sk512 < 0) g_conv_sk512 = on ? 1 : 0;
+  return g_conv_sk512 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C1 == 512 && p.C2 == 0 && p.N % 64 == 0 && p.M >= 65536 && p.M % 256 == 0 &&
+         p.Hs == p.Hd && p.Ws == p.Wd && !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate || p.ksplit > 1) &&
+         !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask);
+}
+int launch_sk512(ConvGemmParams& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_sk512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_sk512_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  p.gridM = p.M / 256; p.gridN = 1;
+  p.trace = g_p8_trace;                 // debug hook shared with the half-tile kernel (sl_debug_p8_trace)
+  if (p.addend) hipLaunchKernelGGL(conv_gemm_sk512_kernel<2>, dim3(p.M / 256), dim3(512), Sk5Geom::LDS, st, p);
+  else hipLaunchKernelGGL(conv_gemm_sk512_kernel<1>, dim3(p.M / 256), dim3(512), Sk5Geom::LDS, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_sk512_kernel");
+  return 0;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_glds(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, BM);
@@ -1946,45 +2180,73 @@ static int splitk_parts(const ConvGemmParams& p, int dtype) {
 }
 
 long long g_ring64_max_tiles = 160;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
-template <typename T>
-int launch_gemm(ConvGemmParams& p, hipStream_t st) {
+// Which kernel a launch runs on: 1000000 * family + 1000 * BM + BN (family 9 = pixel-stationary K = 512, 8 = 3x3 patch (+ 10000000: split-K), 7 = 64 -> 64 patch,
+// 6 = pixel-stationary K <= 256, 5 = half-tile, 4 = ring, 2 = two-stage glds).  The ONE predicate chain: launch_gemm switches on it, sl_conv2d_tile_config(_ex) and
+// sl_conv2d_stat_rows answer from it (round-4 advisor: the query had drifted from the dispatch).
+static int choose_kernel(const ConvGemmParams& p, int dtype) {
   const bool n128 = (p.N % 128 == 0), n256 = (p.N % 256 == 0);
-  // tiny problems (PPM stages, prototype rows) stay on 128-row tiles
-  const bool big = block_rows(p.M) == 256;
-  if constexpr (sizeof(T) == 2) {
-    if (p.ksplit > 1) return launch_p9(p, st);                                        // planned by splitk_parts: the shape is served
+  const bool big = block_rows(p.M) == 256;           // tiny problems (PPM stages, prototype rows) stay on 128-row tiles
+  if (dtype == SL_BF16) {
+    if (p.ksplit > 1) return 18256256;                                                // planned by splitk_parts: the shape is served by the patch kernel
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
-      return launch_c64k3(p, st);
+      return 7016016;
     if (sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
         (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
-      return launch_sk(p, st);
-    if (p9_shape(p)) return launch_p9(p, st);
+      return 6256064;
+    if (sk512_shape(p)) return 9256064;
+    if (p9_shape(p)) return 8256256;
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
-    if (big && n256 && (p.mode == 0 || p.stride == 1)) return launch_p8(p, st);
+    if (big && n256 && (p.mode == 0 || p.stride == 1)) return 5256256;
   }
   if (big) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
-    if (n256) return launch_ring<T, 256, 256, 2, 4, 64, 4>(p, st);
-    if (n128) return launch_ring<T, 256, 128, 4, 2, 64, 4>(p, st);
-    return launch_glds<T, 256, 64, 8, 1>(p, st);        // N = 64 layers: too few weight rows for a 64-byte-row ring
+    if (n256) return 4256256;
+    if (n128) return 4256128;
+    return 2256064;                                     // N = 64 layers: too few weight rows for a 64-byte-row ring
   }
   // 128 x 128 tiles (few rows: Swin stage 3 / 4 token maps, the fine-tune pair's 8 192-row layers): 64-byte rows, 4 stages, 64 KiB, two blocks per CU.  Round 4 measured
   // the other stage geometries of this template end to end (Swin-T POP tiles/s / fine-tune pairs/s, one box): 128-byte rows x 3 stages (96 KiB, one block per CU)
   // 696.6 / 379.5, x 4 stages 712.3 / 408.1, 128-byte rows x 3 stages on eight waves of 64 x 32 705.7 / 392.0 -- against 720.2 / 419.1 for this one
-  if constexpr (sizeof(T) == 2) {
+  if (dtype == SL_BF16) {
     // few 128 x 128 tiles (the fine-tune pair's 8 192-row layers with 128 / 256 output channels: 64 / 128 tiles on 256 CUs; Swin stage 4 projections): 64-row tiles, bit-identical
     // results.  tools/ring64_check.py (us, 128 x 128 -> 64 x 128): 1024 -> 256 19.0 -> 15.4, 3x3 256 -> 256 d2 37.4 -> 30.0, 512 -> 128 11.6 -> 9.3, 3x3 128 -> 128 21.5 -> 16.7;
     // from 256 tiles on the smaller tile loses (2048 -> 512 36.1 -> 38.9, 256 -> 1024 11.1 -> 13.3).  End to end, one box: 440.9 -> 454.3 pairs/s (ResNet-50), 389 -> 406 (Swin-T),
     // Swin-T training step 733.9 -> 736.8 tiles/s; a limit of 200 / 300 tiles: 453.1 / 447.5 pairs/s.  Launches without BN statistic partials only (a training conv's
     // partials keep the 128-row granularity sl_conv2d_stat_rows promises).
-    if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_ring64_max_tiles)
-      return launch_ring<T, 64, 128, 2, 2, 64, 4>(p, st);
+    if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_ring64_max_tiles) return 4064128;
   }
-  if (n128 && p.M >= 128LL * RING128_MIN) return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);
-  if (n128) return launch_glds<T, 128, 128, 2, 2>(p, st);
-  return launch_glds<T, 128, 64, 2, 2>(p, st);
+  if (n128 && p.M >= 128LL * RING128_MIN) return 4128128;
+  if (n128) return 2128128;
+  return 2128064;
+}
+
+template <typename T>
+int launch_gemm(ConvGemmParams& p, hipStream_t st) {
+  const int cfg = choose_kernel(p, sizeof(T) == 2 ? SL_BF16 : SL_F32);
+  if constexpr (sizeof(T) == 2) {
+    switch (cfg) {
+      case 18256256: case 8256256: return launch_p9(p, st);
+      case 7016016: return launch_c64k3(p, st);
+      case 6256064: return launch_sk(p, st);
+      case 9256064: return launch_sk512(p, st);
+      case 5256256: return launch_p8(p, st);
+      case 4064128: return launch_ring<T, 64, 128, 2, 2, 64, 4>(p, st);
+      default: break;
+    }
+  }
+  switch (cfg) {
+    case 4256256: return launch_ring<T, 256, 256, 2, 4, 64, 4>(p, st);
+    case 4256128: return launch_ring<T, 256, 128, 4, 2, 64, 4>(p, st);
+    case 2256064: return launch_glds<T, 256, 64, 8, 1>(p, st);
+    case 4128128: return launch_ring<T, 128, 128, 2, 2, 64, 4>(p, st);
+    case 2128128: return launch_glds<T, 128, 128, 2, 2>(p, st);
+    case 2128064: return launch_glds<T, 128, 64, 2, 2>(p, st);
+    default: break;
+  }
+  sl_set_error("conv: no kernel for configuration %d", cfg);
+  return SL_EINVAL;
 }
 
 int g_conv_affine = -1;    // 1 (default): branch-free affine store phase for biased / folded-BN epilogues; 0: the generic one everywhere
@@ -2016,27 +2278,36 @@ int check_desc(const SlConvDesc* d) {
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
 extern "C" void sl_debug_ring64_max_tiles(int v) { g_ring64_max_tiles = v; }      // tuning hook: see launch_gemm
+extern "C" void sl_debug_conv_sk512(int v) { g_conv_sk512 = v ? 1 : 0; }      // test / A-B hook: K = 512 pixel-stationary kernel on / off
 extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
 extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
-// Which kernel a shape runs on: 1000000*family + 1000*BM + BN  (family 8 = 3x3 patch, 7 = 64 -> 64 patch, 6 = pixel-stationary, 5 = half-tile, 4 = ring, 2 = two-stage glds):
-// the predicate chain of launch_gemm.  mode 0: forward, 1: data gradient.  Used by bench.py to attribute HIP-event timings to rocprof kernel names.
-extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) {
+// Which kernel a launch of this shape runs on (codes: choose_kernel): the SAME function launch_gemm switches on, applied to the parameter block the entry points would
+// build.  mode 0: forward, 1: data gradient.  epi (sl_conv2d_tile_config_ex): what the launch carries besides the raw result -- SL_EPI_STATS (BN statistic partials),
+// SL_EPI_AFFINE (bias / folded BN / ReLU / residual: the inference forms), SL_EPI_ADDEND (data gradient + shortcut gradient), SL_EPI_ADDEND_BITS (gated by ReLU bits),
+// SL_EPI_GATE (gated result + BN-backward column sums, sl_conv2d_bwd_data_bnstat), SL_EPI_SPLITK (the split-K plan of sl_conv2d_affine_fwd_ex applies).
+// sl_conv2d_tile_config(d, mode) = the training forms: forward with statistics, plain data gradient.
+static unsigned char g_cfg_dummy[16];
+extern "C" int sl_conv2d_tile_config_ex(const SlConvDesc* d, int mode, int epi) {
   if (!d) return SL_EINVAL;
-  const long long M = mode == 0 ? (long long)d->B * d->Ho * d->Wo : (long long)d->B * d->H * d->W;
-  const int N = mode == 0 ? d->Cout : d->Cin;
-  const bool n128 = N % 128 == 0, n256 = N % 256 == 0;
-  const bool big = block_rows(M) == 256;
-  if (d->dtype == SL_BF16 && c64k3_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->dil, d->Cin, d->C1, d->Cout, M)) return 7016016;      // conv_c64k3_kernel, 16 x 16-pixel tiles
-  // the short-K kernel serves the unshaped epilogues (training-mode convs: raw result + statistics, or + addend); folded eval-mode convs of these shapes stay on the tile kernels
-  if (sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, mode == 0 ? d->Cin : d->Cout, mode == 0 ? d->C1 : d->Cout, N, M)) return 6256064;
-  if (d->dtype == SL_BF16 && n256 && p9_on() && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == d->dil && (d->dil == 1 || d->dil == 2 || d->dil == 4) &&
-      d->C1 == d->Cin && (mode == 0 ? d->Cin : d->Cout) % 64 == 0 && d->H % 16 == 0 && d->W % 16 == 0 && M >= 32768) return 8256256;      // conv_gemm_p9_kernel (unshaped epilogues)
-  if (big && n256 && d->dtype == SL_BF16 && (mode == 0 || d->stride == 1)) return 5256256;
-  if (big) { if (n256) return 4256256; if (n128) return 4256128; return 2256064; }
-  if (n128 && M >= 128LL * RING128_MIN) return 4128128;
-  return 2000000 + 128000 + (n128 ? 128 : 64);
+  ConvGemmParams p{};
+  void* dm = (void*)g_cfg_dummy;
+  p.src1 = dm; p.wt = dm; p.out = dm;
+  if (mode == 0) {
+    p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.B = d->B; p.Hs = d->H; p.Ws = d->W; p.Hd = d->Ho; p.Wd = d->Wo; p.N = d->Cout; p.M = d->B * d->Ho * d->Wo;
+  } else {
+    p.C1 = d->Cout; p.C2 = 0; p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W; p.N = d->Cin; p.M = d->B * d->H * d->W;
+  }
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = mode;
+  if (epi & SL_EPI_STATS) p.stat_partial = (float*)dm;
+  if (epi & SL_EPI_AFFINE) { p.scale = (const float*)dm; p.bias = (const float*)dm; p.relu = 1; }
+  if (epi & (SL_EPI_ADDEND | SL_EPI_ADDEND_BITS)) p.addend = dm;
+  if (epi & SL_EPI_ADDEND_BITS) p.addend_mask = (const unsigned char*)dm;
+  if (epi & SL_EPI_GATE) { p.gate = (const unsigned char*)dm; p.bn_x = dm; p.bn_mean = (const float*)dm; p.bn_invstd = (const float*)dm; p.stat_partial = (float*)dm; }
+  p.ksplit = (epi & SL_EPI_SPLITK) ? splitk_parts(p, d->dtype) : 1;
+  return choose_kernel(p, d->dtype);
 }
+extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode) { return sl_conv2d_tile_config_ex(d, mode, mode == 0 ? SL_EPI_STATS : 0); }
 
 extern "C" int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
 // Rows of the BN statistic partials a forward launch writes: derived from the SAME predicate chain as launch_gemm (sl_conv2d_tile_config), so a
@@ -2147,7 +2418,7 @@ extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
   if (!d) return 0;
   static const bool off = getenv("SEGLAND_BN_FUSE") && getenv("SEGLAND_BN_FUSE")[0] == '0';
   if (off) return 0;
-  const int cfg = sl_conv2d_tile_config(d, 1);
+  const int cfg = sl_conv2d_tile_config_ex(d, 1, SL_EPI_GATE);
   const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
   const long long M = (long long)d->B * d->H * d->W;
   if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2) || bm <= 0 || M % bm != 0) return 0;

@@ -47,13 +47,16 @@ def _f32(n, dev, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
 
 
+EPI_STATS, EPI_AFFINE, EPI_ADDEND, EPI_ADDEND_BITS, EPI_GATE, EPI_SPLITK = 1, 2, 4, 8, 16, 32      # SL_EPI_* of include/segland_hip.h
+
+
 # --------------------------------------------------------------------------------------------- live kernel timing
 class _Profiler:
     """HIP-event timing of the conv launches on the launch stream (bench.py: roofline of the dominant kernel).
     Off by default.  Launches are attributed to the kernel they are dispatched to (`family`, the name rocprofv3 shows);
     `only` restricts timing to one family so the timed region carries just those event pairs."""
 
-    FAMILY = {8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
+    FAMILY = {9: 'conv_gemm_sk512_kernel', 8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
         self.on, self.only, self.rec, self.rec_bytes = False, None, {}, {}
@@ -61,7 +64,7 @@ class _Profiler:
     def start(self, only=None):
         self.on, self.only, self.rec, self.rec_bytes = True, only, {}, {}
 
-    def family(self, kind, d):
+    def family(self, kind, d, epi=0):
         if kind == 'conv_wgrad':
             # the kernel rocprofv3 names.  Its deterministic slab reduce (a separate small launch behind it on the same stream) is inside the span
             cfg = _lib.lib().sl_conv2d_wgrad_config(C.byref(d))
@@ -74,13 +77,15 @@ class _Profiler:
                 return 'conv_wgrad3_kernel'
             name = 'conv_wgrad_glds_kernel' if cfg // 10000000 == 1 else 'conv_wgrad_kernel'
             return '%s<%s, %d, %d>%s' % (name, dts, (cfg % 500000) // 1000, cfg % 1000, ' pixel pairs' if (cfg // 500000) % 2 else '')
-        cfg = _lib.lib().sl_conv2d_tile_config(C.byref(d), 0 if kind == 'conv_fwd' else 1)
-        return '%s<%s, %d, %d>' % (self.FAMILY.get(cfg // 1000000, '?'), 'bf16' if d.dtype == SL_BF16 else 'f32', (cfg // 1000) % 1000, cfg % 1000)
+        # epi: the SL_EPI_* bits of the launch (the dispatch depends on the epilogue, include/segland_hip.h)
+        cfg = _lib.lib().sl_conv2d_tile_config_ex(C.byref(d), 0 if kind == 'conv_fwd' else 1, epi)
+        return '%s<%s, %d, %d>%s' % (self.FAMILY.get((cfg // 1000000) % 10, '?'), 'bf16' if d.dtype == SL_BF16 else 'f32', (cfg // 1000) % 1000, cfg % 1000,
+                                     ' split-K' if cfg >= 10000000 else '')
 
-    def begin(self, kind, d):
+    def begin(self, kind, d, epi=0):
         if not self.on:
             return None
-        fam = self.family(kind, d)
+        fam = self.family(kind, d, epi)
         if self.only is not None and fam != self.only:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -191,7 +196,7 @@ def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False, pr
     part = None
     if want_stats:
         part = _f32((_lib.lib().sl_conv2d_stat_rows(C.byref(d)), 2, spec.cout), x.device)
-    tok = PROFILER.begin('conv_fwd', d)
+    tok = PROFILER.begin('conv_fwd', d, (EPI_STATS if want_stats else 0) | (EPI_AFFINE if (bias is not None or relu) else 0))
     check(_lib.lib().sl_conv2d_fwd_ex(C.byref(d), _p(x), _p(x2), _p(wf), _p(pre_addend), _p(bias), int(relu), _p(y), _p(part), _s()), 'conv2d_fwd')
     PROFILER.end(tok)
     return y, part
@@ -204,7 +209,7 @@ def linear_fwd(x, wf, spec, bias=None, row_scale=None, residual=None, want_gelu=
     d = conv_desc(x.dtype, B, H, W, spec, None)
     y = torch.empty((B, d.Ho, d.Wo, spec.cout), dtype=x.dtype, device=x.device)
     g = torch.empty_like(y) if want_gelu else None
-    tok = PROFILER.begin('conv_fwd', d)
+    tok = PROFILER.begin('conv_fwd', d, EPI_AFFINE)
     check(_lib.lib().sl_linear_fwd(C.byref(d), _p(x), _p(wf), _p(bias), _p(row_scale), _p(residual), _p(y), _p(g), _s()), 'linear_fwd')
     PROFILER.end(tok)
     return (y, g) if want_gelu else y
@@ -219,7 +224,7 @@ def conv2d_affine_fwd(x, wf, spec, scale, shift, x2=None, residual=None, relu=Tr
     L = _lib.lib()
     need = L.sl_conv2d_affine_fwd_workspace(C.byref(d)) if x2 is None else 0
     ws = workspace(need, x.device, 'splitk') if need else None
-    tok = PROFILER.begin('conv_fwd', d)
+    tok = PROFILER.begin('conv_fwd', d, EPI_AFFINE | (EPI_SPLITK if need else 0))
     check(L.sl_conv2d_affine_fwd_ex(C.byref(d), _p(x), _p(x2), _p(wf), _p(pre_addend), _p(scale), _p(shift), _p(residual), int(relu), _p(y),
                                     _p(ws), ws.numel() if ws is not None else 0, _s()), 'conv2d_affine_fwd')
     PROFILER.end(tok)
@@ -232,7 +237,7 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
     d = conv_desc(dy.dtype, B, H, W, spec, C1)
     dx = out if out is not None else torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
     assert dx.numel() == B * H * W * spec.cin and dx.dtype == dy.dtype
-    tok = PROFILER.begin('conv_dgrad', d)
+    tok = PROFILER.begin('conv_dgrad', d, (EPI_ADDEND if addend is not None else 0) | (EPI_ADDEND_BITS if addend_mask is not None else 0))
     check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(addend_mask), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
     if tok is not None:
         PROFILER.end(tok, sum(t.numel() * t.element_size() for t in (addend, addend_mask, mask_src) if t is not None))
@@ -251,7 +256,7 @@ def conv2d_bwd_data_bnstat(dy, wb, spec, in_hw, gate, bn_x, mean, invstd):
         return None
     dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
     part = _f32((rows, 2, spec.cin), dy.device)
-    tok = PROFILER.begin('conv_dgrad', d)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_GATE)
     check(L.sl_conv2d_bwd_data_bnstat(C.byref(d), _p(dy), _p(wb), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()), 'conv2d_bwd_data_bnstat')
     if tok is not None:
         PROFILER.end(tok, bn_x.numel() * bn_x.element_size() + gate.numel())
@@ -278,7 +283,7 @@ def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean,
         return None
     dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
     part = _f32((rows, 2, spec.cin), dy.device)
-    tok = PROFILER.begin('conv_dgrad', d)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_GATE | EPI_ADDEND)
     check(L.sl_conv2d_bwd_data_addend_bnstat(C.byref(d), _p(dy), _p(wb), _p(addend), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()),
           'conv2d_bwd_data_addend_bnstat')
     if tok is not None:

@@ -81,6 +81,37 @@ def main():
         loss0 = float(engine.reduce_loss_dict(d0)['total_loss']) if two else float(d0['total_loss'].detach())
         stats0 = {k: v.detach().float().cpu() for k, v in m.state_dict().items() if 'running_' in k}
         del d0
+        # (1b) TWO iterations of the same step machinery with a plain SGD update (linear in the gradient: no sign-like first steps), then everything is restored.
+        # The summed update of the two steps must agree between the configurations to the gradient tolerance: a 1 / world_size (or a stale bucket, or a
+        # double all-reduce) that slips in at the SECOND step would be a factor, not a rounding difference.
+        class PlainSGD(torch.optim.Optimizer):
+            """theta -= lr * repeat * grad_scale * grad, with segland_amd.optim.AdamW's step() signature (the clip coefficient carries the 1 / world_size)."""
+            def __init__(self, params, lr):
+                super().__init__(params, dict(lr=lr))
+                self.repeat_next = 1
+
+            @torch.no_grad()
+            def step(self, closure=None, repeat=None, grad_scale=None):
+                repeat = self.repeat_next if repeat is None else repeat
+                self.repeat_next = 1
+                for g in self.param_groups:
+                    for p_ in g['params']:
+                        if p_.grad is not None:
+                            p_.sub_(p_.grad * (grad_scale if grad_scale is not None else 1.0) * (g['lr'] * repeat))
+        saved = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        before = {n: p.detach().clone() for n, p in m.named_parameters()}
+        sgd = PlainSGD(get_parameters(m, lr=1e-3), lr=1e-3)
+        sgd_step = bucket_step.GraphedBucketStep(net, sgd, double_step=True) if two else None
+        sgd_losses = []
+        for it in range(2):
+            d, gn = sgd_step(img, mask) if sgd_step is not None else train_iteration(net, sgd, scaler, img, mask, double_step=True)
+            vals = engine.reduce_loss_dict(d) if two else {k: float(v) for k, v in d.items()}
+            sgd_losses.append([float(vals['total_loss']), float(gn)])
+        sgd_update = {n: (p.detach() - before[n]).float().cpu() for n, p in m.named_parameters() if p.requires_grad}
+        m.load_state_dict(saved)
+        for p_ in m.parameters():
+            p_.grad = None
+        del saved, before, sgd, sgd_step
         losses = []
         for it in range(3):
             d, gn = step(img, mask) if step is not None else train_iteration(net, opt, scaler, img, mask, double_step=True)
@@ -90,7 +121,7 @@ def main():
         with torch.no_grad():
             logits = m(fm.formula_image(2, H, W, 'ddp2/eval').to(dev)).float().cpu()
         if rank <= 0:
-            torch.save({'grads0': grads0, 'loss0': loss0, 'stats0': stats0, 'sd': {k: v.detach().float().cpu() for k, v in m.state_dict().items()}, 'losses': losses, 'logits': logits}, out_path)
+            torch.save({'grads0': grads0, 'loss0': loss0, 'stats0': stats0, 'sgd_update': sgd_update, 'sgd_losses': sgd_losses, 'sd': {k: v.detach().float().cpu() for k, v in m.state_dict().items()}, 'losses': losses, 'logits': logits}, out_path)
     print('DDP2_CHILD rank %d done' % rank, flush=True)
 
 

@@ -179,6 +179,27 @@ def g3():
          orth_rect=orth_rect, d_rect=rect.grad, total12=d12['total_loss'], seg12=d12['seg_loss'], dpreds12=preds12.grad)
 
 
+# ------------------------------------------------------------------------------------------ G3b
+def g3b():
+    """criterion.py:56-60: the aux_preds branch of OrthLoss.forward (total = seg + 10 orth + 0.4 aux; four entries in the dict)."""
+    cr, co = RefOrthLoss(ignore_index=255), po.OrthLossOracle(ignore_index=255)
+    preds = fm.sym('g3b/preds', (2, 8, 8, 8), 2.0).requires_grad_(True)
+    aux = fm.sym('g3b/aux', (2, 8, 16, 16), 1.5).requires_grad_(True)
+    target = fm.formula_mask(2, 64, 64, 8, tag='g3b/mask', block=8, ignore_rows=7)
+    e = F.normalize(fm.sym('g3b/emb', (7, 512), 1.0), dim=-1)
+    sim = (e @ e.t()).requires_grad_(True)
+    d = cr(preds, target, proto_sim=sim, aux_preds=aux)
+    d['total_loss'].backward()
+    p2, a2, s2 = (t.detach().clone().requires_grad_(True) for t in (preds, aux, sim))
+    d_o = co(p2, target, proto_sim=s2, aux_preds=a2)
+    d_o['total_loss'].backward()
+    assert sorted(d) == sorted(d_o) == ['aux_loss', 'orth_loss', 'seg_loss', 'total_loss']
+    for k in d:
+        same(d[k], d_o[k], 'g3b ' + k)
+    same(preds.grad, p2.grad, 'g3b dpreds'); same(aux.grad, a2.grad, 'g3b daux'); same(sim.grad, s2.grad, 'g3b dsim')
+    save('g3b_loss_aux', total=d['total_loss'], seg=d['seg_loss'], aux=d['aux_loss'], orth=d['orth_loss'], dpreds=preds.grad, daux=aux.grad, dsim=sim.grad)
+
+
 # ------------------------------------------------------------------------------------------ G4
 def g4():
     for tag, (feat, outf, hw) in {'a': (64, 64, 12), 'b': (128, 64, 16)}.items():
@@ -788,7 +809,7 @@ def g19():
     save('g19_oem_ft', **out)
 
 
-ALL = dict(g19=g19, g18=g18, g17=g17, g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+ALL = dict(g19=g19, g18=g18, g17=g17, g13=g13, g14=g14, g15=g15, g16=g16, g12=g12, g11=g11, g1=g1, g2=g2, g3=g3, g3b=g3b, g4=g4, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
 
 if __name__ == '__main__':
     which = sys.argv[1:] or list(ALL)

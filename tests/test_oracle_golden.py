@@ -378,3 +378,19 @@ def test_pair_reader_rejects_what_the_reference_cannot_run(tmp_path):
             self._init_lists(os.path.join(str(tmp_path), 'list', 'train.txt'), 2, 'train', (64, 64), 255, 123, False, False)
     with pytest.raises(RuntimeError, match='use_base=False'):
         NoBase()
+
+
+def test_g3b_loss_with_aux_preds():
+    """criterion.py:56-60 (the aux_preds branch): the oracle against what the reference itself produced (tests/golden/make_golden.py g3b)."""
+    g = golden('g3b_loss_aux')
+    co = po.OrthLossOracle(255)
+    preds = fm.sym('g3b/preds', (2, 8, 8, 8), 2.0).requires_grad_(True)
+    aux = fm.sym('g3b/aux', (2, 8, 16, 16), 1.5).requires_grad_(True)
+    target = fm.formula_mask(2, 64, 64, 8, tag='g3b/mask', block=8, ignore_rows=7)
+    e = F.normalize(fm.sym('g3b/emb', (7, 512), 1.0), dim=-1)
+    sim = (e @ e.t()).requires_grad_(True)
+    d = co(preds, target, proto_sim=sim, aux_preds=aux)
+    assert sorted(d) == ['aux_loss', 'orth_loss', 'seg_loss', 'total_loss']
+    d['total_loss'].backward()
+    close(d['total_loss'], g['total']); close(d['seg_loss'], g['seg']); close(d['aux_loss'], g['aux']); close(d['orth_loss'], g['orth'])
+    close(preds.grad, g['dpreds']); close(aux.grad, g['daux']); close(sim.grad, g['dsim'])
