@@ -53,6 +53,8 @@ def parse():
     p.add_argument('--no-step-graph', action='store_true', help='issue the timed steps kernel by kernel (default on one GPU: they replay the step as ONE HIP graph, segland_amd/graph_step.py, '
                    'like train_base does).  Either way a second region of instrumented kernel-by-kernel steps carries the roofline events')
     p.add_argument('--profile-table', default='', help='write a per-kernel-shape timing table (instrumented extra pass) to this file')
+    p.add_argument('--side-config', default='', choices=['', 'c3', 'c4', 'c5'], help='internal: measure ONE of the other BASELINE configurations and print its JSON object (the default N = 1 run '
+                   'starts one fresh child process per configuration, so that a fault in a side measurement cannot take the headline line with it)')
     p.add_argument('--no-other-configs', action='store_true', help='skip the short measurements of BASELINE configs 3 (ResNet-101 shard), 4 (fine-tune pair) and 5 (Swin-T shard) '
                    'that ride on the default N = 1 run (`other_configs` in the JSON line); profiling runs pass this so that the trace holds the headline workload only')
     return p.parse_args()
@@ -171,6 +173,16 @@ def visible_gpus():
     return n
 
 
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the loaded libsegland_hip.so (what the committed counter files are keyed on)."""
+    import hashlib
+    from segland_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _dominant(table, peak):
     """(kernel family with the most time in an instrumented step, its fraction of `peak` TFLOP/s, its ms per step)."""
     if not table:
@@ -287,6 +299,11 @@ def main():
         a.batch = 8 if a.model == 'swin_pop' else 16
     if a.backbone is None:
         a.backbone = 'swin-t' if a.model == 'swin_pop' else 'resnet50'
+    if a.side_config:
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP path has no CPU fallback)'
+        torch.cuda.set_device(0)
+        print(json.dumps(short_config(a.side_config, torch.device('cuda', 0))), flush=True)
+        return
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -454,34 +471,52 @@ def main():
         if live:
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
+            # counter fields: read from the committed PMC passes of THIS library only (profiles/r5_*.json carry the sha256 of the libsegland_hip.so they were collected
+            # with, tools/collect_traffic.py / tools/pmc_families.py); a different library -> null (a kernel change must not keep the old counters in the line)
+            lib_sha = lib_sha16()
             traffic, tsrc = None, None
-            for tname in ('r4_traffic.json', 'r4_traffic_wgrad.json', 'r4_traffic_p8.json', 'r3_traffic.json', 'r3_traffic_wgrad.json', 'r3_traffic_p8.json'):      # PMC passes (tools/collect_traffic.py), bytes per launch
+            for tname in ('r5_traffic.json', 'r5_traffic_wgrad.json', 'r5_traffic_p8.json'):      # bytes per launch of one kernel each
                 tpath = os.path.join(ROOT, 'profiles', tname)
                 if traffic is None and os.path.exists(tpath):
                     try:
                         t = json.load(open(tpath))
                         if t.get('kernel') and t['kernel'] == e['family']:
-                            traffic = t.get('hbm_bytes_per_launch')
-                            tsrc = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed as profiles/%s '
-                                    '(tools/collect_traffic.py)' % tname)
+                            if t.get('lib_sha256_16') == lib_sha:
+                                traffic = t.get('hbm_bytes_per_launch')
+                                tsrc = ('NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command with this library (sha256 %s), committed as '
+                                        'profiles/%s (tools/collect_traffic.py)' % (lib_sha, tname))
+                            else:
+                                tsrc = 'null: profiles/%s was collected with another build of the library (%s, loaded %s)' % (tname, t.get('lib_sha256_16'), lib_sha)
                     except Exception:
                         pass
             clock, mfma_busy, csrc = None, None, None
-            cpath = os.path.join(ROOT, 'profiles', 'r4_pmc_families.json')
+            cpath = os.path.join(ROOT, 'profiles', 'r5_pmc_families.json')
             if os.path.exists(cpath) and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.batch == 16 and a.size == 512 and a.dtype == 'bf16':      # the counter passes are of this workload
                 try:
-                    base, dims = e['family'].split('<')[0], e['family'].split('<')[1].rstrip('>').split(', ')[1:] if '<' in e['family'] else []
-                    cands = [(v['ms_per_step'], v) for k_, v in json.load(open(cpath)).items()
-                             if k_.split('<')[0] == base and (not base.startswith('conv_wgrad') or all(d_ in k_ for d_ in dims))]
-                    if cands:
-                        v = max(cands, key=lambda t: t[0])[1]
-                        clock, mfma_busy = v.get('clock_ghz'), v.get('mfma_busy_over_sq_busy')
-                        csrc = ('NOT measured in this run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of this command (kernel by kernel), committed as '
-                                'profiles/r4_pmc_families.json (tools/r4_pmc.sh): clock = GRBM_GUI_ACTIVE / kernel duration, mfma_busy = MFMA_BUSY / (32 x SQ_BUSY_CYCLES)')
+                    cj = json.load(open(cpath))
+                    if cj.get('lib_sha256_16') != lib_sha:
+                        csrc = 'null: profiles/r5_pmc_families.json was collected with another build of the library (%s, loaded %s)' % (cj.get('lib_sha256_16'), lib_sha)
+                    else:
+                        base = e['family'].split('<')[0]
+                        cands = [(v['ms_per_step'], v) for k_, v in cj.get('kernels', {}).items() if k_.split('<')[0].split('(')[0] == base]
+                        if cands:
+                            v = max(cands, key=lambda t: t[0])[1]
+                            clock, mfma_busy = v.get('clock_ghz'), v.get('mfma_busy_over_sq_busy')
+                            csrc = ('NOT measured in this run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of this command (kernel by kernel) with this '
+                                    'library (sha256 %s), committed as profiles/r5_pmc_families.json (tools/collect_profiles.sh pmc): clock = GRBM_GUI_ACTIVE / kernel duration, '
+                                    'mfma_busy = MFMA_BUSY / (32 x SQ_BUSY_CYCLES)' % lib_sha)
                 except Exception:
                     pass
+            # what north_star asks: MFMA utilisation "in the backbone convs" -- ALL conv / GEMM launches of the instrumented step, not the best kernel
+            conv_gflop = sum(t_['gflop'] for t_ in table.values())
+            conv_ms = sum(t_['ms_total'] for t_ in table.values())
+            backbone_convs = {'gflop_executed_per_step': round(conv_gflop, 1), 'ms_per_step': round(conv_ms, 3), 'launches': sum(t_['calls'] for t_ in table.values()),
+                              'tflops': round(conv_gflop / max(conv_ms, 1e-9), 1), 'frac': round(conv_gflop / max(conv_ms, 1e-9) / peak, 4),
+                              'note': 'every conv / GEMM launch of one instrumented kernel-by-kernel step (forward, data and weight gradients of all layers incl. slab reduces): '
+                                      'executed FLOPs / HIP-event time against the %g TFLOP/s peak; north_star target 0.60' % peak}
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'traffic_source': tsrc, 'clock_ghz_measured': clock, 'mfma_busy_measured': mfma_busy, 'clock_source': csrc,
+                               'backbone_convs': backbone_convs, 'whole_step_frac': round(out['whole_step_tflops'] / peak, 4),
                                'kernel': e['family'], 'launches': e['calls'],
                                'ms_per_launch': round(e['ms_total'] / max(e['calls'], 1), 4),
                                'gflop_per_launch': round(e['gflop'] / max(e['calls'], 1), 2),
@@ -490,15 +525,20 @@ def main():
                                        + 'peak is the 2.4 GHz figure: clock_ghz_measured is what the chip sustained under this kernel on N(0,1) operands in the counter pass (the same binary on '
                                        + 'all-zero operands runs +26...+36 % faster, profiles/r2_dvfs_zero_operands.txt, DESIGN.md 3.1c)'}
         if world == 1 and not use_ddp and not a.no_other_configs and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.dtype == 'bf16' and a.batch == 16 and a.size == 512:
-            # the other BASELINE configurations that fit one GPU, ~5 s each (the headline model is released first)
+            # the other BASELINE configurations that fit one GPU, ~5 s each, each in a FRESH child process (round-4 advisor: a memory fault, hang or OOM kill in a side
+            # measurement must not cost the headline line; the children are started with subprocess -- this GPU-initialised process never execs)
             model = opt = net = params = batches = graphed = eager_fn = fn = img = mask = replica = None      # noqa: F841
             import gc
+            import subprocess
+            gc.collect(); torch.cuda.empty_cache()
             others = {}
             for kind, key in (('c3', 'config3_resnet101_shard'), ('c4', 'config4_ft_pair'), ('c5', 'config5_swin_t_shard')):
-                gc.collect(); torch.cuda.empty_cache()
                 try:
-                    others[key] = short_config(kind, dev)
-                except Exception as e:                  # noqa: BLE001  (the headline line must not be lost to a side measurement)
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--side-config', kind], capture_output=True, text=True, timeout=600,
+                                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+                    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+                    others[key] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {'error': 'child exited with code %d: %s' % (r.returncode, (r.stderr or '').strip().splitlines()[-1:] or '')}
+                except Exception as e:                  # noqa: BLE001
                     others[key] = {'error': '%s: %s' % (type(e).__name__, str(e).splitlines()[0] if str(e) else '')}
             out['other_configs'] = others
         if world == 1 and not a.no_cpu_baseline:

@@ -1,6 +1,6 @@
 /* LD_PRELOAD helper for the GPU box: prints the native call stack of the thread that raises SIGABRT (an abort() inside the HIP runtime or a std::terminate leaves no
-   message otherwise), then lets the default action run.   gcc -shared -fPIC -O1 -o tools/_abort_trace.so tools/abort_trace.c
-   LD_PRELOAD=tools/_abort_trace.so python -m pytest -p no:faulthandler ...                                                                                        */
+   message otherwise), then lets the default action run.   built ON DEMAND, never shipped:  gcc -shared -fPIC -O1 -o /tmp/_abort_trace.so tools/abort_trace.c
+   LD_PRELOAD=/tmp/_abort_trace.so python -m pytest -p no:faulthandler ...                                                                                        */
 #define _GNU_SOURCE
 #include <execinfo.h>
 #include <signal.h>

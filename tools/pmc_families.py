@@ -10,8 +10,10 @@
   pass C / D  FETCH_SIZE / WRITE_SIZE (separate passes; FETCH_SIZE doubled: MI355X_MICROARCH.md)   -> HBM-side bytes per launch and TB/s
 
 usage: pmc_families.py [--min-ms 0.25] [--cmd '<profiled command>'] <out.txt> <out.json> <steps> <dirA> [<dirB> [<dirC> <dirD>]]"""
-import glob, json, re, sqlite3, sys
+import glob, hashlib, json, os, re, sqlite3, sys
 from collections import defaultdict
+
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'segland_amd', 'csrc', 'libsegland_hip.so')
 
 
 def load(path):
@@ -66,5 +68,5 @@ for n in sorted(A, key=lambda k: -sum(durA[k].values())):
     lines.append('%-62s %6d %8.3f %9s %9s %8s %9s %9s %8s %9s %9s' % (n[:62], calls, ms_step, f('mfma_busy_over_sq_busy', '%.3f'), f('mfma_busy_over_all_simd_cycles', '%.3f'), f('clock_ghz', '%.2f'),
                  f('lds_conflict_share', '%.3f'), f('wait_inst_share', '%.3f'), f('active_inst_share', '%.3f'), f('hbm_mb_per_launch', '%.1f'), f('hbm_tb_per_s', '%.2f')))
 open(out_txt, 'w').write('\n'.join(lines) + '\n')
-json.dump(js, open(out_json, 'w'), indent=1)
+json.dump({'lib_sha256_16': hashlib.sha256(open(LIB, 'rb').read()).hexdigest()[:16], 'command': cmd, 'kernels': js}, open(out_json, 'w'), indent=1)      # bench.py reads `kernels` only when the sha matches the loaded library
 print('\n'.join(lines[:40]))
