@@ -125,6 +125,12 @@ int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, const void* w
 int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d);
 int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
                                      const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
+/* The dual form: the previous block is the FIRST bottleneck of a stage, whose output ReLU sits behind bn3 AND the downsample BatchNorm (resnet.py:71-76): the gated
+ * gradient is reduced against both BatchNorm inputs in one store loop.  stat_partial / stat_partial2: [rows][2][Cin] each, (sum g, sum g * xhat) per BatchNorm
+ * (what sl_bn_bwd_reduce2 would produce in a pass of its own over g, bn_x and bn_x2).  Same shapes as above. */
+int sl_conv2d_bwd_data_addend_bnstat2(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
+                                      const float* bn_mean, const float* bn_invstd, const void* bn_x2, const float* bn_mean2, const float* bn_invstd2, void* dx,
+                                      float* stat_partial, float* stat_partial2, sl_stream_t stream);
 
 /* dw (float, OIHW [Cout][Cin][KH][KW]) = sum over pixels of dy (x) x.  Deterministic split-K through `workspace`. */
 size_t sl_conv2d_bwd_weight_workspace(const SlConvDesc* d);

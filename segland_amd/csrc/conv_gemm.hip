@@ -40,6 +40,9 @@ struct ConvGemmParams {
   const unsigned char* gate;            // relu bits of the OUTPUT positions (1 byte per 16-byte vector) or null
   const void* bn_x;                     // [M][N] the BN input c
   const float* bn_mean; const float* bn_invstd;   // [N]
+  // pixel-stationary kernel MODE 5, DUAL: a second BatchNorm behind the same ReLU (bn3 + the downsample BN of a stage's first bottleneck, resnet.py:71-76): the gated result is
+  // also reduced against bn_x2; stat_partial2 [gridM][2][N] receives (sum g, sum g * xhat2)
+  const void* bn_x2; const float* bn_mean2; const float* bn_invstd2; float* stat_partial2;
   const float* row_scale;               // [B] per-sample multiplier of (acc * scale + bias), applied before the addend (DropPath), or null
   void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
@@ -1657,7 +1660,7 @@ template <int KS> struct SkGeom {
   static constexpr int BSTEP = 64 * RB;                                // weight rows of one step
   static constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;     // 32 rows x (128 B + pad) per wave
   static constexpr int OFF_STG = 2 * BSTEP, OFF_RED = OFF_STG + 8 * STG_WAVE;
-  static constexpr int LDS = OFF_RED + 2 * 8 * 2 * 64 * (int)sizeof(float);      // red[parity][wave][sum, sq][64 columns]
+  static constexpr int LDS = OFF_RED + 2 * 8 * 3 * 64 * (int)sizeof(float);      // red[parity][wave][sum, sq, sq2][64 columns] (sq2: the second BatchNorm of MODE 5's dual form)
 };
 template <int KS> __device__ __forceinline__ int sk_swz(int row) { return KS == 16 ? (row & 31) : (KS == 8 ? (row & 15) : ((row >> 1) & 7)); }
 // sums over the lanes 8, 16 and 32 apart (the lanes of a wave that share lane & 7), without the LDS: one rotation inside the 16-lane rows, then the
@@ -1716,8 +1719,9 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
   float* red = (float*)(smem + G::OFF_RED);
   const int srow = lane >> 3, sch = lane & 7;                          // store phase: row it * 8 + srow, 16-byte chunk sch of the wave's 32 x 64 patch (a full 128-byte line per row)
   const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
-  uint4 addv[4], cxv[4];                                               // MODE 5: cxv = the BN input c of the result's positions
-  float bmu[8], bis[8];
+  uint4 addv[4], cxv[4], cxv2[4];                                      // MODE 5: cxv = the BN input c of the result's positions (cxv2: the second BatchNorm's, dual form)
+  float bmu[8], bis[8], bmu2[8], bis2[8];
+  const bool dual = MODE == 5 && p.bn_x2 != nullptr;                   // wave-uniform
   // the gate bytes of the block's 256 rows (N / 8 per row, contiguous over the rows) are copied to the LDS once: read step by step from global memory, each step would
   // pull 8 useful bytes out of every row's line, and 256 lines per step do not survive in the 32 KiB L1 next to the addend stream (measured: 58 -> 73 us on 1024 -> 256)
   const int mpitch = p.N / 8 + 16;
@@ -1743,6 +1747,12 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
         for (int it = 0; it < 4; ++it) cxv[it] = *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bmu[e] = p.bn_mean[ncol + e]; bis[e] = p.bn_invstd[ncol + e]; }
+        if (dual) {
+#pragma unroll
+          for (int it = 0; it < 4; ++it) cxv2[it] = *(const uint4*)((const T*)p.bn_x2 + (orow + it * 8) * p.N + ncol);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { bmu2[e] = p.bn_mean2[ncol + e]; bis2[e] = p.bn_invstd2[ncol + e]; }
+        }
       }
     }
     f32x16_t acc[2];
@@ -1773,9 +1783,9 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     const int cur = s & 1;
     const int ncol = s * 64 + sch * 8;
     wait_vmcnt<0>();                                                   // the next step's weight rows, this step's addend, the previous step's stores
-    float sa[8], sq[8];
+    float sa[8], sq[8], sq2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; sq2[e] = 0.f; }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const uint4 raw = *(const uint4*)(stg + (it * 8 + srow) * G::STG_PITCH + sch * 16);
@@ -1821,6 +1831,16 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
             sa[2 * c] += glo; sq[2 * c] += glo * ((xlo - bmu[2 * c]) * bis[2 * c]);
             sa[2 * c + 1] += ghi; sq[2 * c + 1] += ghi * ((xhi - bmu[2 * c + 1]) * bis[2 * c + 1]);
           }
+          if (dual) {
+            const unsigned yw[4] = {cxv2[it].x, cxv2[it].y, cxv2[it].z, cxv2[it].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float glo = __uint_as_float(ow[c] << 16), ghi = __uint_as_float(ow[c] & 0xffff0000u);
+              const float ylo = __uint_as_float(yw[c] << 16), yhi = __uint_as_float(yw[c] & 0xffff0000u);
+              sq2[2 * c] += glo * ((ylo - bmu2[2 * c]) * bis2[2 * c]);
+              sq2[2 * c + 1] += ghi * ((yhi - bmu2[2 * c + 1]) * bis2[2 * c + 1]);
+            }
+          }
         }
         st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
       }
@@ -1828,21 +1848,27 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     if ((MODE == 1 || MODE == 5) && p.stat_partial) {                  // lanes 8 apart share the column octet
 #pragma unroll
       for (int e = 0; e < 8; ++e) { sa[e] = sk_sum_8_16_32(sa[e]); sq[e] = sk_sum_8_16_32(sq[e]); }
+      if (dual) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sq2[e] = sk_sum_8_16_32(sq2[e]);
+      }
       if (lane < 8) {
-        float* r0 = red + ((cur * 8 + wave) * 2) * 64 + sch * 8;
+        float* r0 = red + ((cur * 8 + wave) * 3) * 64 + sch * 8;
         *(float4*)(r0) = make_float4(sa[0], sa[1], sa[2], sa[3]); *(float4*)(r0 + 4) = make_float4(sa[4], sa[5], sa[6], sa[7]);
         *(float4*)(r0 + 64) = make_float4(sq[0], sq[1], sq[2], sq[3]); *(float4*)(r0 + 68) = make_float4(sq[4], sq[5], sq[6], sq[7]);
+        if (dual) { *(float4*)(r0 + 128) = make_float4(sq2[0], sq2[1], sq2[2], sq2[3]); *(float4*)(r0 + 132) = make_float4(sq2[4], sq2[5], sq2[6], sq2[7]); }
       }
     }
   };
-  auto finalize = [&](int s, int t0) {                                 // 128 threads from t0 on, after the barrier behind the last store phase of step s
-    if ((MODE == 1 || MODE == 5) && p.stat_partial && tid >= t0 && tid < t0 + 128) {
-      const int which = ((tid - t0) >> 6) & 1, col = tid & 63;
-      const float* r0 = red + ((s & 1) * 16 + which) * 64 + col;
+  auto finalize = [&](int s, int t0) {                                 // 128 (dual: 192) threads from t0 on, after the barrier behind the last store phase of step s
+    if ((MODE == 1 || MODE == 5) && p.stat_partial && tid >= t0 && tid < t0 + (dual ? 192 : 128)) {
+      const int which = (tid - t0) >> 6, col = tid & 63;               // 0: sum g, 1: sum g * xhat, 2: sum g * xhat2
+      const float* r0 = red + ((s & 1) * 24 + which) * 64 + col;
       float t = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += r0[k * 128];
-      p.stat_partial[((size_t)bm * 2 + which) * p.N + s * 64 + col] = t;
+      for (int k = 0; k < 8; ++k) t += r0[k * 192];
+      if (which < 2) p.stat_partial[((size_t)bm * 2 + which) * p.N + s * 64 + col] = t;
+      if (dual && which != 1) p.stat_partial2[((size_t)bm * 2 + (which >> 1)) * p.N + s * 64 + col] = t;      // the second BatchNorm's partials repeat sum g
     }
   };
 
@@ -2461,6 +2487,25 @@ extern "C" int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void*
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
   p.addend = addend; p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// The dual form (resnet.py:71-76 backward of a stage's FIRST bottleneck): that block's output ReLU sits behind bn3 AND the downsample BatchNorm, so the gated gradient is
+// reduced against both inputs in the same store loop: stat_partial <- (sum g, sum g * xhat(bn_x)), stat_partial2 <- (sum g, sum g * xhat(bn_x2)); the separate dual
+// reduce pass (sl_bn_bwd_reduce2: three tensor reads) disappears.  Same shapes as sl_conv2d_bwd_data_addend_bnstat.
+extern "C" int sl_conv2d_bwd_data_addend_bnstat2(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
+                                                 const float* bn_mean, const float* bn_invstd, const void* bn_x2, const float* bn_mean2, const float* bn_invstd2, void* dx,
+                                                 float* stat_partial, float* stat_partial2, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && dx && addend && gate && bn_x && bn_mean && bn_invstd && bn_x2 && bn_mean2 && bn_invstd2 && stat_partial && stat_partial2, "conv bwd_data_addend_bnstat2: null buffer");
+  SL_REQUIRE(sl_conv2d_bwd_data_addend_bnstat_rows(d) > 0, "conv bwd_data_addend_bnstat2: shape not served (sl_conv2d_bwd_data_addend_bnstat_rows == 0)");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.addend = addend; p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
+  p.bn_x2 = bn_x2; p.bn_mean2 = bn_mean2; p.bn_invstd2 = bn_invstd2; p.stat_partial2 = stat_partial2;
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

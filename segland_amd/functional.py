@@ -249,7 +249,7 @@ _BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column 
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
-                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None):
+                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None, prevd=None):
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres, partial_below).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue.
@@ -278,9 +278,14 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
             if r is not None:
                 dx, part_below = r
         if prev3 is not None and addend is not None and addend_bits is None and x2 is None and dx_out is None:
-            r = ops.conv2d_bwd_data_addend_bnstat(dc, wb, spec, x.shape[1:3], addend, *prev3)
-            if r is not None:
-                dx, part_below = r
+            if prevd is not None:       # the block in front is a stage's first one: bn3 + downsample BatchNorm behind its ReLU, both reduced here (partial_below is a pair)
+                r = ops.conv2d_bwd_data_addend_bnstat2(dc, wb, spec, x.shape[1:3], addend, *prev3, *prevd)
+                if r is not None:
+                    dx, part_below = r[0], (r[1], r[2])
+            else:
+                r = ops.conv2d_bwd_data_addend_bnstat(dc, wb, spec, x.shape[1:3], addend, *prev3)
+                if r is not None:
+                    dx, part_below = r
         if dx is None:
             dx = ops.conv2d_bwd_data(dc, wb, spec, x.shape[1:3], addend=addend, addend_mask=addend_bits,
                                      C1=(x.shape[3] if x2 is not None else None), out=dx_out)
@@ -323,10 +328,10 @@ class _BlockLink:
     producer module -- checked against its own input -- and keeps it in its ctx; the consumer's backward leaves the column sums its conv1 data-gradient
     epilogue produced in pre3 (with the address of the gradient tensor they belong to), the producer's backward takes them.  Nothing is read from module
     state at backward time."""
-    __slots__ = ('bn3', 'pre3', 'out_ptr', 'out_shape')
+    __slots__ = ('bn3', 'bnd', 'pre3', 'out_ptr', 'out_shape')
 
     def __init__(self):
-        self.bn3 = self.pre3 = self.out_ptr = self.out_shape = None
+        self.bn3 = self.bnd = self.pre3 = self.out_ptr = self.out_shape = None      # bnd: (cd, mean, invstd) of the downsample BatchNorm behind the same ReLU (a stage's first block)
 
 
 class BottleneckFn(torch.autograd.Function):
@@ -357,7 +362,9 @@ class BottleneckFn(torch.autograd.Function):
         ctx.has_ds = blk.downsample is not None
         # the next bottleneck's backward produces this block's incoming gradient: it may gate it and reduce it against c3 right there (_BN_CROSS)
         link = ctx.link = blk.__dict__['_sl_link'] = _BlockLink()
-        link.bn3 = (k3, c3, m3, i3) if (_BN_CROSS and k3 is not None and blk.bn3.training and not ctx.has_ds and any(ctx.needs_input_grad)) else None
+        dual_ok = ctx.has_ds and _BN_DUAL and blk.downsample[1].training and not sync_world(blk.bn3)      # the consumer's one-sweep dual backward (ops.bn_bwd2) must apply
+        link.bn3 = (k3, c3, m3, i3) if (_BN_CROSS and k3 is not None and blk.bn3.training and (not ctx.has_ds or dual_ok) and any(ctx.needs_input_grad)) else None
+        link.bnd = (cd, md, idd) if (link.bn3 is not None and ctx.has_ds) else None
         link.out_ptr, link.out_shape = out.data_ptr(), tuple(out.shape)
         saved = [x, c1, a1, m1, i1, k1, c2, a2, m2, i2, k2, c3, m3, i3]
         if ctx.has_ds:
@@ -382,17 +389,21 @@ class BottleneckFn(torch.autograd.Function):
         # this block's incoming gradient may have been gated and reduced against c3 by the block behind it (its conv1 data gradient epilogue): the tensor
         # autograd hands over must be exactly the one that epilogue wrote (a second consumer of this block's output would have made autograd sum into a new one)
         link = ctx.link
-        pre3, link.pre3, link.bn3 = link.pre3, None, None
-        p3 = None
-        if pre3 is not None and pre3[0] == dout.data_ptr() and pre3[1] == tuple(dout.shape) and not ctx.has_ds:
-            p3, k3 = pre3[2], None                   # dout is gated already: no bits for bn3, none for the identity shortcut
+        pre3, link.pre3, link.bn3, link.bnd = link.pre3, None, None, None
+        p3 = pdual = None
+        if pre3 is not None and pre3[0] == dout.data_ptr() and pre3[1] == tuple(dout.shape):
+            if not ctx.has_ds and not isinstance(pre3[2], tuple):
+                p3, k3 = pre3[2], None               # dout is gated already: no bits for bn3, none for the identity shortcut
+            elif ctx.has_ds and isinstance(pre3[2], tuple):
+                pdual = pre3[2]                      # ... and reduced against c3 AND the downsample BatchNorm's input (round 5: the dual store loop of the block behind)
         done3 = doned = None
         if ctx.has_ds and _BN_DUAL and k3 is not None and blk.bn3.training and blk.downsample[1].training and not sync_world(blk.bn3):
             # bn3 and the downsample BN sit behind the same ReLU: one sweep over dout and its bits for both reduces, one for both applies (ops.bn_bwd2)
             cd, md, idd = sv[14:17]
             bnd = blk.downsample[1]
             g3, b3, gd_, bd_ = (grad_dst(blk.bn3.weight), grad_dst(blk.bn3.bias), grad_dst(bnd.weight), grad_dst(bnd.bias)) if need_w else (None,) * 4
-            dc3, dg3_, db3_, dcd, dgd_, dbd_ = ops.bn_bwd2(dout, k3, c3, m3, i3, blk.bn3.weight, cd, md, idd, bnd.weight, (g3, b3), (gd_, bd_))
+            dc3, dg3_, db3_, dcd, dgd_, dbd_ = ops.bn_bwd2(dout, None if pdual is not None else k3, c3, m3, i3, blk.bn3.weight, cd, md, idd, bnd.weight, (g3, b3), (gd_, bd_),
+                                                           pre_partials=pdual)
             done3 = (dc3, grad_alias(dg3_, g3), grad_alias(db3_, b3))
             doned = (dcd, grad_alias(dgd_, gd_), grad_alias(dbd_, bd_))
         # the block in front of this one can take its bn3 column sums from this block's conv1 data gradient only if the shortcut gradient enters that epilogue
@@ -402,6 +413,7 @@ class BottleneckFn(torch.autograd.Function):
         prev3 = plink.bn3 if (plink is not None and need_x and _BN_CROSS) else None
         if prev3 is not None and (prev3[1].shape != x.shape or prev3[1].dtype != x.dtype or not ops.conv2d_bwd_data_addend_bnstat_ok(x, spec_of(blk.conv1))):
             prev3 = None
+        prevd = plink.bnd if prev3 is not None else None
         want_dres = prev3 is not None and not ctx.has_ds and k3 is not None and p3 is None and done3 is None
         da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,
                                                    below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres)
@@ -421,7 +433,7 @@ class BottleneckFn(torch.autograd.Function):
             prev3 = None
         dx, dw1, dg1, db1, _, pp = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
                                                addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1,
-                                               prev3=prev3)
+                                               prev3=prev3, prevd=prevd)
         if pp is not None and prev3 is not None:
             plink.pre3 = (dx.data_ptr(), tuple(dx.shape), pp)
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds

@@ -291,6 +291,26 @@ def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean,
     return dx, part
 
 
+def conv2d_bwd_data_addend_bnstat2(dy, wb, spec, in_hw, addend, gate, bn_x, mean, invstd, bn_x2, mean2, invstd2):
+    """The dual form of conv2d_bwd_data_addend_bnstat: the gated result is reduced against the inputs of TWO BatchNorms behind the same ReLU (bn3 + the downsample
+    BatchNorm of a stage's first bottleneck).  -> (g, partial, partial2) or None when the shape is not served."""
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    rows = L.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d)) if dy.dtype == torch.bfloat16 else 0
+    if rows <= 0:
+        return None
+    dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    part = _f32((2, rows, 2, spec.cin), dy.device)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_GATE | EPI_ADDEND)
+    check(L.sl_conv2d_bwd_data_addend_bnstat2(C.byref(d), _p(dy), _p(wb), _p(addend), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(bn_x2), _p(mean2), _p(invstd2), _p(dx),
+                                              _p(part[0]), _p(part[1]), _s()), 'conv2d_bwd_data_addend_bnstat2')
+    if tok is not None:
+        PROFILER.end(tok, addend.numel() * addend.element_size() + 2 * bn_x.numel() * bn_x.element_size() + gate.numel())
+    return dx, part[0], part[1]
+
+
 _ws_cache = {}
 
 
@@ -443,19 +463,25 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     return dx, dres, dg, db
 
 
-def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, outs1=(None, None), outs2=(None, None)):
+def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, outs1=(None, None), outs2=(None, None), pre_partials=None):
     """Train-mode backward of TWO BatchNorms whose outputs were added before one ReLU (bn3 + downsample BN, resnet.py:71-76): both see the gradient
-    dy gated by `mask`; dy and the bits are swept once per pass for both.  -> (dx1, dgamma1, dbeta1, dx2, dgamma2, dbeta2)."""
+    dy gated by `mask`; dy and the bits are swept once per pass for both.  -> (dx1, dgamma1, dbeta1, dx2, dgamma2, dbeta2).
+    pre_partials = (partial1, partial2): dy is ALREADY gated (mask must be None) and both column-sum partials were produced by the data-gradient epilogue that wrote it
+    (conv2d_bwd_data_addend_bnstat2): no reduce pass runs here."""
     Cn = x1.shape[-1]
     rows = x1.numel() // Cn
     L = _lib.lib()
-    nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
-    part = _f32((2, nblk, 2, Cn), x1.device)
     nb = x1.numel() * x1.element_size()
-    tok = PROFILER.begin_bytes('bn_bwd_reduce', 3 * nb + mask.numel())
-    check(L.sl_bn_bwd_reduce2(dt(x1), _p(dy), _p(mask), _p(x1), _p(mean1), _p(invstd1), _p(part[0]), _p(x2), _p(mean2), _p(invstd2), _p(part[1]), rows, Cn, _s()),
-          'bn_bwd_reduce2')
-    PROFILER.end_bytes(tok)
+    if pre_partials is not None:
+        assert mask is None
+        part, nblk = pre_partials, pre_partials[0].shape[0]
+    else:
+        nblk = L.sl_bn_bwd_reduce_rows(rows, Cn)
+        part = _f32((2, nblk, 2, Cn), x1.device)
+        tok = PROFILER.begin_bytes('bn_bwd_reduce', 3 * nb + mask.numel())
+        check(L.sl_bn_bwd_reduce2(dt(x1), _p(dy), _p(mask), _p(x1), _p(mean1), _p(invstd1), _p(part[0]), _p(x2), _p(mean2), _p(invstd2), _p(part[1]), rows, Cn, _s()),
+              'bn_bwd_reduce2')
+        PROFILER.end_bytes(tok)
     o = _f32((2, 5, Cn), x1.device)
     res = []
     for k, (gamma, mean, invstd, outs) in enumerate(((gamma1, mean1, invstd1, outs1), (gamma2, mean2, invstd2, outs2))):
@@ -465,7 +491,7 @@ def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, ou
               'bn_bwd_finalize')
         res.append((dg, db))
     dx1, dx2 = torch.empty_like(x1), torch.empty_like(x2)
-    tok = PROFILER.begin_bytes('bn_bwd_apply', 5 * nb + mask.numel())
+    tok = PROFILER.begin_bytes('bn_bwd_apply', 5 * nb + (mask.numel() if mask is not None else 0))
     check(L.sl_bn_bwd_apply2(dt(x1), _p(dy), _p(mask), _p(x1), _p(o[0, 2]), _p(o[0, 3]), _p(o[0, 4]), _p(mean1), _p(dx1),
                              _p(x2), _p(o[1, 2]), _p(o[1, 3]), _p(o[1, 4]), _p(mean2), _p(dx2), rows, Cn, _s()), 'bn_bwd_apply2')
     PROFILER.end_bytes(tok)

@@ -223,3 +223,88 @@ def test_orth_loss_with_aux_preds_golden_g3b(hip):
         np.testing.assert_allclose(float(d[k]), float(g[gk]), rtol=2e-5, err_msg=k)
     for t, gk in ((preds, 'dpreds'), (aux, 'daux'), (sim, 'dsim')):
         np.testing.assert_allclose(t.grad.cpu().numpy(), g[gk], rtol=1e-4, atol=1e-7, err_msg=gk)
+
+
+@pytest.mark.parametrize('cin,cout', [(1024, 256), (512, 128), (256, 64)])
+def test_conv1_dgrad_reduces_for_two_batchnorms_behind_one_relu(hip, cin, cout):
+    """resnet.py:71-78 backward into a stage's FIRST bottleneck: its output ReLU sits behind bn3 and the downsample BatchNorm, and the conv1 data gradient of the block
+    behind it (pixel-stationary kernel, MODE 5) gates its result with that ReLU's bits and reduces it against BOTH BatchNorm inputs (sl_conv2d_bwd_data_addend_bnstat2):
+    gated gradient bit-identical to the single form, first partials identical to it, second partials equal to a reduce pass of their own (1e-5), and
+    ops.bn_bwd2 on the pair equals ops.bn_bwd2 with its own dual reduce pass."""
+    from segland_amd import _lib, ops
+    B, H, W = 16, 64, 64
+    if cin == 256:
+        H = W = 128
+    g = torch.Generator(device='cpu').manual_seed(5)
+    spec = ops.ConvSpec(cin, cout, 1, 1, 0, 1)
+    _, wb = ops.weight_prep((torch.randn(cout, cin, 1, 1, generator=g) * (3.0 / cin) ** 0.5).to(DEV), torch.bfloat16)
+    dy = torch.randn(B, H, W, cout, generator=g).to(torch.bfloat16).to(DEV)
+    add = torch.randn(B, H, W, cin, generator=g).to(torch.bfloat16).to(DEV)
+    c3 = (torch.randn(B, H, W, cin, generator=g) * 2 + 0.5).to(torch.bfloat16).to(DEV)
+    cd = (torch.randn(B, H, W, cin, generator=g) * 1.5 - 0.25).to(torch.bfloat16).to(DEV)
+    bits = torch.randint(0, 256, (c3.numel() // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    m3, md = torch.randn(cin, generator=g).to(DEV) * 0.3, torch.randn(cin, generator=g).to(DEV) * 0.2
+    i3, idd = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.rand(cin, generator=g) + 0.7).to(DEV)
+    r1 = ops.conv2d_bwd_data_addend_bnstat(dy, wb, spec, (H, W), add, bits, c3, m3, i3)
+    r2 = ops.conv2d_bwd_data_addend_bnstat2(dy, wb, spec, (H, W), add, bits, c3, m3, i3, cd, md, idd)
+    assert r1 is not None and r2 is not None, 'shape not served'
+    assert torch.equal(r2[0], r1[0]) and torch.equal(r2[1], r1[1])
+    L = _lib.lib()
+    M = B * H * W
+    nblk = L.sl_bn_bwd_reduce_rows(M, cin)
+    rp = torch.empty((nblk, 2, cin), dtype=torch.float32, device=DEV)
+    _lib.check(L.sl_bn_bwd_reduce(ops.dt(cd), ops._p(r1[0]), None, None, ops._p(cd), ops._p(md), ops._p(idd), ops._p(rp), M, cin, ops._s()), 'reduce')
+    s_f, s_r = r2[2].double().sum(0), rp.double().sum(0)
+    gd = r1[0].double()
+    sc1 = float(gd.abs().sum((0, 1, 2)).max())
+    sc2 = float((gd * ((cd.double() - md.double()) * idd.double())).abs().sum((0, 1, 2)).max())
+    e1, e2 = float((s_f[0] - s_r[0]).abs().max()) / sc1, float((s_f[1] - s_r[1]).abs().max()) / sc2
+    print('dual MODE 5 %d -> %d: second BatchNorm column sums rel err %.2e / %.2e' % (cin, cout, e1, e2))
+    assert e1 <= 1e-5 and e2 <= 1e-5
+    g3, gdd = torch.rand(cin, device=DEV) + 0.5, torch.rand(cin, device=DEV) + 0.5
+    ones = torch.full((M * cin // 8,), 255, dtype=torch.uint8, device=DEV)
+    a = ops.bn_bwd2(r1[0], ones, c3, m3, i3, g3, cd, md, idd, gdd)
+    b = ops.bn_bwd2(r2[0], None, c3, m3, i3, g3, cd, md, idd, gdd, pre_partials=(r2[1], r2[2]))
+    for u, v, what in zip(a, b, ('dx3', 'dgamma3', 'dbeta3', 'dxd', 'dgammad', 'dbetad')):
+        close(v, u, 'bn_bwd2 from the fused partials: ' + what, tol=1e-2 if what.startswith('dx') else 2e-5)
+
+
+def test_stage_first_blocks_take_the_dual_route(hip):
+    """Model level (R50 bf16, 4 tiles of 256 x 256... the bench shape family): the blocks behind layer1 / layer2 / layer3's first bottleneck hand it both BatchNorms' column
+    sums (three sl_conv2d_bwd_data_addend_bnstat2 launches per backward) and every parameter gradient agrees with the route through the dual reduce pass."""
+    from segland_amd import functional as sf, ops
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    img = fm.formula_image(16, 512, 512, 'dual/img').to(DEV)
+    mask = fm.formula_mask(16, 512, 512, 8, 'dual/mask', block=32, ignore_rows=40).to(DEV)
+    torch.manual_seed(3)
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=torch.bfloat16).to(DEV).train()
+    calls = [0]
+    real = ops.conv2d_bwd_data_addend_bnstat2
+
+    def counted(*a, **k):
+        out = real(*a, **k)
+        calls[0] += out is not None
+        return out
+    grads = {}
+    try:
+        ops.conv2d_bwd_data_addend_bnstat2 = counted
+        for flag in (False, True):
+            calls[0] = 0
+            real_dual = sf._BN_DUAL
+            sf._BN_DUAL = real_dual and flag            # False: no link.bnd -> the first blocks run their own dual... (single) reduce passes
+            try:
+                m.zero_grad(set_to_none=True)
+                d = m(img, mask)
+                d['total_loss'].backward()
+            finally:
+                sf._BN_DUAL = real_dual
+            grads[flag] = ({k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}, calls[0], float(d['total_loss'].detach()))
+    finally:
+        ops.conv2d_bwd_data_addend_bnstat2 = real
+    (g0, n0, l0), (g1, n1, l1) = grads[False], grads[True]
+    num = sum(float(((g1[k] - v) ** 2).sum()) for k, v in g0.items())
+    den = sum(float((v ** 2).sum()) for v in g0.values())
+    print('dual route: %d launches (off: %d); loss %.6f / %.6f; gradients global relative L2 %.3e' % (n1, n0, l1, l0, (num / den) ** 0.5))
+    assert n0 == 0 and n1 == 3 and l0 == l1
+    assert (num / den) ** 0.5 <= 2e-2
