@@ -1724,18 +1724,14 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
   const bool dual = MODE == 5 && p.bn_x2 != nullptr;                   // wave-uniform
   // the gate bytes of the block's 256 rows (N / 8 per row, contiguous over the rows) are copied to the LDS once: read step by step from global memory, each step would
   // pull 8 useful bytes out of every row's line, and 256 lines per step do not survive in the 32 KiB L1 next to the addend stream (measured: 58 -> 73 us on 1024 -> 256)
-  const int mpitch = p.N >= 128 ? p.N / 8 + 16 : p.N / 8;              // N = 64 (8 gate bytes per row): rows packed, two per 16-byte chunk
+  const int mpitch = p.N / 8 + 16;
   unsigned char* msk = smem + (MODE == 5 ? G::LDS : G::OFF_RED);       // MODE 5 keeps the statistic partials too: its gate bytes sit behind them
   if ((MODE == 2 && p.addend_mask) || MODE == 5) {
+    const int cpr = p.N / 128;                                         // 16-byte chunks per row
     const unsigned char* src = (MODE == 5 ? p.gate : p.addend_mask) + (size_t)bm * 256 * (p.N / 8);
-    if (p.N >= 128) {
-      const int cpr = p.N / 128;                                       // 16-byte chunks per row
-      for (int e = tid; e < 256 * cpr; e += 512) {
-        const int row = e / cpr, c = e - row * cpr;
-        *(uint4*)(msk + row * mpitch + c * 16) = *(const uint4*)(src + (size_t)e * 16);
-      }
-    } else {
-      for (int e = tid; e < 256 * (p.N / 8) / 16; e += 512) *(uint4*)(msk + e * 16) = *(const uint4*)(src + (size_t)e * 16);
+    for (int e = tid; e < 256 * cpr; e += 512) {
+      const int row = e / cpr, c = e - row * cpr;
+      *(uint4*)(msk + row * mpitch + c * 16) = *(const uint4*)(src + (size_t)e * 16);
     }
   }
 
@@ -1744,13 +1740,8 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     if (issuer && s + 1 < NS) issueB(s + 1, cur ^ 1);
     if constexpr (MODE == 2 || MODE == 5) {
       const int ncol = s * 64 + sch * 8;
-      if (MODE == 2 || p.addend) {                                     // MODE 5 without an addend: the gated-statistics data gradient (what MODE 3 is on the tile kernels)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
-      } else {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) addv[it] = make_uint4(0, 0, 0, 0);
-      }
+      for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
       if constexpr (MODE == 5) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) cxv[it] = *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
@@ -2228,7 +2219,7 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
       return 7016016;
     if (sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
-        (!p.gate || (!p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || ((p.N % 128 == 0 || (p.gate && p.N == 64)) && p.N <= 1024)))
+        (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
       return 6256064;
     if (sk512_shape(p)) return 9256064;
     if (p9_shape(p)) return 8256256;
@@ -2456,7 +2447,7 @@ extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
   const int cfg = sl_conv2d_tile_config_ex(d, 1, SL_EPI_GATE);
   const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
   const long long M = (long long)d->B * d->H * d->W;
-  if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2 || fam == 6) || bm <= 0 || M % bm != 0) return 0;      // 6: the pixel-stationary kernel's MODE 5 without an addend (round 5)
+  if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2) || bm <= 0 || M % bm != 0) return 0;
   return (int)(M / bm);
 }
 
