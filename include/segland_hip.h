@@ -125,6 +125,12 @@ int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, const void* w
 int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d);
 int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* gate, const void* bn_x,
                                      const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
+/* Data gradient + a half-resolution addend at the even positions: addend_half [B][H/2][W/2][Cin] is the dense data gradient of a 1x1 stride-2 conv on its own output
+ * grid (the downsample branch of a stride-2 stage entry, resnet.py:109-110); its zero-filled full-resolution form is never written.  gate .. stat_partial: all NULL, or
+ * the cross-block statistics of sl_conv2d_bwd_data_addend_bnstat.  Served where sl_conv2d_bwd_data_addend_half_ok(d) != 0 (pixel-stationary kernel, even H and W). */
+int sl_conv2d_bwd_data_addend_half_ok(const SlConvDesc* d);
+int sl_conv2d_bwd_data_addend_half(const SlConvDesc* d, const void* dy, const void* wt, const void* addend_half, const uint8_t* gate, const void* bn_x,
+                                   const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
 /* The dual form: the previous block is the FIRST bottleneck of a stage, whose output ReLU sits behind bn3 AND the downsample BatchNorm (resnet.py:71-76): the gated
  * gradient is reduced against both BatchNorm inputs in one store loop.  stat_partial / stat_partial2: [rows][2][Cin] each, (sum g, sum g * xhat) per BatchNorm
  * (what sl_bn_bwd_reduce2 would produce in a pass of its own over g, bn_x and bn_x2).  Same shapes as above. */

@@ -43,6 +43,7 @@ struct ConvGemmParams {
   // pixel-stationary kernel MODE 5, DUAL: a second BatchNorm behind the same ReLU (bn3 + the downsample BN of a stage's first bottleneck, resnet.py:71-76): the gated result is
   // also reduced against bn_x2; stat_partial2 [gridM][2][N] receives (sum g, sum g * xhat2)
   const void* bn_x2; const float* bn_mean2; const float* bn_invstd2; float* stat_partial2;
+  int addend_half;                      // pixel-stationary kernel: the addend is [B][Hd/2][Wd/2][N] and enters at the EVEN positions only (the data gradient of a 1x1 stride-2 conv, never scattered)
   const float* row_scale;               // [B] per-sample multiplier of (acc * scale + bias), applied before the addend (DropPath), or null
   void* out2;                           // [M][N] or null: GELU of the stored (rounded) acc * scale + bias, written next to `out` (Mlp fc1)
   int M;
@@ -1719,6 +1720,21 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
   float* red = (float*)(smem + G::OFF_RED);
   const int srow = lane >> 3, sch = lane & 7;                          // store phase: row it * 8 + srow, 16-byte chunk sch of the wave's 32 x 64 patch (a full 128-byte line per row)
   const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
+  // addend rows of this lane's four result rows (the same in every step): the result row itself, or -- addend_half -- row (b, y/2, x/2) of the half-resolution
+  // tensor at even (y, x) and none (-1) elsewhere: dx of a 1x1 stride-2 conv is zero at the odd positions (resnet.py:109-110 downsample backward)
+  long long arow[4];
+  if constexpr (MODE == 2 || MODE == 5) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long long m = (long long)orow + it * 8;
+      arow[it] = m;
+      if (p.addend_half) {
+        const int hw = p.Hd * p.Wd;
+        const int b = (int)(m / hw), rem = (int)(m - (long long)b * hw), y = rem / p.Wd, x = rem - y * p.Wd;
+        arow[it] = ((y | x) & 1) ? -1 : ((long long)b * (p.Hd >> 1) + (y >> 1)) * (p.Wd >> 1) + (x >> 1);
+      }
+    }
+  }
   uint4 addv[4], cxv[4], cxv2[4];                                      // MODE 5: cxv = the BN input c of the result's positions (cxv2: the second BatchNorm's, dual form)
   float bmu[8], bis[8], bmu2[8], bis2[8];
   const bool dual = MODE == 5 && p.bn_x2 != nullptr;                   // wave-uniform
@@ -1741,7 +1757,7 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     if constexpr (MODE == 2 || MODE == 5) {
       const int ncol = s * 64 + sch * 8;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
+      for (int it = 0; it < 4; ++it) addv[it] = arow[it] >= 0 ? *(const uint4*)((const T*)p.addend + arow[it] * p.N + ncol) : make_uint4(0, 0, 0, 0);
       if constexpr (MODE == 5) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) cxv[it] = *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
@@ -2487,6 +2503,31 @@ extern "C" int sl_conv2d_bwd_data_addend_bnstat(const SlConvDesc* d, const void*
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
   p.addend = addend; p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// Data gradient + a HALF-RESOLUTION addend at the even positions (resnet.py:109-110, 71-76 backward of a stride-2 stage entry: the downsample branch is a 1x1 stride-2
+// conv, whose data gradient is non-zero at the even positions only): addend_half [B][H/2][W/2][Cin] is the DENSE data gradient of that conv on its own output grid
+// (sl_conv2d_bwd_data of the stride-1 form), added where (y, x) are both even -- the zero-filled full-resolution tensor (3/4 zeros, written and read back as an addend)
+// never exists.  Served: the pixel-stationary kernel's shapes with even H, W (sl_conv2d_bwd_data_addend_half_ok); optional cross-block statistics as in
+// sl_conv2d_bwd_data_addend_bnstat (gate / bn_x / bn_mean / bn_invstd / stat_partial all NULL: plain).
+extern "C" int sl_conv2d_bwd_data_addend_half_ok(const SlConvDesc* d) {
+  if (!d || d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo || (d->H & 1) || (d->W & 1)) return 0;
+  return sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->Cout, d->Cout, d->Cin, (long long)d->B * d->H * d->W) ? 1 : 0;
+}
+extern "C" int sl_conv2d_bwd_data_addend_half(const SlConvDesc* d, const void* dy, const void* wt, const void* addend_half, const uint8_t* gate, const void* bn_x,
+                                              const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && dx && addend_half, "conv bwd_data_addend_half: null buffer");
+  SL_REQUIRE(sl_conv2d_bwd_data_addend_half_ok(d), "conv bwd_data_addend_half: shape not served (sl_conv2d_bwd_data_addend_half_ok == 0)");
+  SL_REQUIRE(!gate || (bn_x && bn_mean && bn_invstd && stat_partial && sl_conv2d_bwd_data_addend_bnstat_rows(d) > 0), "conv bwd_data_addend_half: statistics not served for this shape");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.addend = addend_half; p.addend_half = 1;
+  if (gate) { p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial; }
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

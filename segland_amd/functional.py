@@ -243,13 +243,14 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
+_DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
 _BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm.hip MODE 3)
 _BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
 _BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
-                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None, prevd=None):
+                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None, prevd=None, dx_half=False, addend_half=False):
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres, partial_below).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue.
@@ -271,7 +272,15 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     dx = dw = part_below = None
     if need_dw:
         dw = grad_alias(ops.conv2d_bwd_weight(x, dc, spec, x2=x2, out=gw), gw)
-    if need_dx:
+    if need_dx and dx_half:
+        # a 1x1 stride-2 conv (a stage entry's downsample branch): its data gradient is non-zero at the even positions only -- return the DENSE gradient on the conv's own
+        # output grid; the consumer adds it at the even positions (ops.conv2d_bwd_data_addend_half), the zero-filled tensor is never written
+        _, wb = prepared(conv.weight, c.dtype)
+        dx = ops.conv2d_bwd_data(dc, wb, ConvSpec(spec.cin, spec.cout, 1, 1, 0, 1), dc.shape[1:3])
+    elif need_dx and addend_half:
+        _, wb = prepared(conv.weight, c.dtype)
+        dx, part_below = ops.conv2d_bwd_data_addend_half(dc, wb, spec, x.shape[1:3], addend, prev3)
+    elif need_dx:
         _, wb = prepared(conv.weight, c.dtype)
         if below is not None and _BN_FUSE and addend is None and x2 is None and dx_out is None:
             r = ops.conv2d_bwd_data_bnstat(dc, wb, spec, x.shape[1:3], *below)
@@ -422,7 +431,10 @@ class BottleneckFn(torch.autograd.Function):
         grads_ds = ()
         if ctx.has_ds:
             cd, md, idd = sv[14:17]
-            dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, blk.downsample[0], blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned)
+            dsc = blk.downsample[0]
+            half = (_DS_HALF and need_x and dsc.kernel_size == (1, 1) and dsc.stride == (2, 2) and dsc.padding == (0, 0) and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
+                    and ops.conv2d_bwd_data_addend_half_ok(x, spec_of(blk.conv1)))
+            dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, dsc, blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned, dx_half=half)
             grads_ds = (dwd, dgd, dbd)
             addend, abits = dxd, None
         elif dres is not None:
@@ -433,7 +445,7 @@ class BottleneckFn(torch.autograd.Function):
             prev3 = None
         dx, dw1, dg1, db1, _, pp = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
                                                addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1,
-                                               prev3=prev3, prevd=prevd)
+                                               prev3=prev3, prevd=prevd, addend_half=ctx.has_ds and half)
         if pp is not None and prev3 is not None:
             plink.pre3 = (dx.data_ptr(), tuple(dx.shape), pp)
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds

@@ -291,6 +291,39 @@ def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean,
     return dx, part
 
 
+def conv2d_bwd_data_addend_half_ok(x, spec):
+    """Would conv2d_bwd_data_addend_half serve the data gradient of conv `spec` on input x [B,H,W,Cin]?"""
+    if x.dtype != torch.bfloat16:
+        return False
+    B, H, W, _ = x.shape
+    return _lib.lib().sl_conv2d_bwd_data_addend_half_ok(C.byref(conv_desc(x.dtype, B, H, W, spec, None))) > 0
+
+
+def conv2d_bwd_data_addend_half(dy, wb, spec, in_hw, addend_half, prev3=None):
+    """dx = data gradient + addend_half [B,H/2,W/2,Cin] at the even positions (the dense data gradient of a 1x1 stride-2 conv on its own grid; its zero-filled
+    full-resolution form never exists).  prev3 = (gate bits, bn_x, mean, invstd): also the cross-block statistics of conv2d_bwd_data_addend_bnstat.
+    -> (dx, partial or None)."""
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    assert addend_half.shape == (B, H // 2, W // 2, spec.cin) and addend_half.is_contiguous()
+    dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    part = None
+    gate = bn_x = mean = invstd = None
+    if prev3 is not None:
+        rows = L.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d))
+        if rows > 0:
+            gate, bn_x, mean, invstd = prev3
+            part = _f32((rows, 2, spec.cin), dy.device)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_ADDEND | (EPI_GATE if part is not None else 0))
+    check(L.sl_conv2d_bwd_data_addend_half(C.byref(d), _p(dy), _p(wb), _p(addend_half), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()),
+          'conv2d_bwd_data_addend_half')
+    if tok is not None:
+        PROFILER.end(tok, addend_half.numel() * addend_half.element_size() + (bn_x.numel() * bn_x.element_size() + gate.numel() if part is not None else 0))
+    return dx, part
+
+
 def conv2d_bwd_data_addend_bnstat2(dy, wb, spec, in_hw, addend, gate, bn_x, mean, invstd, bn_x2, mean2, invstd2):
     """The dual form of conv2d_bwd_data_addend_bnstat: the gated result is reduced against the inputs of TWO BatchNorms behind the same ReLU (bn3 + the downsample
     BatchNorm of a stage's first bottleneck).  -> (g, partial, partial2) or None when the shape is not served."""

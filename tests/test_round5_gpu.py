@@ -308,3 +308,55 @@ def test_stage_first_blocks_take_the_dual_route(hip):
     print('dual route: %d launches (off: %d); loss %.6f / %.6f; gradients global relative L2 %.3e' % (n1, n0, l1, l0, (num / den) ** 0.5))
     assert n0 == 0 and n1 == 3 and l0 == l1
     assert (num / den) ** 0.5 <= 2e-2
+
+
+def test_half_resolution_addend_of_a_stride2_downsample(hip):
+    """resnet.py:109-110 / 71-76 backward at a stride-2 stage entry: the downsample branch's data gradient (1x1 stride 2) is non-zero at the even positions only.  It stays
+    on its own 64 x 64 grid and enters conv1's data gradient there (sl_conv2d_bwd_data_addend_half): bit-identical to the route through the zero-filled tensor, with and
+    without the cross-block statistics; model level: all gradients agree with the scattered route."""
+    from segland_amd import functional as sf, ops
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    B, H, W, cin, cout = 16, 128, 128, 256, 128
+    g = torch.Generator(device='cpu').manual_seed(9)
+    spec = ops.ConvSpec(cin, cout, 1, 1, 0, 1)
+    _, wb = ops.weight_prep((torch.randn(cout, cin, 1, 1, generator=g) * (3.0 / cin) ** 0.5).to(DEV), torch.bfloat16)
+    dy = torch.randn(B, H, W, cout, generator=g).to(torch.bfloat16).to(DEV)
+    half = torch.randn(B, H // 2, W // 2, cin, generator=g).to(torch.bfloat16).to(DEV)
+    full = torch.zeros(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+    full[:, ::2, ::2] = half
+    x_like = torch.empty(B, H, W, cin, dtype=torch.bfloat16, device=DEV)
+    assert ops.conv2d_bwd_data_addend_half_ok(x_like, spec)
+    dx, part = ops.conv2d_bwd_data_addend_half(dy, wb, spec, (H, W), half)
+    assert part is None and torch.equal(dx, ops.conv2d_bwd_data(dy, wb, spec, (H, W), addend=full))
+    c3 = (torch.randn(B, H, W, cin, generator=g) * 2 + 0.5).to(torch.bfloat16).to(DEV)
+    bits = torch.randint(0, 256, (c3.numel() // 8,), dtype=torch.uint8, generator=g).to(DEV)
+    m3, i3 = torch.randn(cin, generator=g).to(DEV) * 0.3, (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    dx2, part2 = ops.conv2d_bwd_data_addend_half(dy, wb, spec, (H, W), half, (bits, c3, m3, i3))
+    ref = ops.conv2d_bwd_data_addend_bnstat(dy, wb, spec, (H, W), full, bits, c3, m3, i3)
+    assert part2 is not None and torch.equal(dx2, ref[0]) and torch.equal(part2, ref[1])
+    # model level
+    img = fm.formula_image(16, 512, 512, 'half/img').to(DEV)                 # the pixel-stationary kernel takes layers of >= 65 536 pixels
+    mask = fm.formula_mask(16, 512, 512, 8, 'half/mask', block=32, ignore_rows=20).to(DEV)
+    torch.manual_seed(3)
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=torch.bfloat16).to(DEV).train()
+    calls, real, grads = [0], ops.conv2d_bwd_data_addend_half, {}
+
+    def counted(*a, **k):
+        calls[0] += 1
+        return real(*a, **k)
+    try:
+        ops.conv2d_bwd_data_addend_half = counted
+        for flag in (False, True):
+            sf._DS_HALF, calls[0] = flag, 0
+            m.zero_grad(set_to_none=True)
+            d = m(img, mask)
+            d['total_loss'].backward()
+            grads[flag] = ({k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}, calls[0], float(d['total_loss'].detach()))
+    finally:
+        ops.conv2d_bwd_data_addend_half, sf._DS_HALF = real, True
+    (g0, n0, l0), (g1, n1, l1) = grads[False], grads[True]
+    num = sum(float(((g1[k] - v) ** 2).sum()) for k, v in g0.items())
+    den = sum(float((v ** 2).sum()) for v in g0.values())
+    print('half-resolution addend: %d launch(es) (off: %d); loss %.6f / %.6f; gradients global relative L2 %.3e' % (n1, n0, l1, l0, (num / den) ** 0.5))
+    assert n0 == 0 and n1 == 1 and l0 == l1 and (num / den) ** 0.5 <= 1e-2
