@@ -213,13 +213,30 @@ class BucketedReplica(nn.Module):
             w.wait()
         return loss, call(upd)
 
-    def agree(self, ok):
-        """True when EVERY rank says ok (MIN all-reduce of one flag; one host read-back, used once per capture attempt)."""
+    def agree(self, ok, signature=None, timeout_s=120.0):
+        """True when EVERY rank says ok AND every rank is attempting the capture of the SAME input signature (one MIN all-reduce of (flag, h, -h) with h a hash of the
+        signature; one host read-back, used once per capture attempt).  The ranks must reach their attempts at the same step (DistributedSampler + drop_last give every
+        rank the same signature sequence); a rank whose sequence diverged would sit here while the others issue bucket all-reduces -- the wait is bounded, and what is
+        raised names the cause (round-4 advisor) instead of a silent hang."""
         if not self.active:
             return bool(ok)
-        flag = torch.full((1,), 1.0 if ok else 0.0, dtype=torch.float32, device=self.buckets[0].device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        return bool(flag.item() > 0.5)
+        import datetime
+        import zlib
+        h = float(zlib.crc32(repr(signature).encode()) % (1 << 22)) if signature is not None else 0.0      # exact in fp32
+        flag = torch.tensor([1.0 if ok else 0.0, h, -h], dtype=torch.float32, device=self.buckets[0].device)
+        try:
+            work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+            if work.wait(datetime.timedelta(seconds=timeout_s)) is False:
+                raise RuntimeError('timed out')
+            v = flag.tolist()
+        except Exception as e:                                # noqa: BLE001
+            raise RuntimeError('bucket_step: the ranks did not all reach a capture attempt at the same step (%s).  Every rank must see the same sequence of input '
+                               'signatures (DistributedSampler + drop_last); start with --no-step-graph to issue the steps kernel by kernel.' % e) from e
+        if v[1] != -v[2]:
+            import logging
+            logging.getLogger('Segmentation').warning('bucket_step: the ranks attempted a capture with different input signatures; all stay kernel by kernel')
+            return False
+        return bool(v[0] > 0.5)
 
     def train_iteration(self, optimizer, img, mask, double_step=True):
         """The loop body of train_base.py:250-264 issued kernel by kernel (what GraphedBucketStep replays)."""
@@ -284,7 +301,7 @@ class GraphedBucketStep:
             if torch.cuda.is_available():
                 from . import ops
                 ops.after_failed_capture()
-        if not self.replica.agree(err is None):
+        if not self.replica.agree(err is None, signature=key):
             self.graphs, self.key = None, None
             from . import functional
             functional.after_failed_capture()                # counters queued and caches filled by the attempt (here or on the rank that did capture): nothing of it ran

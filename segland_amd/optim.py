@@ -157,7 +157,10 @@ class SGD(torch.optim.Optimizer):
         self._cap = None              # HIP-graph capture: persistent {pinned table, device table, device (lr, wd) vector}
         self._captured = False
 
-    def _records(self):
+    def _records(self, capturing=False):
+        """The per-parameter launch records.  (lr, weight_decay) are NOT in them: the kernel reads both from the device vector `hyper` (one entry pair per group), so the
+        records -- and the device table built from them -- change only when a pointer does (round-4 advisor: ft_pop changes lr every iteration, which used to rebuild the
+        table, pin a fresh host tensor and copy it on every kernel-by-kernel step)."""
         rec, n, chunks, mom, dev = bytearray(), 0, 0, None, None
         for gi, group in enumerate(self.param_groups):
             if mom is not None and group['momentum'] != mom:
@@ -173,9 +176,12 @@ class SGD(torch.optim.Optimizer):
                 if mom:
                     st = self.state[p]
                     if 'momentum_buffer' not in st or st['momentum_buffer'] is None:
+                        if capturing:        # an allocation + fill recorded into the graph would zero the buffer again on every replay
+                            raise RuntimeError('segland_amd.optim.SGD: a parameter received its first gradient inside a captured step (requires_grad toggled after '
+                                               'capture_begin()?); capture again')
                         st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)      # torch: buf = clone(d) on the first step == 0 * momentum + d
                     buf = st['momentum_buffer'].data_ptr()
-                rec += struct.pack('<QQQQqffqii', p.data_ptr(), p.grad.data_ptr(), buf, 0, p.numel(), group['lr'], group['weight_decay'], chunks, gi, 0)
+                rec += struct.pack('<QQQQqffqii', p.data_ptr(), p.grad.data_ptr(), buf, 0, p.numel(), 0.0, 0.0, chunks, gi, 0)
                 chunks += (p.numel() + 4095) // 4096
                 n += 1
         return rec, n, chunks, mom or 0.0, dev
@@ -189,7 +195,7 @@ class SGD(torch.optim.Optimizer):
         capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
         if capturing and self._cap is None:
             raise RuntimeError('segland_amd.optim.SGD: call capture_begin() before capturing step() into a graph (segland_amd.graph_step does)')
-        rec, n, chunks, mom, dev = self._records()
+        rec, n, chunks, mom, dev = self._records(capturing)
         if n == 0:
             return loss
         if capturing:
@@ -203,8 +209,12 @@ class SGD(torch.optim.Optimizer):
             return loss
         ent = self._table
         if ent is None or ent[0] != rec:
-            ent = self._table = (bytes(rec), torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True))
-        ops.sgd_multi(ent[1], n, chunks, mom, grad_scale=grad_scale)
+            if 2 * len(self.param_groups) > 16:
+                raise RuntimeError('segland_amd.optim.SGD: at most 8 parameter groups')
+            ent = self._table = (bytes(rec), torch.frombuffer(bytearray(rec), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True),
+                                 torch.zeros(16, dtype=torch.float32, device=dev))
+        ops.store_floats(ent[2], [v for g in self.param_groups for v in (g['lr'], g['weight_decay'])])      # kernel arguments of a one-block launch: no host -> device copy
+        ops.sgd_multi(ent[1], n, chunks, mom, hyper=ent[2], grad_scale=grad_scale)
         return loss
 
     # ---- whole-step HIP graphs (segland_amd/graph_step.py): same protocol as AdamW

@@ -92,3 +92,43 @@ def test_kernel_dispatch_and_statistic_rows_by_shape(lib):
     # a small map of the same layer stays on the tile kernels (128-row blocks below 24 576 pixels)
     d = desc(2, 64, 64, 64, 64, 3, pad=1)
     assert lib.sl_conv2d_tile_config(C.byref(d), 0) // 1000000 == 2 and lib.sl_conv2d_stat_rows(C.byref(d)) == 2 * 64 * 64 // 128
+
+
+def _desc(dtype, B, H, W, cin, cout, k, stride, pad, dil):
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return _lib.SlConvDesc(dtype, B, H, W, cin, cout, k, k, stride, pad, dil, Ho, Wo, cin)
+
+
+def test_dispatch_queries_answer_from_the_dispatch_itself(lib):
+    """Round 5: sl_conv2d_tile_config(_ex) and sl_conv2d_wgrad_config are the predicate chains the launches switch on (host code only: runs without a GPU).
+    ResNet-50 bench shapes (B 16, 64 x 64 / 128 x 128): which kernel, by epilogue."""
+    STATS, AFFINE, ADDEND, BITS, GATE = 1, 2, 4, 8, 16
+    fam = lambda d, mode, epi: lib.sl_conv2d_tile_config_ex(C.byref(d), mode, epi) // 1000000
+    d = _desc(_lib.SL_BF16, 16, 64, 64, 512, 2048, 1, 1, 0, 1)
+    assert lib.sl_conv2d_tile_config_ex(C.byref(d), 0, STATS) == 5256256 and lib.sl_conv2d_tile_config(C.byref(d), 0) == 5256256      # half-tile kernel (the K = 512 pixel-stationary form is off by default)
+    d = _desc(_lib.SL_BF16, 16, 64, 64, 256, 1024, 1, 1, 0, 1)
+    assert fam(d, 0, STATS) == 6 and fam(d, 0, AFFINE) == 5                  # pixel-stationary for the training form, half-tile for the folded-BN inference form
+    assert fam(d, 1, GATE) == 5                                               # conv3's data gradient (K = 1024) with the gated-statistics store phase
+    d = _desc(_lib.SL_BF16, 16, 64, 64, 1024, 256, 1, 1, 0, 1)
+    assert fam(d, 1, ADDEND | GATE) == 6 and fam(d, 1, ADDEND | BITS) == 6    # conv1's data gradient (K = 256): MODE 5 / MODE 2 of the pixel-stationary kernel
+    assert lib.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d)) == 16 * 64 * 64 // 256
+    d = _desc(_lib.SL_BF16, 16, 64, 64, 2048, 512, 1, 1, 0, 1)
+    assert lib.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d)) == 0          # K = 512: the half-tile kernel has no cross-block store phase (profiles/r5_ab_bn_fusions.txt)
+    d = _desc(_lib.SL_BF16, 16, 64, 64, 512, 512, 3, 1, 4, 4)
+    assert fam(d, 0, STATS) == 8 and fam(d, 1, GATE) == 8 and lib.sl_conv2d_wgrad_config(C.byref(d)) == 3      # 3x3 patch kernel both ways, nine-tap weight gradient
+    d = _desc(_lib.SL_BF16, 2, 64, 64, 2048, 512, 3, 1, 1, 1)
+    assert lib.sl_conv2d_tile_config_ex(C.byref(d), 0, AFFINE | 32) >= 10000000      # the fine-tune pair's pyramid conv: split-K on the patch kernel
+    d = _desc(_lib.SL_BF16, 16, 128, 128, 128, 128, 3, 2, 1, 1)
+    assert lib.sl_conv2d_wgrad_config(C.byref(d)) != 3                       # stride 2: per-tap kernels
+    d = _desc(_lib.SL_F32, 16, 64, 64, 256, 256, 3, 1, 2, 2)
+    assert lib.sl_conv2d_wgrad_config(C.byref(d)) != 3                       # fp32 parity mode: per-tap kernels
+    out = (C.c_int * 8)()
+    for shape, blocks in (((16, 64, 64, 2048, 512, 1), 256), ((16, 64, 64, 512, 512, 4), 256), ((16, 64, 64, 256, 256, 2), 256), ((16, 64, 64, 128, 128, 1), 256)):
+        B, H, W, cin, cout, dil = shape
+        d = _desc(_lib.SL_BF16, B, H, W, cin, cout, 3, 1, dil, dil)
+        assert lib.sl_debug_wgrad3_plan(C.byref(d), out) == 1 and out[7] == blocks, (shape, list(out))
+        served, ppu, L, SP, ppb, splits, tiles, nblk = list(out)
+        units = B * dil * dil * (W // dil // 16)
+        assert tiles == (cout // 128) * (cin // 64) and splits * ppb >= units * ppu and SP == L + (1 if ppu == 1 else 2) and L * ppu >= H // dil
+        assert lib.sl_conv2d_bwd_weight_workspace(C.byref(d)) >= nblk * 8 * 4 * 9 * 64 * 4 * 4
