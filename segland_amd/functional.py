@@ -243,6 +243,7 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
+_STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
 _BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm.hip MODE 3)
 _BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
@@ -591,7 +592,7 @@ class PPMFn(torch.autograd.Function):
         gstage, off = [], 0
         grouped = None
         call = sv[9 + 3 * nl]
-        if _BN_FUSE and call.numel() and not any(sync_world(st[2]) for st in dec.stages):
+        if _BN_FUSE and _STAGE_BN_GROUPED and call.numel() and not any(sync_world(st[2]) for st in dec.stages):
             # all levels' BatchNorm + ReLU backward in ONE launch (round 5): twelve latency-bound launches less per step
             dsts = [(grad_dst(st[2].weight), grad_dst(st[2].bias)) if need_w else (None, None) for st in dec.stages]
             tmp = torch.empty((nl, 2, Cs), dtype=torch.float32, device=x4.device)

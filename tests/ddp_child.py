@@ -93,6 +93,11 @@ def main():
             print('ddp_child: wrapped %s eval done' % wrapped, file=sys.stderr, flush=True)
             return {k: v.detach().float().cpu() for k, v in m.state_dict().items()}, losses, logits
 
+        if sync in ('force', 'bucket_force'):
+            # the comparison below is between a SyncBatchNorm run and a plain-BatchNorm run to 2e-4 after AdamW iterations: that needs the SAME kernels on both sides (Adam's
+            # first steps turn last-bit differences of near-zero gradients into O(lr) parameter differences).  The one-launch backward of the pyramid stages' BatchNorms
+            # (round 5) cannot serve SyncBatchNorm (a collective sits between its two sweeps), so the plain run takes the per-level chain here as well.
+            sf._STAGE_BN_GROUPED = False
         sf.set_sync_bn('0')
         ref_sd, ref_losses, ref_logits = run(False, nn.BatchNorm2d)
         sf.set_sync_bn('force' if sync in ('force', 'bucket_force') else '0')

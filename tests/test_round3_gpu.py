@@ -317,16 +317,21 @@ def test_bn3_statistics_from_the_next_blocks_data_gradient(hip):
     torch.manual_seed(3)
     m = GFSS_Model(n_base=7, criterion=OrthLoss(255), backbone='resnet50', pretrained_model=None, dilated=True, os=8, compute_dtype=torch.bfloat16).to(DEV).train()
     calls = [0]
-    real = ops.conv2d_bwd_data_addend_bnstat
+    real, real_half = ops.conv2d_bwd_data_addend_bnstat, ops.conv2d_bwd_data_addend_half
 
     def counted(*a, **k):
         out = real(*a, **k)
         calls[0] += out is not None
         return out
+
+    def counted_half(*a, **k):          # round 5: layer2's first block hands layer1's last block its statistics through the half-resolution-addend form
+        out = real_half(*a, **k)
+        calls[0] += out[1] is not None
+        return out
     grads = {}
     old = sf._BN_CROSS
     try:
-        ops.conv2d_bwd_data_addend_bnstat = counted
+        ops.conv2d_bwd_data_addend_bnstat, ops.conv2d_bwd_data_addend_half = counted, counted_half
         for flag in (False, True):
             sf._BN_CROSS = flag
             calls[0] = 0
@@ -335,7 +340,7 @@ def test_bn3_statistics_from_the_next_blocks_data_gradient(hip):
             d['total_loss'].backward()
             grads[flag] = ({k: p.grad.detach().float().clone() for k, p in m.named_parameters() if p.grad is not None}, calls[0], float(d['total_loss'].detach()))
     finally:
-        ops.conv2d_bwd_data_addend_bnstat = real
+        ops.conv2d_bwd_data_addend_bnstat, ops.conv2d_bwd_data_addend_half = real, real_half
         sf._BN_CROSS = old
     (g0, n0, l0), (g1, n1, l1) = grads[False], grads[True]
     print('fused block boundaries: %d (unfused run: %d); loss %.6f / %.6f' % (n1, n0, l1, l0))
