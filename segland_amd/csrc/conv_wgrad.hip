@@ -235,7 +235,7 @@ __device__ __attribute__((aligned(256))) unsigned char g_wzero_page[256];
 
 typedef __attribute__((address_space(3))) void wlds_void_t;
 typedef const __attribute__((address_space(1))) void wgbl_void_t;
-__device__ __forceinline__ void wglds16_asm(const void* g, unsigned lds_addr) {      // see conv_gemm.hip: glds16_asm
+__device__ __forceinline__ void wglds16_asm(const void* g, unsigned lds_addr) {      // see conv_gemm_common.h: glds16_asm
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");

@@ -46,7 +46,7 @@ __device__ __forceinline__ uint2 w3_tr16(const unsigned char* p) {       // ds_r
   const w3s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) w3s16x4_t*)(p));
   return __builtin_bit_cast(uint2, v);
 }
-__device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_addr) {      // see conv_gemm.hip: glds16_asm
+__device__ __forceinline__ void w3_glds16(const void* g, unsigned lds_addr) {      // see conv_gemm_common.h: glds16_asm
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");

@@ -325,7 +325,7 @@ __global__ void ppm_upsample_bwd_y_kernel(PpmGeom g, int Cs, const float* __rest
 // u_tap = [pixel shifted by the tap is inside the map] * (bilinear weight of the shifted pixel on cell (i,j)), which is
 // separable in y and x.  Exact by linearity; removes 77 of the 154.6 GFLOP/tile of this conv (and of its dgrad / wgrad).
 
-// weight re-layout W_oihw [N][Ctot][3][3] -> per level wq_f [9N][Cs] (1x1 forward layout) and wq_b [Cs][9N] (dgrad layout): sl_ppm_wq_prep in conv_gemm.hip
+// weight re-layout W_oihw [N][Ctot][3][3] -> per level wq_f [9N][Cs] (1x1 forward layout) and wq_b [Cs][9N] (dgrad layout): sl_ppm_wq_prep in conv_weight_prep.hip
 
 // dwq [l][(tap,n)][c] -> dw_oihw[n][l*Cs + c][tap]
 __global__ void ppm_dwq_scatter_kernel(const float* __restrict__ dwq, int N, int Ctot, int Cs, int nl, float* __restrict__ dw) {

@@ -1,6 +1,6 @@
 // Swin-POP path on gfx950: the token-side kernels of networks/backbones/swintransformer.py and the
 // resize / gather helpers of networks/swin_pop.py's UperNet_Decoder_Plus.  The dense contractions (qkv / proj / fc1 / fc2 / patch-merge
-// reduction Linear layers, 3x3 decoder convs) run on the MFMA implicit-GEMM kernels of conv_gemm.hip / conv_wgrad.hip: a token map
+// reduction Linear layers, 3x3 decoder convs) run on the MFMA implicit-GEMM kernels of conv_gemm*.hip / conv_wgrad.hip: a token map
 // [B,H,W,Cp] IS an NHWC image and nn.Linear a 1x1 conv.  Channel counts that are not multiples of 64 (Swin-T/S: C = 96) are carried with
 // a zero-filled channel pad (pitch Cp = 128); every kernel here takes (C, pitch) and keeps the pad at exactly zero.
 //

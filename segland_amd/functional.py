@@ -245,7 +245,7 @@ def _frozen(ctx, *bns):
 
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
-_BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm.hip MODE 3)
+_BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm_common.h: conv_epilogue_fast MODE 3)
 _BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
 _BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
 

@@ -246,7 +246,7 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
 
 def conv2d_bwd_data_bnstat(dy, wb, spec, in_hw, gate, bn_x, mean, invstd):
     """Data gradient gated with the ReLU bits `gate` of its own positions + the reduce pass of the BatchNorm backward below it in the epilogue
-    (csrc/conv_gemm.hip MODE 3).  -> (g, partial [rows][2][Cin]) or None when the shape is not served (caller: conv2d_bwd_data + bn_bwd)."""
+    (csrc/conv_gemm_common.h: conv_epilogue_fast MODE 3).  -> (g, partial [rows][2][Cin]) or None when the shape is not served (caller: conv2d_bwd_data + bn_bwd)."""
     B = dy.shape[0]
     H, W = in_hw
     d = conv_desc(dy.dtype, B, H, W, spec, None)
@@ -273,7 +273,7 @@ def conv2d_bwd_data_addend_bnstat_ok(x, spec):
 
 def conv2d_bwd_data_addend_bnstat(dy, wb, spec, in_hw, addend, gate, bn_x, mean, invstd):
     """dx = data gradient + addend, gated with the ReLU bits `gate` of the block output it is the gradient of, + that block's bn3 backward column
-    sums (csrc/conv_gemm.hip: pixel-stationary kernel MODE 5).  -> (g, partial [rows][2][Cin]) or None when the shape is not served."""
+    sums (csrc/conv_gemm_sk.hip: pixel-stationary kernel MODE 5).  -> (g, partial [rows][2][Cin]) or None when the shape is not served."""
     B = dy.shape[0]
     H, W = in_hw
     d = conv_desc(dy.dtype, B, H, W, spec, None)

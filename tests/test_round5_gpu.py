@@ -360,3 +360,88 @@ def test_half_resolution_addend_of_a_stride2_downsample(hip):
     den = sum(float((v ** 2).sum()) for v in g0.values())
     print('half-resolution addend: %d launch(es) (off: %d); loss %.6f / %.6f; gradients global relative L2 %.3e' % (n1, n0, l1, l0, (num / den) ** 0.5))
     assert n0 == 0 and n1 == 1 and l0 == l1 and (num / den) ** 0.5 <= 1e-2
+
+
+R192_CASES = [
+    # B, H, W, K, N, k        Swin-T stage 2 on a 512 x 512 tile: 64 x 64 tokens, 192 channels (swintransformer.py:127-140, 249-252)
+    (8, 64, 64, 768, 192, 1),      # Mlp fc2
+    (2, 64, 64, 192, 576, 1),      # qkv: three 192-column tiles
+    (1, 100, 60, 192, 192, 1),     # proj on a ragged row count (6 000 rows: a partial last row tile)
+    (2, 32, 48, 192, 192, 3),      # a 3x3 gather with 192 output channels
+]
+
+
+@pytest.mark.parametrize('case', R192_CASES)
+def test_192_column_ring_tile(hip, case):
+    """Output widths that are 64- but not 128-multiples (192, 576: Swin-T stage 2) run on 128 x 192 tiles of the 4-stage ring kernel instead of the two-stage 256 x 64
+    kernel: forward (+ BN statistic partials), the Linear epilogue (bias, DropPath row scale, residual, GELU side output) and the data gradient (+ addend), against fp32
+    torch and, for the 1x1 layers, bit-identical to the kernel they ran on before (same MFMA sequence per output element)."""
+    from segland_amd import ops
+    dt_ = torch.bfloat16
+    B, H, W, K, N, k = case
+    M = B * H * W
+    torch.manual_seed(5)
+    x = torch.randn(B, H, W, K, device=DEV).to(dt_)
+    w = (torch.randn(N, K, k, k, device=DEV) * (1.0 / (K * k * k)) ** 0.5)
+    spec = ops.ConvSpec(K, N, k, 1, k // 2, 1)
+    wf, wb = ops.weight_prep(w, dt_)
+    d = ops.conv_desc(dt_, B, H, W, spec, None)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(dt_).float(), padding=k // 2).permute(0, 2, 3, 1).reshape(M, N)
+
+    def both(fn):
+        hip.sl_debug_conv_ring192(1)
+        assert hip.sl_conv2d_tile_config_ex(C.byref(d), 0, 0) == 4128192
+        a = fn()
+        hip.sl_debug_conv_ring192(0)
+        try:
+            assert hip.sl_conv2d_tile_config_ex(C.byref(d), 0, 0) != 4128192
+            b = fn()
+        finally:
+            hip.sl_debug_conv_ring192(1)
+        return a, b
+
+    (y, part), (y0, part0) = both(lambda: ops.conv2d_fwd(x, wf, spec, want_stats=True))
+    close(y.float().reshape(M, N), ref, '192-column tile forward %s' % (case,))
+    if k == 1:          # a 3x3 gather walks (channel chunk, tap) in another order on the ring: same sums, other rounding
+        assert torch.equal(y, y0), 'forward: 128 x 192 ring tile vs two-stage kernel'
+    else:
+        close(y, y0, 'forward vs two-stage kernel', tol=1e-2)
+    yr = y.float().reshape(M, N)
+    close(part.sum(0)[0], yr.sum(0), 'statistics: sum', tol=1e-4)
+    close(part.sum(0)[1], (yr * yr).sum(0), 'statistics: sum of squares', tol=1e-4)
+    if k == 1:
+        bias = torch.randn(N, device=DEV)
+        rs = torch.rand(B, device=DEV) + 0.5
+        res = torch.randn(B, H, W, N, device=DEV).to(dt_)
+        (l1, g1), (l0, g0) = both(lambda: ops.linear_fwd(x, wf, spec, bias=bias, want_gelu=True))
+        close(l1.float().reshape(M, N), ref + bias, 'Linear + bias')
+        close(g1.float().reshape(M, N), F.gelu(l1.float().reshape(M, N)), 'GELU side output', tol=1e-2)
+        assert torch.equal(l1, l0) and torch.equal(g1, g0)
+        l1, l0 = both(lambda: ops.linear_fwd(x, wf, spec, bias=bias, row_scale=rs, residual=res))
+        want = (ref + bias).reshape(B, H * W, N) * rs.view(B, 1, 1) + res.float().reshape(B, H * W, N)
+        close(l1.float().reshape(B, H * W, N), want, 'Linear + DropPath scale + residual')
+        assert torch.equal(l1, l0)
+    # data gradient of a conv N -> K' with K' = 192-multiple: dy has Kd channels, dx has Nd = 192 / 576
+    Kd, Nd = (K, N)
+    spec_b = ops.ConvSpec(Nd, Kd, k, 1, k // 2, 1)
+    w2 = (torch.randn(Kd, Nd, k, k, device=DEV) * (1.0 / (Kd * k * k)) ** 0.5)
+    _, wb2 = ops.weight_prep(w2, dt_)
+    refd = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w2.to(dt_).float(), padding=k // 2).permute(0, 2, 3, 1).reshape(M, Nd)
+    add = torch.randn(B, H, W, Nd, device=DEV).to(dt_)
+    db = ops.conv_desc(dt_, B, H, W, spec_b, None)
+    hip.sl_debug_conv_ring192(1)
+    assert hip.sl_conv2d_tile_config_ex(C.byref(db), 1, 0) == 4128192
+    g1 = ops.conv2d_bwd_data(x, wb2, spec_b, (H, W))
+    ga1 = ops.conv2d_bwd_data(x, wb2, spec_b, (H, W), addend=add)
+    hip.sl_debug_conv_ring192(0)
+    try:
+        g0 = ops.conv2d_bwd_data(x, wb2, spec_b, (H, W))
+        ga0 = ops.conv2d_bwd_data(x, wb2, spec_b, (H, W), addend=add)
+    finally:
+        hip.sl_debug_conv_ring192(1)
+    close(g1.float().reshape(M, Nd), refd, 'data gradient')
+    close(ga1.float().reshape(M, Nd), refd.to(dt_).float() + add.float().reshape(M, Nd), 'data gradient + addend')
+    if k == 1:
+        assert torch.equal(g1, g0) and torch.equal(ga1, ga0), 'data gradient: 128 x 192 ring tile vs two-stage kernel'
+    else:
+        close(g1, g0, 'data gradient vs two-stage kernel', tol=1e-2)
