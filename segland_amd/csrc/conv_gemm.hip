@@ -33,7 +33,7 @@ static bool ring192_on() {
   if (g_ring192 < 0) g_ring192 = (getenv("SEGLAND_CONV_RING192") && getenv("SEGLAND_CONV_RING192")[0] == '0') ? 0 : 1;
   return g_ring192 != 0;
 }
-long long g_ring64_max_tiles = 160;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
+long long g_ring64_max_tiles = 256;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
 // Which kernel a launch runs on: 1000000 * family + 1000 * BM + BN (family 9 = pixel-stationary K = 512, 8 = 3x3 patch (+ 10000000: split-K), 7 = 64 -> 64 patch,
 // 6 = pixel-stationary K <= 256, 5 = half-tile, 4 = ring, 2 = two-stage glds).  The ONE predicate chain: launch_gemm switches on it, sl_conv2d_tile_config(_ex) and
 // sl_conv2d_stat_rows answer from it (round-4 advisor: the query had drifted from the dispatch).
@@ -72,6 +72,9 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
     // from 256 tiles on the smaller tile loses (2048 -> 512 36.1 -> 38.9, 256 -> 1024 11.1 -> 13.3).  End to end, one box: 440.9 -> 454.3 pairs/s (ResNet-50), 389 -> 406 (Swin-T),
     // Swin-T training step 733.9 -> 736.8 tiles/s; a limit of 200 / 300 tiles: 453.1 / 447.5 pairs/s.  Launches without BN statistic partials only (a training conv's
     // partials keep the 128-row granularity sl_conv2d_stat_rows promises).
+    // Round 5 (profiles/r5_ab_ring64_geom.txt): the 64-row tiles stream 128-byte stage rows (conv_gemm_tiles.hip: launch_tile): 1024 -> 256 16.0 -> 13.6 us, 3x3 256 -> 256 d2
+    // 30.7 -> 26.0, 2048 -> 512 (256 tiles) 36.7 -> 32.6 where it lost before; 459.5 -> 473 pairs/s (ResNet-50), 400 -> 413 (Swin-T) with the limit at 256 tiles
+    // (320: 469, 512: 465).  1x1 layers stay bit-identical to the 128 x 128 tiles; 3x3 layers sum (64-channel chunk, tap) instead of (32-channel chunk, tap).
     if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_ring64_max_tiles) return 4064128;
   }
   if (n128 && p.M >= 128LL * RING128_MIN) return 4128128;

@@ -373,7 +373,12 @@ int launch_glds(ConvGemmParams& p, hipStream_t st) {
 }  // namespace
 
 int slconv::launch_tile(int cfg, int dtype, ConvGemmParams& p, hipStream_t st) {
-  if (dtype == SL_BF16 && cfg == 4064128) return launch_ring<bf16_t, 64, 128, 2, 2, 64, 4>(p, st);
+  if (dtype == SL_BF16 && cfg == 4064128) {
+    // 64 x 128 tiles of the few-tile inference layers: 128-byte stage rows (half as many stages per K, twice the bytes in flight per wave).  Up to 256 tiles one block
+    // per CU is resident anyway: four stages (96 KiB); beyond, three stages (72 KiB) keep two blocks per CU.  profiles/r5_ab_ring64_geom.txt
+    if ((long long)cdiv(p.M, 64) * (p.N / 128) <= 256) return launch_ring<bf16_t, 64, 128, 2, 2, 128, 4>(p, st);
+    return launch_ring<bf16_t, 64, 128, 2, 2, 128, 3>(p, st);
+  }
   if (dtype == SL_BF16 && cfg == 4128192) return launch_ring<bf16_t, 128, 192, 4, 1, 64, SL_RING192_NST>(p, st);
 #define SL_TILE_CASES(T)                                                           \
   switch (cfg) {                                                                   \

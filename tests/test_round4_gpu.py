@@ -270,7 +270,8 @@ def test_workspace_of_a_captured_call_belongs_to_its_graph(hip):
 def test_few_tile_inference_convs_on_64_row_tiles(hip, cin, cout, k, dil):
     """A frozen conv + folded BatchNorm of a fine-tune pair (8 192 rows, 128 / 256 output channels) has 64 / 128 tiles of 128 x 128 for 256 CUs; launch_gemm gives such
     launches 64 x 128 tiles (conv_gemm_ring_kernel<64, 128>: 1024 -> 256 19.0 -> 15.4 us, 3x3 256 -> 256 d2 37.4 -> 30.0; 441 -> 454 pairs/s, tools/ring64_check.py).
-    Same K order per output element: bit-identical to the 128 x 128 tiles (hook sl_debug_ring64_max_tiles(0)), incl. a ragged last row block, and close to fp32 torch."""
+    1x1 layers: same K order per output element, bit-identical to the 128 x 128 tiles (hook sl_debug_ring64_max_tiles(0)), incl. a ragged last row block; all close to fp32 torch.
+    Round 5: the 64-row tiles stream 128-byte stage rows (profiles/r5_ab_ring64_geom.txt: 459.5 -> 469.6 pairs/s)."""
     import torch.nn.functional as F
     from segland_amd import ops
     dt = torch.bfloat16
@@ -286,9 +287,12 @@ def test_few_tile_inference_convs_on_64_row_tiles(hip, cin, cout, k, dil):
             hip.sl_debug_ring64_max_tiles(0)
             y128 = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True).clone()
         finally:
-            hip.sl_debug_ring64_max_tiles(160)
+            hip.sl_debug_ring64_max_tiles(256)
         y64 = ops.conv2d_affine_fwd(x, wf, spec, scale, shift, residual=rs, relu=True)
-        assert torch.equal(y64, y128)
+        if k == 1:
+            assert torch.equal(y64, y128)
+        else:          # round 5: 128-byte stage rows = 64-channel chunks; a 3x3 gather sums (chunk, tap) in another order than the 32-channel chunks of the 128 x 128 tiles
+            assert float((y64.float() - y128.float()).abs().max()) <= 1e-2 * float(y128.float().abs().max())
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, None, 1, dil * (k // 2), dil).permute(0, 2, 3, 1).to(dt).float()
         ref = torch.relu(ref * scale + shift + rs.float())
         assert float((y64.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
