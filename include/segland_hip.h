@@ -65,6 +65,7 @@ int sl_conv2d_tile_config(const SlConvDesc* d, int mode);
 #define SL_EPI_ADDEND_BITS 8
 #define SL_EPI_GATE 16
 #define SL_EPI_SPLITK 32
+#define SL_EPI_GELU 64      /* data gradient behind a GELU (sl_conv2d_bwd_data_gelu) */
 int sl_conv2d_tile_config_ex(const SlConvDesc* d, int mode, int epi);
 /* the same for the weight gradient: 1 = conv_wgrad_c64k3_kernel, 2 = conv_wgrad_c64p_kernel, 3 = conv_wgrad3_kernel (3x3 stride 1, nine taps per block), 10000000 + 1000*BN + BC = conv_wgrad_glds_kernel,
  * 20000000 + ... = conv_wgrad_kernel (+ 500000: rows are pixel pairs); every one is followed by its fixed-order slab reduce. */
@@ -108,6 +109,11 @@ int sl_conv2d_affine_fwd_ex(const SlConvDesc* d, const void* x, const void* x2, 
  * the shortcut gradient `dout * relu'(out)` of a bottleneck is applied here instead of being materialised. */
 int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const void* wt, const void* addend, const uint8_t* addend_mask,
                        const void* mask_src, void* dx, sl_stream_t stream);
+
+/* dx = conv_transpose(dy, w) * GELU'(h): the data gradient of an Mlp's fc2 lands behind the activation (networks/backbones/swintransformer.py:26-31, x = fc2(act(fc1(x)))
+ * backward) in one launch; h: [B][H][W][Cin], the stored pre-activation.  Same result as sl_conv2d_bwd_data followed by sl_gelu_bwd (the epilogue works on the rounded
+ * data gradient), one write and two reads of the block's widest tensor less. */
+int sl_conv2d_bwd_data_gelu(const SlConvDesc* d, const void* dy, const void* wt, const void* h, void* dx, sl_stream_t stream);
 
 /* Data gradient + the reduce pass of the BatchNorm backward below it, in one kernel (resnet.py:57-78 backward: conv3 <- bn2/relu, conv2 <- bn1/relu).
  * The result is the gradient wrt a = relu(bn(c)); the epilogue gates it with the ReLU bits of `gate` (1 byte per 16-byte vector of dx), stores the gated

@@ -68,6 +68,15 @@ template <typename T> __device__ __forceinline__ float sl_gelu(float x) {
   else return 0.5f * x * (1.f + sl_erf_as(x * 0.70710678118654752440f));
 }
 
+// d GELU(x) / dx = Phi(x) + x phi(x), the same erf per element type as sl_gelu (gelu_bwd_kernel and the data-gradient epilogue with a GELU pre-activation operand)
+template <typename T> __device__ __forceinline__ float sl_gelu_grad(float x) {
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  float cdf;
+  if constexpr (sizeof(T) == 4) cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  else cdf = 0.5f * (1.f + sl_erf_as(x * 0.70710678118654752440f));
+  return cdf + x * pdf;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -50,13 +50,14 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
         (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
       return 6256064;
     if (sk512_shape(p)) return 9256064;
-    if (p9_shape(p)) return 8256256;
+    if (p9_shape(p) && !(p.flags & 4)) return 8256256;
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
-    if (big && n256 && (p.mode == 0 || p.stride == 1)) return 5256256;
+    if (big && n256 && (p.mode == 0 || p.stride == 1) && !(p.flags & 4)) return 5256256;      // (flags bit 2, a GELU behind the data gradient: store phases of the tile kernels only)
   }
   // 192-column tiles (N = 192, 576, ...: Swin-T stage 2 -- qkv / proj / fc2 and their data gradients on 32 768 tokens): these widths are 64- but not 128-multiples and
   // ran on the two-stage 256 x 64 kernel
-  if (dtype == SL_BF16 && ring192_on() && p.N % 192 == 0 && !n128 && p.M >= 128LL * RING128_MIN) return 4128192;
+  // (a data gradient behind a GELU -- flags bit 2 -- takes them for every 192-multiple: the persistent half-tile kernel has no fast store phase for it; Swin-T stage 2: 768)
+  if (dtype == SL_BF16 && ring192_on() && p.N % 192 == 0 && (!n128 || (p.flags & 4)) && p.M >= 128LL * RING128_MIN) return 4128192;
   if (big) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
     if (n256) return 4256256;
@@ -152,6 +153,7 @@ extern "C" int sl_conv2d_tile_config_ex(const SlConvDesc* d, int mode, int epi) 
   if (epi & (SL_EPI_ADDEND | SL_EPI_ADDEND_BITS)) p.addend = dm;
   if (epi & SL_EPI_ADDEND_BITS) p.addend_mask = (const unsigned char*)dm;
   if (epi & SL_EPI_GATE) { p.gate = (const unsigned char*)dm; p.bn_x = dm; p.bn_mean = (const float*)dm; p.bn_invstd = (const float*)dm; p.stat_partial = (float*)dm; }
+  if (epi & SL_EPI_GELU) { p.mask_src = dm; p.flags = 4; }
   p.ksplit = (epi & SL_EPI_SPLITK) ? splitk_parts(p, d->dtype) : 1;
   return choose_kernel(p, d->dtype);
 }
@@ -255,6 +257,20 @@ extern "C" int sl_conv2d_bwd_data(const SlConvDesc* d, const void* dy, const voi
   p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
   p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
   p.addend = addend; p.mask_src = mask_src; p.addend_mask = addend ? addend_mask : nullptr;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
+// dx = (data gradient) * GELU'(h): the Mlp of a transformer block (swintransformer.py:26-31: fc2(act(fc1(x)))) -- the data gradient of fc2 lands behind the activation in
+// one launch; h = the stored pre-activation fc1(x), [B][H][W][Cin].  Replaces sl_conv2d_bwd_data + sl_gelu_bwd (one write and two reads of the block's widest tensor less).
+extern "C" int sl_conv2d_bwd_data_gelu(const SlConvDesc* d, const void* dy, const void* wt, const void* h, void* dx, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(dy && wt && h && dx, "conv bwd_data_gelu: null buffer");
+  ConvGemmParams p{};
+  p.src1 = dy; p.src2 = nullptr; p.C1 = d->Cout; p.C2 = 0; p.wt = wt; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil; p.mode = 1;
+  p.mask_src = h; p.flags = 4;
   p.M = d->B * d->H * d->W;
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }

@@ -49,6 +49,7 @@ struct ConvGemmParams {
   int gridM, gridN;
   int tile16;                           // patch kernel: row block bm is a 16 x 16-pixel tile (b, y0 / 16, x0 / 16), its 256 rows are 16 segments of 16 pixels
   int flags;                            // p8: bit 0 = counted first wait (always set); bit 1 = generic store phase instead of conv_epilogue_affine (test hook sl_debug_conv_affine: the bit-identity test)
+                                        // bit 2: mask_src holds the pre-activation of a GELU and the result is multiplied by GELU'(mask_src) instead of gated by mask_src > 0
   // split-K (inference convs on few row tiles: the fine-tune pair's 8 192-row layers): the K range is cut into `ksplit` parts, block (tile, part) writes its raw fp32
   // accumulators to ws [part][M][N] and conv_splitk_finish_kernel sums the parts in a fixed order and applies pre_addend / scale / bias / addend / ReLU
   float* ws; int ksplit;
@@ -258,8 +259,9 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
         for (int it = 0; it < NIT; ++it) st16(o + soff(it), *(const uint4*)(l + it * (RS * G::PITCH)));
       }
     } else {
-      const unsigned char* ad = (const unsigned char*)p.addend + goff;
-      const unsigned char* ab = p.addend_mask ? p.addend_mask + goff / 16 : nullptr;
+      // MODE 6: the second operand is the pre-activation of a GELU (mask_src) and multiplies the result by GELU'(.) instead of being added
+      const unsigned char* ad = (const unsigned char*)(MODE == 6 ? p.mask_src : p.addend) + goff;
+      const unsigned char* ab = (MODE != 6 && p.addend_mask) ? p.addend_mask + goff / 16 : nullptr;
 #pragma unroll 1
       for (int it0 = 0; it0 < NIT; it0 += CH) {
         uint4 addv[CH]; unsigned bits[CH];
@@ -288,8 +290,13 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
           }
           f2_t v[EPC / 2], w[EPC / 2];
           unpack2(raw, v); unpack2(a, w);
+          if constexpr (MODE == 6) {
 #pragma unroll
-          for (int e = 0; e < EPC / 2; ++e) v[e] += w[e];
+            for (int e = 0; e < EPC / 2; ++e) { v[e].x *= sl_gelu_grad<T>(w[e].x); v[e].y *= sl_gelu_grad<T>(w[e].y); }
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC / 2; ++e) v[e] += w[e];
+          }
           uint4 r;
           if constexpr (sizeof(T) == 2) {
             typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -450,6 +457,13 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
   const bool shaped = p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2;
   // Returns the number of vector-memory instructions the wave issued (loads + stores; every path below issues the same count in every wave), or -1 when that is
   // not a compile-time fact of the path: the persistent half-tile kernel uses it to wait for loads that are OLDER than these instructions without waiting for them.
+  if constexpr (!SPLIT) {
+    // the data gradient behind a GELU (sl_conv2d_bwd_data_gelu): the fast store phase with a multiplicative second operand (not in the persistent kernels: register limit)
+    if (full && (p.flags & 4) && p.mask_src && !(p.bias || p.scale || p.relu || p.pre_addend || p.row_scale || p.out2 || p.addend || p.stat_partial)) {
+      conv_epilogue_fast<T, BM, BN, WM, WN, 6, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+      return -1;
+    }
+  }
   if constexpr (GATE) {
     if (full && !shaped && !p.addend && p.gate) {
       conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
@@ -602,8 +616,15 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
           if (p.mask_src) {
             float k[EPC];
             unpack16<T>(mskv[u], k);
+            bool gelu = false;
+            if constexpr (!SPLIT) gelu = (p.flags & 4) != 0;      // the persistent kernels never see such a launch (choose_kernel) and stay free of the code
+            if (gelu) {                                     // k = the pre-activation of a GELU: the result is the gradient behind it (Mlp fc2 data gradient, swintransformer.py:26-31)
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
+              for (int e = 0; e < EPC; ++e) v[e] *= sl_gelu_grad<T>(k[e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) v[e] = k[e] > 0.f ? v[e] : 0.f;
+            }
           }
           st16(out + (size_t)m * p.N + ncol, pack16<T>(v));
         }

@@ -292,7 +292,7 @@ int slconv::launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, 256);
   p.gridN = p.N / 256;
   p.trace = g_p8_trace;
-  p.flags = 1;                                  // the next tile's first wait is counted past the epilogue's own loads and stores
+  p.flags |= 1;                                 // the next tile's first wait is counted past the epilogue's own loads and stores
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);

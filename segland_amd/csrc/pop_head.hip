@@ -215,6 +215,15 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
   double s = 0.0;
   if (c < C) {
     int r = rl;
+    // up to 2 048 partial rows = 128 loads per lane: sixteen in flight (round 5: four made this launch 14 us of pure load latency, 12 launches per Swin-T step); the additions
+    // keep the row order, so the sums did not change
+    for (; r + 15 * 16 < nblk; r += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(r + u * 16) * C + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
     for (; r + 3 * 16 < nblk; r += 4 * 16) {
       const float v0 = part[(size_t)r * C + c], v1 = part[(size_t)(r + 16) * C + c], v2 = part[(size_t)(r + 32) * C + c], v3 = part[(size_t)(r + 48) * C + c];
       s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
@@ -255,6 +264,15 @@ __global__ __launch_bounds__(1024) void colsum_finalize_multi_kernel(ColsumBatch
   double s = 0.0;
   if (c < C) {
     int r = rl;
+    // up to 2 048 partial rows = 128 loads per lane: sixteen in flight (round 5: four made this launch 14 us of pure load latency, 12 launches per Swin-T step); the additions
+    // keep the row order, so the sums did not change
+    for (; r + 15 * 16 < nblk; r += 16 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(r + u * 16) * C + c];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += (double)v[u];
+    }
     for (; r + 3 * 16 < nblk; r += 4 * 16) {
       const float v0 = part[(size_t)r * C + c], v1 = part[(size_t)(r + 16) * C + c], v2 = part[(size_t)(r + 32) * C + c], v3 = part[(size_t)(r + 48) * C + c];
       s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;

@@ -275,11 +275,7 @@ __global__ void gelu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ d
     unpack16<T>(((const uint4*)h)[i], t);
     unpack16<T>(((const uint4*)dy)[i], g);
 #pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const float cdf = 0.5f * (1.f + erff(t[e] * 0.70710678118654752440f));
-      const float pdf = 0.39894228040143267794f * __expf(-0.5f * t[e] * t[e]);
-      g[e] *= cdf + t[e] * pdf;
-    }
+    for (int e = 0; e < V; ++e) g[e] *= sl_gelu_grad<T>(t[e]);
     ((uint4*)dh)[i] = pack16<T>(g);
   }
 }

@@ -15,6 +15,9 @@ from .functional import _nbt_pending, _wver
 from .ops import ConvSpec
 from .ops_swin import pad_to
 
+import os
+_GELU_FUSE = os.environ.get('SEGLAND_SWIN_GELU_FUSE', '1') != '0'      # fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); 0: + a gelu_bwd launch (A/B)
+
 
 # ------------------------------------------------------------------------------------------------ prepared (padded) weights
 class _Lin:
@@ -192,9 +195,13 @@ def lin_fwd(x, L, residual=None, x2=None, row_scale=None, want_gelu=False):
     return ops.conv2d_fwd(x, L.wf, L.spec, bias=L.bias, pre_addend=residual, x2=x2)[0]
 
 
-def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=None):
-    """(dx, dw in the parameter's shape, dbias) of lin_fwd.  batch (ops.ColsumBatch): dbias is filled by batch.run()."""
-    dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
+def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=None, gelu_h=None):
+    """(dx, dw in the parameter's shape, dbias) of lin_fwd.  batch (ops.ColsumBatch): dbias is filled by batch.run().
+    gelu_h: x = GELU(gelu_h) -- dx is then the gradient wrt gelu_h (the activation's backward in the data gradient's epilogue)."""
+    if need_dx and gelu_h is not None:
+        dx = ops.conv2d_bwd_data_gelu(dy, L.wb, L.spec, x.shape[1:3], gelu_h)
+    else:
+        dx = ops.conv2d_bwd_data(dy, L.wb, L.spec, x.shape[1:3], C1=(x.shape[3] if x2 is not None else None)) if need_dx else None
     dw = db = None
     if need_w:
         clip = col_map is None and x2 is None and L.K < L.spec.cin          # zero-padded input channels: the reduce writes the parameter's shape, no slicing copy
@@ -317,8 +324,11 @@ class SwinBlockFn(torch.autograd.Function):
         # the eight column sums of this backward (four bias gradients, two LayerNorm (dgamma, dbeta) pairs, the attention bias and the pad-token
         # bias) are finalised by ONE launch at the end
         batch = ops.ColsumBatch() if need_w else None
-        dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch)
-        dh = osw.gelu_bwd(h, dg)
+        if _GELU_FUSE:
+            dh, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch, gelu_h=h)       # fc2's data gradient * GELU'(h) in one launch
+        else:
+            dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch)
+            dh = osw.gelu_bwd(h, dg)
         dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w, batch=batch)
         dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch)
         dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)

@@ -47,7 +47,7 @@ def _f32(n, dev, zero=False):
     return (torch.zeros if zero else torch.empty)(n, dtype=torch.float32, device=dev)
 
 
-EPI_STATS, EPI_AFFINE, EPI_ADDEND, EPI_ADDEND_BITS, EPI_GATE, EPI_SPLITK = 1, 2, 4, 8, 16, 32      # SL_EPI_* of include/segland_hip.h
+EPI_STATS, EPI_AFFINE, EPI_ADDEND, EPI_ADDEND_BITS, EPI_GATE, EPI_SPLITK, EPI_GELU = 1, 2, 4, 8, 16, 32, 64      # SL_EPI_* of include/segland_hip.h
 
 
 # --------------------------------------------------------------------------------------------- live kernel timing
@@ -241,6 +241,19 @@ def conv2d_bwd_data(dy, wb, spec, in_hw, addend=None, mask_src=None, C1=None, ou
     check(_lib.lib().sl_conv2d_bwd_data(C.byref(d), _p(dy), _p(wb), _p(addend), _p(addend_mask), _p(mask_src), _p(dx), _s()), 'conv2d_bwd_data')
     if tok is not None:
         PROFILER.end(tok, sum(t.numel() * t.element_size() for t in (addend, addend_mask, mask_src) if t is not None))
+    return dx
+
+
+def conv2d_bwd_data_gelu(dy, wb, spec, in_hw, h):
+    """conv2d_bwd_data(dy) * GELU'(h) in one launch (h: the stored pre-activation, the data gradient's shape): sl_conv2d_bwd_data_gelu."""
+    B = dy.shape[0]
+    H, W = in_hw
+    d = conv_desc(dy.dtype, B, H, W, spec, None)
+    assert (d.Ho, d.Wo) == tuple(dy.shape[1:3]) and tuple(h.shape) == (B, H, W, spec.cin) and h.dtype == dy.dtype and h.is_contiguous()
+    dx = torch.empty((B, H, W, spec.cin), dtype=dy.dtype, device=dy.device)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_GELU)
+    check(_lib.lib().sl_conv2d_bwd_data_gelu(C.byref(d), _p(dy), _p(wb), _p(h), _p(dx), _s()), 'conv2d_bwd_data_gelu')
+    PROFILER.end(tok, extra_bytes=h.numel() * h.element_size())
     return dx
 
 

@@ -445,3 +445,29 @@ def test_192_column_ring_tile(hip, case):
         assert torch.equal(g1, g0) and torch.equal(ga1, ga0), 'data gradient: 128 x 192 ring tile vs two-stage kernel'
     else:
         close(g1, g0, 'data gradient vs two-stage kernel', tol=1e-2)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 64, 192, 768), (1, 64, 64, 128, 384), (1, 32, 32, 384, 1536), (1, 16, 16, 768, 3072)])
+def test_data_gradient_behind_a_gelu(hip, case):
+    """Mlp backward (swintransformer.py:26-31): fc2's data gradient times GELU'(h) in the GEMM's store phase (sl_conv2d_bwd_data_gelu) equals the data gradient
+    followed by sl_gelu_bwd bit for bit (the store phase works on the rounded data gradient), on every kernel the Swin-T stages dispatch to, and is torch's."""
+    from segland_amd import ops, ops_swin as osw
+    dt_ = torch.bfloat16
+    B, H, W, Cn, Hid = case
+    M = B * H * W
+    torch.manual_seed(7)
+    dz = torch.randn(B, H, W, Cn, device=DEV).to(dt_)                     # gradient behind fc2 (Hid -> Cn)
+    h = (torch.randn(B, H, W, Hid, device=DEV) * 1.5).to(dt_)              # fc1's stored pre-activation
+    w2 = torch.randn(Cn, Hid, 1, 1, device=DEV) * (1.0 / Hid) ** 0.5
+    spec = ops.ConvSpec(Hid, Cn, 1, 1, 0, 1)
+    _, wb = ops.weight_prep(w2, dt_)
+    d = ops.conv_desc(dt_, B, H, W, spec, None)
+    fam = hip.sl_conv2d_tile_config_ex(C.byref(d), 1, 64) // 1000000
+    assert fam in (4, 2), 'a tile kernel (the persistent kernels have no GELU store phase): %d' % fam
+    fused = ops.conv2d_bwd_data_gelu(dz, wb, spec, (H, W), h)
+    two = osw.gelu_bwd(h, ops.conv2d_bwd_data(dz, wb, spec, (H, W)))
+    assert torch.equal(fused, two), 'fused vs data gradient + gelu_bwd'
+    hf = h.float().reshape(M, Hid).requires_grad_(True)
+    y = F.gelu(hf) @ w2.to(dt_).float().reshape(Cn, Hid).t()
+    y.backward(dz.float().reshape(M, Cn))
+    close(fused.float().reshape(M, Hid), hf.grad, 'data gradient behind the GELU %s' % (case,))
