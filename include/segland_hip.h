@@ -153,8 +153,10 @@ int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const void* x2, con
 int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                             int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream);
 /* Weight gradient and the bias gradient's column-sum partials of one nn.Linear / biased conv (swintransformer.py:40-52 Mlp, :95-98 qkv / proj: the autograd of F.linear
- * yields dW = dy^T x and db = sum_rows dy).  colsum_partial: float [sl_colsum_rows_blocks(B*Ho*Wo, Cout, dtype)][Cout]; finalize with sl_colsum_finalize(_multi).
- * 1x1 layers carry the column sums in the slab-reduce launch of the weight gradient; other shapes run sl_colsum_rows_partial after it. */
+ * yields dW = dy^T x and db = sum_rows dy).  colsum_partial: float [sl_conv2d_bwd_weight_bias_rows(d, n_valid, c_valid)][Cout]; finalize with sl_colsum_finalize(_multi).
+ * 1x1 layers on the LDS-DMA tile kernel form the column sums inside the weight-gradient kernel (its dy fragments times an all-ones fragment: one partial row per split of
+ * the pixel range, no second pass over dy); other shapes run sl_colsum_rows_partial after the weight gradient (sl_colsum_rows_blocks rows). */
+int sl_conv2d_bwd_weight_bias_rows(const SlConvDesc* d, int n_valid, int c_valid);      /* n_valid / c_valid: as sl_conv2d_bwd_weight_clip, 0 = all */
 int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                               float* colsum_partial, sl_stream_t stream);
 /* The same for layers computed at zero-padded channel counts (Swin-T/S carry C = 96 at pitch 128, section 10 of DESIGN.md): the GEMM runs at d->Cout x d->Cin, dw is the

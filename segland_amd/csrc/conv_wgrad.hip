@@ -28,6 +28,8 @@ struct WgradParams {
   int M;             // B*Ho*Wo
   int rows_per_split;  // multiple of 32
   int gridN, gridC, taps, splits;
+  float* colsum;     // BIAS instantiations: [splits * (pair ? 2 : 1)][colsum_cout] column sums of dy per split (the bias gradient partials of an nn.Linear), or null
+  int colsum_cout;   // the layer's own Cout (Cout / 2 when rows are pixel pairs)
   int pair;          // 1: a row is a PAIR of consecutive pixels (64-channel layers, see plan()); Cout, C1, M are the paired sizes
   unsigned long long* trace;   // debug (tools/wgrad_trace.py, conv_wgrad_glds_kernel only): per block {s_memtime at entry, ring primed, main loop done, slab stored, HW_ID, XCC_ID, stages}; null in production
 };
@@ -245,7 +247,10 @@ __device__ __forceinline__ unsigned wlds_addr_of(const unsigned char* p) {
 }
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR>
+// BIAS: the waves of the first c tile's first wave column also multiply their dy fragments with an all-ones x fragment -- every column of that product is the column
+// sum of dy over the block's rows, i.e. this split's share of the bias gradient (p.colsum): the separate pass over dy (colsum blocks in the reduce launch: a second read
+// of the layer's largest tensor) goes away.  TM extra MFMAs per TM x TN in a quarter / half of the waves of kernels that wait for HBM.
+template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR, bool BIAS = false>
 __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradParams p) {
   constexpr int ES = sizeof(T), EPC = 16 / ES, NW = WNN * WCC;
   constexpr int KM = 32, NST = 4;                                  // rows per stage, stages in the LDS ring
@@ -307,7 +312,8 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   }
   auto issue = [&](int it, int slot) {
     const int m0 = m_begin + it * KM;
-    const unsigned la = lds_base + slot * STAGE, lb = la + KM * RB_A;
+    // (BIAS: the wave-uniform branch around the extra MFMAs makes the compiler's divergence analysis give up on the ring slot -- say that it is uniform)
+    const unsigned la = BIAS ? (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_base + slot * STAGE)) : lds_base + slot * STAGE, lb = la + KM * RB_A;
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
       const int ins = wave * IA + j, r = ins * RPI_A + a_rin, m = m0 + r;
@@ -349,6 +355,15 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool bias_on = BIAS && __builtin_amdgcn_readfirstlane((int)(p.colsum != nullptr && bc == 0 && tap == 0 && wn == 0)) != 0;      // wave-uniform (and said so)
+  f32x16_t accb[BIAS ? TM : 1];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+  }
+  const uint4 ones = sizeof(T) == 2 ? make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u) : make_uint4(0x3f800000u, 0, 0, 0);
   const int frow = lane & 31, fhalf = lane >> 5;
   // fragment loaders: bf16 -> one uint4 (8 k) per 32-column tile via two transpose reads; f32 -> one float (1 k)
   auto ldfrag = [&](uint4* af, uint4* bf, int slot, int ks) {
@@ -407,6 +422,15 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
         if constexpr (sizeof(T) == 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[i].x), __uint_as_float(bf[j].x), acc[i][j], 0, 0, 0);
         else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf[j]), acc[i][j], 0, 0, 0);
       }
+    if constexpr (BIAS) {
+      if (bias_on) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if constexpr (sizeof(T) == 4) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(af[i].x), __uint_as_float(ones.x), accb[i], 0, 0, 0);
+          else accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, ones), accb[i], 0, 0, 0);
+        }
+      }
+    }
   };
 
   // same pipeline as conv_gemm_ring_kernel: stages i, i+1 complete at the top of iteration i, fragments of the next
@@ -454,6 +478,19 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
         ws[((size_t)n * p.taps + tap) * CT + c] = acc[i][j][r];
       }
     }
+  if constexpr (BIAS) {
+    if (bias_on && frow == 0) {              // column 0 of the product (lanes 0 and 32): rows (r & 3) + 8 (r >> 2) + 4 fhalf
+      const int pr = p.pair ? 2 : 1;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = bn * BNN + wm * (BNN / WNN) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          const int par = n >= p.colsum_cout ? 1 : 0;          // pixel pairs: the second half of the paired row's channels is the odd pixel
+          p.colsum[((size_t)split * pr + par) * p.colsum_cout + (n - par * p.colsum_cout)] = accb[i][r];
+        }
+    }
+  }
   if (p.trace && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stamp counts the slab stores of this wave as issued AND accepted
     unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
@@ -864,6 +901,19 @@ int launch_wgrad_glds(dim3 grid, WgradParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  if (p.colsum) {
+    if constexpr (BNN == 256 && BCC == 256) { sl_set_error("conv bwd_weight: no bias instantiation of the 256 x 256 tile"); return SL_EINVAL; }
+    else {
+      static bool attr_set_b = false;
+      if (!attr_set_b && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set_b = true;
+      }
+      hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR, true>), grid, dim3(64 * WNN * WCC), lds, st, p);
+      SL_LAUNCH_CHECK("conv_wgrad_glds_kernel (bias)");
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>), grid, dim3(64 * WNN * WCC), lds, st, p);
   SL_LAUNCH_CHECK("conv_wgrad_glds_kernel");
   return 0;
@@ -952,6 +1002,24 @@ extern "C" int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, con
   return bwd_weight_impl(d, x, x2, dy, dw, c_valid, 0, workspace, workspace_bytes, stream, colsum_partial, n_valid, c_valid);
 }
 
+// Does the weight-gradient kernel of this shape carry the bias-gradient partials itself (BIAS instantiation: one row per split, two for pixel pairs)?
+int g_wgrad_bias = -1;      // SEGLAND_WGRAD_BIAS=0 / sl_debug_wgrad_bias(0): the column sums of dy back in the reduce launch (A/B hook)
+static bool wgrad_bias_fused(const SlConvDesc* d, const WgradPlan& pl) {
+  if (g_wgrad_bias < 0) g_wgrad_bias = (getenv("SEGLAND_WGRAD_BIAS") && getenv("SEGLAND_WGRAD_BIAS")[0] == '0') ? 0 : 1;
+  return g_wgrad_bias && pl.glds && pl.taps == 1 && !(pl.bnn == 256 && pl.bcc == 256) && use_tr();
+}
+extern "C" void sl_debug_wgrad_bias(int v) { g_wgrad_bias = v ? 1 : 0; }
+extern "C" int sl_colsum_rows_blocks(long long rows, int C, int dtype);
+// rows of the colsum_partial buffer sl_conv2d_bwd_weight_bias / _clip (n_valid, c_valid: 0 = all channels) fill: the same path selection as bwd_weight_impl
+extern "C" int sl_conv2d_bwd_weight_bias_rows(const SlConvDesc* d, int n_valid, int c_valid) {
+  if (!d || d->Cout % 64 || d->Cin % 64) return SL_EINVAL;
+  const int generic = sl_colsum_rows_blocks((long long)d->B * d->Ho * d->Wo, d->Cout, d->dtype);
+  const bool full = (n_valid <= 0 || n_valid == d->Cout) && (c_valid <= 0 || c_valid == d->Cin);
+  if (use_tr() && ((full && c64k3_eligible(d, d->Cin, 0)) || c64p_eligible(d) || (full && sl_wgrad3_eligible(d, nullptr)))) return generic;
+  const WgradPlan pl = plan(d);
+  return wgrad_bias_fused(d, pl) ? pl.splits * (pl.pair ? 2 : 1) : generic;
+}
+
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                            int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
@@ -1023,6 +1091,8 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   p.pair = pl.pair ? 1 : 0;
   p.trace = g_wgrad_trace;
   if (pl.pair) { p.Cout = 2 * d->Cout; p.C1 = 2 * d->Cin; p.M /= 2; }
+  const bool bias_fused = colsum_partial && wgrad_bias_fused(d, pl);
+  if (bias_fused) { p.colsum = colsum_partial; p.colsum_cout = d->Cout; colsum_partial = nullptr; }      // the kernel writes the partials; nothing left for the reduce launch
   hipStream_t st = (hipStream_t)stream;
   int e;
   if (d->dtype == SL_F32) e = launch_wgrad<float, false>(pl, p, st);

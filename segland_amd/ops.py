@@ -410,7 +410,7 @@ def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
     Cn = dy.shape[-1]
     rows = dy.numel() // Cn
     assert Cn == spec.cout and dy.is_contiguous()
-    part = _f32((L.sl_colsum_rows_blocks(rows, Cn, dt(dy)), Cn), dy.device)
+    part = _f32((L.sl_conv2d_bwd_weight_bias_rows(C.byref(d), 0, 0), Cn), dy.device)
     tok = PROFILER.begin('conv_wgrad', d)
     check(L.sl_conv2d_bwd_weight_bias(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_bias')
     PROFILER.end(tok)
@@ -429,7 +429,7 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
     if want_bias:
         Cn = dy.shape[-1]
         assert Cn == spec.cout and dy.is_contiguous()
-        part = _f32((L.sl_colsum_rows_blocks(dy.numel() // Cn, Cn, dt(dy)), Cn), dy.device)
+        part = _f32((L.sl_conv2d_bwd_weight_bias_rows(C.byref(d), n_valid, c_valid), Cn), dy.device)
     tok = PROFILER.begin('conv_wgrad', d)
     check(L.sl_conv2d_bwd_weight_clip(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_clip')
     PROFILER.end(tok)

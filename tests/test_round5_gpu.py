@@ -471,3 +471,43 @@ def test_data_gradient_behind_a_gelu(hip, case):
     y = F.gelu(hf) @ w2.to(dt_).float().reshape(Cn, Hid).t()
     y.backward(dz.float().reshape(M, Cn))
     close(fused.float().reshape(M, Hid), hf.grad, 'data gradient behind the GELU %s' % (case,))
+
+
+@pytest.mark.parametrize('case', [
+    # tokens (B, H, W), Cin, Cout, dtype                  tile of the weight-gradient kernel
+    ((8, 128, 128), 128, 384, torch.bfloat16),          # 128 x 128 (Swin-T stage 1 qkv / fc1 at pitch 128)
+    ((2, 64, 64), 768, 192, torch.bfloat16),            # pixel pairs (192 is not a 128-multiple): two partial rows per split
+    ((2, 64, 64), 256, 384, torch.bfloat16),            # 128 x 256
+    ((1, 64, 64), 384, 1536, torch.bfloat16),           # 256 x 128
+    ((1, 32, 32), 768, 3072, torch.bfloat16),           # 256 x 256: no bias instantiation, the column sums stay in the reduce launch
+    ((1, 40, 52), 128, 384, torch.float32),             # fp32, ragged row count
+])
+def test_bias_gradient_inside_the_weight_gradient_kernel(hip, case):
+    """nn.Linear backward (swintransformer.py:26-31, 95-98): db = sum_rows dy from the weight-gradient kernel's own dy fragments (times an all-ones fragment on the
+    MFMA) instead of a second pass over dy: equals the column sums, dw is bit-identical to the launch without it (hook sl_debug_wgrad_bias(0))."""
+    from segland_amd import ops
+    (B, H, W), K, N, dt_ = case
+    M = B * H * W
+    torch.manual_seed(11)
+    x = torch.randn(B, H, W, K, device=DEV).to(dt_)
+    dy = (torch.randn(B, H, W, N, device=DEV) + 0.25).to(dt_)
+    spec = ops.ConvSpec(K, N, 1, 1, 0, 1)
+    d = ops.conv_desc(dt_, B, H, W, spec, None)
+    rows1 = hip.sl_conv2d_bwd_weight_bias_rows(C.byref(d), 0, 0)
+    dw1, db1 = ops.conv2d_bwd_weight_bias(x, dy, spec)
+    hip.sl_debug_wgrad_bias(0)
+    try:
+        rows0 = hip.sl_conv2d_bwd_weight_bias_rows(C.byref(d), 0, 0)
+        dw0, db0 = ops.conv2d_bwd_weight_bias(x, dy, spec)
+    finally:
+        hip.sl_debug_wgrad_bias(1)
+    print('partial rows: %d in the kernel, %d by the column-sum blocks' % (rows1, rows0))
+    assert torch.equal(dw1, dw0), 'weight gradient with / without the bias fragment'
+    ref = dy.float().reshape(M, N).sum(0)
+    close(db1, ref, 'bias gradient %s' % (case,), tol=2e-5 if dt_ == torch.float32 else 1e-5)
+    close(db0, ref, 'bias gradient (reduce launch)', tol=2e-5 if dt_ == torch.float32 else 1e-5)
+    close(dw1.reshape(N, K), dy.float().reshape(M, N).t() @ x.float().reshape(M, K), 'weight gradient', tol=2.5e-2 if dt_ == torch.bfloat16 else 1e-4)
+    # zero-padded channel counts (Swin-T stage 1: C = 96 at pitch 128): the parameter-shaped outputs
+    if K == 128 and dt_ == torch.bfloat16:
+        dwc, dbc = ops.conv2d_bwd_weight_clip(x, dy, spec, N - 96, 96, want_bias=True)
+        assert torch.equal(dwc, dw1[:N - 96, :96]) and torch.equal(dbc, db1)
