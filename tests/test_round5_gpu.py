@@ -447,7 +447,7 @@ def test_192_column_ring_tile(hip, case):
         close(g1, g0, 'data gradient vs two-stage kernel', tol=1e-2)
 
 
-@pytest.mark.parametrize('case', [(2, 64, 64, 192, 768), (1, 64, 64, 128, 384), (1, 32, 32, 384, 1536), (1, 16, 16, 768, 3072)])
+@pytest.mark.parametrize('case', [(2, 64, 64, 192, 768), (1, 64, 64, 128, 384), (1, 32, 32, 384, 1536), (1, 16, 16, 768, 3072), (1, 50, 52, 128, 384), (3, 20, 28, 192, 768)])   # the last two: a partial last row tile
 def test_data_gradient_behind_a_gelu(hip, case):
     """Mlp backward (swintransformer.py:26-31): fc2's data gradient times GELU'(h) in the GEMM's store phase (sl_conv2d_bwd_data_gelu) equals the data gradient
     followed by sl_gelu_bwd bit for bit (the store phase works on the rounded data gradient), on every kernel the Swin-T stages dispatch to, and is torch's."""
