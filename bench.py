@@ -191,15 +191,18 @@ def _dominant(table, peak):
     return e['family'], round(e['gflop'] / max(e['ms_total'], 1e-9) / peak, 4), round(e['ms_total'], 3)
 
 
-def short_config(kind, dev, steps=10):
+def short_config(kind, dev, steps=None):
     """One of BASELINE.json's other single-GPU workloads, measured briefly in this process after the headline region so that the driver's N = 1 line shows them:
     'c3' = config 3's per-GPU shard (PSPNet-POP ResNet-101, bf16, 16 tiles), 'c5' = config 5's (Swin-T POP, bf16, 8 tiles), both the train_base.py loop body
     replayed as one HIP graph; 'c4' = config 4 (ft_pop.py:233-269: one novel + one base tile per step, frozen backbone + decoder, SGD on the novel head).
-    3 eager warm-up steps (the last one instrumented: dominant conv kernel family and its fraction of the 2 500 TFLOP/s peak), graph capture, `steps` timed replays."""
+    3 eager warm-up steps (the last one instrumented: dominant conv kernel family and its fraction of the 2 500 TFLOP/s peak), graph capture, `steps` timed replays
+    (default: 20 / 200 / 40 for c3 / c4 / c5)."""
     from segland_amd import graph_step, networks, ops
     from segland_amd.loss.criterion import OrthLoss
     torch.manual_seed(0)
     dt = torch.bfloat16
+    if steps is None:
+        steps = {'c3': 20, 'c4': 200, 'c5': 40}[kind]          # >= 0.4 s of timed replays each (10 steps of the 2 ms pair step read 2-3 % low against tools/bench_ft.py)
     if kind in ('c3', 'c5'):
         name, backbone, batch = ('pspnet_pop', 'resnet101', 16) if kind == 'c3' else ('swin_pop', 'swin-t', 8)
         kw = dict(dilated=True, os=8) if name == 'pspnet_pop' else {}
