@@ -346,16 +346,17 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
 //   v = acc * scale[n] + bias[n];  GELU: out2 = gelu(round(v));  RS: v *= row_scale[image of the row];  ADD: v += addend;  relu (runtime floor);  out = round(v)
 // -- the generic store phase evaluates every optional operand per row behind run-time tests and always carries the statistic sums: 59 us against 25 us for the plain store
 // on the 131 072 x 128 -> 384 qkv GEMM of Swin-T stage 1 (tools/gemm_time.py).  Same operation order as conv_epilogue_generic (bit-identical results).
-template <typename T, int BM, int BN, int WM, int WN, bool ADD, bool RS_, bool GELU, bool SCRELU>
+// SPLIT: the half-tile kernel's staging (two passes = the two operand halves, every wave stages in both; conv_gemm_p8_kernel<2>).
+template <typename T, int BM, int BN, int WM, int WN, bool ADD, bool RS_, bool GELU, bool SCRELU, bool SPLIT = false>
 __device__ __forceinline__ void conv_epilogue_affine(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                      int lane, int tid, unsigned char* smem) {
-  using G = EpiGeom<T, BM, BN, WM, WN, false>;
+  using G = EpiGeom<T, BM, BN, WM, WN, SPLIT>;
   constexpr int EPC = 16 / sizeof(T), EP2 = EPC / 2;
   constexpr int NT = 64 * WM * WN;
   constexpr int CPR = BN / EPC;
   constexpr int RS = NT / CPR;
   constexpr int ROWS = BM / G::NPASS;
-  constexpr int NIT = ROWS / RS, CH = NIT < 8 ? NIT : 8;
+  constexpr int NIT = ROWS / RS, CH = SPLIT ? 4 : (NIT < 8 ? NIT : 8);
   typedef __attribute__((ext_vector_type(2))) float f2_t;       // pairs: v_pk_mul_f32 / v_pk_add_f32, one v_cvt_pk_bf16_f32 per pair
   const int cc = tid % CPR, r0 = tid / CPR;
   const int ncol = bn * BN + cc * EPC;
@@ -388,7 +389,7 @@ __device__ __forceinline__ void conv_epilogue_affine(const ConvGemmParams& p, f3
   };
 #pragma unroll
   for (int pass = 0; pass < G::NPASS; ++pass) {
-    epi_stage_acc<T, BM, BN, WM, WN, false>(acc, pass, wm, wn, lane, smem);
+    epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
     lds_barrier();
     const int m0 = bm * BM + pass * ROWS + r0;
     const size_t goff = ((size_t)m0 * p.N + ncol) * sizeof(T);
@@ -450,7 +451,9 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
 // GATE: this instantiation carries the gated-statistics store phase (MODE 3).  The two persistent 512-thread kernels are compiled once with and once without it: they sit
 // at the register limit (the half-tile kernel: 12 -> 19 spilled VGPRs with MODE 3 inlined), and every launch paid for it, gated or not: 25.98 vs 25.78 ms per ResNet-50
 // step, A/B/A/B on one box (profiles/r3_ab_gate_split.txt).
-template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true>
+// AFF: this instantiation carries the branch-free affine store phases (bias / folded BatchNorm / residual / GELU side output); the tile kernels always, the half-tile
+// kernel in an instantiation of its own (conv_gemm_p8_kernel<2>: inference convs and biased Linears with N % 256 == 0 on >= 24 576 rows).
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true, bool AFF = !SPLIT>
 __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
@@ -470,7 +473,9 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
       return SPLIT ? 49 : -1;                                           // 2 passes x 8 sweeps x (BN input + gate byte + store), + the statistic partial
     }
   }
-  if (full && !shaped && !p.addend) {
+  if constexpr (SPLIT && AFF) {
+    // conv_gemm_p8_kernel<2> is launched for biased / folded-BatchNorm launches only: the plain store phases are not compiled into it (register limit)
+  } else if (full && !shaped && !p.addend) {
     if constexpr (SPLIT) asm volatile("; EPI_BEGIN mode1");
     conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     if constexpr (SPLIT) asm volatile("; EPI_END mode1");
@@ -481,18 +486,18 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
     if constexpr (SPLIT) asm volatile("; EPI_END mode2");
     return SPLIT ? (p.addend_mask ? 48 : 32) : -1;                      // per sweep: addend load (+ gate byte) + store
   }
-  if constexpr (!SPLIT) {
+  if constexpr (AFF) {
     if (full && (p.bias || p.scale) && !p.mask_src && !p.pre_addend && !p.addend_mask && !p.stat_partial && !p.tile16 && !(p.flags & 2)) {
       const bool sr = p.scale || p.relu;              // eval-mode BatchNorm folded into the conv (+ residual + ReLU); the Swin linears have neither
       if (p.out2) {
-        if (!p.addend && !p.row_scale && !sr) { conv_epilogue_affine<T, BM, BN, WM, WN, false, false, true, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+        if (!p.addend && !p.row_scale && !sr) { conv_epilogue_affine<T, BM, BN, WM, WN, false, false, true, false, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
       } else if (p.addend) {
-        if (p.row_scale) { if (!sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, true, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; } }
-        else if (sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, true>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
-        else { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+        if (p.row_scale) { if constexpr (!SPLIT) { if (!sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, true, false, false, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; } } }
+        else if (sr) { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, true, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
+        else { conv_epilogue_affine<T, BM, BN, WM, WN, true, false, false, false, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem); return -1; }
       } else if (!p.row_scale) {
-        if (sr) conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
-        else conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, false>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+        if (sr) conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, true, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+        else conv_epilogue_affine<T, BM, BN, WM, WN, false, false, false, false, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
         return -1;
       }
     }

@@ -98,9 +98,9 @@ __device__ __forceinline__ int p8_slot_a1(int par) { return (par ? 2 : 7) * P8_S
 __device__ __forceinline__ int p8_slot_b1(int par) { return (par ? 3 : 8) * P8_SLOT; }
 __device__ __forceinline__ int p8_slot_b0(int j) { return (j == 0 ? 9 : j + 3) * P8_SLOT; }
 
-template <int EPI>       // 0: the store phases without MODE 3, 1: with the gated-statistics store phase (MODE 3)
+template <int EPI>       // 0: the store phases without MODE 3, 1: with the gated-statistics store phase (MODE 3), 2: with the affine store phases (inference convs, biased Linears)
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
-  constexpr bool GATE = EPI == 1;
+  constexpr bool GATE = EPI == 1, AFF = EPI == 2;
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       setup(bm, bn);
       issue_first();
     }
-    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
+    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE, AFF>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
     if (!counted) younger = 0;
     lds_barrier();                              // statistic partials are read from the staging area: the next tile's second K-tile goes to slots inside it
   }
@@ -297,11 +297,14 @@ int slconv::launch_p8(ConvGemmParams& p, hipStream_t st) {
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     attr_set = true;
   }
   const int ntiles = p.gridM * p.gridN;
   // persistent: min(tiles, 256) blocks walk over the tiles; the instantiation with the gated-statistics store phase only where it is used
+  static const bool aff_off = getenv("SEGLAND_CONV_P8_AFFINE") && getenv("SEGLAND_CONV_P8_AFFINE")[0] == '0';      // A/B: biased launches back on the generic store phase
   if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<1>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  else if ((p.bias || p.scale) && !p.stat_partial && !aff_off) hipLaunchKernelGGL(conv_gemm_p8_kernel<2>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   else        hipLaunchKernelGGL(conv_gemm_p8_kernel<0>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;

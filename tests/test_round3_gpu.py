@@ -472,7 +472,8 @@ def test_relpos_bias_tiles_of_all_blocks_in_one_launch(hip):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize('tokens,cin,cout', [(8192, 384, 1152), (32768, 128, 384), (4096 + 96, 192, 192), (2048, 768, 768)])
+@pytest.mark.parametrize('tokens,cin,cout', [(8192, 384, 1152), (32768, 128, 384), (4096 + 96, 192, 192), (2048, 768, 768),
+                                             (32768, 192, 768), (24576 + 192, 64, 256)])      # the last two (bf16): the half-tile kernel's affine instantiation (round 5), whole and ragged
 def test_affine_store_phase_equals_the_generic_one(hip, tokens, cin, cout, dtype):
     """conv_epilogue_affine (bias / DropPath row scale / residual / GELU side output / folded BatchNorm + ReLU as branch-free template specialisations) against the generic
     store phase of the same kernels (SEGLAND_CONV_AFFINE=0): bit-identical outputs on whole and ragged tiles, and the GELU output against torch."""
