@@ -33,6 +33,11 @@ static bool ring192_on() {
   if (g_ring192 < 0) g_ring192 = (getenv("SEGLAND_CONV_RING192") && getenv("SEGLAND_CONV_RING192")[0] == '0') ? 0 : 1;
   return g_ring192 != 0;
 }
+int g_ringn64 = -1;      // SEGLAND_CONV_RINGN64=0 / sl_debug_conv_ringn64(0): 64-column inference layers back on the two-stage kernel (A/B hook)
+static bool ringn64_on() {
+  if (g_ringn64 < 0) g_ringn64 = (getenv("SEGLAND_CONV_RINGN64") && getenv("SEGLAND_CONV_RINGN64")[0] == '0') ? 0 : 1;
+  return g_ringn64 != 0;
+}
 long long g_ring64_max_tiles = 256;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
 // Which kernel a launch runs on: 1000000 * family + 1000 * BM + BN (family 9 = pixel-stationary K = 512, 8 = 3x3 patch (+ 10000000: split-K), 7 = 64 -> 64 patch,
 // 6 = pixel-stationary K <= 256, 5 = half-tile, 4 = ring, 2 = two-stage glds).  The ONE predicate chain: launch_gemm switches on it, sl_conv2d_tile_config(_ex) and
@@ -58,6 +63,9 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
   // ran on the two-stage 256 x 64 kernel
   // (a data gradient behind a GELU -- flags bit 2 -- takes them for every 192-multiple: the persistent half-tile kernel has no fast store phase for it; Swin-T stage 2: 768)
   if (dtype == SL_BF16 && ring192_on() && p.N % 192 == 0 && (!n128 || (p.flags & 4)) && p.M >= 128LL * RING128_MIN) return 4128192;
+  // 64-column inference layers (a fine-tune pair's frozen layer1: 256 -> 64 and 3x3 64 -> 64 on 32 768 rows): 128 x 64 tiles of the ring kernel, four waves of 32 rows x 64
+  // columns, three blocks per CU -- 256 blocks where the two-stage 256 x 64 kernel has 128.  Launches without BN statistic partials only (the partial rows' granularity).
+  if (dtype == SL_BF16 && ringn64_on() && !n128 && p.N % 192 != 0 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN) return 4128064;
   if (big) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
     if (n256) return 4256256;
@@ -125,6 +133,7 @@ int check_desc(const SlConvDesc* d) {
 
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
+extern "C" void sl_debug_conv_ringn64(int v) { g_ringn64 = v ? 1 : 0; }      // test / A-B hook: 128 x 64 ring tile on / off
 extern "C" void sl_debug_conv_ring192(int v) { g_ring192 = v ? 1 : 0; }      // test / A-B hook: 128 x 192 ring tile on / off
 extern "C" void sl_debug_ring64_max_tiles(int v) { g_ring64_max_tiles = v; }      // tuning hook: see launch_gemm
 extern "C" void sl_debug_conv_sk512(int v) { g_conv_sk512 = v ? 1 : 0; }      // test / A-B hook: K = 512 pixel-stationary kernel on / off

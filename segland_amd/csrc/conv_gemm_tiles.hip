@@ -379,6 +379,7 @@ int slconv::launch_tile(int cfg, int dtype, ConvGemmParams& p, hipStream_t st) {
     if ((long long)cdiv(p.M, 64) * (p.N / 128) <= 256) return launch_ring<bf16_t, 64, 128, 2, 2, 128, 4>(p, st);
     return launch_ring<bf16_t, 64, 128, 2, 2, 128, 3>(p, st);
   }
+  if (dtype == SL_BF16 && cfg == 4128064) return launch_ring<bf16_t, 128, 64, 4, 1, 64, 4>(p, st);
   if (dtype == SL_BF16 && cfg == 4128192) return launch_ring<bf16_t, 128, 192, 4, 1, 64, SL_RING192_NST>(p, st);
 #define SL_TILE_CASES(T)                                                           \
   switch (cfg) {                                                                   \
