@@ -33,6 +33,11 @@ static bool ring192_on() {
   if (g_ring192 < 0) g_ring192 = (getenv("SEGLAND_CONV_RING192") && getenv("SEGLAND_CONV_RING192")[0] == '0') ? 0 : 1;
   return g_ring192 != 0;
 }
+int g_rows_small = -1;      // SEGLAND_CONV_ROWS_SMALL=0 / sl_debug_conv_rows_small(0): <= 32-row launches back on the tile kernels (A/B hook)
+static bool rows_small_on() {
+  if (g_rows_small < 0) g_rows_small = (getenv("SEGLAND_CONV_ROWS_SMALL") && getenv("SEGLAND_CONV_ROWS_SMALL")[0] == '0') ? 0 : 1;
+  return g_rows_small != 0;
+}
 int g_ringn64 = -1;      // SEGLAND_CONV_RINGN64=0 / sl_debug_conv_ringn64(0): 64-column inference layers back on the two-stage kernel (A/B hook)
 static bool ringn64_on() {
   if (g_ringn64 < 0) g_ringn64 = (getenv("SEGLAND_CONV_RINGN64") && getenv("SEGLAND_CONV_RINGN64")[0] == '0') ? 0 : 1;
@@ -46,6 +51,10 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
   const bool n128 = (p.N % 128 == 0), n256 = (p.N % 256 == 0);
   const bool big = block_rows(p.M) == 256;           // tiny problems (PPM stages, prototype rows) stay on 128-row tiles
   if (dtype == SL_BF16) {
+    // <= 32 rows of a 1x1 layer (prototype rows of the POP head's MLP): one wave per 32 columns, operands straight from global memory (conv_rows_small_kernel)
+    if (rows_small_on() && p.M <= 32 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C2 == 0 && p.Hs == p.Hd && p.Ws == p.Wd && p.N % 32 == 0 && p.ksplit <= 1 &&
+        !(p.bias || p.scale || p.addend || p.pre_addend || p.row_scale || p.out2 || p.stat_partial || p.gate || p.addend_mask || (p.flags & 4)))
+      return 3032032;
     if (p.ksplit > 1) return 18256256;                                                // planned by splitk_parts: the shape is served by the patch kernel
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
@@ -134,6 +143,7 @@ int check_desc(const SlConvDesc* d) {
 // test hook (not part of the public ABI)
 extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
 extern "C" void sl_debug_conv_ringn64(int v) { g_ringn64 = v ? 1 : 0; }      // test / A-B hook: 128 x 64 ring tile on / off
+extern "C" void sl_debug_conv_rows_small(int v) { g_rows_small = v ? 1 : 0; }      // test / A-B hook: the <= 32-row kernel on / off
 extern "C" void sl_debug_conv_ring192(int v) { g_ring192 = v ? 1 : 0; }      // test / A-B hook: 128 x 192 ring tile on / off
 extern "C" void sl_debug_ring64_max_tiles(int v) { g_ring64_max_tiles = v; }      // tuning hook: see launch_gemm
 extern "C" void sl_debug_conv_sk512(int v) { g_conv_sk512 = v ? 1 : 0; }      // test / A-B hook: K = 512 pixel-stationary kernel on / off

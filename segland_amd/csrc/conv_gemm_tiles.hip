@@ -370,6 +370,60 @@ int launch_glds(ConvGemmParams& p, hipStream_t st) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// At most 32 rows (the +-prototype rows of the POP head's classifier MLP, pspnet_pop.py:46-52 on [2K, 512]: 14 / 8 rows per launch): the tile kernels run such a launch as
+// one 128-row tile per 128 columns -- 8 K-tiles of prologue / barrier / LDS round trips for 3.7 MFLOP, 17 us.  Here one wave owns 32 output columns: both operands are K-major
+// rows, so a lane reads its 16-byte fragment pieces straight from global memory (rows >= M: zeros), sixteen k-steps of loads in flight, one accumulator chain over ascending k
+// (the same MFMA sequence per output element as the tile kernels: bit-identical), then ReLU / ReLU-mask and 8-byte stores.  Epilogues: none, relu, mask_src.
+__global__ __launch_bounds__(64) void conv_rows_small_kernel(ConvGemmParams p) {
+  const int lane = threadIdx.x, row = lane & 31, half = lane >> 5;
+  const int n0 = blockIdx.x * 32;
+  const int K = p.C1;
+  const bf16_t* xr = (const bf16_t*)p.src1 + (size_t)(row < p.M ? row : 0) * K + half * 8;
+  const bf16_t* wr = (const bf16_t*)p.wt + (size_t)(n0 + row) * K + half * 8;
+  const bool live = row < p.M;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr int U = 16;
+  for (int k0 = 0; k0 < K; k0 += 16 * U) {
+    uint4 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 16 * u;
+      if (k < K) { a[u] = live ? *(const uint4*)(xr + k) : make_uint4(0, 0, 0, 0); b[u] = *(const uint4*)(wr + k); }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (k0 + 16 * u < K) Mma<bf16_t>::run(b[u], a[u], acc);          // operand roles as in the tile kernels: A = weight rows, B = pixel rows
+  }
+  // lane holds, for pixel m = lane & 31, channels n0 + 8 (r >> 2) + 4 half + (r & 3)
+  if (!live) return;
+  const bf16_t* ms = p.mask_src ? (const bf16_t*)p.mask_src + (size_t)row * p.N : nullptr;
+  bf16_t* o = (bf16_t*)p.out + (size_t)row * p.N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int n = n0 + 8 * q + 4 * half;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(acc[4 * q + e]));          // the store phases of the tile kernels work on the rounded accumulators
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+    }
+    if (ms) {
+      const uint2 mk = *(const uint2*)(ms + n);
+      const float k4[4] = {__uint_as_float(mk.x << 16), __uint_as_float(mk.x & 0xffff0000u), __uint_as_float(mk.y << 16), __uint_as_float(mk.y & 0xffff0000u)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = k4[e] > 0.f ? v[e] : 0.f;
+    }
+    uint2 r;
+    r.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    r.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *(uint2*)(o + n) = r;
+  }
+}
+
 }  // namespace
 
 int slconv::launch_tile(int cfg, int dtype, ConvGemmParams& p, hipStream_t st) {
@@ -378,6 +432,12 @@ int slconv::launch_tile(int cfg, int dtype, ConvGemmParams& p, hipStream_t st) {
     // per CU is resident anyway: four stages (96 KiB); beyond, three stages (72 KiB) keep two blocks per CU.  profiles/r5_ab_ring64_geom.txt
     if ((long long)cdiv(p.M, 64) * (p.N / 128) <= 256) return launch_ring<bf16_t, 64, 128, 2, 2, 128, 4>(p, st);
     return launch_ring<bf16_t, 64, 128, 2, 2, 128, 3>(p, st);
+  }
+  if (dtype == SL_BF16 && cfg == 3032032) {
+    p.gridM = 1; p.gridN = p.N / 32;
+    hipLaunchKernelGGL(conv_rows_small_kernel, dim3(p.N / 32), dim3(64), 0, st, p);
+    SL_LAUNCH_CHECK("conv_rows_small_kernel");
+    return 0;
   }
   if (dtype == SL_BF16 && cfg == 4128064) return launch_ring<bf16_t, 128, 64, 4, 1, 64, 4>(p, st);
   if (dtype == SL_BF16 && cfg == 4128192) return launch_ring<bf16_t, 128, 192, 4, 1, 64, SL_RING192_NST>(p, st);

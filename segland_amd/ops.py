@@ -56,7 +56,7 @@ class _Profiler:
     Off by default.  Launches are attributed to the kernel they are dispatched to (`family`, the name rocprofv3 shows);
     `only` restricts timing to one family so the timed region carries just those event pairs."""
 
-    FAMILY = {9: 'conv_gemm_sk512_kernel', 8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
+    FAMILY = {9: 'conv_gemm_sk512_kernel', 8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 3: 'conv_rows_small_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
         self.on, self.only, self.rec, self.rec_bytes = False, None, {}, {}

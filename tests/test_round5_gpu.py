@@ -511,3 +511,39 @@ def test_bias_gradient_inside_the_weight_gradient_kernel(hip, case):
     if K == 128 and dt_ == torch.bfloat16:
         dwc, dbc = ops.conv2d_bwd_weight_clip(x, dy, spec, N - 96, 96, want_bias=True)
         assert torch.equal(dwc, dw1[:N - 96, :96]) and torch.equal(dbc, db1)
+
+
+@pytest.mark.parametrize('case', [(14, 512, 512), (8, 512, 512), (30, 512, 512), (32, 2048, 64), (1, 64, 128)])
+def test_prototype_rows_kernel(hip, case):
+    """The +-prototype rows of the POP head's classifier MLP (pspnet_pop.py:46-52 on [2K, 512]; functional._row_parts) are launches of <= 32 rows: conv_rows_small_kernel
+    (one wave per 32 columns, operands straight from global memory) against the tile kernel they ran on (hook off): bit-identical forward + ReLU and data gradient + ReLU
+    mask, and against fp32 torch."""
+    from segland_amd import ops
+    dt_ = torch.bfloat16
+    M, K, N = case
+    torch.manual_seed(M + K)
+    x = torch.randn(1, 1, M, K, device=DEV).to(dt_)
+    w = torch.randn(N, K, 1, 1, device=DEV) * (1.0 / K) ** 0.5
+    spec = ops.ConvSpec(K, N, 1, 1, 0, 1)
+    wf, wb = ops.weight_prep(w, dt_)
+    d = ops.conv_desc(dt_, 1, 1, M, spec, None)
+    assert hip.sl_conv2d_tile_config_ex(C.byref(d), 0, 0) == 3032032
+    y1 = ops.conv2d_fwd(x, wf, spec, relu=True)[0]
+    dy = torch.randn(1, 1, M, N, device=DEV).to(dt_)
+    hm = torch.randn(1, 1, M, K, device=DEV).to(dt_)
+    g1 = ops.conv2d_bwd_data(dy, wb, spec, (1, M), mask_src=hm)
+    p1 = ops.conv2d_bwd_data(dy, wb, spec, (1, M))
+    hip.sl_debug_conv_rows_small(0)
+    try:
+        assert hip.sl_conv2d_tile_config_ex(C.byref(d), 0, 0) != 3032032
+        y0 = ops.conv2d_fwd(x, wf, spec, relu=True)[0]
+        g0 = ops.conv2d_bwd_data(dy, wb, spec, (1, M), mask_src=hm)
+        p0 = ops.conv2d_bwd_data(dy, wb, spec, (1, M))
+    finally:
+        hip.sl_debug_conv_rows_small(1)
+    assert torch.equal(y1, y0) and torch.equal(g1, g0) and torch.equal(p1, p0), 'prototype-rows kernel vs tile kernel'
+    ref = torch.relu(x.float().reshape(M, K) @ w.to(dt_).float().reshape(N, K).t())
+    close(y1.float().reshape(M, N), ref, 'forward + ReLU %s' % (case,))
+    refg = dy.float().reshape(M, N) @ w.to(dt_).float().reshape(N, K)
+    close(p1.float().reshape(M, K), refg, 'data gradient')
+    close(g1.float().reshape(M, K), torch.where(hm.float().reshape(M, K) > 0, refg.to(dt_).float(), torch.zeros((), device=DEV)), 'data gradient + ReLU mask')
