@@ -27,6 +27,9 @@ def ft_iteration(model, optimizer, loss_scaler, batch, device, dataset=None):
     return loss_dict, grad_norm
 
 
+_CLIP_IN_STEP = os.environ.get('SEGLAND_FT_CLIP_IN_STEP', '1') != '0'      # 0: torch's clip_grad_norm_ (scales the gradients in place) + a plain step (A/B)
+
+
 def ft_graph_body(model, clip_grad=5.0, optimizer=None):
     """forward + backward + clip_grad_norm_ (+ the optimizer step) of ft_iteration as a function of the four batch tensors, for graph_step.GraphedStep.
     optimizer: a segland_amd.optim.SGD -- its one-launch step reads the learning rate from device memory, so it sits inside the graph although ft_pop changes the
@@ -35,6 +38,13 @@ def ft_graph_body(model, clip_grad=5.0, optimizer=None):
         loss_dict = model(img, mask, img_b, mask_b)
         loss_dict['total_loss'].backward()
         params = [p for p in model.parameters() if p.grad is not None]
+        if optimizer is not None and _CLIP_IN_STEP:
+            # the clip coefficient goes into the optimizer's one launch (as train_base.py's AdamW step does): the in-place scaling launches of clip_grad_norm_ fall away;
+            # the gradients themselves stay unscaled (ft_iteration_graphed zeroes them right behind the step)
+            from .optim import clip_coefficient
+            norm, coef = clip_coefficient(params, clip_grad)
+            optimizer.step(grad_scale=coef)
+            return loss_dict, norm
         norm = torch.nn.utils.clip_grad_norm_(params, clip_grad)
         if optimizer is not None:
             optimizer.step()

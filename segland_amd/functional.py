@@ -245,6 +245,7 @@ def _frozen(ctx, *bns):
 
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
+_BASE_CHAIN_CACHE = os.environ.get('SEGLAND_BASE_CHAIN_CACHE', '1') != '0'      # ft mode: the frozen base classifier's rows are computed once (0: every iteration; A/B)
 _BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm_common.h: conv_epilogue_fast MODE 3)
 _BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
 _BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
@@ -706,6 +707,28 @@ def _mlp_bwd(X, h1, h2, cls, dz, need_w, need_x, big=0):
     return dX, dw1, dw2, (dw3.view_as(cls[4].weight) if need_w else None)
 
 
+def _base_chain(model, S_b, dtype, frozen):
+    """ft mode: the base classifier over the +-base prototype rows (pspnet_pop.py:210-216).  With the base prototypes and the base classifier frozen (ft_pop.py:197-203)
+    its result is the same every iteration: kept on the model, keyed on the versions of what it is computed from (four launches per step less).  Never created while a
+    graph is being captured (its tensors would live in the graph's pool)."""
+    def run():
+        Xb = torch.empty((2 * S_b.shape[0], S_b.shape[1]), dtype=dtype, device=S_b.device)
+        ops.pop_proto_rows(S_b.contiguous(), Xb)
+        return (Xb,) + tuple(_mlp_fwd(Xb, model.classifier))
+    emb = getattr(model, 'base_emb', None)
+    if not (frozen and _BASE_CHAIN_CACHE and emb is not None and not emb.requires_grad):
+        return run()
+    ws = cls_params(model.classifier)
+    key = (tuple((_wver(w), w.data_ptr()) for w in ws), emb._version, emb.data_ptr(), dtype, tuple(S_b.shape))
+    ent = model.__dict__.get('_sl_base_chain')
+    if ent is not None and ent[0] == key:
+        return ent[1]
+    out = run()
+    if not (S_b.is_cuda and torch.cuda.is_current_stream_capturing()):
+        model.__dict__['_sl_base_chain'] = (key, out)
+    return out
+
+
 class PopHeadFn(torch.autograd.Function):
     """orthogonal_decompose + classifier(s) in the collapsed form.
     feat NHWC [B,h,w,512]; S_b / S_n: L2-normalised prototypes (float).  Returns preds [B, 1+Kb+Kn, h, w] float,
@@ -730,9 +753,7 @@ class PopHeadFn(torch.autograd.Function):
         cls_main = model.classifier_n if ft else model.classifier
         h1, h2, z = _mlp_fwd(X, cls_main, big=R)
         if ft:
-            Xb = torch.empty((2 * Kb, Cn), dtype=feat.dtype, device=feat.device)
-            ops.pop_proto_rows(S_b.contiguous(), Xb)
-            h1b, h2b, zb = _mlp_fwd(Xb, model.classifier)
+            Xb, h1b, h2b, zb = _base_chain(model, S_b, feat.dtype, frozen=not (ctx.needs_input_grad[1] or ctx.needs_input_grad[4]))
             a = torch.cat([zb[:Kb], z[R:R + Kn]]).contiguous()
             b = torch.cat([zb[Kb:], z[R + Kn:]]).contiguous()
         else:

@@ -143,6 +143,7 @@ class SGD(torch.optim.Optimizer):
     group's (lr, weight_decay) from device memory, which graph_prepare() refreshes before every replay -- ft_pop changes the learning rate every iteration
     (ft_pop.py:246-249), which is what kept torch's SGD (it bakes lr into its launches: four small launches per step) outside the captured step until round 4.
     dampening / nesterov / maximize are not implemented (the reference uses none of them)."""
+    supports_grad_scale = True      # step(grad_scale=coef): the clip_grad_norm_ coefficient applied inside the kernel (utils.pyt_utils.NativeScalerWithGradNormCount, ft_pop.ft_graph_body)
 
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, maximize=False, **unused):
         if lr < 0 or momentum < 0 or weight_decay < 0:

@@ -99,8 +99,8 @@ class NativeScalerWithGradNormCount:
         if not update_grad:
             return None
         params = [p for p in parameters if p.grad is not None]
-        if clip_grad is not None and hasattr(optimizer, 'repeat_next'):
-            from ..optim import clip_coefficient           # segland_amd.optim.AdamW applies the clip coefficient inside its kernel
+        if clip_grad is not None and (hasattr(optimizer, 'repeat_next') or getattr(optimizer, 'supports_grad_scale', False)):
+            from ..optim import clip_coefficient           # segland_amd.optim.AdamW / SGD apply the clip coefficient inside their kernel
             norm, coef = clip_coefficient(params, clip_grad, self.grad_div)
             optimizer.step(grad_scale=coef)
             return norm
