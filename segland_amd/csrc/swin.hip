@@ -104,10 +104,12 @@ __global__ void patch_im2col_kernel(const float* __restrict__ img, T* __restrict
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // rows of C channels (pitch px / py); a row belongs to LPR lanes; stats[row] = {mean, rstd}
-template <typename T, int LPR>
+// NVL > 0: a lane keeps its (at most NVL) channel vectors of the row in registers -- x is read once (round 5: the three passes re-read it from the L1 / L2, three dependent
+// load latencies per row; the 8 192- and 2 048-token maps of stages 3 / 4 ran at 0.6-1.5 TB/s); same arithmetic in the same order as the streaming form (NVL = 0).
+template <typename T, int LPR, int NVL>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             T* __restrict__ y, float* __restrict__ stats, long long rows, int C, int px, int py, float eps) {
-  constexpr int V = Vec16<T>::N, RPW = 64 / LPR;
+  constexpr int V = Vec16<T>::N, RPW = 64 / LPR, NR = NVL > 0 ? NVL : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
   const int nvec = C / V;
   for (long long rb = ((long long)blockIdx.x * 4 + wave) * RPW; rb < rows; rb += (long long)gridDim.x * 4 * RPW) {
@@ -115,29 +117,56 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     const bool live = r < rows;
     const T* xr = x + (size_t)(live ? r : 0) * px;
     float s = 0.f;
-    for (int v = sub; v < nvec; v += LPR) {
-      float t[V];
-      unpack16<T>(*(const uint4*)(xr + v * V), t);
+    uint4 xv[NR];
+    if constexpr (NVL > 0) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) s += t[e];
+      for (int j = 0; j < NVL; ++j) { const int v = sub + j * LPR; if (v < nvec) xv[j] = *(const uint4*)(xr + v * V); }
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) {
+        if (sub + j * LPR < nvec) {
+          float t[V];
+          unpack16<T>(xv[j], t);
+#pragma unroll
+          for (int e = 0; e < V; ++e) s += t[e];
+        }
+      }
+    } else {
+      for (int v = sub; v < nvec; v += LPR) {
+        float t[V];
+        unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s += t[e];
+      }
     }
     const float mean = grp_sum<LPR>(s) / (float)C;
     float q = 0.f;
-    for (int v = sub; v < nvec; v += LPR) {
-      float t[V];
-      unpack16<T>(*(const uint4*)(xr + v * V), t);
+    if constexpr (NVL > 0) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) { const float d = t[e] - mean; q = fmaf(d, d, q); }
+      for (int j = 0; j < NVL; ++j) {
+        if (sub + j * LPR < nvec) {
+          float t[V];
+          unpack16<T>(xv[j], t);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { const float d = t[e] - mean; q = fmaf(d, d, q); }
+        }
+      }
+    } else {
+      for (int v = sub; v < nvec; v += LPR) {
+        float t[V];
+        unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float d = t[e] - mean; q = fmaf(d, d, q); }
+      }
     }
     const float rstd = rsqrtf(grp_sum<LPR>(q) / (float)C + eps);
     if (!live) continue;
     if (sub == 0 && stats) { stats[2 * r] = mean; stats[2 * r + 1] = rstd; }
     T* yr = y + (size_t)r * py;
-    for (int v = sub; v < py / V; v += LPR) {
+    auto emit = [&](int v, const uint4* held) {
       float o[V];
       if (v < nvec) {
         float t[V];
-        unpack16<T>(*(const uint4*)(xr + v * V), t);
+        unpack16<T>(held ? *held : *(const uint4*)(xr + v * V), t);
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = (t[e] - mean) * rstd * gamma[v * V + e] + beta[v * V + e];
       } else {
@@ -145,6 +174,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         for (int e = 0; e < V; ++e) o[e] = 0.f;
       }
       *(uint4*)(yr + v * V) = pack16<T>(o);
+    };
+    if constexpr (NVL > 0) {
+#pragma unroll
+      for (int j = 0; j < NVL; ++j) { const int v = sub + j * LPR; if (v < py / V) emit(v, &xv[j]); }
+    } else {
+      for (int v = sub; v < py / V; v += LPR) emit(v, nullptr);
     }
   }
 }
@@ -180,26 +215,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const T* xr = x + (size_t)rr * px;
     const float mean = stats[2 * rr], rstd = stats[2 * rr + 1];
     float s1 = 0.f, s2 = 0.f;
-    for (int v = sub; v < nvec; v += LPR) {
-      float g[V], t[V];
-      unpack16<T>(*(const uint4*)(dyr + v * V), g);
-      unpack16<T>(*(const uint4*)(xr + v * V), t);
+    uint4 gv[NA], tv[NA];               // NV > 0: the lane's vectors of dy and x stay in registers between the two passes (round 5; same arithmetic, same order)
+    if constexpr (NV > 0) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) { const float ge = g[e] * gamma[v * V + e]; s1 += ge; s2 = fmaf(ge, (t[e] - mean) * rstd, s2); }
+      for (int j = 0; j < NV; ++j) { const int v = sub + j * LPR; if (v < nvec) { gv[j] = *(const uint4*)(dyr + v * V); tv[j] = *(const uint4*)(xr + v * V); } }
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int v = sub + j * LPR;
+        if (v < nvec) {
+          float g[V], t[V];
+          unpack16<T>(gv[j], g);
+          unpack16<T>(tv[j], t);
+#pragma unroll
+          for (int e = 0; e < V; ++e) { const float ge = g[e] * gamma[v * V + e]; s1 += ge; s2 = fmaf(ge, (t[e] - mean) * rstd, s2); }
+        }
+      }
+    } else {
+      for (int v = sub; v < nvec; v += LPR) {
+        float g[V], t[V];
+        unpack16<T>(*(const uint4*)(dyr + v * V), g);
+        unpack16<T>(*(const uint4*)(xr + v * V), t);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { const float ge = g[e] * gamma[v * V + e]; s1 += ge; s2 = fmaf(ge, (t[e] - mean) * rstd, s2); }
+      }
     }
     s1 = grp_sum<LPR>(s1) / (float)C;
     s2 = grp_sum<LPR>(s2) / (float)C;
     if (!live) continue;
     T* dxr = dx + (size_t)r * pdx;
-#pragma unroll
-    for (int j = 0; j < (NV > 0 ? NV : 64); ++j) {
+    auto emit = [&](int j) {
       const int v = sub + j * LPR;
-      if (v >= pdx / V) break;
+      if (v >= pdx / V) return;
       float o[V];
       if (v < nvec) {
         float g[V], t[V];
-        unpack16<T>(*(const uint4*)(dyr + v * V), g);
-        unpack16<T>(*(const uint4*)(xr + v * V), t);
+        if constexpr (NV > 0) { unpack16<T>(gv[j < NA ? j : 0], g); unpack16<T>(tv[j < NA ? j : 0], t); }
+        else { unpack16<T>(*(const uint4*)(dyr + v * V), g); unpack16<T>(*(const uint4*)(xr + v * V), t); }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
           const float xh = (t[e] - mean) * rstd;
@@ -217,6 +268,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < V; ++e) o[e] = 0.f;
       }
       *(uint4*)(dxr + v * V) = pack16<T>(o);
+    };
+    if constexpr (NV > 0) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) emit(j);
+    } else {
+      for (int j = 0; sub + j * LPR < pdx / V; ++j) emit(j);          // (a 64-fold unrolled loop here cost the dx-only form 300 registers)
     }
   }
   if (NV > 0 && part) {
@@ -1346,11 +1403,12 @@ extern "C" int sl_patch_im2col(int dtype, const float* img, void* col, int B, in
 template <typename T>
 static int launch_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* stats, long long rows, int C, int px, int py, float eps, hipStream_t st) {
   constexpr int V = Vec16<T>::N;
-  const int nvec = C / V;
-  const int grid = (int)(rows / 16 + 1 > 8192 ? 8192 : rows / 16 + 1);
-  if (nvec <= 16) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
-  else if (nvec <= 32) hipLaunchKernelGGL((layernorm_fwd_kernel<T, 32>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
-  else hipLaunchKernelGGL((layernorm_fwd_kernel<T, 64>), dim3(grid), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps);
+  const int nvec = C / V, nvp = py / V > nvec ? py / V : nvec;      // vectors of a row incl. the zero pad of the output pitch
+  // one row group per wave where the map is small (a grid of rows / 16 blocks left 2 048 rows x 768 channels to 129 blocks: four dependent rows per wave)
+  auto grid_of = [&](int lpr) { const long long g = (rows + 4 * (64 / lpr) - 1) / (4 * (64 / lpr)); return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g)); };
+#define LN_FWD(LPR, NVL) hipLaunchKernelGGL((layernorm_fwd_kernel<T, LPR, NVL>), dim3(grid_of(LPR)), dim3(256), 0, st, (const T*)x, gamma, beta, (T*)y, stats, rows, C, px, py, eps)
+  if (nvp <= 16) LN_FWD(16, 1); else if (nvp <= 32) LN_FWD(32, 1); else if (nvp <= 64) LN_FWD(64, 1); else if (nvp <= 128) LN_FWD(64, 2); else if (nvp <= 192) LN_FWD(64, 3); else LN_FWD(64, 0);
+#undef LN_FWD
   return 0;
 }
 
@@ -1367,6 +1425,16 @@ extern "C" int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, co
 }
 
 constexpr int LN_BWD_BLOCKS = 2048;     // partial rows of the fused column sums (grid-stride over the rows)
+// blocks (= partial rows) of the fused backward
+static int ln_bwd_fused_blocks(long long rows, int nvp) {
+  // every block writes a partial row of 2 C floats that the finalize reads again: rows / 16 blocks keep that at a quarter of the tensor's own bytes (one row group per
+  // wave -- rows / 4 blocks at 64 lanes per row -- made the 8 192-token backward 13.5 -> 19.8 us); maps of few rows get up to 512 blocks (2 048 tokens: 13.2 -> 10.6 us)
+  const int lpr = nvp <= 16 ? 16 : (nvp <= 32 ? 32 : 64), rpb = 4 * (64 / lpr);
+  const long long one_group = (rows + rpb - 1) / rpb;
+  long long want = rows / 16 + 1;
+  if (want < 512) want = one_group < 512 ? one_group : 512;
+  return (int)(want > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : (want < 1 ? 1 : want));
+}
 
 // fused column sums need every lane's channel vectors in registers: up to 3 per lane (C <= 3 * 64 * 8 = 1536 in bf16, 768 in fp32)
 
@@ -1377,7 +1445,7 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, cons
   const int nvec = C / V, nvp = pdx / V;
   long long want = rows / 16 + 1;
   const bool fused = part != nullptr && nvp <= 192;
-  const int grid = (int)(fused ? (want > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : want) : (want > 8192 ? 8192 : want));
+  const int grid = (int)(fused ? ln_bwd_fused_blocks(rows, nvp) : (want > 8192 ? 8192 : want));
   const size_t lds = fused ? (size_t)8 * C * sizeof(float) : 0;
 #define LN_BWD(LPR, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, NV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, part, rows, C, pdy, px, pdx)
   if (fused) {
@@ -1391,7 +1459,7 @@ static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, cons
 
 extern "C" int sl_layernorm_bwd_rows(int dtype, long long rows, int C, int dx_pitch) {
   const int vb = dtype == SL_BF16 ? 8 : 4;
-  if (dx_pitch / vb <= 192) { const long long want = rows / 16 + 1; return (int)(want > LN_BWD_BLOCKS ? LN_BWD_BLOCKS : want); }
+  if (dx_pitch / vb <= 192) return ln_bwd_fused_blocks(rows, dx_pitch / vb);
   const long long b = (rows + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
