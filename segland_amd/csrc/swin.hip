@@ -984,10 +984,15 @@ __device__ __forceinline__ void store_dT(bf16_t* base, const f32x16_t& o, int hf
 //   (K^T, Q^T, dO^T: rows = d, k index = tokens) are ds_read_b64_tr_b16 reads of them -- no 2-byte scatter; the tokens of a 16-block sit in the order
 //   {0-3, 8-11, 4-7, 12-15} so that the hardware's k order (rows 8*half + e) is the D-layout order of the probability registers they multiply;
 // * 72 KiB of LDS per block instead of 156: two blocks per CU, i.e. a second wave on every SIMD under the first one's load / exp / LDS latencies.
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinGeom g, const bf16_t* __restrict__ qkv, const float* __restrict__ qkv_bias,
                                                                             const float* __restrict__ rel_bias, const bf16_t* __restrict__ dout, bf16_t* __restrict__ dqkv,
-                                                                            float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin) {
+                                                                            float* __restrict__ drel_part, float* __restrict__ pad_part, int wpw, int nwin,
+                                                                            unsigned long long* __restrict__ trace) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // debug (tools/attn_trace.py, sl_debug_attn_trace): s_memtime of thread 0 at the phase boundaries of the block's first window, [blocks][16]; null in production
+  auto stamp = [&](int i) { if constexpr (TRACE) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memtime(); } };
+  stamp(0);
   float* biasl = (float*)smem_raw;                          // [49][52] (+16): bias[query][key]
   unsigned char* tbase = (unsigned char*)(biasl + WN * BLP + 16);      // per wave: K, Q, dO tiles
   float* mzbase = (float*)(tbase + 4 * 3 * WB2_TILE);       // per wave: [64][4] = {max, 1/sum, rowdot, -}
@@ -1003,6 +1008,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
   }
   for (int e = tid; e < WN * WB2_AP; e += 256) dacc[e] = 0.f;
   __syncthreads();
+  stamp(1);
   unsigned char* tk = tbase + wave * 3 * WB2_TILE;
   unsigned char* tq = tk + WB2_TILE;
   unsigned char* tg = tq + WB2_TILE;
@@ -1076,6 +1082,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
     unsigned pk[8];
     win_pack_regions(g, wy, wx, lane, pk);
     __builtin_amdgcn_wave_barrier();
+    if (t == 0) stamp(2);
     // ---------------- T-layout, one 32-query block at a time
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb) {
@@ -1131,6 +1138,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
       for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp[ib][r] = st[ib][r] * (dp[ib][r] - rs);
+      if (t == 0) stamp(3 + 3 * jb);
       // sum of dS over the block's windows: the four waves add their registers to the shared tile one after the other (fixed order -> bit-stable)
       for (int w = 0; w < 4; ++w) {
         if (wave == w && j < WN) {
@@ -1146,6 +1154,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
         }
         __syncthreads();
       }
+      if (t == 0) stamp(4 + 3 * jb);
       // dQ^T[d][query] = sum_key K^T[d][key] dS[query][key]
       f32x16_t oq;
 #pragma unroll
@@ -1161,6 +1170,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
           for (int c = 3 * g.C; c < g.P3; c += 8) *(uint4*)(dst + c) = make_uint4(0, 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (t == 0) stamp(5 + 3 * jb);
     }
     // ---------------- N-layout (lane = key), one 32-key block at a time
     float padk = 0.f, padv = 0.f;                          // lane (half, l31 < 16): sum over the window's pad keys of d-register l31 of that half
@@ -1227,6 +1237,7 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (t == 0) stamp(9);
     float* padp = pad_part + ((size_t)wic * g.heads + head) * 96;
     if (!active) continue;
     if (l31 < 16) {
@@ -1237,6 +1248,8 @@ __global__ __launch_bounds__(256, 2) void window_attention_bwd_mfma2_kernel(WinG
   __syncthreads();
   float* dr = drel_part + ((size_t)chunk * g.heads + head) * (WN * WN);
   for (int e = tid; e < WN * WN; e += 256) dr[e] = dacc[(e / WN) * WB2_AP + e % WN];
+  stamp(10);
+  if constexpr (TRACE) { if (trace && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + 11] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); }
 }
 
 // backward of one (window, head); block (head, chunk) walks `wpb` windows and keeps the sum of dS (= gradient of the relative position bias)
@@ -1650,6 +1663,9 @@ extern "C" int sl_window_attention_windows(const SlWinDesc* d) {
   return g.B * g.nWy * g.nWx;
 }
 
+static unsigned long long* g_attn_trace = nullptr;
+extern "C" void sl_debug_attn_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; }      // test hook: [blocks][16] u64 phase stamps of window_attention_bwd_mfma2_kernel
+
 extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
                                        float* drel_partial, float* pad_partial, sl_stream_t stream) {
   WinGeom g;
@@ -1661,9 +1677,17 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
     const int wpw = win_wpw(g), chunks = cdiv(nwin, 4 * wpw);
     const size_t lds2 = (size_t)(WN * BLP + 16) * sizeof(float) + (size_t)4 * 3 * WB2_TILE + (size_t)4 * 256 * sizeof(float) + (size_t)WN * WB2_AP * sizeof(float);
     static bool attr2 = false;
-    if (!attr2) { (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); attr2 = true; }
-    hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
-                       (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin);
+    if (!attr2) {
+      (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      attr2 = true;
+    }
+    if (g_attn_trace)      // debug instantiation (the stamps cost 8 registers and 6 spills: not in the production kernel)
+      hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel<true>, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
+                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin, g_attn_trace);
+    else
+      hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel<false>, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
+                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin, nullptr);
     SL_LAUNCH_CHECK("window_attention_bwd_mfma2_kernel");
     return 0;
   }
