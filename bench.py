@@ -80,15 +80,18 @@ def train_step(model, opt, img, mask, params, double_step, grad_div=1):
     opt.zero_grad(set_to_none=True)
     loss = model(img, mask)
     loss['total_loss'].backward()
-    if hasattr(opt, 'repeat_next'):
-        from segland_amd.optim import clip_coefficient
-        _, coef = clip_coefficient(params, 5.0, grad_div)   # clip_grad_norm_(5.0): the coefficient is applied inside the optimizer kernel
-        opt.step(repeat=2 if double_step else 1, grad_scale=coef)      # the reference's two steps on the same gradients in one pass
-    else:
-        torch.nn.utils.clip_grad_norm_(params, 5.0)
-        opt.step()
-        if double_step:
+    from segland_amd import ops
+    # the optimizer part of the step (reported separately as optimizer_ms_per_step): gradient norm (4 B per parameter) + AdamW (read p, g, m, v; write p, m, v: 28 B)
+    with ops.PROFILER.region('optimizer (clip_grad_norm_ + AdamW)', 32 * sum(p.numel() for p in params) if ops.PROFILER.on else 0):
+        if hasattr(opt, 'repeat_next'):
+            from segland_amd.optim import clip_coefficient
+            _, coef = clip_coefficient(params, 5.0, grad_div)   # clip_grad_norm_(5.0): the coefficient is applied inside the optimizer kernel
+            opt.step(repeat=2 if double_step else 1, grad_scale=coef)      # the reference's two steps on the same gradients in one pass
+        else:
+            torch.nn.utils.clip_grad_norm_(params, 5.0)
             opt.step()
+            if double_step:
+                opt.step()
     return loss
 
 
@@ -429,11 +432,18 @@ def main():
         with open(a.profile_table, 'w') as f:
             f.write('# one instrumented step, %s %s batch %d: conv launches by kernel and shape (HIP events on the launch stream)\n' % (a.backbone, a.dtype, a.batch))
             for fam in sorted(table.values(), key=lambda e: -e['ms_total']):
-                f.write('== %-58s calls %4d  %8.3f ms  %9.1f GFLOP  %7.1f TFLOP/s  %6.2f TB/s\n' % (fam['family'], fam['calls'], fam['ms_total'], fam['gflop'], fam['gflop'] / max(fam['ms_total'], 1e-9),
-                                                                                                      fam.get('gbytes', 0.0) / max(fam['ms_total'], 1e-9)))
-                for shape, (n, ms, gf) in sorted(fam['shapes'].items(), key=lambda kv: -kv[1][1]):
-                    f.write('   %-50s %4d %9.3f ms %9.1f GFLOP %8.1f TFLOP/s\n' % (shape, n, ms, gf, gf / max(ms, 1e-9)))
-            f.write('# total conv time %.2f ms, total conv GFLOP %.1f\n' % (sum(e['ms_total'] for e in table.values()), sum(e['gflop'] for e in table.values())))
+                f.write('== %-58s calls %4d  %8.3f ms  %9.1f GFLOP  %7.1f TFLOP/s  %6.2f TB/s   floor %7.3f ms (%.2f of it)\n' % (
+                    fam['family'], fam['calls'], fam['ms_total'], fam['gflop'], fam['gflop'] / max(fam['ms_total'], 1e-9), fam.get('gbytes', 0.0) / max(fam['ms_total'], 1e-9),
+                    fam['floor_ms'], fam['floor_ms'] / max(fam['ms_total'], 1e-9)))
+                for shape, (n, ms, gf, fl) in sorted(fam['shapes'].items(), key=lambda kv: -kv[1][1]):
+                    f.write('   %-50s %4d %9.3f ms %9.1f GFLOP %8.1f TFLOP/s   floor %7.3f ms (%.2f)\n' % (shape, n, ms, gf, gf / max(ms, 1e-9), fl, fl / max(ms, 1e-9)))
+            f.write('# total conv time %.2f ms, total conv GFLOP %.1f, total conv floor %.2f ms\n' % (sum(e['ms_total'] for e in table.values()), sum(e['gflop'] for e in table.values()),
+                                                                                                        sum(e['floor_ms'] for e in table.values())))
+            f.write('# floor of a launch = max(FLOP / dense MFMA peak (2500 TFLOP/s bf16, 157.3 fp32), algorithmic operand + result bytes / 6.3 TB/s achievable HBM); a weight-gradient span includes its slab reduce\n')
+            f.write('# streaming families of the same step (algorithmic bytes; floor = bytes / 6.3 TB/s):\n')
+            for k_, e in sorted(table_bytes.items(), key=lambda kv: -kv[1]['ms_total']):
+                f.write('== %-58s calls %4d  %8.3f ms  %9.3f GB  %6.2f TB/s   floor %7.3f ms (%.2f of it)\n' % (k_, e['calls'], e['ms_total'], e['gbytes'], e['gbytes'] / max(e['ms_total'], 1e-9),
+                                                                                                              e['floor_ms'], e['floor_ms'] / max(e['ms_total'], 1e-9)))
 
     if rank == 0:
         tiles = a.batch * world * a.steps
@@ -463,14 +473,31 @@ def main():
         out['executed_tflops'] = round(value * exec_gflop / max(a.batch, 1) / 1e3, 1)
         fams = {}
         for k_, e in table.items():
-            fams[k_] = {'tflops': round(e['gflop'] / max(e['ms_total'], 1e-9), 1), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls']}
+            fams[k_] = {'tflops': round(e['gflop'] / max(e['ms_total'], 1e-9), 1), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls'], 'floor_ms': round(e['floor_ms'], 3)}
             if e.get('gbytes'):
                 # algorithmic operand + result bytes (activations in and out, weights once, residual addend + gate bits): the HBM-bound families
                 # (conv_gemm_sk_kernel: K <= 256 1x1 convs; conv_c64k3_kernel) are judged on this figure against the 8 TB/s peak, the MFMA-bound ones on tflops
                 fams[k_]['gb_per_s'] = round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0)
         for k_, e in table_bytes.items():
-            fams[k_] = {'gb_per_s': round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls'], 'gbytes_per_step': round(e['gbytes'], 3)}
+            fams[k_] = {'gb_per_s': round(e['gbytes'] / max(e['ms_total'], 1e-9) * 1e3, 0), 'ms_per_step': round(e['ms_total'], 3), 'launches': e['calls'], 'gbytes_per_step': round(e['gbytes'], 3),
+                        'floor_ms': round(e['floor_ms'], 3)}
         out['families'] = fams               # one instrumented (un-timed) step: MFMA families in TFLOP/s, BatchNorm passes in algorithmic GB/s vs the 8 TB/s HBM peak
+        # ---- the step's own speed of light: every instrumented launch priced at max(FLOP / dense MFMA peak, algorithmic bytes / 6.3 TB/s achievable HBM);
+        # what is not instrumented (finalize / column-sum launches, pyramid row GEMMs, head combine, dispatch gaps) enters at its MEASURED time, so the floor errs high
+        opt_key = 'optimizer (clip_grad_norm_ + AdamW)'
+        inst_ms = sum(e['ms_total'] for e in table.values()) + sum(e['ms_total'] for e in table_bytes.values())
+        inst_floor = sum(e['floor_ms'] for e in table.values()) + sum(e['floor_ms'] for e in table_bytes.values())
+        step_ms = 1e3 * dt_s / a.steps
+        rest_ms = max(0.0, step_ms - inst_ms)
+        if opt_key in table_bytes:
+            out['optimizer_ms_per_step'] = round(table_bytes[opt_key]['ms_total'], 3)
+            out['optimizer_note'] = ('clip_grad_norm_(5.0) coefficient + both AdamW steps of train_base.py:262-264 (one launch), HIP events in the instrumented step; it is INSIDE '
+                                     'ms_per_step and value (fwd + bwd alone: ms_per_step - optimizer_ms_per_step)')
+        step_floor = {'step_floor_ms': round(inst_floor + rest_ms, 3), 'frac_of_floor': round((inst_floor + rest_ms) / max(step_ms, 1e-9), 4),
+                      'instrumented_ms': round(inst_ms, 3), 'instrumented_floor_ms': round(inst_floor, 3), 'uninstrumented_ms_at_measured_time': round(rest_ms, 3),
+                      'conv_floor_ms': round(sum(e['floor_ms'] for e in table.values()), 3), 'streaming_floor_ms': round(sum(e['floor_ms'] for e in table_bytes.values()), 3),
+                      'note': 'sum over the launches of one instrumented step of max(FLOP / %g TFLOP/s, algorithmic bytes / 6.3 TB/s); families[*].floor_ms has it per kernel family; '
+                              'frac_of_floor = step_floor_ms / ms_per_step (1.0 = the step runs at its own speed of light)' % peak}
         if live:
             e = list(live.values())[0]
             ach = e['gflop'] / max(e['ms_total'], 1e-9)        # GFLOP / ms == TFLOP/s
@@ -518,6 +545,7 @@ def main():
                               'note': 'every conv / GEMM launch of one instrumented kernel-by-kernel step (forward, data and weight gradients of all layers incl. slab reduces): '
                                       'executed FLOPs / HIP-event time against the %g TFLOP/s peak; north_star target 0.60' % peak}
             out['roofline'] = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                               'step_floor_ms': step_floor['step_floor_ms'], 'frac_of_floor': step_floor['frac_of_floor'], 'step_floor': step_floor,
                                'traffic': traffic, 'traffic_source': tsrc, 'clock_ghz_measured': clock, 'mfma_busy_measured': mfma_busy, 'clock_source': csrc,
                                'backbone_convs': backbone_convs, 'whole_step_frac': round(out['whole_step_tflops'] / peak, 4),
                                'kernel': e['family'], 'launches': e['calls'],

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('SEGLAND_LIB_PATH') or os.path.join(CSRC, 'libsegland_hip.so')      # SEGLAND_LIB_PATH: a differently built library (kernel A/B from one checkout)
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'segland_hip.h')
+DEBUG_HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'segland_hip_debug.h')      # test / tuning hooks (sl_debug_*): not part of the product ABI
 
 SL_F32, SL_BF16 = 0, 1
 
@@ -55,15 +56,15 @@ def _arg_ctype(decl):
     return _CTYPE[base]
 
 
-def declared_functions():
-    """{name: (restype, [argtypes])} parsed from the header, so the binding cannot drift from the ABI."""
-    src = open(HEADER).read()
+def declared_functions(header=None):
+    """{name: (restype, [argtypes])} parsed from the header (default: the product ABI, include/segland_hip.h), so the binding cannot drift from the ABI."""
+    src = open(header or HEADER).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     out = {}
-    for m in re.finditer(r'(int|size_t|const char\s*\*)\s+(sl_\w+)\s*\(([^;{]*?)\)\s*;', src):
+    for m in re.finditer(r'(int|size_t|void|const char\s*\*)\s+(sl_\w+)\s*\(([^;{]*?)\)\s*;', src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = [] if args in ('', 'void') else [_arg_ctype(a) for a in args.split(',')]
-        restype = C.c_int if ret == 'int' else (C.c_size_t if ret == 'size_t' else C.c_char_p)
+        restype = {'int': C.c_int, 'size_t': C.c_size_t, 'void': None}.get(ret, C.c_char_p)
         out[name] = (restype, argtypes)
     return out
 
@@ -88,9 +89,10 @@ def lib():
             raise RuntimeError('libsegland_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
                                'or `make -C segland_amd/csrc`; there is no fallback path' % LIB_PATH)
         l = C.CDLL(LIB_PATH)
-        for name, (restype, argtypes) in declared_functions().items():
-            fn = getattr(l, name)            # AttributeError here == header/library mismatch
-            fn.restype, fn.argtypes = restype, argtypes
+        for hdr in (HEADER, DEBUG_HEADER):
+            for name, (restype, argtypes) in declared_functions(hdr).items():
+                fn = getattr(l, name)            # AttributeError here == header/library mismatch
+                fn.restype, fn.argtypes = restype, argtypes
         _lib = l
     return _lib
 

@@ -60,6 +60,9 @@ class BucketedReplica(nn.Module):
         self.group = process_group
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if self.active else 1
+        # the capture handshake (agree) runs on a group of its own: a rank whose step sequence diverged then waits THERE while the others' bucket all-reduces wait on
+        # the data group -- both sides time out with a message, instead of a 3-float all-reduce pairing up with a bucket all-reduce of another size (round-5 advisor)
+        self.hs_group = dist.new_group(ranks=dist.get_process_group_ranks(process_group) if process_group is not None else None) if (self.active and self.world > 1) else process_group
         if self.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -225,13 +228,20 @@ class BucketedReplica(nn.Module):
         h = float(zlib.crc32(repr(signature).encode()) % (1 << 22)) if signature is not None else 0.0      # exact in fp32
         flag = torch.tensor([1.0 if ok else 0.0, h, -h], dtype=torch.float32, device=self.buckets[0].device)
         try:
-            work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+            work = dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.hs_group, async_op=True)
             if work.wait(datetime.timedelta(seconds=timeout_s)) is False:
-                raise RuntimeError('timed out')
-            v = flag.tolist()
-        except Exception as e:                                # noqa: BLE001
+                raise TimeoutError('timed out after %g s' % timeout_s)
+        except (dist.DistBackendError, dist.DistNetworkError, TimeoutError) as e:
             raise RuntimeError('bucket_step: the ranks did not all reach a capture attempt at the same step (%s).  Every rank must see the same sequence of input '
                                'signatures (DistributedSampler + drop_last); start with --no-step-graph to issue the steps kernel by kernel.' % e) from e
+        except RuntimeError as e:
+            # the process-group backends report a timed-out or aborted collective as a plain RuntimeError; anything else (an earlier asynchronous device fault
+            # surfacing at this wait) is handed on unchanged
+            if not any(w in str(e).lower() for w in ('timed out', 'timeout', 'connection', 'aborted', 'socket')):
+                raise
+            raise RuntimeError('bucket_step: the ranks did not all reach a capture attempt at the same step (%s).  Every rank must see the same sequence of input '
+                               'signatures (DistributedSampler + drop_last); start with --no-step-graph to issue the steps kernel by kernel.' % e) from e
+        v = flag.tolist()                                     # (outside the handler: a device fault that surfaces at this read-back is not a rendezvous problem)
         if v[1] != -v[2]:
             import logging
             logging.getLogger('Segmentation').warning('bucket_step: the ranks attempted a capture with different input signatures; all stay kernel by kernel')

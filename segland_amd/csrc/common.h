@@ -85,6 +85,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // ---- host side
 void sl_set_error(const char* fmt, ...);
+
+// Test / tuning hooks (include/segland_hip_debug.h; NOT part of the product ABI): ONE record of process-wide dispatch overrides and trace buffers, every field at its
+// default in production.  Only the sl_debug_* functions (api.cpp) write it; sl_debug_reset() restores the defaults (tests/conftest.py calls it after every GPU test).
+struct SlDebugState {
+  int conv_affine = 1;             // branch-free affine store phase for biased / folded-BN epilogues (0: the generic one everywhere -- the bit-identity test)
+  int conv_p9 = 1;                 // 3x3 patch kernel (0: the half-tile / ring kernels take the 3x3 layers)
+  int conv_ring192 = 1;            // 128 x 192 ring tile for 192-multiple output widths
+  int conv_ringn64 = 1;            // 128 x 64 ring tile for 64-column inference layers
+  int conv_rows_small = 1;         // <= 32-row launches on conv_rows_small_kernel
+  long long ring64_max_tiles = 256;   // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks (0: never)
+  int wgrad3 = 1;                  // nine-tap 3x3 weight gradient (0: per-tap kernels)
+  int wgrad_bias = 1;              // bias-gradient column sums out of the weight-gradient kernel's dy fragments (0: blocks of the slab-reduce launch)
+  int wgrad_tr = 1;                // bf16 fragments by ds_read_b64_tr_b16 (0: scalar LDS reads; the two must agree bit for bit)
+  long long wgrad_pair_min_rows = 0;  // > 0: 1x1 layers with a 64- (not 128-) multiple channel count run as pixel pairs from this many rows
+  int attn_valu = -1;              // 1: window attention on the VALU kernels (the MFMA kernels' reference)
+  unsigned long long* p8_trace = nullptr;      // [blocks][8] u64 phase stamps (tools/p8_trace.py)
+  unsigned long long* wgrad_trace = nullptr;   // [blocks][8] (tools/wgrad_trace.py)
+  unsigned long long* wgrad3_trace = nullptr;  // [blocks][8]
+  unsigned long long* attn_trace = nullptr;    // [blocks][16] (tools/attn_trace.py)
+};
+extern SlDebugState g_sl_debug;
 #define SL_REQUIRE(cond, ...)            \
   do {                                   \
     if (!(cond)) {                       \

@@ -28,23 +28,11 @@ static int splitk_parts(const ConvGemmParams& p, int dtype) {
   return s;
 }
 
-int g_ring192 = -1;      // SEGLAND_CONV_RING192=0 / sl_debug_conv_ring192(0): the 128 x 192 ring tile off (A/B hook)
-static bool ring192_on() {
-  if (g_ring192 < 0) g_ring192 = (getenv("SEGLAND_CONV_RING192") && getenv("SEGLAND_CONV_RING192")[0] == '0') ? 0 : 1;
-  return g_ring192 != 0;
-}
-int g_rows_small = -1;      // SEGLAND_CONV_ROWS_SMALL=0 / sl_debug_conv_rows_small(0): <= 32-row launches back on the tile kernels (A/B hook)
-static bool rows_small_on() {
-  if (g_rows_small < 0) g_rows_small = (getenv("SEGLAND_CONV_ROWS_SMALL") && getenv("SEGLAND_CONV_ROWS_SMALL")[0] == '0') ? 0 : 1;
-  return g_rows_small != 0;
-}
-int g_ringn64 = -1;      // SEGLAND_CONV_RINGN64=0 / sl_debug_conv_ringn64(0): 64-column inference layers back on the two-stage kernel (A/B hook)
-static bool ringn64_on() {
-  if (g_ringn64 < 0) g_ringn64 = (getenv("SEGLAND_CONV_RINGN64") && getenv("SEGLAND_CONV_RINGN64")[0] == '0') ? 0 : 1;
-  return g_ringn64 != 0;
-}
-long long g_ring64_max_tiles = 256;      // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks; tuning hook sl_debug_ring64_max_tiles (0: never)
-// Which kernel a launch runs on: 1000000 * family + 1000 * BM + BN (family 9 = pixel-stationary K = 512, 8 = 3x3 patch (+ 10000000: split-K), 7 = 64 -> 64 patch,
+// route overrides of the tests (include/segland_hip_debug.h); all on in production
+static bool ring192_on() { return g_sl_debug.conv_ring192 != 0; }          // the 128 x 192 ring tile
+static bool rows_small_on() { return g_sl_debug.conv_rows_small != 0; }    // <= 32-row launches on conv_rows_small_kernel
+static bool ringn64_on() { return g_sl_debug.conv_ringn64 != 0; }          // 64-column inference layers on 128 x 64 ring tiles
+// Which kernel a launch runs on: 1000000 * family + 1000 * BM + BN (family 8 = 3x3 patch (+ 10000000: split-K), 7 = 64 -> 64 patch,
 // 6 = pixel-stationary K <= 256, 5 = half-tile, 4 = ring, 2 = two-stage glds).  The ONE predicate chain: launch_gemm switches on it, sl_conv2d_tile_config(_ex) and
 // sl_conv2d_stat_rows answer from it (round-4 advisor: the query had drifted from the dispatch).
 static int choose_kernel(const ConvGemmParams& p, int dtype) {
@@ -63,7 +51,6 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
         (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
       return 6256064;
-    if (sk512_shape(p)) return 9256064;
     if (p9_shape(p) && !(p.flags & 4)) return 8256256;
     // half-tile kernel: needs the affine row -> pixel map (forward, or data gradient of a stride-1 conv) and <= 32 taps in the mask
     if (big && n256 && (p.mode == 0 || p.stride == 1) && !(p.flags & 4)) return 5256256;      // (flags bit 2, a GELU behind the data gradient: store phases of the tile kernels only)
@@ -93,7 +80,7 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
     // Round 5 (profiles/r5_ab_ring64_geom.txt): the 64-row tiles stream 128-byte stage rows (conv_gemm_tiles.hip: launch_tile): 1024 -> 256 16.0 -> 13.6 us, 3x3 256 -> 256 d2
     // 30.7 -> 26.0, 2048 -> 512 (256 tiles) 36.7 -> 32.6 where it lost before; 459.5 -> 473 pairs/s (ResNet-50), 400 -> 413 (Swin-T) with the limit at 256 tiles
     // (320: 469, 512: 465).  1x1 layers stay bit-identical to the 128 x 128 tiles; 3x3 layers sum (64-channel chunk, tap) instead of (32-channel chunk, tap).
-    if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_ring64_max_tiles) return 4064128;
+    if (n128 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN && (long long)cdiv(p.M, 128) * (p.N / 128) <= g_sl_debug.ring64_max_tiles) return 4064128;
   }
   if (n128 && p.M >= 128LL * RING128_MIN) return 4128128;
   if (n128) return 2128128;
@@ -107,7 +94,6 @@ int launch_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
       case 18256256: case 8256256: return launch_p9(p, st);
       case 7016016: return launch_c64k3(p, st);
       case 6256064: return launch_sk(p, st);
-      case 9256064: return launch_sk512(p, st);
       case 5256256: return launch_p8(p, st);
       default: break;
     }
@@ -115,10 +101,8 @@ int launch_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
   return launch_tile(cfg, dtype, p, st);       // families 4 (ring) and 2 (two-stage): conv_gemm_tiles.hip
 }
 
-int g_conv_affine = -1;    // 1 (default): branch-free affine store phase for biased / folded-BN epilogues; 0: the generic one everywhere
 int run_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
-  if (g_conv_affine < 0) g_conv_affine = 1;
-  if (!g_conv_affine) p.flags |= 2;
+  if (!g_sl_debug.conv_affine) p.flags |= 2;      // test hook: the generic store phase instead of the branch-free affine one (bit-identity test)
   const int bke = dtype == SL_BF16 ? 64 : 32;
   SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "conv: bad dtype %d", dtype);
   SL_REQUIRE(p.C1 > 0 && p.C1 % bke == 0 && p.C2 % bke == 0, "conv: source channels (%d,%d) must be multiples of %d", p.C1, p.C2, bke);
@@ -139,16 +123,6 @@ int check_desc(const SlConvDesc* d) {
 }
 
 }  // namespace
-
-// test hook (not part of the public ABI)
-extern "C" void sl_debug_conv_affine(int v) { g_conv_affine = v ? 1 : 0; }      // test hook: affine store phase on / off
-extern "C" void sl_debug_conv_ringn64(int v) { g_ringn64 = v ? 1 : 0; }      // test / A-B hook: 128 x 64 ring tile on / off
-extern "C" void sl_debug_conv_rows_small(int v) { g_rows_small = v ? 1 : 0; }      // test / A-B hook: the <= 32-row kernel on / off
-extern "C" void sl_debug_conv_ring192(int v) { g_ring192 = v ? 1 : 0; }      // test / A-B hook: 128 x 192 ring tile on / off
-extern "C" void sl_debug_ring64_max_tiles(int v) { g_ring64_max_tiles = v; }      // tuning hook: see launch_gemm
-extern "C" void sl_debug_conv_sk512(int v) { g_conv_sk512 = v ? 1 : 0; }      // test / A-B hook: K = 512 pixel-stationary kernel on / off
-extern "C" void sl_debug_conv_p9(int v) { g_conv_p9 = (v & 1) ? 1 : 0; }      // test hook: 3x3 patch kernel on / off
-extern "C" void sl_debug_p8_trace(void* buf) { g_p8_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see ConvGemmParams::trace
 
 // Which kernel a launch of this shape runs on (codes: choose_kernel): the SAME function launch_gemm switches on, applied to the parameter block the entry points would
 // build.  mode 0: forward, 1: data gradient.  epi (sl_conv2d_tile_config_ex): what the launch carries besides the raw result -- SL_EPI_STATS (BN statistic partials),
@@ -299,12 +273,11 @@ extern "C" int sl_conv2d_bwd_data_gelu(const SlConvDesc* d, const void* dy, cons
 // shapes that the tile kernels with the LDS-staged store phase take (half-tile, 3x3 patch, ring, two-stage) when every row block is full.
 extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
   if (!d) return 0;
-  static const bool off = getenv("SEGLAND_BN_FUSE") && getenv("SEGLAND_BN_FUSE")[0] == '0';
-  if (off) return 0;
   const int cfg = sl_conv2d_tile_config_ex(d, 1, SL_EPI_GATE);
   const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
   const long long M = (long long)d->B * d->H * d->W;
   if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2) || bm <= 0 || M % bm != 0) return 0;
+  if (cfg % 1000 == 192) return 0;      // the 128 x 192 ring tile's gated-statistics store phase is not exercised by any BatchNorm model (192-multiple widths are Swin's LayerNorm layers): not offered
   return (int)(M / bm);
 }
 
@@ -327,9 +300,8 @@ extern "C" int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, co
 // (dout, c3) disappears, and dout arrives gated.  Served: the shapes of the pixel-stationary kernel (1x1, K = 64 / 128 / 256, N % 128 == 0, N <= 1024, M % 256 == 0).
 extern "C" int sl_conv2d_bwd_data_addend_bnstat_rows(const SlConvDesc* d) {
   if (!d) return 0;
-  static const bool off = getenv("SEGLAND_BN_FUSE_CROSS") && getenv("SEGLAND_BN_FUSE_CROSS")[0] == '0';
   const long long M = (long long)d->B * d->H * d->W;
-  if (off || d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo) return 0;
+  if (d->dtype != SL_BF16 || d->H != d->Ho || d->W != d->Wo) return 0;
   if (!sk_shape(d->dtype, d->KH, d->KW, d->stride, d->pad, d->Cout, d->Cout, d->Cin, M) || d->Cin % 128 != 0 || d->Cin > 1024) return 0;
   return (int)(M / 256);
 }

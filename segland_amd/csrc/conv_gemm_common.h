@@ -69,10 +69,6 @@ int launch_c64k3(ConvGemmParams& p, hipStream_t st);
 bool c64k3_shape(int dtype, int KH, int KW, int stride, int pad, int dil, int Cin, int C1, int Cout, long long M);
 int launch_sk(ConvGemmParams& p, hipStream_t st);
 bool sk_shape(int dtype, int KH, int KW, int stride, int pad, int Cin, int C1, int N, long long M);
-int launch_sk512(ConvGemmParams& p, hipStream_t st);
-bool sk512_shape(const ConvGemmParams& p);
-extern int g_conv_p9, g_conv_sk512;
-extern unsigned long long* g_p8_trace;
 }  // namespace slconv
 
 namespace {

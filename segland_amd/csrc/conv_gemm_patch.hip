@@ -287,11 +287,10 @@ int launch_splitk_finish(ConvGemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-unsigned long long* slconv::g_p8_trace = nullptr;
 int slconv::launch_p8(ConvGemmParams& p, hipStream_t st) {
   p.gridM = cdiv(p.M, 256);
   p.gridN = p.N / 256;
-  p.trace = g_p8_trace;
+  p.trace = g_sl_debug.p8_trace;
   p.flags |= 1;                                 // the next tile's first wait is counted past the epilogue's own loads and stores
   static bool attr_set = false;
   if (!attr_set) {
@@ -302,9 +301,8 @@ int slconv::launch_p8(ConvGemmParams& p, hipStream_t st) {
   }
   const int ntiles = p.gridM * p.gridN;
   // persistent: min(tiles, 256) blocks walk over the tiles; the instantiation with the gated-statistics store phase only where it is used
-  static const bool aff_off = getenv("SEGLAND_CONV_P8_AFFINE") && getenv("SEGLAND_CONV_P8_AFFINE")[0] == '0';      // A/B: biased launches back on the generic store phase
   if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<1>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
-  else if ((p.bias || p.scale) && !p.stat_partial && !aff_off) hipLaunchKernelGGL(conv_gemm_p8_kernel<2>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  else if ((p.bias || p.scale) && !p.stat_partial) hipLaunchKernelGGL(conv_gemm_p8_kernel<2>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   else        hipLaunchKernelGGL(conv_gemm_p8_kernel<0>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");
   return 0;
@@ -491,11 +489,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p9_kernel(ConvGemmParams p) {
 
 }  // namespace
 
-int slconv::g_conv_p9 = -1;      // SEGLAND_CONV_P9 / sl_debug_conv_p9
-bool slconv::p9_on() {
-  if (g_conv_p9 < 0) g_conv_p9 = (getenv("SEGLAND_CONV_P9") && getenv("SEGLAND_CONV_P9")[0] == '0') ? 0 : 1;
-  return g_conv_p9 != 0;
-}
+bool slconv::p9_on() { return g_sl_debug.conv_p9 != 0; }      // test hook sl_debug_conv_p9
 bool slconv::p9_shape(const ConvGemmParams& p) {
   return p9_on() && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && (p.dil == 1 || p.dil == 2 || p.dil == 4) && p.C2 == 0 && p.C1 % 64 == 0 && p.N % 256 == 0 &&
          p.Hs == p.Hd && p.Ws == p.Wd && p.Hs % 16 == 0 && p.Ws % 16 == 0 && ((long long)p.M >= 32768 || p.ksplit > 1) &&

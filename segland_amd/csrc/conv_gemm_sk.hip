@@ -1,9 +1,6 @@
-// 64 -> 64 3x3 patch kernel (family 7) and the pixel-stationary 1x1 kernels (family 6: K <= 256, family 9: K = 512) of the implicit-GEMM convolution.  See conv_gemm_common.h.
+// 64 -> 64 3x3 patch kernel (family 7) and the pixel-stationary 1x1 kernels (family 6: K <= 256) of the implicit-GEMM convolution.  See conv_gemm_common.h.
 #include "conv_gemm_common.h"
 
-#ifndef SL_SK512_PF
-#define SL_SK512_PF 4
-#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -147,8 +144,7 @@ __global__ __launch_bounds__(256) void conv_c64k3_kernel(ConvGemmParams p, int n
 }  // namespace
 
 bool slconv::c64k3_shape(int dtype, int KH, int KW, int stride, int pad, int dil, int Cin, int C1, int Cout, long long M) {
-  static const bool off = getenv("SEGLAND_CONV_C64K3") && getenv("SEGLAND_CONV_C64K3")[0] == '0';
-  return !off && dtype == SL_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && Cin == 64 && C1 == 64 && Cout == 64 && M >= 65536;
+  return dtype == SL_BF16 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && Cin == 64 && C1 == 64 && Cout == 64 && M >= 65536;
 }
 
 int slconv::launch_c64k3(ConvGemmParams& p, hipStream_t st) {
@@ -442,8 +438,7 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
 }  // namespace
 
 bool slconv::sk_shape(int dtype, int KH, int KW, int stride, int pad, int Cin, int C1, int N, long long M) {
-  static const bool off = getenv("SEGLAND_CONV_SK") && getenv("SEGLAND_CONV_SK")[0] == '0';
-  return !off && dtype == SL_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && C1 == Cin && (Cin == 64 || Cin == 128 || Cin == 256) &&
+  return dtype == SL_BF16 && KH == 1 && KW == 1 && stride == 1 && pad == 0 && C1 == Cin && (Cin == 64 || Cin == 128 || Cin == 256) &&
          N % 64 == 0 && M >= 65536 && M % 256 == 0;
 }
 
@@ -474,236 +469,3 @@ int slconv::launch_sk(ConvGemmParams& p, hipStream_t st) {
   return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);
 }
 
-namespace {
-// ---------------------------------------------------------------------------------------------------------------
-// K = 512 1x1 convs at >= 65 536 pixels (layer4 conv3 forward 512 -> 2048, the data gradient of layer4 conv1 2048 <- 512 with its shortcut addend, 512 -> 1024 / 512 -> 256):
-// on the half-tile kernel a 256 x 256 tile of these layers is 8 K-tiles of main loop between a prologue and a store phase that nothing overlaps (tools/p8_trace.py: 15 / 61 / 24 %
-// and 15 / 46 / 40 %; 600-700 TFLOP/s), and BOTH operands pass the LDS-DMA path at 32 B per clock and CU.  The pixel-stationary form of conv_gemm_sk_kernel at K = 512:
-//   * each wave keeps its 32 pixel rows x 512 channels in 128 registers as MFMA fragments (read once from HBM); only the WEIGHT rows stream (from the L2): 16 B per clock
-//     and CU at the MFMA rate; a step's 64 x 32 x 32 result tile is stored (full 128-byte lines, + addend / gate bits / statistics) while the next step multiplies;
-//   * the weight rows of a step (64 rows x 1 KiB) arrive as two halves of 32 rows through a ring of THREE 32 KiB slots, each half issued a full step before its first
-//     read: half 2s+3 right behind the barrier that ends the reads of half 2s (its slot), half 2s+4 behind the step's second barrier;
-//   * counted vmcnt waits (a wave's VMEM order per step: addend (+ gate byte) loads, 4 LDS-DMA, 4 stores, 4 LDS-DMA), vmcnt(0) on the last two steps.
-struct Sk5Geom {
-  static constexpr int KS = 32, RB = 1024;                             // k-steps, operand row bytes
-  static constexpr int HSLOT = 32 * RB;                                // half a step of weight rows
-  static constexpr int OFF_STG = 3 * HSLOT;
-  static constexpr int STG_PITCH = 144, STG_WAVE = 32 * STG_PITCH;
-  static constexpr int OFF_RED = OFF_STG + 8 * STG_WAVE;
-  static constexpr int LDS = OFF_RED + 2 * 8 * 2 * 64 * (int)sizeof(float);
-};
-template <int MODE>       // 1: store (+ statistics), 2: + addend, gated by the bits of addend_mask when given
-__global__ __launch_bounds__(512, 2) void conv_gemm_sk512_kernel(ConvGemmParams p) {
-  using G = Sk5Geom;
-  using T = bf16_t;
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, fh = lane >> 5;
-  const int bm = blockIdx.x;
-  const int NS = p.N / 64, NH = 2 * NS;
-  const unsigned long long tr_entry = p.trace ? __builtin_amdgcn_s_memtime() : 0ull;
-  const unsigned lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  // half-step H = weight rows 32 H .. 32 H + 31, one KiB instruction per row, four rows per wave; source-side swizzle: chunk ^ (row & 31)
-  const unsigned char* bsrc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = wave * 4 + j;
-    bsrc[j] = (const unsigned char*)p.wt + (size_t)row * G::RB + ((lane ^ (row & 31)) << 4);
-  }
-  auto issueH = [&](int H, int slot) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16_asm(bsrc[j] + (size_t)H * G::HSLOT, lds_base + slot * G::HSLOT + (wave * 4 + j) * 1024);
-  };
-  issueH(0, 0);
-  issueH(1, 1);
-  uint4 a[G::KS];
-  {
-    const unsigned char* arow = (const unsigned char*)p.src1 + ((size_t)bm * 256 + wave * 32 + l31) * G::RB + fh * 16;
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) a[ks] = *(const uint4*)(arow + ks * 32);
-  }
-  const int fbase = l31 * G::RB, fx = l31;                              // fragment chunk (2 ks + fh) ^ (row & 31) of weight row l31 of the half
-  unsigned char* stg = smem + G::OFF_STG + wave * G::STG_WAVE;
-  float* red = (float*)(smem + G::OFF_RED);
-  const int srow = lane >> 3, sch = lane & 7;
-  const size_t orow = (size_t)bm * 256 + wave * 32 + srow;
-  const bool gated = MODE == 2 && p.addend_mask != nullptr;
-  uint4 addv[4];
-  unsigned gbyte[4];
-
-  // weight fragments are read PF k-steps ahead of their MFMA (the compiler's own schedule keeps ONE ds_read_b128 in flight: a wave alone on its SIMD then issues an
-  // MFMA every ~86 clocks instead of every 32 -- tools/sk512_trace.py)
-  auto half = [&](const unsigned char* bb, f32x16_t& acc) {
-    constexpr int PF = SL_SK512_PF;
-    const unsigned char* rowp = bb + fbase;
-    uint4 bq[PF];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int u = 0; u < PF; ++u) bq[u] = *(const uint4*)(rowp + (((2 * u + fh) ^ fx) << 4));
-#pragma unroll
-    for (int ks = 0; ks < G::KS; ++ks) {
-      const uint4 b = bq[ks % PF];
-      if (ks + PF < G::KS) bq[ks % PF] = *(const uint4*)(rowp + (((2 * (ks + PF) + fh) ^ fx) << 4));
-      Mma<T>::run(b, a[ks], acc);
-    }
-    // pin the order the source has (hipcc would sink every read to just in front of its MFMA): PF reads, then MFMA / read pairs, then the last PF MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-    for (int ks = 0; ks < G::KS - PF; ++ks) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
-  };
-  auto stage = [&](const f32x16_t& acc, int j) {                      // D layout: lane = pixel (l31), register r = column (r & 3) + 8 (r >> 2) + 4 fh of column half j
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint2 v;
-      v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[4 * q + 0], acc[4 * q + 1]}, bf16x2_t));
-      v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){acc[4 * q + 2], acc[4 * q + 3]}, bf16x2_t));
-      *(uint2*)(stg + l31 * G::STG_PITCH + 64 * j + 16 * q + 8 * fh) = v;
-    }
-  };
-  auto store = [&](int s) {
-    const int cur = s & 1;
-    const int ncol = s * 64 + sch * 8;
-    float sa[8], sq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sq[e] = 0.f; }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const uint4 raw = *(const uint4*)(stg + (it * 8 + srow) * G::STG_PITCH + sch * 16);
-      T* o = (T*)p.out + (orow + it * 8) * p.N + ncol;
-      if constexpr (MODE == 1) {
-        st16(o, raw);
-        if (p.stat_partial) {
-          const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float lo = __uint_as_float(w[c] << 16), hi = __uint_as_float(w[c] & 0xffff0000u);
-            sa[2 * c] += lo; sq[2 * c] += lo * lo; sa[2 * c + 1] += hi; sq[2 * c + 1] += hi * hi;
-          }
-        }
-      } else {
-        uint4 ad = addv[it];
-        if (gated) {
-          const unsigned b = gbyte[it];
-          ad.x &= ((unsigned)__builtin_amdgcn_sbfe(b, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 1, 1) & 0xffff0000u);
-          ad.y &= ((unsigned)__builtin_amdgcn_sbfe(b, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 3, 1) & 0xffff0000u);
-          ad.z &= ((unsigned)__builtin_amdgcn_sbfe(b, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 5, 1) & 0xffff0000u);
-          ad.w &= ((unsigned)__builtin_amdgcn_sbfe(b, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(b, 7, 1) & 0xffff0000u);
-        }
-        const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w}, aw[4] = {ad.x, ad.y, ad.z, ad.w};
-        unsigned ow[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f32x2_t v = (f32x2_t){__uint_as_float(rw[c] << 16) + __uint_as_float(aw[c] << 16), __uint_as_float(rw[c] & 0xffff0000u) + __uint_as_float(aw[c] & 0xffff0000u)};
-          ow[c] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-        }
-        st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
-      }
-    }
-    if (MODE == 1 && p.stat_partial) {                                 // lanes 8 apart share the column octet
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { sa[e] = sk_sum_8_16_32(sa[e]); sq[e] = sk_sum_8_16_32(sq[e]); }
-      if (lane < 8) {
-        float* r0 = red + ((cur * 8 + wave) * 2) * 64 + sch * 8;
-        *(float4*)(r0) = make_float4(sa[0], sa[1], sa[2], sa[3]); *(float4*)(r0 + 4) = make_float4(sa[4], sa[5], sa[6], sa[7]);
-        *(float4*)(r0 + 64) = make_float4(sq[0], sq[1], sq[2], sq[3]); *(float4*)(r0 + 68) = make_float4(sq[4], sq[5], sq[6], sq[7]);
-      }
-    }
-  };
-  auto finalize = [&](int s) {                                         // 128 threads, behind the barrier that follows the store phase of step s
-    if (MODE == 1 && p.stat_partial && tid < 128) {
-      const int which = (tid >> 6) & 1, col = tid & 63;
-      const float* r0 = red + ((s & 1) * 16 + which) * 64 + col;
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += r0[k * 128];
-      p.stat_partial[((size_t)bm * 2 + which) * p.N + s * 64 + col] = t;
-    }
-  };
-  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  wait_vmcnt<0>();
-  bar();
-  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = 0;        // debug (tools/sk512_trace.py): [0] entry -> ring primed, then per-phase sums over the steps
-  const bool tron = p.trace != nullptr;
-  if (tron) { tl = __builtin_amdgcn_s_memtime(); tr[0] = tl - tr_entry; }
-  auto lap = [&](int k) { if (tron) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tr[k] += t - tl; tl = t; } };
-  // SKEW BY ONE HALF: the two waves of a SIMD (w in group 0, w + 4 in group 1) must not store at the same time, and the one that does not store must have MFMAs to
-  // issue meanwhile.  In interval k (one barrier per interval) group g multiplies half H = k - g; a group stores step s at the START of the interval that follows its
-  // second half (group 0: interval 2s+2, group 1: 2s+3) -- while the other group's wave of the SIMD runs its half at the full rate of the matrix pipe.  Half H is read
-  // in intervals H and H+1, its slot is refilled with half H+3 behind the barrier that ends interval H+1, one interval (~2 000 clocks; the weights are L2-resident)
-  // before its first read.  Every interval ends with vmcnt(0) (the stores were issued at its start, the LDS-DMA behind them) + the barrier.
-  // First version (both groups in lockstep, store phase behind the second half): 7 000 ticks per step against 4 096 MFMA-issue cycles (tools/sk512_trace.py).
-  const int grp = wave >> 2;
-  auto load_addend = [&](int s) {
-    if constexpr (MODE == 2) {
-      const int ncol = s * 64 + sch * 8;
-#pragma unroll
-      for (int it = 0; it < 4; ++it) addv[it] = *(const uint4*)((const T*)p.addend + (orow + it * 8) * p.N + ncol);
-      if (gated) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) gbyte[it] = p.addend_mask[(orow + it * 8) * (size_t)(p.N / 8) + s * 8 + sch];
-      }
-    }
-  };
-  int hslot = 0;                                                       // slot of this group's half H = k - grp (advanced from H = 0 on)
-  int islot = 2;                                                       // slot of the half issued in interval k: H = k + 1
-#pragma unroll 1
-  for (int k = 0; k <= NH + 1; ++k) {
-    const int H = k - grp;
-    if (H >= 2 && !(H & 1)) { store((H >> 1) - 1); lap(5); }
-    if (k >= 1 && k + 1 < NH) issueH(k + 1, islot);
-    if (H >= 0 && H < NH) {
-      if (H & 1) load_addend(H >> 1);
-      f32x16_t acc;
-      half(smem + hslot * G::HSLOT, acc);
-      stage(acc, H & 1);
-      lap(1);
-    }
-    wait_vmcnt<0>();
-    lap(2);
-    bar();
-    lap(3);
-    if (k >= 3 && (k & 1)) finalize((k - 3) >> 1);
-    if (H >= 0) { if (++hslot == 3) hslot = 0; }
-    if (k >= 1) { if (++islot == 3) islot = 0; }
-  }
-  if (tron && lane == 0) {
-    unsigned long long* t = p.trace + ((size_t)blockIdx.x * 8 + wave) * 8;          // per WAVE (tools/sk512_trace.py)
-    tr[7] = __builtin_amdgcn_s_memtime() - tr_entry;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t[k] = tr[k];
-  }
-}
-
-}  // namespace
-
-int slconv::g_conv_sk512 = -1;      // SEGLAND_CONV_SK512=1 / sl_debug_conv_sk512(1): default OFF -- faster in isolation, equal inside the step (profiles/r5_ab_sk512.txt)
-bool slconv::sk512_shape(const ConvGemmParams& p) {
-  static const bool on = getenv("SEGLAND_CONV_SK512") && getenv("SEGLAND_CONV_SK512")[0] == '1';
-  if (g_conv_sk512 < 0) g_conv_sk512 = on ? 1 : 0;
-  return g_conv_sk512 && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.C1 == 512 && p.C2 == 0 && p.N % 64 == 0 && p.M >= 65536 && p.M % 256 == 0 &&
-         p.Hs == p.Hd && p.Ws == p.Wd && !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate || p.ksplit > 1) &&
-         !(p.addend && p.stat_partial) && (p.addend || !p.addend_mask);
-}
-int slconv::launch_sk512(ConvGemmParams& p, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)conv_gemm_sk512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_gemm_sk512_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  p.gridM = p.M / 256; p.gridN = 1;
-  p.trace = g_p8_trace;                 // debug hook shared with the half-tile kernel (sl_debug_p8_trace)
-  if (p.addend) hipLaunchKernelGGL(conv_gemm_sk512_kernel<2>, dim3(p.M / 256), dim3(512), Sk5Geom::LDS, st, p);
-  else hipLaunchKernelGGL(conv_gemm_sk512_kernel<1>, dim3(p.M / 256), dim3(512), Sk5Geom::LDS, st, p);
-  SL_LAUNCH_CHECK("conv_gemm_sk512_kernel");
-  return 0;
-}

@@ -682,8 +682,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c64k3_kernel(const bf16_t* __r
   }
 }
 inline bool c64k3_eligible(const SlConvDesc* d, int dw_cin_total, int dw_ci_off) {
-  static const bool off = getenv("SEGLAND_WGRAD_C64K3") && getenv("SEGLAND_WGRAD_C64K3")[0] == '0';
-  return !off && d->dtype == SL_BF16 && d->Cin == 64 && d->Cout == 64 && d->C1 == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 &&
+  return d->dtype == SL_BF16 && d->Cin == 64 && d->Cout == 64 && d->C1 == 64 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil == 1 && d->pad == 1 &&
          dw_cin_total == 64 && dw_ci_off == 0 && (long long)d->B * d->H * d->W >= 65536;
 }
 inline int c64k3_blocks(const SlConvDesc* d) { const int t = d->B * cdiv(d->H, C3_T) * cdiv(d->W, C3_T); return t < 256 ? t : 256; }
@@ -805,17 +804,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_c64p_kernel(const bf16_t* __re
       }
 }
 inline bool c64p_eligible(const SlConvDesc* d) {
-  static const bool off = getenv("SEGLAND_WGRAD_C64P") && getenv("SEGLAND_WGRAD_C64P")[0] == '0';
   const long long M = (long long)d->B * d->H * d->W;
   const bool shape = (d->Cout == 256 && d->Cin == 64) || (d->Cout == 64 && d->Cin == 256) || (d->Cout == 64 && d->Cin == 64) || (d->Cout == 128 && d->Cin == 128);
-  return !off && d->dtype == SL_BF16 && shape && d->C1 == d->Cin && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && M >= 65536 && M % CP_T == 0;
+  return d->dtype == SL_BF16 && shape && d->C1 == d->Cin && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && M >= 65536 && M % CP_T == 0;
 }
 inline int c64p_blocks(const SlConvDesc* d) { const long long t = (long long)d->B * d->H * d->W / CP_T; return t < 256 ? (int)t : 256; }
 inline int c64p_slabs(const SlConvDesc* d) { return c64p_blocks(d) * ((d->Cout == 64 && d->Cin == 64) ? 4 : 1); }
 
-unsigned long long* g_wgrad_trace = nullptr;
-int g_use_tr = -1;
-int use_tr() { return g_use_tr != 0; }      // bf16 fragments by ds_read_b64_tr_b16 (default) or scalar LDS reads (test hook sl_debug_wgrad_tr: the two must agree bit for bit)
+int use_tr() { return g_sl_debug.wgrad_tr != 0; }      // bf16 fragments by ds_read_b64_tr_b16 (default) or scalar LDS reads (test hook sl_debug_wgrad_tr: the two must agree bit for bit)
 
 struct WgradPlan { int bnn, bcc, gridN, gridC, taps, splits, rows_per_split; bool glds, pair; size_t ws_bytes; };
 
@@ -828,10 +824,9 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M);
 // From how many rows a 1x1 layer with a 64-multiple (not 128-multiple) channel count runs as pixel pairs.  64-channel layers: 2^19 (round 1: shorter ones are faster on the
 // 64-wide register-staged kernel; ResNet's layer1 has kernels of its own anyway).  Layers with >= 192 channels on both sides -- Swin stage 2: 192 <-> 576 / 768 on 32 768
 // tokens -- from 16 384 rows (round 4, tools/gemm_time.py: 192 -> 576 66.2 -> 37.4 us, 192 -> 768 53.1 -> 38.3, 768 -> 192 54.3 -> 39.5, 192 -> 192 27.8 -> 24.8;
-// Swin-T POP 717.3 -> 733.7 tiles/s on one box).  g_pair_min_rows > 0: tuning hook sl_debug_wgrad_pair_min overrides both.
-long long g_pair_min_rows = 0;
+// Swin-T POP 717.3 -> 733.7 tiles/s on one box).  The tuning hook sl_debug_wgrad_pair_min (> 0) overrides both.
 static long long pair_min_rows(const SlConvDesc* d) {
-  if (g_pair_min_rows > 0) return g_pair_min_rows;
+  if (g_sl_debug.wgrad_pair_min_rows > 0) return g_sl_debug.wgrad_pair_min_rows;
   return (d->Cin >= 192 && d->Cout >= 192) ? 16384 : (1 << 19);
 }
 WgradPlan plan(const SlConvDesc* d) {
@@ -944,11 +939,6 @@ int launch_wgrad(const WgradPlan& pl, WgradParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" void sl_debug_wgrad_trace(void* buf) { g_wgrad_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see WgradParams::trace
-extern "C" void sl_debug_wgrad_pair_min(int rows) { g_pair_min_rows = rows; }      // tuning hook: 1x1 layers with a 64-multiple (not 128-multiple) channel count run as pixel pairs from this many rows
-// test hook (not part of the public ABI): select the bf16 fragment path, 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
-extern "C" void sl_debug_wgrad_tr(int v) { g_use_tr = v ? 1 : 0; }
-
 // Which kernel sl_conv2d_bwd_weight runs for a shape (bench.py attributes HIP-event timings to rocprof kernel names with it):
 // 1 conv_wgrad_c64k3_kernel, 2 conv_wgrad_c64p_kernel, 10000000 + 1000*BNN + BCC conv_wgrad_glds_kernel, 20000000 + ... conv_wgrad_kernel;
 // + 500000 when the rows are pixel pairs.
@@ -1003,16 +993,13 @@ extern "C" int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, con
 }
 
 // Does the weight-gradient kernel of this shape carry the bias-gradient partials itself (BIAS instantiation: one row per split, two for pixel pairs)?
-int g_wgrad_bias = -1;      // SEGLAND_WGRAD_BIAS=0 / sl_debug_wgrad_bias(0): the column sums of dy back in the reduce launch (A/B hook)
-static bool wgrad_bias_fused(const SlConvDesc* d, const WgradPlan& pl) {
-  if (g_wgrad_bias < 0) g_wgrad_bias = (getenv("SEGLAND_WGRAD_BIAS") && getenv("SEGLAND_WGRAD_BIAS")[0] == '0') ? 0 : 1;
-  return g_wgrad_bias && pl.glds && pl.taps == 1 && !(pl.bnn == 256 && pl.bcc == 256) && use_tr();
+static bool wgrad_bias_fused(const SlConvDesc* d, const WgradPlan& pl) {      // test hook sl_debug_wgrad_bias(0): the column sums of dy back in the reduce launch
+  return g_sl_debug.wgrad_bias && pl.glds && pl.taps == 1 && !(pl.bnn == 256 && pl.bcc == 256) && use_tr();
 }
-extern "C" void sl_debug_wgrad_bias(int v) { g_wgrad_bias = v ? 1 : 0; }
 extern "C" int sl_colsum_rows_blocks(long long rows, int C, int dtype);
 // rows of the colsum_partial buffer sl_conv2d_bwd_weight_bias / _clip (n_valid, c_valid: 0 = all channels) fill: the same path selection as bwd_weight_impl
 extern "C" int sl_conv2d_bwd_weight_bias_rows(const SlConvDesc* d, int n_valid, int c_valid) {
-  if (!d || d->Cout % 64 || d->Cin % 64) return SL_EINVAL;
+  if (!d || d->Cout % 64 || d->Cin % 64) { sl_set_error("conv bwd_weight_bias_rows: null descriptor or channel counts that are not multiples of 64"); return SL_EINVAL; }
   const int generic = sl_colsum_rows_blocks((long long)d->B * d->Ho * d->Wo, d->Cout, d->dtype);
   const bool full = (n_valid <= 0 || n_valid == d->Cout) && (c_valid <= 0 || c_valid == d->Cin);
   if (use_tr() && ((full && c64k3_eligible(d, d->Cin, 0)) || c64p_eligible(d) || (full && sl_wgrad3_eligible(d, nullptr)))) return generic;
@@ -1026,8 +1013,12 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   const int nv = n_valid > 0 ? n_valid : d->Cout, cv = c_valid > 0 ? c_valid : d->Cin;
   SL_REQUIRE(nv <= d->Cout && cv <= d->Cin, "conv bwd_weight: valid channel counts exceed the (padded) problem");
   // column sums of dy by the stand-alone kernel: every path below that does not carry them in its reduce launch
+  // the caller sized colsum_partial by sl_conv2d_bwd_weight_bias_rows, a second statement of the path selection below: every path checks that the rows it is about to
+  // write are the rows that query promised (round-5 advisor: the two must not drift apart silently)
+  const int promised_rows = colsum_partial ? sl_conv2d_bwd_weight_bias_rows(d, n_valid, c_valid) : 0;
   auto colsum_separately = [&]() -> int {
     if (!colsum_partial) return 0;
+    SL_REQUIRE(sl_colsum_rows_blocks((long long)d->B * d->Ho * d->Wo, d->Cout, d->dtype) == promised_rows, "conv bwd_weight: bias partial rows (stand-alone pass) != sl_conv2d_bwd_weight_bias_rows (%d)", promised_rows);
     return sl_colsum_rows_partial(d->dtype, dy, (long long)d->B * d->Ho * d->Wo, d->Cout, colsum_partial, stream);
   };
   // the fixed-order slab reduces follow their MFMA kernel on the same stream (on a second stream they measured slower inside the captured step:
@@ -1089,9 +1080,10 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   p.M = d->B * d->Ho * d->Wo; p.rows_per_split = pl.rows_per_split;
   p.gridN = pl.gridN; p.gridC = pl.gridC; p.taps = pl.taps; p.splits = pl.splits;
   p.pair = pl.pair ? 1 : 0;
-  p.trace = g_wgrad_trace;
+  p.trace = g_sl_debug.wgrad_trace;
   if (pl.pair) { p.Cout = 2 * d->Cout; p.C1 = 2 * d->Cin; p.M /= 2; }
   const bool bias_fused = colsum_partial && wgrad_bias_fused(d, pl);
+  if (bias_fused) SL_REQUIRE(pl.splits * (pl.pair ? 2 : 1) == promised_rows, "conv bwd_weight: bias partial rows (in-kernel) != sl_conv2d_bwd_weight_bias_rows (%d)", promised_rows);
   if (bias_fused) { p.colsum = colsum_partial; p.colsum_cout = d->Cout; colsum_partial = nullptr; }      // the kernel writes the partials; nothing left for the reduce launch
   hipStream_t st = (hipStream_t)stream;
   int e;
@@ -1109,6 +1101,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     if (colsum_partial) {
       const long long rows = (long long)d->B * d->Ho * d->Wo, ch = sl_colsum_rows_chunk(rows, d->Cout, d->dtype == SL_BF16 ? 2 : 4);
       const int ncol = (int)((rows + ch - 1) / ch);
+      SL_REQUIRE(ncol == promised_rows, "conv bwd_weight: bias partial rows (reduce launch) != sl_conv2d_bwd_weight_bias_rows (%d)", promised_rows);
       if (d->dtype == SL_BF16)
         hipLaunchKernelGGL(wgrad_reduce_flat_colsum_kernel<bf16_t>, dim3(nred + ncol), dim3(256), 0, st, (const float*)workspace, dw, total, pl.splits, d->Cin, dw_cin_total, dw_ci_off,
                            nred, (const bf16_t*)dy, rows, d->Cout, ch, colsum_partial, nv, cv);

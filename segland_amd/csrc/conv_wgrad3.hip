@@ -275,15 +275,12 @@ __global__ __launch_bounds__(576) void wgrad3_reduce_kernel(const float* __restr
   *(f32x4_t*)o = *(const f32x4_t*)(tilebuf + row * 288 + k4 * 4);
 }
 
-int g_w3_on = -1;             // SEGLAND_WGRAD3=0 / sl_debug_wgrad3(0): the per-tap kernels take the 3x3 layers again (A/B)
-
 struct Wg3Plan { int ok, d, Hs, Ws, nstrips, L, SP, ppu, pieces, ppb, splits, tilesN, tilesC; size_t ws_bytes; };
 
 Wg3Plan wg3_plan(const SlConvDesc* d) {
   Wg3Plan pl{};
-  if (g_w3_on < 0) g_w3_on = (getenv("SEGLAND_WGRAD3") && getenv("SEGLAND_WGRAD3")[0] == '0') ? 0 : 1;
   const int c2 = d->Cin - d->C1;
-  if (!g_w3_on || d->dtype != SL_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->dil < 1) return pl;
+  if (!g_sl_debug.wgrad3 || d->dtype != SL_BF16 || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->pad != d->dil || d->dil < 1) return pl;
   if (d->Cout % W3_BN || d->C1 % W3_BC || c2 % W3_BC || d->H % d->dil || d->W % d->dil) return pl;
   const int Hs = d->H / d->dil, Ws = d->W / d->dil;
   if (Ws % 16 || Hs < 4 || Hs > 4096 || Ws > 4096) return pl;
@@ -318,18 +315,14 @@ Wg3Plan wg3_plan(const SlConvDesc* d) {
   return pl;
 }
 
-unsigned long long* g_w3_trace = nullptr;
-
 }  // namespace
 
-extern "C" void sl_debug_wgrad3(int on) { g_w3_on = on ? 1 : 0; }                                   // test / A-B hook
-// test hook: the plan of a shape: out[0..7] = {served, pieces per strip, rows per piece, steps per piece, pieces per block, splits, tiles, blocks}
+// test hook (include/segland_hip_debug.h): the plan of a shape: out[0..7] = {served, pieces per strip, rows per piece, steps per piece, pieces per block, splits, tiles, blocks}
 extern "C" int sl_debug_wgrad3_plan(const SlConvDesc* d, int* out) {
   const Wg3Plan pl = wg3_plan(d);
   out[0] = pl.ok; out[1] = pl.ppu; out[2] = pl.L; out[3] = pl.SP; out[4] = pl.ppb; out[5] = pl.splits; out[6] = pl.tilesN * pl.tilesC; out[7] = pl.tilesN * pl.tilesC * pl.splits;
   return pl.ok;
 }
-extern "C" void sl_debug_wgrad3_trace(void* buf) { g_w3_trace = (unsigned long long*)buf; }      // test hook: [blocks][8] u64, see Wg3Params::trace
 
 // internal (conv_wgrad.hip): does the nine-tap kernel take this layer, and with how much workspace
 bool sl_wgrad3_eligible(const SlConvDesc* d, size_t* ws_bytes) {
@@ -348,7 +341,7 @@ int sl_wgrad3_run(const SlConvDesc* d, const void* x, const void* x2, const void
   p.x1 = (const bf16_t*)x; p.x2 = (const bf16_t*)x2; p.C1 = d->C1; p.C2 = d->Cin - d->C1; p.dy = (const bf16_t*)dy; p.Cout = d->Cout; p.ws = (float*)workspace;
   p.H = d->H; p.W = d->W; p.d = pl.d; p.Hs = pl.Hs; p.Ws = pl.Ws; p.nstrips = pl.nstrips;
   p.L = pl.L; p.SP = pl.SP; p.ppu = pl.ppu; p.pieces = pl.pieces; p.ppb = pl.ppb; p.tilesN = pl.tilesN; p.tilesC = pl.tilesC;
-  p.trace = g_w3_trace;
+  p.trace = g_sl_debug.wgrad3_trace;
   const int tiles = pl.tilesN * pl.tilesC;
   const size_t lds = (size_t)W3_NST * W3_STAGE + (size_t)(pl.ppb + 1) * sizeof(int2);
   static bool attr_set = false;

@@ -1594,9 +1594,7 @@ extern "C" int sl_scale_add(int dtype, const void* x, const float* scale, const 
 }
 
 // test hook (not part of the public ABI): 1 = the fp32-arithmetic VALU kernels (what float32 tensors always run on) also for bf16, 0 / -1 = MFMA kernels for bf16
-static int g_attn_valu_override = -1;
-extern "C" void sl_debug_attn_valu(int v) { g_attn_valu_override = v; }
-static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && g_attn_valu_override != 1; }
+static bool use_attn_mfma(int dtype) { return dtype == SL_BF16 && g_sl_debug.attn_valu != 1; }      // test hook sl_debug_attn_valu(1): the VALU reference kernels
 static bool use_attn_bwd_mfma(int dtype) { return use_attn_mfma(dtype); }
 
 extern "C" int sl_window_attention_fwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, void* out, sl_stream_t stream) {
@@ -1663,8 +1661,6 @@ extern "C" int sl_window_attention_windows(const SlWinDesc* d) {
   return g.B * g.nWy * g.nWx;
 }
 
-static unsigned long long* g_attn_trace = nullptr;
-extern "C" void sl_debug_attn_trace(void* buf) { g_attn_trace = (unsigned long long*)buf; }      // test hook: [blocks][16] u64 phase stamps of window_attention_bwd_mfma2_kernel
 
 extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
                                        float* drel_partial, float* pad_partial, sl_stream_t stream) {
@@ -1682,9 +1678,9 @@ extern "C" int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, cons
       (void)hipFuncSetAttribute((const void*)window_attention_bwd_mfma2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       attr2 = true;
     }
-    if (g_attn_trace)      // debug instantiation (the stamps cost 8 registers and 6 spills: not in the production kernel)
+    if (g_sl_debug.attn_trace)      // debug instantiation (the stamps cost 8 registers and 6 spills: not in the production kernel)
       hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel<true>, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
-                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin, g_attn_trace);
+                         (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin, g_sl_debug.attn_trace);
     else
       hipLaunchKernelGGL(window_attention_bwd_mfma2_kernel<false>, dim3(chunks * g.heads), dim3(256), lds2, st, g, (const bf16_t*)qkv, qkv_bias, rel_bias, (const bf16_t*)dout,
                          (bf16_t*)dqkv, drel_partial, pad_partial, wpw, nwin, nullptr);

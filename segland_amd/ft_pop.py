@@ -27,7 +27,7 @@ def ft_iteration(model, optimizer, loss_scaler, batch, device, dataset=None):
     return loss_dict, grad_norm
 
 
-_CLIP_IN_STEP = os.environ.get('SEGLAND_FT_CLIP_IN_STEP', '1') != '0'      # 0: torch's clip_grad_norm_ (scales the gradients in place) + a plain step (A/B)
+_CLIP_IN_STEP = True      # test hook: the clip coefficient enters the SGD launch; False: torch's clip_grad_norm_ (scales the gradients in place) + a plain step (profiles/r5_ab_ft_small_launches.txt)
 
 
 def ft_graph_body(model, clip_grad=5.0, optimizer=None):

@@ -95,7 +95,8 @@ class _PrepPlan:
                 self.items.append((w, d, wf, wb))
             self.table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(ws[0].device)
             self.total, self.key = start, key
-        ops.weight_prep_batched(self.table, len(self.items), self.total)
+        ops.weight_prep_batched(self.table, len(self.items), self.total,
+                                nbytes=sum(w.numel() * (4 + 2 * wf.element_size()) for w, _, wf, _ in self.items))
         for w, d, wf, wb in self.items:
             w._sl_prep = (_wver(w), d, w.data_ptr(), wf, wb)
 
@@ -245,10 +246,11 @@ def _frozen(ctx, *bns):
 
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
-_BASE_CHAIN_CACHE = os.environ.get('SEGLAND_BASE_CHAIN_CACHE', '1') != '0'      # ft mode: the frozen base classifier's rows are computed once (0: every iteration; A/B)
+_BASE_CHAIN_CACHE = True   # test hook: ft mode, the frozen base classifier's rows are computed once (False: every iteration)
+# The ONE environment switch of the BatchNorm-backward fusions (A/B of the whole feature against stand-alone reduce passes): SEGLAND_BN_FUSE=0 switches all three off.
 _BN_FUSE = os.environ.get('SEGLAND_BN_FUSE', '1') != '0'        # BN-backward statistics in the data-gradient epilogues (conv_gemm_common.h: conv_epilogue_fast MODE 3)
-_BN_DUAL = os.environ.get('SEGLAND_BN_DUAL', '1') != '0'        # bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
-_BN_CROSS = os.environ.get('SEGLAND_BN_FUSE_CROSS', '1') != '0'  # bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
+_BN_DUAL = _BN_FUSE        # test hook: bn3 + downsample BN backward in one sweep each (bn.hip reduce2 / apply2)
+_BN_CROSS = _BN_FUSE       # test hook: bn3's column sums from the NEXT block's conv1 data-gradient epilogue (pixel-stationary kernel MODE 5)
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
@@ -715,11 +717,10 @@ def _base_chain(model, S_b, dtype, frozen):
         Xb = torch.empty((2 * S_b.shape[0], S_b.shape[1]), dtype=dtype, device=S_b.device)
         ops.pop_proto_rows(S_b.contiguous(), Xb)
         return (Xb,) + tuple(_mlp_fwd(Xb, model.classifier))
-    emb = getattr(model, 'base_emb', None)
-    if not (frozen and _BASE_CHAIN_CACHE and emb is not None and not emb.requires_grad):
+    key = base_chain_key(model) if frozen else None
+    if key is None:
         return run()
-    ws = cls_params(model.classifier)
-    key = (tuple((_wver(w), w.data_ptr()) for w in ws), emb._version, emb.data_ptr(), dtype, tuple(S_b.shape))
+    key = key + (dtype, tuple(S_b.shape))
     ent = model.__dict__.get('_sl_base_chain')
     if ent is not None and ent[0] == key:
         return ent[1]
@@ -727,6 +728,20 @@ def _base_chain(model, S_b, dtype, frozen):
     if not (S_b.is_cuda and torch.cuda.is_current_stream_capturing()):
         model.__dict__['_sl_base_chain'] = (key, out)
     return out
+
+
+def base_chain_key(model):
+    """What the cached rows of _base_chain are computed from (versions + addresses of the frozen base classifier's weights and of base_emb), or None when the cache does
+    not apply.  graph_step.GraphedStep puts it into its state key: a captured fine-tune step has the cached tensors baked in, so a change of these weights behind a
+    graph (load_state_dict, init_cls_n) must force a re-capture -- every other weight is picked up through its pointer, these rows are not (round-5 advisor)."""
+    emb = getattr(model, 'base_emb', None)
+    cls = getattr(model, 'classifier', None)
+    if not (_BASE_CHAIN_CACHE and getattr(model, 'is_ft', False) and emb is not None and cls is not None and not emb.requires_grad):
+        return None
+    ws = cls_params(cls)
+    if any(w.requires_grad for w in ws):
+        return None
+    return (tuple((_wver(w), w.data_ptr()) for w in ws), emb._version, emb.data_ptr())
 
 
 class PopHeadFn(torch.autograd.Function):
@@ -830,7 +845,12 @@ class ProtoFn(torch.autograd.Function):
         Sa, Sb, inv, G, orth = ops.pop_proto_fwd(Ea, Ebc)
         ctx.has_b = Eb is not None
         ctx.save_for_backward(Sa, inv, G, *([Sb] if ctx.has_b else []))
-        return Sa, (Sb if ctx.has_b else Sa.new_empty(0)), orth.reshape(())
+        Sb_out = Sb if ctx.has_b else Sa.new_empty(0)
+        if not (ctx.has_b and ctx.needs_input_grad[1]):
+            # every output of a Function requires grad as soon as ONE input does: without this the frozen base prototypes of ft mode (base_emb.requires_grad False,
+            # ft_pop.py:197-203) look trainable to PopHeadFn -- its frozen-base-chain cache never engaged and it ran the base MLP backward for a gradient nobody takes
+            ctx.mark_non_differentiable(Sb_out)
+        return Sa, Sb_out, orth.reshape(())
 
     @staticmethod
     @once_differentiable

@@ -16,7 +16,7 @@ from .ops import ConvSpec
 from .ops_swin import pad_to
 
 import os
-_GELU_FUSE = os.environ.get('SEGLAND_SWIN_GELU_FUSE', '1') != '0'      # fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); 0: + a gelu_bwd launch (A/B)
+_GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
 
 
 # ------------------------------------------------------------------------------------------------ prepared (padded) weights

@@ -44,13 +44,16 @@ class GraphedStep:
         self.body, self.model, self.optimizer, self.warmup = body, model, optimizer, warmup
         self.seen, self.key, self.graph = {}, None, None
         self.static_in, self.static_out, self.static_grads = None, None, None
-        self.replays, self.failures = 0, 0
+        self.replays, self.failures, self.baked = 0, 0, None
         self.bn_training = True
 
     def _state_key(self, tensors):
         trainable = sum(1 for p in self.model.parameters() if p.requires_grad)
         modes = sum(1 for m in self.model.modules() if m.training)
-        return tuple((tuple(t.shape), t.dtype) for t in tensors) + (trainable, modes)
+        from . import functional
+        # ft mode: the frozen base classifier's prototype rows are cached tensors baked into a captured step (functional._base_chain): what they are computed from is
+        # part of the key, so a weight change behind the graph (load_state_dict, init_cls_n) re-captures instead of replaying stale rows
+        return tuple((tuple(t.shape), t.dtype) for t in tensors) + (trainable, modes, functional.base_chain_key(self.model))
 
     def _eager(self, tensors):
         return _detached(self.body(*tensors))
@@ -67,6 +70,7 @@ class GraphedStep:
         with torch.cuda.graph(g, capture_error_mode='thread_local'):
             out = self._eager(self.static_in)
         self.graph, self.key, self.static_out = g, key, out
+        self.baked = self.model.__dict__.get('_sl_base_chain')      # tensors of the cache entry the captured launches read: alive as long as this graph is
         self.bn_training = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training for m in self.model.modules())
         STATS['captures'] += 1
         # the gradients the replays write: tensors of the graph's pool that the parameters keep pointing at

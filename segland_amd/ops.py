@@ -56,7 +56,10 @@ class _Profiler:
     Off by default.  Launches are attributed to the kernel they are dispatched to (`family`, the name rocprofv3 shows);
     `only` restricts timing to one family so the timed region carries just those event pairs."""
 
-    FAMILY = {9: 'conv_gemm_sk512_kernel', 8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 3: 'conv_rows_small_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
+    PEAK_TFLOPS = {SL_BF16: 2500.0, SL_F32: 157.3}      # dense MFMA peaks (MI355X_MICROARCH.md); the floor of a launch is priced against these
+    HBM_TBS = 6.3                                       # achievable HBM rate (same guide: 8 TB/s peak, ~6.3 achievable)
+
+    FAMILY = {8: 'conv_gemm_p9_kernel', 7: 'conv_c64k3_kernel', 6: 'conv_gemm_sk_kernel', 5: 'conv_gemm_p8_kernel', 4: 'conv_gemm_ring_kernel', 3: 'conv_rows_small_kernel', 2: 'conv_gemm_glds_kernel', 1: 'conv_gemm_kernel'}
 
     def __init__(self):
         self.on, self.only, self.rec, self.rec_bytes = False, None, {}, {}
@@ -102,7 +105,21 @@ class _Profiler:
         es = 2 if d.dtype == SL_BF16 else 4
         gbytes = ((d.B * d.H * d.W * d.Cin + d.B * d.Ho * d.Wo * d.Cout + d.Cout * d.Cin * d.KH * d.KW) * es + extra_bytes) / 1e9
         shape = '%s B%d %dx%d %d->%d k%d s%d d%d' % (kind, d.B, d.H, d.W, d.Cin, d.Cout, d.KH, d.stride, d.dil)
-        self.rec.setdefault(fam, []).append((e0, e1, gflop, shape, gbytes))
+        # speed of light of THIS launch: the larger of its MFMA time at the dense peak and its algorithmic bytes at the achievable HBM rate (ms)
+        floor = max(gflop / self.PEAK_TFLOPS[d.dtype], gbytes / self.HBM_TBS)
+        self.rec.setdefault(fam, []).append((e0, e1, gflop, shape, gbytes, floor))
+
+    def region(self, family, nbytes):
+        """Context manager form of begin_bytes / end_bytes (bench.py: the optimizer part of a step)."""
+        prof = self
+
+        class _R:
+            def __enter__(self_):
+                self_.tok = prof.begin_bytes(family, nbytes)
+
+            def __exit__(self_, *exc):
+                prof.end_bytes(self_.tok)
+        return _R()
 
     def begin_bytes(self, family, nbytes):
         """HBM-bound kernel families (BatchNorm passes): algorithmic bytes instead of FLOPs; only in the instrumented (un-timed) step."""
@@ -123,22 +140,23 @@ class _Profiler:
         """{family: {calls, ms_total, gbytes}} of the spans recorded since start(); call after stop() (which synchronises)."""
         out = {}
         for fam, evs in self.rec_bytes.items():
-            out[fam] = {'calls': len(evs), 'ms_total': sum(a.elapsed_time(b) for a, b, _ in evs), 'gbytes': sum(n for _, _, n in evs) / 1e9}
+            gb = sum(n for _, _, n in evs) / 1e9
+            out[fam] = {'calls': len(evs), 'ms_total': sum(a.elapsed_time(b) for a, b, _ in evs), 'gbytes': gb, 'floor_ms': gb / self.HBM_TBS}
         self.rec_bytes = {}
         return out
 
     def stop(self):
-        """{family: {calls, ms_total, gflop, shapes: {shape: [calls, ms, gflop]}}}"""
+        """{family: {calls, ms_total, gflop, gbytes, floor_ms, shapes: {shape: [calls, ms, gflop, floor_ms]}}}"""
         self.on = False
         torch.cuda.synchronize()
         out = {}
         for fam, evs in self.rec.items():
-            ent = out[fam] = {'family': fam, 'calls': 0, 'ms_total': 0.0, 'gflop': 0.0, 'gbytes': 0.0, 'shapes': {}}
-            for e0, e1, gflop, shape, gbytes in evs:
+            ent = out[fam] = {'family': fam, 'calls': 0, 'ms_total': 0.0, 'gflop': 0.0, 'gbytes': 0.0, 'floor_ms': 0.0, 'shapes': {}}
+            for e0, e1, gflop, shape, gbytes, floor in evs:
                 ms = e0.elapsed_time(e1)
-                ent['calls'] += 1; ent['ms_total'] += ms; ent['gflop'] += gflop; ent['gbytes'] += gbytes
-                sh = ent['shapes'].setdefault(shape, [0, 0.0, 0.0])
-                sh[0] += 1; sh[1] += ms; sh[2] += gflop
+                ent['calls'] += 1; ent['ms_total'] += ms; ent['gflop'] += gflop; ent['gbytes'] += gbytes; ent['floor_ms'] += floor
+                sh = ent['shapes'].setdefault(shape, [0, 0.0, 0.0, 0.0])
+                sh[0] += 1; sh[1] += ms; sh[2] += gflop; sh[3] += floor
         self.rec = {}
         return out
 
@@ -184,8 +202,11 @@ def weight_prep(w, dtype, want_fwd=True, want_bwd=True):
     return wf, wb
 
 
-def weight_prep_batched(table, n, total):
+def weight_prep_batched(table, n, total, nbytes=0):
+    """nbytes: algorithmic bytes of the launch (fp32 masters in, both GEMM layouts out), for the profiler only."""
+    tok = PROFILER.begin_bytes('weight_prep_batched', nbytes)
     check(_lib.lib().sl_weight_prep_batched(_p(table), n, int(total), _s()), 'weight_prep_batched')
+    PROFILER.end_bytes(tok)
 
 
 def conv2d_fwd(x, wf, spec, x2=None, bias=None, relu=False, want_stats=False, pre_addend=None, out=None):
@@ -399,6 +420,14 @@ def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0):
     return dw
 
 
+def _bias_rows(d, n_valid, c_valid):
+    """Rows of the bias-gradient partial buffer; the library's own message instead of torch's negative-dimension error when the shape is refused."""
+    r = _lib.lib().sl_conv2d_bwd_weight_bias_rows(C.byref(d), n_valid, c_valid)
+    if r <= 0:
+        check(r if r < 0 else -1, 'conv2d_bwd_weight_bias_rows')
+    return r
+
+
 def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
     """(dw float OIHW, db): weight and bias gradient of a biased 1x1 conv / nn.Linear; the column sums of dy ride in the weight gradient's slab-reduce launch.
     batch (ColsumBatch): db is filled by batch.run()."""
@@ -410,7 +439,7 @@ def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
     Cn = dy.shape[-1]
     rows = dy.numel() // Cn
     assert Cn == spec.cout and dy.is_contiguous()
-    part = _f32((L.sl_conv2d_bwd_weight_bias_rows(C.byref(d), 0, 0), Cn), dy.device)
+    part = _f32((_bias_rows(d, 0, 0), Cn), dy.device)
     tok = PROFILER.begin('conv_wgrad', d)
     check(L.sl_conv2d_bwd_weight_bias(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_bias')
     PROFILER.end(tok)
@@ -429,7 +458,7 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
     if want_bias:
         Cn = dy.shape[-1]
         assert Cn == spec.cout and dy.is_contiguous()
-        part = _f32((L.sl_conv2d_bwd_weight_bias_rows(C.byref(d), n_valid, c_valid), Cn), dy.device)
+        part = _f32((_bias_rows(d, n_valid, c_valid), Cn), dy.device)
     tok = PROFILER.begin('conv_wgrad', d)
     check(L.sl_conv2d_bwd_weight_clip(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_clip')
     PROFILER.end(tok)
@@ -566,7 +595,9 @@ def stem_conv_fwd(img, w, dtype, want_stats):
     part = _f32((L.sl_stem_conv_stat_rows(B, H, W), 2, 64), img.device) if want_stats else None
     need = L.sl_stem_conv_fwd_workspace(_DT[dtype])
     ws = torch.empty(need, dtype=torch.uint8, device=img.device) if need else None
+    tok = PROFILER.begin_bytes('stem_conv_fwd', img.numel() * img.element_size() + y.numel() * y.element_size())
     check(L.sl_stem_conv_fwd(_DT[dtype], _p(img), _p(w), _p(y), _p(part), B, H, W, _p(ws), _s()), 'stem_conv_fwd')
+    PROFILER.end_bytes(tok)
     return y, part
 
 
@@ -574,7 +605,9 @@ def stem_bn_relu_pool(c0, scale, shift, want_idx):
     B, Hc, Wc, _ = c0.shape
     pooled = torch.empty((B, Hc // 2, Wc // 2, 64), dtype=c0.dtype, device=c0.device)
     idx = torch.empty((B, Hc // 2, Wc // 2, 64), dtype=torch.uint8, device=c0.device) if want_idx else None
+    tok = PROFILER.begin_bytes('stem_bn_relu_pool_fwd', c0.numel() * c0.element_size() + pooled.numel() * pooled.element_size() + (idx.numel() if idx is not None else 0))
     check(_lib.lib().sl_stem_bn_relu_pool_fwd(dt(c0), _p(c0), _p(scale), _p(shift), _p(pooled), _p(idx), B, Hc, Wc, _s()), 'stem_bn_relu_pool_fwd')
+    PROFILER.end_bytes(tok)
     return pooled, idx
 
 
@@ -622,7 +655,9 @@ def stem_conv_bwd_weight_direct(img, dc0):
     L = _lib.lib()
     ws = workspace(L.sl_stem_conv_bwd_weight_workspace(B, H, W), img.device)
     dw = torch.empty((64, 3, 7, 7), dtype=torch.float32, device=img.device)
+    tok = PROFILER.begin_bytes('stem_conv_bwd_weight', img.numel() * img.element_size() + dc0.numel() * dc0.element_size())
     check(L.sl_stem_conv_bwd_weight(dt(dc0), _p(img), _p(dc0), _p(dw), _p(ws), ws.numel(), B, H, W, _s()), 'stem_conv_bwd_weight')
+    PROFILER.end_bytes(tok)
     return dw
 
 
@@ -641,7 +676,9 @@ def ppm_pool_fwd(x, sizes):
     L = _lib.lib()
     ws = workspace(L.sl_ppm_workspace(C.byref(d)), x.device)
     pooled = torch.empty((ppm_rows(x.shape[0], sizes), x.shape[3]), dtype=torch.float32, device=x.device)
+    tok = PROFILER.begin_bytes('ppm_pool_fwd', x.numel() * x.element_size())
     check(L.sl_ppm_pool_fwd(C.byref(d), _p(x), _p(pooled), _p(ws), ws.numel(), _s()), 'ppm_pool_fwd')
+    PROFILER.end_bytes(tok)
     return pooled
 
 
@@ -653,7 +690,9 @@ def ppm_pool_bwd(dpooled, x_shape, dtype, sizes, dcat=None, cat_off=0):
     pitch = dcat.shape[-1] if dcat is not None else 0
     L = _lib.lib()
     ws = workspace(L.sl_ppm_workspace(C.byref(d)), dpooled.device)
+    tok = PROFILER.begin_bytes('ppm_pool_bwd', dx.numel() * dx.element_size() * (2 if dcat is not None else 1))
     check(L.sl_ppm_pool_bwd(C.byref(d), _p(dpooled), _p(dcat), pitch, cat_off, _p(dx), _p(ws), ws.numel(), _s()), 'ppm_pool_bwd')
+    PROFILER.end_bytes(tok)
     return dx
 
 
@@ -746,7 +785,9 @@ def ppm_fact_gather(q, x_shape, sizes, N, dtype):
     ws = workspace(L.sl_ppm_fact_workspace(C.byref(d), N), q.device)
     B, H, W, _ = x_shape
     g = torch.empty((B, H, W, N), dtype=dtype, device=q.device)
+    tok = PROFILER.begin_bytes('ppm_fact_gather', g.numel() * g.element_size() + q.numel() * 4)
     check(L.sl_ppm_fact_gather(C.byref(d), N, _p(q), _p(g), _p(ws), ws.numel(), _s()), 'ppm_fact_gather')
+    PROFILER.end_bytes(tok)
     return g
 
 
@@ -756,7 +797,9 @@ def ppm_fact_scatter(dcb, x_shape, sizes):
     L = _lib.lib()
     ws = workspace(L.sl_ppm_fact_workspace(C.byref(d), N), dcb.device)
     gq = _f32((ppm_rows(x_shape[0], sizes), 9 * N), dcb.device)
+    tok = PROFILER.begin_bytes('ppm_fact_scatter', dcb.numel() * dcb.element_size() + gq.numel() * 4)
     check(L.sl_ppm_fact_scatter(C.byref(d), N, _p(dcb), _p(gq), _p(ws), ws.numel(), _s()), 'ppm_fact_scatter')
+    PROFILER.end_bytes(tok)
     return gq
 
 
@@ -765,7 +808,9 @@ def pop_decompose_into(feats2d, S, bg_out):
     R, Cn = feats2d.shape
     Kt = S.shape[0]
     proj = _f32((R, Kt), feats2d.device)
+    tok = PROFILER.begin_bytes('pop_decompose_fwd', 2 * feats2d.numel() * feats2d.element_size() + proj.numel() * 4)
     check(_lib.lib().sl_pop_decompose_fwd(dt(feats2d), _p(feats2d), _p(S), Kt, _p(proj), _p(bg_out), R, Cn, _s()), 'pop_decompose_fwd')
+    PROFILER.end_bytes(tok)
     return proj
 
 
@@ -777,7 +822,9 @@ def pop_proto_rows(S, dst):
 def rowdot_fwd(h, w):
     R, Cn = h.shape
     z = _f32((R,), h.device)
+    tok = PROFILER.begin_bytes('rowdot_fwd', h.numel() * h.element_size())
     check(_lib.lib().sl_rowdot_fwd(dt(h), _p(h), _p(w), _p(z), R, Cn, _s()), 'rowdot_fwd')
+    PROFILER.end_bytes(tok)
     return z
 
 
@@ -831,7 +878,9 @@ def rowdot_bwd(h, w, dz):
     nblk = L.sl_rowdot_bwd_rows(R, Cn)
     part = _f32((nblk, Cn), h.device)
     dh = torch.empty_like(h)
+    tok = PROFILER.begin_bytes('rowdot_bwd', 2 * h.numel() * h.element_size())
     check(L.sl_rowdot_bwd(dt(h), _p(h), _p(w), _p(dz), _p(dh), _p(part), R, Cn, _s()), 'rowdot_bwd')
+    PROFILER.end_bytes(tok)
     return dh, colsum(part)
 
 
@@ -861,7 +910,9 @@ def pop_decompose_bwd(dg, feats2d, S, proj, dproj):
     nblk = L.sl_pop_decompose_bwd_rows(R)
     part = _f32((nblk, Kt, Cn), feats2d.device)
     dq = torch.empty_like(feats2d)
+    tok = PROFILER.begin_bytes('pop_decompose_bwd', 3 * feats2d.numel() * feats2d.element_size() + 2 * proj.numel() * 4)
     check(L.sl_pop_decompose_bwd(dt(feats2d), _p(dg), _p(feats2d), _p(S), _p(proj), _p(dproj), Kt, _p(dq), _p(part), R, Cn, _s()), 'pop_decompose_bwd')
+    PROFILER.end_bytes(tok)
     return dq, colsum(part)
 
 
@@ -872,7 +923,9 @@ def upsample_ce_fwd(logits, target, ignore_index):
     L = _lib.lib()
     nblk = L.sl_upsample_ce_rows(B, H, W)
     part = _f32((nblk, 2), logits.device)
+    tok = PROFILER.begin_bytes('upsample_ce_fwd', logits.numel() * 4 + target.numel() * target.element_size())
     check(L.sl_upsample_ce_fwd(_p(logits), _p(target), B, K, h, w, H, W, ignore_index, _p(part), _s()), 'upsample_ce_fwd')
+    PROFILER.end_bytes(tok)
     out = _f32((2,), logits.device)
     check(L.sl_upsample_ce_finalize(_p(part), nblk, _p(out), _s()), 'upsample_ce_finalize')
     return out
@@ -882,7 +935,9 @@ def upsample_ce_bwd(logits, target, loss_cnt, gscale, ignore_index):
     B, K, h, w = logits.shape
     H, W = target.shape[1:]
     dl = torch.empty_like(logits)
+    tok = PROFILER.begin_bytes('upsample_ce_bwd', 2 * logits.numel() * 4 + target.numel() * target.element_size())
     check(_lib.lib().sl_upsample_ce_bwd(_p(logits), _p(target), _p(loss_cnt), _p(gscale), B, K, h, w, H, W, ignore_index, _p(dl), _s()), 'upsample_ce_bwd')
+    PROFILER.end_bytes(tok)
     return dl
 
 

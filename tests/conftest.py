@@ -29,6 +29,17 @@ def hip():
 
 
 @pytest.fixture(autouse=True)
+def _reset_debug_hooks(request):
+    """The sl_debug_* hooks (include/segland_hip_debug.h) write process-wide dispatch state: whatever a GPU test set -- also one that failed between set and reset -- is
+    put back before the next test runs."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        from segland_amd import _lib
+        if _lib._lib is not None:
+            _lib._lib.sl_debug_reset()
+
+
+@pytest.fixture(autouse=True)
 def _parity_log(request):
     """SEGLAND_PARITY_LOG=<file>: what the tests print (differing-pixel counts, cosines, relative errors: the numbers behind the tolerance gates) is appended to that file,
     one section per test -- `pytest -q` drops it otherwise.  profiles/r4_parity_log.txt is such a file from one MI355X box."""

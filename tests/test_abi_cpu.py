@@ -23,6 +23,20 @@ def test_every_declared_symbol_is_exported(lib):
     assert lib.sl_version() >= 100
 
 
+def test_no_exported_symbol_is_undeclared(lib):
+    """Every `sl_*` symbol the library exports is declared in the product header or in the debug header (include/segland_hip_debug.h: test / tuning hooks, which a
+    deployment never calls); every hook of the debug header exists, and sl_debug_reset() is callable without a GPU."""
+    import subprocess
+    names = subprocess.run('nm -D --defined-only %s' % _lib.LIB_PATH, shell=True, capture_output=True, text=True, check=True).stdout.split('\n')
+    exported = {l.split()[-1] for l in names if ' T sl_' in l}
+    prod, dbg = _lib.declared_functions(), _lib.declared_functions(_lib.DEBUG_HEADER)
+    assert exported and not (exported - set(prod) - set(dbg)), sorted(exported - set(prod) - set(dbg))
+    assert all(n.startswith('sl_debug_') for n in dbg) and not any(n.startswith('sl_debug_') for n in prod)
+    for n in dbg:
+        assert hasattr(lib, n), n
+    lib.sl_debug_reset()
+
+
 def test_bad_descriptor_is_rejected_without_launch(lib):
     d = _lib.SlConvDesc(_lib.SL_BF16, 1, 8, 8, 48, 64, 1, 1, 1, 0, 1, 8, 8, 48)   # Cin not a multiple of 64
     dummy = C.c_void_p(16)

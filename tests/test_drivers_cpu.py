@@ -415,3 +415,58 @@ def test_bucket_step_capture_failure_on_one_rank_is_a_collective_decision(fail_r
         assert same, 'rank %d: parameters differ from the kernel-by-kernel run' % rank
         assert same_as_rank0, 'rank %d: parameters differ from rank 0' % rank
         assert (failures, attempts, replays) == (1, 2, 3), (rank, failures, attempts, replays)      # step 0 warm-up, 1 failed attempt -> eager, 2 capture + replay, 3-4 replays
+
+
+def _agree_worker(rank, world, port, q, case):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', init_method='env://')
+    from segland_amd import bucket_step
+    rep = bucket_step.BucketedReplica(_CutToy(), cap_mb=0.001)
+    import time
+    if case == 'signatures':
+        # every rank says its capture went through, but rank 1 captured another input shape: nobody may replay
+        got = rep.agree(True, signature=((5, 8), 'f32') if rank == 0 else ((4, 8), 'f32'), timeout_s=60)
+        same = rep.agree(True, signature=((5, 8), 'f32'), timeout_s=60)                       # ... and the group still works afterwards
+        q.put((rank, got, same, None))
+        dist.barrier()
+    else:
+        # rank 1 never reaches the handshake (its step sequence diverged): rank 0 must come back with an error inside the bound instead of hanging
+        if rank == 0:
+            t0, err = time.time(), None
+            try:
+                rep.agree(True, signature='x', timeout_s=3.0)
+            except RuntimeError as e:
+                err = str(e)
+            q.put((rank, time.time() - t0, None, err))
+        else:
+            time.sleep(8.0)
+            q.put((rank, 0.0, None, 'skipped'))
+    try:
+        dist.destroy_process_group()
+    except Exception:                # noqa: BLE001  (the timed-out handshake may have left the group unusable: the process is about to end)
+        pass
+
+
+@pytest.mark.parametrize('case', ['signatures', 'skipped'])
+def test_bucket_step_agree_mismatched_signatures_and_bounded_wait(case):
+    """Round-5 advisor: the two untested branches of BucketedReplica.agree on two gloo ranks.  'signatures': both ranks report a successful capture of DIFFERENT input
+    signatures -> agree() is False on both (all stay kernel by kernel) and the next handshake works.  'skipped': one rank never calls agree -> the other gets a
+    RuntimeError naming the cause within the bound (3 s here), not a hang."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q, case)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    if case == 'signatures':
+        for rank, got, same, _ in res:
+            assert got is False and same is True, (rank, got, same)
+        assert all(p.exitcode == 0 for p in procs)
+    else:
+        rank, took, _, err = res[0]
+        assert err is not None and 'did not all reach a capture attempt' in err, err
+        assert took < 30.0, took

@@ -235,8 +235,24 @@ def test_c2_train_mode_bf16_gate(hip, size):
             m = _model(dtype=dt)
             m.load_state_dict(state, strict=True)
             m = m.to(DEV).train()
+            from segland_amd import ops
+            watch = gate and dt == torch.bfloat16 and size == 512
+            if watch:
+                ops.PROFILER.start()
             d = m(gi, gm)
             d['total_loss'].backward()
+            if watch:
+                # round 6: the gated bf16 run IS the bench's default dispatch -- every conv launch of this forward + backward attributed to the
+                # kernel family it ran on (the same query bench.py uses), and the BatchNorm-backward fusions taken (4 stand-alone reduce launches of 58 BatchNorms)
+                fams, tb = ops.PROFILER.stop(), ops.PROFILER.stop_bytes()
+                need = {'conv_gemm_p9_kernel<bf16, 256, 256>', 'conv_gemm_p8_kernel<bf16, 256, 256>', 'conv_gemm_sk_kernel<bf16, 256, 64>', 'conv_wgrad3_kernel',
+                        'conv_wgrad_glds_kernel<bf16, 256, 256>', 'conv_wgrad_glds_kernel<bf16, 128, 256>', 'conv_wgrad_c64k3_kernel', 'conv_wgrad_c64p_kernel',
+                        'conv_c64k3_kernel<bf16, 16, 16>'}
+                print('C2 bf16 run: conv launches by family: %s; bn_bwd_reduce launches %d' % (', '.join('%s x%d' % (k, v['calls']) for k, v in sorted(fams.items())),
+                                                                                           tb.get('bn_bwd_reduce', {}).get('calls', 0)))
+                assert need <= set(fams), 'the gated bf16 run did not take the bench kernels: missing %s' % sorted(need - set(fams))
+                assert fams['conv_wgrad3_kernel']['calls'] == 13 and fams['conv_gemm_p9_kernel<bf16, 256, 256>']['calls'] == 20, {k: v['calls'] for k, v in fams.items()}
+                assert tb.get('bn_bwd_reduce', {}).get('calls', 0) <= 4, tb.get('bn_bwd_reduce')
             rel = abs(float(d['seg_loss'].detach()) - float(do['seg_loss'].detach())) / abs(float(do['seg_loss'].detach()))
             cos = _group_cosines(m, o)
             print('C2 %dx%d %s %-8s seg_loss hip %.5f oracle %.5f (rel %.1e) | gradient cosine / rel.L2: %s' % (

@@ -1,0 +1,156 @@
+"""Round 6: the bf16 DEFAULT dispatch is what the parity gates run, the fine-tune head's frozen base chain really is cached (advisor), and the
+kernels the round added.  Tolerances as in test_kernels_gpu.py / test_round5_gpu.py: bf16 kernels 2.5e-2 of the tensor scale, gradients in relative L2."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import formula as fm
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def nhwc(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+
+
+def nchw(x):
+    return x.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel_l2(got, ref):
+    got, ref = got.detach().float().cpu().double(), ref.detach().float().cpu().double()
+    return float((got - ref).norm() / max(float(ref.norm()), 1e-30))
+
+
+# The kernels `python bench.py` runs the ResNet-50 step on (profiles/r5_conv_shapes.txt): per bench-sized block, the families the instrumented launches must be
+# attributed to.  A dispatch change that silently routes these shapes to a fallback kernel fails here.
+BENCH_BLOCKS = {
+    # name: (inplanes, planes, dilation, B, H, W, families that MUST appear)
+    'layer3': (1024, 256, 2, 16, 64, 64, {'conv_gemm_p8_kernel<bf16, 256, 256>', 'conv_gemm_p9_kernel<bf16, 256, 256>', 'conv_gemm_sk_kernel<bf16, 256, 64>', 'conv_wgrad3_kernel',
+                                          'conv_wgrad_glds_kernel<bf16, 128, 256>'}),
+    'layer1': (256, 64, 1, 4, 128, 128, {'conv_gemm_sk_kernel<bf16, 256, 64>', 'conv_c64k3_kernel<bf16, 16, 16>', 'conv_wgrad_c64k3_kernel', 'conv_wgrad_c64p_kernel',
+                                         'conv_gemm_glds_kernel<bf16, 256, 64>'}),
+    'layer4': (2048, 512, 4, 16, 64, 64, {'conv_gemm_p8_kernel<bf16, 256, 256>', 'conv_gemm_p9_kernel<bf16, 256, 256>', 'conv_wgrad3_kernel', 'conv_wgrad_glds_kernel<bf16, 256, 256>'}),
+}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('name', list(BENCH_BLOCKS))
+def test_bench_sized_bottleneck_pair_bf16_default_dispatch_vs_oracle(hip, name):
+    """Two consecutive identity bottlenecks (resnet.py:57-78) at the BENCH shapes of layer1 / layer3 / layer4 (the G5 goldens use 16 x 16 maps, which dispatch to the
+    small-map kernels), bf16, train-mode BatchNorm, through the default dispatch: (1) the instrumented launches are attributed to the kernels the bench runs --
+    half-tile, 3x3 patch, pixel-stationary, nine-tap weight gradient, ...; (2) the cross-block BatchNorm fusions are taken (ONE stand-alone bn_bwd_reduce launch for six
+    BatchNorms: the last block's bn3); (3) output, input gradient and every weight gradient agree with the fp32 CPU oracle on this machine at the bf16 gates."""
+    from oracle import pop_oracle as po
+    from segland_amd import ops
+    from segland_amd.functional import flush_num_batches_tracked
+    from segland_amd.networks.backbones.resnet import Bottleneck
+    inp, pl, dil, B, H, W, want = BENCH_BLOCKS[name]
+    torch.manual_seed(11)
+    blocks = [Bottleneck(inp, pl, stride=1, dilation=dil) for _ in range(2)]
+    oracles = [po.make_bottleneck(inp, pl, 1, dil, False) for _ in range(2)]
+    for b, o in zip(blocks, oracles):
+        with torch.no_grad():
+            for m in b.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.weight.copy_(m.weight.to(torch.bfloat16).float())        # both sides multiply the same bf16 weights
+                if isinstance(m, nn.BatchNorm2d):
+                    m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.2, 0.2)
+        o.load_state_dict(b.state_dict())
+        b.to(DEV).train(); o.train()
+    blocks[1].__dict__['_sl_prev'] = blocks[0]          # what ResNet.base_forward does (resnet.py of the build): block 1's only input is block 0's output
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, inp, H, W, generator=g).relu_().to(torch.bfloat16).float()
+    coef = torch.randn(B, inp, H, W, generator=g)
+    xg = nhwc(x, torch.bfloat16).requires_grad_(True)
+    ops.PROFILER.start()
+    y = blocks[1](blocks[0](xg))
+    (y.float() * nhwc(coef, torch.float32)).sum().backward()
+    table = ops.PROFILER.stop()
+    tb = ops.PROFILER.stop_bytes()
+    flush_num_batches_tracked()
+    seen = set(table)
+    print('%s pair: conv families %s; bn_bwd_reduce launches %d' % (name, sorted(seen), tb.get('bn_bwd_reduce', {}).get('calls', 0)))
+    assert want <= seen, 'bench kernels not taken: %s' % sorted(want - seen)
+    assert not any(f.startswith('conv_wgrad_kernel') or f.startswith('conv_gemm_kernel') for f in seen), seen       # the register-staged fallbacks
+    # layer4's conv1 data gradients (K = 512) run on the half-tile kernel, whose store phase does not carry the cross-block sums: both bn3 passes stand alone
+    assert tb.get('bn_bwd_reduce', {}).get('calls', 0) == (2 if name == 'layer4' else 1), tb.get('bn_bwd_reduce')
+    xo = x.clone().requires_grad_(True)
+    yo = po.bottleneck_forward(oracles[1], po.bottleneck_forward(oracles[0], xo))
+    (yo * coef).sum().backward()
+    e = rel_l2(nchw(y), yo)
+    print('  y rel L2 %.4f' % e)
+    assert e <= 2e-2, e
+    e = rel_l2(nchw(xg.grad), xo.grad)
+    print('  dx rel L2 %.4f' % e)
+    assert e <= 6e-2, e
+    for bi, (b, o) in enumerate(zip(blocks, oracles)):
+        for k, p in b.named_parameters():
+            ref = dict(o.named_parameters())[k].grad
+            e = rel_l2(p.grad, ref)
+            print('  block %d d_%s rel L2 %.4f' % (bi, k, e))
+            assert e <= 8e-2, (bi, k, e)
+
+
+def test_dispatch_table_of_the_bench_shapes(hip):
+    """Host logic only (sl_conv2d_tile_config_ex / sl_conv2d_wgrad_config: the same predicate chain the launches switch on): the ResNet-50 bench shapes and the kernel
+    family each must run on.  Family codes: 8 = 3x3 patch, 6 = pixel-stationary, 5 = half-tile, 7 = 64 -> 64 patch; weight gradients 3 = nine-tap, 1 / 2 = the 64-channel
+    kernels, 10256256 / 10128256 = the LDS-DMA tile kernel."""
+    from segland_amd import _lib
+    from segland_amd.ops import EPI_ADDEND, EPI_GATE, EPI_STATS
+    bf = _lib.SL_BF16
+
+    def desc(B, H, W, cin, cout, k, dil=1, stride=1):
+        pad = dil if k == 3 else 0
+        Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        return _lib.SlConvDesc(bf, B, H, W, cin, cout, k, k, stride, pad, dil, Ho, Wo, cin)
+    fam = lambda d, mode, epi: hip.sl_conv2d_tile_config_ex(C.byref(d), mode, epi) // 1000000 % 10      # noqa: E731
+    for cin, cout, dil in ((256, 256, 2), (512, 512, 4), (2048, 512, 1)):                                  # layer3 / layer4 conv2, the pyramid conv
+        d = desc(16, 64, 64, cin, cout, 3, dil)
+        assert fam(d, 0, EPI_STATS) == 8 and fam(d, 1, 0) == 8 and fam(d, 1, EPI_GATE) == 8, (cin, cout)
+        assert hip.sl_conv2d_wgrad_config(C.byref(d)) == 3, (cin, cout)
+    d = desc(16, 64, 64, 1024, 256, 1)                     # layer3 conv1: forward K = 1024 -> half-tile; data gradient K = 256 -> pixel-stationary with the cross-block store loop
+    assert fam(d, 0, EPI_STATS) == 5 and fam(d, 1, EPI_GATE | EPI_ADDEND) == 6 and hip.sl_conv2d_bwd_data_addend_bnstat_rows(C.byref(d)) == 256
+    assert hip.sl_conv2d_wgrad_config(C.byref(d)) == 10128256
+    d = desc(16, 64, 64, 256, 1024, 1)                     # layer3 conv3: forward K = 256 -> pixel-stationary; data gradient K = 1024 -> half-tile with gated statistics
+    assert fam(d, 0, EPI_STATS) == 6 and fam(d, 1, EPI_GATE) == 5 and hip.sl_conv2d_bwd_data_bnstat_rows(C.byref(d)) == 256
+    d = desc(16, 64, 64, 512, 2048, 1)                     # layer4 conv3
+    assert fam(d, 0, EPI_STATS) == 5 and fam(d, 1, EPI_GATE) == 5 and hip.sl_conv2d_wgrad_config(C.byref(d)) == 10256256
+    d = desc(16, 128, 128, 64, 64, 3)                      # layer1 conv2
+    assert fam(d, 0, EPI_STATS) == 7 and hip.sl_conv2d_wgrad_config(C.byref(d)) == 1
+    d = desc(16, 128, 128, 64, 256, 1)                     # layer1 conv3
+    assert fam(d, 0, EPI_STATS) == 6 and hip.sl_conv2d_wgrad_config(C.byref(d)) == 2
+
+
+def test_ft_base_chain_cache_engages_and_is_part_of_the_graph_key(hip):
+    """Round-5 advisor: every output of an autograd.Function requires grad when any input does, so the frozen base prototypes of ft mode looked trainable to the head
+    and functional._base_chain never cached.  ProtoFn now marks them non-differentiable: after ONE fine-tune training step the cache entry exists, a second step reuses
+    it (same tensors), and what it is computed from is part of GraphedStep's state key (a base-classifier weight change behind a captured step re-captures)."""
+    from segland_amd import functional as sf
+    from segland_amd import graph_step
+    from segland_amd.loss.criterion import OrthLoss
+    from segland_amd.networks.pspnet_pop import GFSS_Model
+    torch.manual_seed(0)
+    m = GFSS_Model(n_base=7, criterion=OrthLoss(255), is_ft=True, n_novel=4, backbone='resnet50', pretrained_model=None, compute_dtype=torch.bfloat16, dilated=True, os=8).to(DEV)
+    m.init_cls_n()
+    m.train_mode()
+    m.ft_freeze()
+    g = torch.Generator().manual_seed(7)
+    img, img_b = torch.randn(1, 3, 128, 128, generator=g).to(DEV), torch.randn(1, 3, 128, 128, generator=g).to(DEV)
+    mask = torch.randint(8, 12, (1, 128, 128), generator=g).to(DEV)
+    mask_b = torch.randint(0, 8, (1, 128, 128), generator=g).to(DEV)
+    assert '_sl_base_chain' not in m.__dict__
+    m(img, mask, img_b, mask_b.clone())['total_loss'].backward()
+    ent = m.__dict__.get('_sl_base_chain')
+    assert ent is not None, 'the frozen base chain was not cached'
+    assert m.base_emb.grad is None and all(p.grad is None for p in m.classifier.parameters())
+    m(img, mask, img_b, mask_b.clone())['total_loss'].backward()
+    assert m.__dict__['_sl_base_chain'][1][0] is ent[1][0], 'second step recomputed the cached rows'
+    gs = graph_step.GraphedStep(lambda *a: None, m)
+    k0 = gs._state_key((img,))
+    with torch.no_grad():
+        m.classifier[0].weight.add_(0.0)                  # an in-place write (what load_state_dict does): the version counter moves
+    assert gs._state_key((img,)) != k0 and sf.base_chain_key(m) is not None
