@@ -20,6 +20,7 @@ void sl_debug_conv_p9(int on);             /* 3x3 patch kernel (conv_gemm_p9_ker
 void sl_debug_conv_ring192(int on);        /* 128 x 192 ring tiles for 192-multiple output widths vs the two-stage 256 x 64 kernel */
 void sl_debug_conv_ringn64(int on);        /* 128 x 64 ring tiles for 64-column inference layers vs the two-stage kernel */
 void sl_debug_conv_rows_small(int on);     /* <= 32-row launches on conv_rows_small_kernel vs the tile kernels */
+void sl_debug_conv_parity(int on);         /* stride-2 3x3 data gradients as four parity-plane launches vs one launch over all nine taps */
 void sl_debug_ring64_max_tiles(int tiles); /* 64 x 128 ring tiles up to this many 128 x 128 tiles (default 256, 0: never) */
 void sl_debug_wgrad3(int on);              /* nine-tap 3x3 weight gradient (conv_wgrad3_kernel) vs the per-tap kernels */
 void sl_debug_wgrad_bias(int on);          /* bias-gradient column sums inside the weight-gradient kernel vs in the slab-reduce launch */

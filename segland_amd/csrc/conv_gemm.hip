@@ -87,7 +87,33 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
   return 2128064;
 }
 
+// Data gradient of a stride-2 3x3 conv (resnet.py:46, a stage entry's conv2): a destination pixel of parity (py, px) receives only the taps with ky = py + pad, kx = px + pad
+// (mod 2) -- one, two, two or four of the nine.  The undecomposed launch multiplies all nine per pixel, three quarters of them against the zero page (layer2.0.conv2 at the
+// bench shape: 177 us at 109 TFLOP/s; its forward takes 41).  Here the four parity classes run as four launches of the ring kernel's SUBP instantiation, each over the
+// half-resolution grid with its own tap list, writing its pixels in place (the store phases address 2 N elements apart).  Same store phases, same partial-row count.
+static int parity_cfg(const ConvGemmParams& p, int dtype) {
+  if (!g_sl_debug.conv_parity || dtype != SL_BF16 || p.mode != 1 || p.stride != 2 || p.KH != 3 || p.KW != 3 || p.C2 || (p.C1 % 32)) return 0;
+  if (p.Hd != 2 * p.Hs || p.Wd != 2 * p.Ws || (p.N % 128)) return 0;
+  if (p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.addend_mask || p.ksplit > 1 || (p.flags & 4) || p.addend_half) return 0;
+  if (p.gate ? (p.addend || !p.stat_partial) : (p.addend && p.stat_partial)) return 0;             // the three fast store phases: gated statistics, plain (+ statistics), + addend
+  const int Wh = p.Wd / 2, hw = (p.Hd / 2) * Wh;
+  const long long Ms = (long long)p.B * hw;
+  if ((Wh & (Wh - 1)) || Wh % 32 || hw % 256 || Ms < 256LL * MIN_TILES256) return 0;                // a sweep inside one image row, a tile inside one image, enough tiles per plane
+  return p.N % 256 == 0 ? 4256256 : 4256128;
+}
+static int launch_parity_planes(int cfg, int dtype, const ConvGemmParams& p, hipStream_t st) {
+  const long long Ms = (long long)p.B * (p.Hd / 2) * (p.Wd / 2);
+  for (int k = 0; k < 4; ++k) {
+    ConvGemmParams q = p;
+    q.sub = 1; q.sub_py = k >> 1; q.sub_px = k & 1; q.M = (int)Ms;
+    if (q.stat_partial) q.stat_partial = p.stat_partial + (size_t)k * (Ms / 256) * 2 * p.N;       // plane k's row blocks: partial rows [k Ms / 256, (k + 1) Ms / 256)
+    if (int e = launch_tile(cfg, dtype, q, st)) return e;
+  }
+  return 0;
+}
+
 int launch_gemm(int dtype, ConvGemmParams& p, hipStream_t st) {
+  if (const int pc = parity_cfg(p, dtype)) return launch_parity_planes(pc, dtype, p, st);
   const int cfg = choose_kernel(p, dtype);
   if (dtype == SL_BF16) {
     switch (cfg) {

@@ -53,6 +53,10 @@ struct ConvGemmParams {
   // split-K (inference convs on few row tiles: the fine-tune pair's 8 192-row layers): the K range is cut into `ksplit` parts, block (tile, part) writes its raw fp32
   // accumulators to ws [part][M][N] and conv_splitk_finish_kernel sums the parts in a fixed order and applies pre_addend / scale / bias / addend / ReLU
   float* ws; int ksplit;
+  // parity planes of a stride-2 data gradient (conv_gemm.hip: launch_parity_planes; SUBP instantiations of the ring kernel): the rows of this launch are the positions
+  // (b, i, j) of the half-resolution grid [Hd/2][Wd/2]; row (b, i, j) is destination pixel (2i + sub_py, 2j + sub_px), and only the taps whose source index is an
+  // integer for that parity are multiplied (4 / 2 / 2 / 1 of a 3x3 window's nine)
+  int sub, sub_py, sub_px;
   unsigned long long* trace;            // debug (tools/p8_trace.py): per block {s_memtime at entry, after the prologue, after the main loop, at the end, HW_ID}; null in production
 };
 
@@ -159,7 +163,7 @@ __device__ __forceinline__ void epi_stage_acc(f32x16_t (&acc)[BM / WM / 32][BN /
 // Branch-free store phase for the two shapes of epilogue that carry almost all of the traffic, on tiles that lie completely
 // inside M:  MODE 1 = store the staged tile as is (+ BN statistic partials when requested),  MODE 2 = add the (optionally
 // bit-gated) addend and store.  No per-row predicates, one pointer increment per row, operand loads batched CH rows deep.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool SPLIT = false, bool SUBP = false>
 __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                    int lane, int tid, unsigned char* smem) {
   using G = EpiGeom<T, BM, BN, WM, WN, SPLIT>;
@@ -174,7 +178,14 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
   const int ncol = bn * BN + cc * EPC;
   const size_t rstep = (p.tile16 ? (size_t)p.Wd : (size_t)RS) * p.N * sizeof(T);          // tile16: a sweep of RS = 16 rows is one 16-pixel segment, the next sweep is the next image row
   // byte offset of sweep `it` from the thread's first row.  tile16 with RS == 8 (the four-wave patch kernel: 256 threads): two sweeps per 16-pixel segment
+  // SUBP (parity plane of a stride-2 data gradient): tile rows are positions of the half-resolution grid; a sweep of RS rows lies inside one half-resolution image row
+  // (Wd / 2 is a power of two and a multiple of RS, a tile never crosses an image: launch_parity_planes checks), its pixels are 2 N elements apart in the destination
+  const int sub_lw = SUBP ? 31 - __builtin_clz((unsigned)(p.Wd >> 1)) : 0;
   auto soff = [&](int it) -> size_t {
+    if constexpr (SUBP) {
+      const int q = it * RS;                                    // rows behind the pass's first sweep: q >> lw image rows further, q & (Wh - 1) pixels to the right
+      return ((size_t)(q >> sub_lw) * (2 * p.Wd) + (size_t)(q & ((p.Wd >> 1) - 1)) * 2) * p.N * sizeof(T);
+    }
     if constexpr (RS == 8) { if (p.tile16) return (size_t)(it >> 1) * rstep + (size_t)(it & 1) * (8 * p.N * sizeof(T)); }
     return (size_t)it * rstep;
   };
@@ -195,7 +206,12 @@ __device__ __forceinline__ void conv_epilogue_fast(const ConvGemmParams& p, f32x
     epi_stage_acc<T, BM, BN, WM, WN, SPLIT>(acc, pass, wm, wn, lane, smem);
     lds_barrier();
     size_t grow = (size_t)(bm * BM + pass * ROWS + r0);
-    if (p.tile16) {
+    if constexpr (SUBP) {
+      const int Wh = p.Wd >> 1, hw = (p.Hd >> 1) * Wh;
+      const int u = bm * BM + pass * ROWS;                      // first half-resolution position of this pass (a multiple of RS)
+      const int b = u / hw, rem = u - b * hw, i = rem >> sub_lw, j = rem & (Wh - 1);
+      grow = ((size_t)b * p.Hd + 2 * i + p.sub_py) * p.Wd + 2 * (j + r0) + p.sub_px;
+    } else if (p.tile16) {
       const int tx = p.Wd >> 4, ty = p.Hd >> 4;
       const int bx = bm % tx, by = (bm / tx) % ty, b = bm / (tx * ty);
       grow = ((size_t)b * p.Hd + by * 16 + pass * (ROWS / 16)) * p.Wd + bx * 16 + r0;
@@ -449,7 +465,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
 // step, A/B/A/B on one box (profiles/r3_ab_gate_split.txt).
 // AFF: this instantiation carries the branch-free affine store phases (bias / folded BatchNorm / residual / GELU side output); the tile kernels always, the half-tile
 // kernel in an instantiation of its own (conv_gemm_p8_kernel<2>: inference convs and biased Linears with N % 256 == 0 on >= 24 576 rows).
-template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true, bool AFF = !SPLIT>
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true, bool AFF = !SPLIT, bool SUBP = false>
 __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
@@ -462,6 +478,13 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
       conv_epilogue_fast<T, BM, BN, WM, WN, 6, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
       return -1;
     }
+  }
+  if constexpr (SUBP) {
+    // a parity plane of a stride-2 data gradient: launch_parity_planes (conv_gemm.hip) only launches whole tiles with one of the three fast store phases
+    if constexpr (GATE) conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    else if (p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    else conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    return -1;
   }
   if constexpr (GATE) {
     if (full && !shaped && !p.addend && p.gate) {

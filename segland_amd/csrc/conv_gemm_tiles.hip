@@ -160,7 +160,8 @@ struct RingGeom {
   static constexpr int LDS_BYTES = RING_BYTES > EPI ? RING_BYTES : EPI;
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST, bool GATE = false>
+// SUBP: one parity plane of a stride-2 data gradient (ConvGemmParams::sub): rows are half-resolution positions, only the taps that exist for the plane's parity are walked
+template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST, bool GATE = false, bool SUBP = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmParams p) {
   constexpr int EPC = 16 / sizeof(T);
   constexpr int CPRW = RBYTES / 16;             // 16-byte chunks per stage row
@@ -188,8 +189,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
   const int taps = p.KH * p.KW;
   const int CT = p.C1 + p.C2;
   const int ctiles = CT / BKE;
-  const int nk = taps * ctiles;
-  const bool affine = (p.mode == 0) || (p.stride == 1);
+  // SUBP: the taps whose source index (yd + pad - ky dil) / 2 is an integer for this plane's parity, four bits each (block-uniform); every other launch walks all taps
+  unsigned long long taplist = 0; int ntaps = taps;
+  if constexpr (SUBP) {
+    ntaps = 0;
+    for (int t = 0; t < taps; ++t) {
+      const int ky = t / p.KW, kx = t - ky * p.KW;
+      if (((p.sub_py + p.pad - ky * p.dil) & 1) == 0 && ((p.sub_px + p.pad - kx * p.dil) & 1) == 0) { taplist |= (unsigned long long)t << (4 * ntaps); ++ntaps; }
+    }
+  }
+  const int nk = ntaps * ctiles;
+  const bool affine = !SUBP && ((p.mode == 0) || (p.stride == 1));
   const int sgn = p.mode == 0 ? 1 : -1;
 
   int rb[AR], ry[AR], rx[AR], rbase[AR], rsw[AR]; unsigned vmask[AR];
@@ -199,7 +209,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
     rsw[j] = (lpos ^ ring_swz<RBYTES>(row)) * 16;             // byte offset of the source chunk inside the K slice
     const int m = bm * BM + row;
     rb[j] = -1; ry[j] = 0; rx[j] = 0;
-    if (m < p.M) {
+    if constexpr (SUBP) {
+      if (m < p.M) {
+        const int Wh = p.Wd >> 1, hw = (p.Hd >> 1) * Wh;
+        const int b = m / hw, rem = m - b * hw, i = rem / Wh, jj = rem - i * Wh;
+        rb[j] = b; ry[j] = 2 * i + p.sub_py + p.pad; rx[j] = 2 * jj + p.sub_px + p.pad;
+      }
+    } else if (m < p.M) {
       const int b = m / (p.Hd * p.Wd), rem = m - b * (p.Hd * p.Wd);
       const int yd = rem / p.Wd, xd = rem - yd * p.Wd;
       rb[j] = b;
@@ -240,20 +256,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
     const unsigned char* base; unsigned pitchb;
     if (c0 < p.C1) { base = (const unsigned char*)p.src1 + (size_t)c0 * sizeof(T); pitchb = p.C1 * (unsigned)sizeof(T); }
     else           { base = (const unsigned char*)p.src2 + (size_t)(c0 - p.C1) * sizeof(T); pitchb = p.C2 * (unsigned)sizeof(T); }
-    const int ky = tap / p.KW, kx = tap - ky * p.KW;
+    const int rt = SUBP ? (int)((taplist >> (4 * tap)) & 15) : tap;      // the tap this K-tile multiplies
+    const int ky = rt / p.KW, kx = rt - ky * p.KW;
     const int delta = sgn * (ky * p.dil * p.Ws + kx * p.dil);
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
       int pix; bool ok;
-      if (affine) { pix = rbase[j] + delta; ok = (vmask[j] >> tap) & 1u; }
-      else { pix = slow_pix(j, tap); ok = pix >= 0; }
+      if constexpr (SUBP) {
+        // the parity is right by construction: (ry - ky dil, rx - kx dil) are even
+        const int ty = ry[j] - ky * p.dil, tx = rx[j] - kx * p.dil;
+        const int ys = ty >> 1, xs = tx >> 1;
+        ok = rb[j] >= 0 && ty >= 0 && tx >= 0 && ys < p.Hs && xs < p.Ws;
+        pix = (rb[j] * p.Hs + ys) * p.Ws + xs;
+      } else if (affine) { pix = rbase[j] + delta; ok = (vmask[j] >> rt) & 1u; }
+      else { pix = slow_pix(j, rt); ok = pix >= 0; }
       const unsigned char* src = base + (size_t)((unsigned)pix) * pitchb + rsw[j];
       glds16_asm(ok ? src : zsrc, la + (wave * AR + j) * 1024);
     }
-    const size_t koff = ((size_t)tap * CT + c0) * sizeof(T);
+    const size_t koff = ((size_t)rt * CT + c0) * sizeof(T);
 #pragma unroll
     for (int j = 0; j < BR; ++j) glds16_asm(wrow[j] + koff, lb + (wave * BR + j) * 1024);
-    if (++tap == taps) { tap = 0; ++ct; }
+    if (++tap == ntaps) { tap = 0; ++ct; }
   };
 
   f32x16_t acc[TM][TN];
@@ -330,8 +353,27 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
     };
     store64(std::integral_constant<int, 0>{}); store64(std::integral_constant<int, 1>{}); store64(std::integral_constant<int, 2>{});
   } else {
-    conv_epilogue_lds<T, BM, BN, WM, WN, false, GATE>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    conv_epilogue_lds<T, BM, BN, WM, WN, false, GATE, true, SUBP>(p, acc, bm, bn, wm, wn, lane, tid, smem);
   }
+}
+
+// one parity plane of a stride-2 data gradient on the 256-row ring tiles (bf16; conv_gemm.hip: launch_parity_planes has checked the shape)
+template <int BN, int WM, int WN>
+int launch_ring_subp(ConvGemmParams& p, hipStream_t st) {
+  using RG = RingGeom<bf16_t, 256, BN, WM, WN, 64, 4>;
+  p.gridM = p.M / 256;
+  p.gridN = p.N / BN;
+  const size_t lds = RG::LDS_BYTES;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<bf16_t, 256, BN, WM, WN, 64, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_ring_kernel<bf16_t, 256, BN, WM, WN, 64, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (p.gate) hipLaunchKernelGGL((conv_gemm_ring_kernel<bf16_t, 256, BN, WM, WN, 64, 4, true, true>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  else        hipLaunchKernelGGL((conv_gemm_ring_kernel<bf16_t, 256, BN, WM, WN, 64, 4, false, true>), dim3(p.gridM * p.gridN), dim3(64 * WM * WN), lds, st, p);
+  SL_LAUNCH_CHECK("conv_gemm_ring_kernel (parity plane)");
+  return 0;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
@@ -427,6 +469,12 @@ __global__ __launch_bounds__(64) void conv_rows_small_kernel(ConvGemmParams p) {
 }  // namespace
 
 int slconv::launch_tile(int cfg, int dtype, ConvGemmParams& p, hipStream_t st) {
+  if (p.sub) {
+    if (dtype == SL_BF16 && cfg == 4256256) return launch_ring_subp<256, 2, 4>(p, st);
+    if (dtype == SL_BF16 && cfg == 4256128) return launch_ring_subp<128, 4, 2>(p, st);
+    sl_set_error("conv: no parity-plane kernel for configuration %d", cfg);
+    return SL_EINVAL;
+  }
   if (dtype == SL_BF16 && cfg == 4064128) {
     // 64 x 128 tiles of the few-tile inference layers: 128-byte stage rows (half as many stages per K, twice the bytes in flight per wave).  Up to 256 tiles one block
     // per CU is resident anyway: four stages (96 KiB); beyond, three stages (72 KiB) keep two blocks per CU.  profiles/r5_ab_ring64_geom.txt

@@ -15,7 +15,6 @@ from .functional import _nbt_pending, _wver
 from .ops import ConvSpec
 from .ops_swin import pad_to
 
-import os
 _GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
 
 

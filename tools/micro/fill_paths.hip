@@ -3,6 +3,7 @@
 //   MODE 0  entirely as LDS-DMA (global_load_lds_dwordx4, what conv_gemm_p8_kernel / conv_wgrad_glds_kernel do),
 //   MODE 1  entirely through registers (global_load_dwordx4 -> VGPR -> ds_write_b128, the vector-L1 path),
 //   MODE 2  A rows as LDS-DMA, B rows through registers (the split the review proposes),
+//   MODE 3  no fill at all (with CONSUME: what the fragment reads + MFMAs + barriers of the loop cost on their own),
 // each alone (CONSUME 0) and beside the fragment reads + MFMAs of such a tile (CONSUME 1: 24 ds_read_b128 + 32 v_mfma_f32_32x32x16_bf16 per wave and stage).
 // A is `mtiles` distinct 256-row tiles (HBM / Infinity-Cache sourced when large), B is one 256-row tile every block re-reads (L2 sourced).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/micro/fill_paths.hip -o tools/micro/fill_paths ; run on the GPU box:  fill_paths [pitch_bytes] [mtiles] [nblocks]
@@ -22,8 +23,8 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
   constexpr int RB = 128, HALF = ROWS * RB;       // bytes per operand and stage (ROWS = 256: 32 KiB, a whole K-tile of a 256 x 256 tile; 128: half of one)
   constexpr int STAGE = 2 * HALF;
   constexpr int LH = ROWS / 64;                   // 1 KiB wave-instructions per wave, operand and stage (ROWS rows / 8 rows per instruction / 8 waves)
-  constexpr int LA = MODE == 1 ? 0 : LH, LB_DMA = MODE == 0 ? LH : 0;     // LDS-DMA instructions per wave and stage
-  constexpr int VA = MODE == 1 ? LH : 0, VB = MODE == 0 ? 0 : LH;         // register-path loads per wave and stage
+  constexpr int LA = (MODE == 1 || MODE == 3) ? 0 : LH, LB_DMA = MODE == 0 ? LH : 0;     // LDS-DMA instructions per wave and stage
+  constexpr int VA = MODE == 1 ? LH : 0, VB = (MODE == 0 || MODE == 3) ? 0 : LH;         // register-path loads per wave and stage
   constexpr int NV = VA + VB, ND = LA + LB_DMA;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 3, lpos = lane & 7;
@@ -150,12 +151,13 @@ int main(int argc, char** argv) {
   hipMalloc(&A, (size_t)mtiles * 256 * pitch + 65536); hipMalloc(&B, 256 * pitch + 65536); hipMalloc(&sink, nblocks * 8 * 4); hipMalloc(&ticks, nblocks * 8);
   hipMemset(A, 0x3c, (size_t)mtiles * 256 * pitch + 65536); hipMemset(B, 0x3c, 256 * pitch + 65536);
   printf("pitch %zu B, %d A tiles (%.1f MB), %d blocks of 512 threads, one per CU (64-128 KiB of LDS)\n", pitch, mtiles, mtiles * 256.0 * pitch / 1e6, nblocks);
-  const char* nm[3] = {"all LDS-DMA           ", "all through registers ", "A LDS-DMA, B registers"};
+  const char* nm[4] = {"all LDS-DMA           ", "all through registers ", "A LDS-DMA, B registers", "NO fill (loop only)   "};
   char buf[128];
 #define RUN3(ROWS, NST, FLY, C) \
   snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[0], ROWS, NST, FLY); run<ROWS, NST, FLY, 0, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
   snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[1], ROWS, NST, FLY); run<ROWS, NST, FLY, 1, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
-  snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[2], ROWS, NST, FLY); run<ROWS, NST, FLY, 2, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks);
+  snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[2], ROWS, NST, FLY); run<ROWS, NST, FLY, 2, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
+  if (C) { snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", "with MFMA", nm[3], ROWS, NST, FLY); run<ROWS, NST, FLY, 3, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); }
   RUN3(256, 2, 1, 0)
   RUN3(128, 4, 2, 0)
   RUN3(128, 4, 3, 0)
