@@ -216,7 +216,10 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
 #pragma unroll
     for (int j = 0; j < NI; ++j) glds16_asm(bsrc[j] + (size_t)s * G::BSTEP, lds_base + buf * G::BSTEP + (iw * NI + j) * 1024);
   };
-  if (issuer) issueB(0, 0);
+  // (Round 6, measured and left out: walking the column steps in an order rotated by the block index -- so that the resident blocks do not all touch the same 128-byte
+  // column slice of their rows at the same time -- changed nothing: 1.842 vs 1.844 ms per step for the family, profiles/r6_ab_sk_rotation.txt.  No channel camping here.)
+  auto colstep = [&](int i) { return i; };
+  if (issuer) issueB(colstep(0), 0);
   uint4 a[KS];
   {
     const unsigned char* arow = (const unsigned char*)p.src1 + ((size_t)bm * 256 + wave * 32 + l31) * G::RB + fh * 16;
@@ -264,9 +267,9 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     }
   }
 
-  auto multiply = [&](int s) {
-    const int cur = s & 1;
-    if (issuer && s + 1 < NS) issueB(s + 1, cur ^ 1);
+  auto multiply = [&](int i) {
+    const int cur = i & 1, s = colstep(i);
+    if (issuer && i + 1 < NS) issueB(colstep(i + 1), cur ^ 1);
     if constexpr (MODE == 2 || MODE == 5) {
       const int ncol = s * 64 + sch * 8;
 #pragma unroll
@@ -308,8 +311,8 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
       }
   };
 
-  auto store = [&](int s) {
-    const int cur = s & 1;
+  auto store = [&](int i) {
+    const int cur = i & 1, s = colstep(i);
     const int ncol = s * 64 + sch * 8;
     wait_vmcnt<0>();                                                   // the next step's weight rows, this step's addend, the previous step's stores
     float sa[8], sq[8], sq2[8];
@@ -389,10 +392,11 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
       }
     }
   };
-  auto finalize = [&](int s, int t0) {                                 // 128 (dual: 192) threads from t0 on, after the barrier behind the last store phase of step s
+  auto finalize = [&](int i, int t0) {                                 // 128 (dual: 192) threads from t0 on, after the barrier behind the last store phase of step i
+    const int s = colstep(i);
     if ((MODE == 1 || MODE == 5) && p.stat_partial && tid >= t0 && tid < t0 + (dual ? 192 : 128)) {
       const int which = (tid - t0) >> 6, col = tid & 63;               // 0: sum g, 1: sum g * xhat, 2: sum g * xhat2
-      const float* r0 = red + ((s & 1) * 24 + which) * 64 + col;
+      const float* r0 = red + ((i & 1) * 24 + which) * 64 + col;
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 8; ++k) t += r0[k * 192];

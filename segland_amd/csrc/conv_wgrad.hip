@@ -245,6 +245,15 @@ __device__ __forceinline__ void wglds16_asm(const void* g, unsigned lds_addr) { 
 __device__ __forceinline__ unsigned wlds_addr_of(const unsigned char* p) {
   return (unsigned)(size_t)((const __attribute__((address_space(3))) unsigned char*)p);
 }
+#ifndef SL_WG_NST_256
+#define SL_WG_NST_256 4      // ring depth of the 256 x 256 bf16 tile (32 KiB stages; 5 = the whole 160 KiB) and of the 128 x 256 / 256 x 128 tiles (24 KiB stages; up to 6): A/B builds
+#endif
+#ifndef SL_WG_NST_384
+#define SL_WG_NST_384 4
+#endif
+template <typename T, int BNN, int BCC> __host__ __device__ constexpr int wg_ring_depth() {
+  return (BNN + BCC == 512 && sizeof(T) == 2) ? SL_WG_NST_256 : ((BNN + BCC == 384 && sizeof(T) == 2) ? SL_WG_NST_384 : 4);
+}
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BIAS: the waves of the first c tile's first wave column also multiply their dy fragments with an all-ones x fragment -- every column of that product is the column
@@ -253,7 +262,9 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile(
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool USE_TR, bool BIAS = false>
 __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradParams p) {
   constexpr int ES = sizeof(T), EPC = 16 / ES, NW = WNN * WCC;
-  constexpr int KM = 32, NST = 4;                                  // rows per stage, stages in the LDS ring
+  constexpr int KM = 32;                                           // rows per stage
+  constexpr int NST = wg_ring_depth<T, BNN, BCC>();               // stages in the LDS ring
+  constexpr int D = NST - 1;                                       // stages issued ahead of the one being multiplied
   constexpr int RB_A = BNN * ES, RB_B = BCC * ES;                  // stage row bytes
   constexpr int RPI_A = 1024 / RB_A, RPI_B = 1024 / RB_B;          // rows per 1 KiB wave-instruction
   constexpr int IA = KM / RPI_A / NW, IB = KM / RPI_B / NW;        // LDS-DMA instructions per wave per stage
@@ -437,9 +448,15 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   // k-step (reaching into stage i+1) are loaded before the MFMAs of the current one, LDS-DMA of i+2 / i+3 in flight.
   uint4 afA[TM], bfA[TN], afB[TM], bfB[TN];
 #pragma unroll
-  for (int st = 0; st < 3; ++st)
+  for (int st = 0; st < D; ++st)
     if (st < nit) issue(st, st);
-  if (nit >= 3) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
+  // stages 0 and 1 complete; later ones may stay in flight.  fl = issued stages that need not have landed yet (block-uniform)
+  auto wait_fl = [&](int fl) {
+    if constexpr (D >= 5) { if (fl >= 3) { wg_wait_vmcnt<3 * L>(); return; } }
+    if constexpr (D >= 4) { if (fl == 2) { wg_wait_vmcnt<2 * L>(); return; } }
+    if (fl >= 1) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
+  };
+  wait_fl(min(nit, D) - 2);
   __builtin_amdgcn_s_barrier();
   if (p.trace) tr1 = __builtin_amdgcn_s_memtime();
   ldfrag(afA, bfA, 0, 0);
@@ -447,20 +464,26 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   // the two waves of a SIMD (w, w + NW/2 in an 8-wave block) place their address/issue section one MFMA cluster apart, so one
   // wave's MFMAs cover the other's VALU + LDS-DMA issue (measured on the conv kernel: +1-3 %)
   const bool late = NW == 8 && wave >= 4;
+#ifndef SL_WG_ABL
+#define SL_WG_ABL 0        // ablation builds (tools/wgrad_ablation.sh; never in the product): bit 0 = no LDS-DMA in the loop, bit 1 = no fragment reads in the loop
+#endif
+  if constexpr ((SL_WG_ABL & 2) != 0) ldfrag(afB, bfB, 0, 1);
   for (int it = 0; it < nit; ++it) {
-    int ns3 = slot + 3; if (ns3 >= NST) ns3 -= NST;
-    if (!late && it + 3 < nit) issue(it + 3, ns3);
+    int ns3 = slot + D; if (ns3 >= NST) ns3 -= NST;
+    if (!(SL_WG_ABL & 1) && !late && it + D < nit) issue(it + D, ns3);
     int nslot = slot + 1; if (nslot == NST) nslot = 0;
 #pragma unroll
     for (int ks = 0; ks < KS; ks += 2) {
-      ldfrag(afB, bfB, slot, ks + 1);
+      if constexpr (!(SL_WG_ABL & 2)) ldfrag(afB, bfB, slot, ks + 1);
       mma(afA, bfA);
-      if (ks == 0 && late && it + 3 < nit) issue(it + 3, ns3);
-      if (ks + 2 < KS) ldfrag(afA, bfA, slot, ks + 2);
-      else             ldfrag(afA, bfA, nslot, 0);
+      if (!(SL_WG_ABL & 1) && ks == 0 && late && it + D < nit) issue(it + D, ns3);
+      if constexpr (!(SL_WG_ABL & 2)) {
+        if (ks + 2 < KS) ldfrag(afA, bfA, slot, ks + 2);
+        else             ldfrag(afA, bfA, nslot, 0);
+      }
       mma(afB, bfB);
     }
-    if (it + 3 < nit) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
+    wait_fl(min(it + D, nit - 1) - (it + 2));                  // stage it + 2 complete before anyone starts iteration it + 1; it + 3 .. it + D may stay in flight
     __builtin_amdgcn_s_barrier();
     slot = nslot;
   }
@@ -890,7 +913,7 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M) {
 
 template <typename T, int BNN, int BCC, int WNN, int WCC, bool TR>
 int launch_wgrad_glds(dim3 grid, WgradParams& p, hipStream_t st) {
-  const size_t lds = 4 * 32 * (BNN + BCC) * sizeof(T);        // 4-stage ring of 32-row stages
+  const size_t lds = (size_t)wg_ring_depth<T, BNN, BCC>() * 32 * (BNN + BCC) * sizeof(T);        // ring of 32-row stages
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_glds_kernel<T, BNN, BCC, WNN, WCC, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

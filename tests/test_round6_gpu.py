@@ -159,3 +159,62 @@ def test_ft_base_chain_cache_engages_and_is_part_of_the_graph_key(hip):
     with torch.no_grad():
         m.classifier[0].weight.add_(0.0)                  # an in-place write (what load_state_dict does): the version counter moves
     assert gs._state_key((img,)) != k0 and sf.base_chain_key(m) is not None
+
+
+@pytest.mark.parametrize('cin,cout,B,H', [(128, 128, 16, 128), (256, 256, 16, 128), (128, 256, 24, 64)])
+def test_stride2_data_gradient_as_parity_planes(hip, cin, cout, B, H):
+    """The data gradient of a stride-2 3x3 conv (resnet.py:46: a stage entry's conv2; the bench has one, 128 -> 128 at 128 x 128) runs as four parity-plane launches --
+    each destination parity class only walks the taps that reach it (4 / 2 / 2 / 1 of 9): against torch's fp32 gradient on the same bf16 operands, bit-identical to the
+    one-launch route it replaces (hook sl_debug_conv_parity(0): the same products in the same order, the skipped ones were exact zeros), plain and with the gated
+    BatchNorm-backward statistics in the store phase (column sums of the two routes to 1e-5); and faster."""
+    import torch.nn.functional as F
+    from segland_amd import ops
+    dt_ = torch.bfloat16
+    torch.manual_seed(5)
+    spec = ops.ConvSpec(cin, cout, 3, 2, 1, 1)
+    Ho = H // 2
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * (1.0 / (9 * cin)) ** 0.5
+    _, wb = ops.weight_prep(w, dt_)
+    dy = torch.randn(B, Ho, Ho, cout, device=DEV).to(dt_)
+    x0 = torch.zeros(B, cin, H, H, device=DEV, requires_grad=True)
+    (F.conv2d(x0, w.to(dt_).float(), stride=2, padding=1) * dy.float().permute(0, 3, 1, 2)).sum().backward()
+    ref = x0.grad.permute(0, 2, 3, 1).contiguous()
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            out = fn()
+        e1.record(); torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1) / 10
+    g1, t1 = timed(lambda: ops.conv2d_bwd_data(dy, wb, spec, (H, H)))
+    hip.sl_debug_conv_parity(0)
+    try:
+        g0, t0 = timed(lambda: ops.conv2d_bwd_data(dy, wb, spec, (H, H)))
+    finally:
+        hip.sl_debug_conv_parity(1)
+    s = float(ref.abs().max())
+    err = float((g1.float() - ref).abs().max())
+    print('stride-2 3x3 data gradient %d -> %d, B %d %dx%d: parity planes %.1f us, one launch %.1f us; max err %.2e of scale %.2e' % (cin, cout, B, H, H, 1e3 * t1, 1e3 * t0, err, s))
+    assert err <= 2.5e-2 * s
+    assert torch.equal(g1, g0), 'parity planes vs one launch: not bit-identical'
+    # gated + BatchNorm-backward column sums of the layer below (MODE 3 of the store phase)
+    bn_x = torch.randn(B, H, H, cin, device=DEV).to(dt_)
+    gate = torch.randint(0, 256, (B * H * H * cin // 8,), dtype=torch.uint8, device=DEV)
+    mean, invstd = torch.randn(cin, device=DEV) * 0.1, torch.rand(cin, device=DEV) + 0.5
+    r1 = ops.conv2d_bwd_data_bnstat(dy, wb, spec, (H, H), gate, bn_x, mean, invstd)
+    assert r1 is not None
+    hip.sl_debug_conv_parity(0)
+    try:
+        r0 = ops.conv2d_bwd_data_bnstat(dy, wb, spec, (H, H), gate, bn_x, mean, invstd)
+    finally:
+        hip.sl_debug_conv_parity(1)
+    assert torch.equal(r1[0], r0[0]), 'gated gradient: parity planes vs one launch'
+    bits = ((gate.view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).reshape(B, H, H, cin).bool()
+    assert torch.equal(r1[0], torch.where(bits, g1, torch.zeros((), dtype=dt_, device=DEV)))
+    s1, s0 = r1[1].sum(0), r0[1].sum(0)
+    rel = float((s1 - s0).abs().max() / s0.abs().max())
+    print('  gated statistics: column sums of the two routes differ by %.1e of scale' % rel)
+    assert rel <= 1e-5
+    assert t1 < t0, (t1, t0)

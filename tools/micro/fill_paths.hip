@@ -4,7 +4,11 @@
 //   MODE 1  entirely through registers (global_load_dwordx4 -> VGPR -> ds_write_b128, the vector-L1 path),
 //   MODE 2  A rows as LDS-DMA, B rows through registers (the split the review proposes),
 //   MODE 3  no fill at all (with CONSUME: what the fragment reads + MFMAs + barriers of the loop cost on their own),
-// each alone (CONSUME 0) and beside the fragment reads + MFMAs of such a tile (CONSUME 1: 24 ds_read_b128 + 32 v_mfma_f32_32x32x16_bf16 per wave and stage).
+//   MODE 4  all LDS-DMA, but issued by waves 0-3 only (one wave per SIMD issues for two; its SIMD partner, waves 4-7, never touches the vector-memory pipe),
+//   MODE 5  all LDS-DMA, issued by waves 0-1 only (four waves' worth each),
+// each alone (CONSUME 0) and beside the fragment reads + MFMAs of such a tile (CONSUME 1: 24 ds_read_b128 + 32 v_mfma_f32_32x32x16_bf16 per wave and K-tile;
+// CONSUME 2, 128-row stages only: the fragment reads of conv_wgrad_glds_kernel<256, 256> -- the 32 KiB stage read as [32 pixel rows][512 B dy | 512 B x] with
+// ds_read_b64_tr_b16, 24 per wave and stage for the same 16 MFMAs, software-pipelined one k-step ahead like that kernel).
 // A is `mtiles` distinct 256-row tiles (HBM / Infinity-Cache sourced when large), B is one 256-row tile every block re-reads (L2 sourced).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/micro/fill_paths.hip -o tools/micro/fill_paths ; run on the GPU box:  fill_paths [pitch_bytes] [mtiles] [nblocks]
 #include <hip/hip_runtime.h>
@@ -23,8 +27,8 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
   constexpr int RB = 128, HALF = ROWS * RB;       // bytes per operand and stage (ROWS = 256: 32 KiB, a whole K-tile of a 256 x 256 tile; 128: half of one)
   constexpr int STAGE = 2 * HALF;
   constexpr int LH = ROWS / 64;                   // 1 KiB wave-instructions per wave, operand and stage (ROWS rows / 8 rows per instruction / 8 waves)
-  constexpr int LA = (MODE == 1 || MODE == 3) ? 0 : LH, LB_DMA = MODE == 0 ? LH : 0;     // LDS-DMA instructions per wave and stage
-  constexpr int VA = MODE == 1 ? LH : 0, VB = (MODE == 0 || MODE == 3) ? 0 : LH;         // register-path loads per wave and stage
+  constexpr int LA = (MODE == 1 || MODE == 3) ? 0 : LH, LB_DMA = (MODE == 0 || MODE >= 4) ? LH : 0;     // LDS-DMA instructions per wave and stage
+  constexpr int VA = MODE == 1 ? LH : 0, VB = (MODE == 0 || MODE >= 3) ? 0 : LH;         // register-path loads per wave and stage
   constexpr int NV = VA + VB, ND = LA + LB_DMA;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 3, lpos = lane & 7;
@@ -43,7 +47,23 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
   };
   u32x4 regs[FLY][NV > 0 ? NV : 1];
   // issue order inside iteration i: LDS-DMA of stage i + FLY, then register loads of stage i + FLY + 1 (they are written to the LDS one iteration before they are read)
+  constexpr int SHARE = MODE == 4 ? 2 : (MODE == 5 ? 4 : 1);          // how many waves' instructions a loader wave issues
+  const bool loader = wave < 8 / SHARE;
   auto issue_dma = [&](int k, int slot) {
+    if constexpr (MODE >= 4) {
+      if (loader) {
+#pragma unroll
+        for (int w = 0; w < SHARE; ++w) {
+          const int vw = wave * SHARE + w;                                // the wave whose rows these are
+          const size_t roff = (size_t)(vw - wave) * LH * 8 * pitch + (size_t)k * RB;
+#pragma unroll
+          for (int j = 0; j < LH; ++j) dma(srcA[j] + roff, lds_base + slot * STAGE + (vw * LH + j) * 1024);
+#pragma unroll
+          for (int j = 0; j < LH; ++j) dma(srcB[j] + roff, lds_base + slot * STAGE + HALF + (vw * LH + j) * 1024);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < LA; ++j) dma(srcA[j] + (size_t)k * RB, lds_base + slot * STAGE + (wave * LH + j) * 1024);
 #pragma unroll
@@ -61,11 +81,40 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
 #pragma unroll
     for (int j = 0; j < VB; ++j) *(u32x4*)(smem + slot * STAGE + HALF + (wave * LH + j) * 1024 + lane * 16) = r[VA + j];
   };
-  f32x16 acc[4];
+  f32x16 acc[CONSUME == 2 ? 8 : 4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < (CONSUME == 2 ? 8 : 4); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  // CONSUME 2: conv_wgrad_glds_kernel<bf16, 256, 256, 2, 4>'s fragment geometry (TM = 4, TN = 2, row bytes 512, source-side swizzle)
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  auto tr = [](const unsigned char* q) -> uint2 { return __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q))); };
+  auto ldfrag_tr = [&](u32x4* af, u32x4* bf, const unsigned char* st, int ks) {
+    const int g = lane >> 4, l = lane & 15, wm = wave >> 2, wn = wave & 3;
+    const int r = 16 * ks + 8 * (g >> 1) + (l >> 2), sw = (l >> 2) << 2, cofs = 16 * (g & 1) + 4 * (l & 3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = wm * 128 + i * 32 + cofs;
+      const unsigned char* a0 = st + r * 512 + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+      const uint2 lo = tr(a0), hi = tr(a0 + 4 * 512);
+      af[i] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = wn * 64 + j * 32 + cofs;
+      const unsigned char* b0 = st + 16384 + r * 512 + (((e >> 3) ^ sw) << 4) + (e & 7) * 2;
+      const uint2 lo = tr(b0), hi = tr(b0 + 4 * 512);
+      bf[j] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+    }
+  };
+  auto mma_tr = [&](const u32x4* af, const u32x4* bf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i * 2 + j], 0, 0, 0);
+  };
+  u32x4 afA[4], bfA[2], afB[4], bfB[2];
 
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   // prologue: DMA stages 0 .. FLY-1; register stages 0 .. FLY (stage 0 written before the loop)
@@ -87,7 +136,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
       const int k = k0 + f;
       // needed now: DMA(k) landed, REG(k+1) in registers.  In the steady state the queue is DMA(k) REG(k+1) DMA(k+1) REG(k+2) ... DMA(k+FLY-1) REG(k+FLY); the prologue's
       // queue (all DMA first) only makes the first waits stricter.
-      if (k == 0) wait_vmcnt<0>(); else wait_vmcnt<(FLY - 1) * (ND + NV)>();
+      if (k == 0) wait_vmcnt<0>(); else if (MODE >= 4) { if (loader) wait_vmcnt<(FLY - 1) * ND * SHARE>(); } else wait_vmcnt<(FLY - 1) * (ND + NV)>();
       int nslot = slot + 1; if (nslot == NST) nslot = 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous iteration's ds_write of stage k
       __builtin_amdgcn_s_barrier();
@@ -95,7 +144,14 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
       int fslot = slot + FLY; if (fslot >= NST) fslot -= NST;
       issue_dma(k + FLY, fslot);                      // (reads past the end of the row range stay inside the allocation: see main)
       if constexpr (NV > 0) issue_reg(k + FLY + 1, regs[f]);
-      if constexpr (CONSUME) {
+      if constexpr (CONSUME == 2) {
+        static_assert(CONSUME != 2 || ROWS == 128, "the weight-gradient fragment geometry reads a 32 KiB stage");
+        const unsigned char* st = smem + slot * STAGE;
+        ldfrag_tr(afA, bfA, st, 0);
+        ldfrag_tr(afB, bfB, st, 1);
+        mma_tr(afA, bfA);
+        mma_tr(afB, bfB);
+      } else if constexpr (CONSUME) {
         const unsigned char* st = smem + slot * STAGE;
 #pragma unroll
         for (int q = 0; q < ROWS / 64; ++q) {
@@ -115,7 +171,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
   __syncthreads();
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) s += acc[i][0];
+  for (int i = 0; i < (CONSUME == 2 ? 8 : 4); ++i) s += acc[i][0];
   if (lane == 0) sink[blockIdx.x * 8 + wave] = s + (float)((unsigned*)smem)[wave];
   if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
@@ -151,18 +207,23 @@ int main(int argc, char** argv) {
   hipMalloc(&A, (size_t)mtiles * 256 * pitch + 65536); hipMalloc(&B, 256 * pitch + 65536); hipMalloc(&sink, nblocks * 8 * 4); hipMalloc(&ticks, nblocks * 8);
   hipMemset(A, 0x3c, (size_t)mtiles * 256 * pitch + 65536); hipMemset(B, 0x3c, 256 * pitch + 65536);
   printf("pitch %zu B, %d A tiles (%.1f MB), %d blocks of 512 threads, one per CU (64-128 KiB of LDS)\n", pitch, mtiles, mtiles * 256.0 * pitch / 1e6, nblocks);
-  const char* nm[4] = {"all LDS-DMA           ", "all through registers ", "A LDS-DMA, B registers", "NO fill (loop only)   "};
+  const char* nm[6] = {"all LDS-DMA           ", "all through registers ", "A LDS-DMA, B registers", "NO fill (loop only)   ", "LDS-DMA by waves 0-3  ", "LDS-DMA by waves 0-1  "};
   char buf[128];
 #define RUN3(ROWS, NST, FLY, C) \
   snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[0], ROWS, NST, FLY); run<ROWS, NST, FLY, 0, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
   snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[1], ROWS, NST, FLY); run<ROWS, NST, FLY, 1, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
   snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[2], ROWS, NST, FLY); run<ROWS, NST, FLY, 2, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
-  if (C) { snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", "with MFMA", nm[3], ROWS, NST, FLY); run<ROWS, NST, FLY, 3, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); }
+  if (C) { snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", "with MFMA", nm[3], ROWS, NST, FLY); run<ROWS, NST, FLY, 3, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); } \
+  snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[4], ROWS, NST, FLY); run<ROWS, NST, FLY, 4, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks); \
+  snprintf(buf, sizeof buf, "%s %s %3d-row stages, %d slots, %d in flight", C ? "with MFMA" : "fill only", nm[5], ROWS, NST, FLY); run<ROWS, NST, FLY, 5, C>(buf, A, B, pitch, mtiles, nblocks, sink, ticks);
   RUN3(256, 2, 1, 0)
   RUN3(128, 4, 2, 0)
   RUN3(128, 4, 3, 0)
   RUN3(256, 2, 1, 1)
   RUN3(128, 4, 2, 1)
   RUN3(128, 4, 3, 1)
+  printf("-- the same with the weight-gradient kernel's transpose reads (24 ds_read_b64_tr_b16 per wave and stage instead of 12 ds_read_b128)\n");
+  RUN3(128, 4, 2, 2)
+  RUN3(128, 4, 3, 2)
   return 0;
 }
