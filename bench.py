@@ -505,7 +505,7 @@ def main():
             # with, tools/collect_traffic.py / tools/pmc_families.py); a different library -> null (a kernel change must not keep the old counters in the line)
             lib_sha = lib_sha16()
             traffic, tsrc = None, None
-            for tname in ('r5_traffic.json', 'r5_traffic_wgrad.json', 'r5_traffic_p8.json'):      # bytes per launch of one kernel each
+            for tname in ('r6_traffic.json', 'r6_traffic_wgrad.json', 'r6_traffic_p8.json', 'r5_traffic.json', 'r5_traffic_wgrad.json', 'r5_traffic_p8.json'):      # bytes per launch of one kernel each; the newest set whose sha matches
                 tpath = os.path.join(ROOT, 'profiles', tname)
                 if traffic is None and os.path.exists(tpath):
                     try:
@@ -520,12 +520,15 @@ def main():
                     except Exception:
                         pass
             clock, mfma_busy, csrc = None, None, None
-            cpath = os.path.join(ROOT, 'profiles', 'r5_pmc_families.json')
+            cpath = os.path.join(ROOT, 'profiles', 'r6_pmc_families.json')
+            if not os.path.exists(cpath):
+                cpath = os.path.join(ROOT, 'profiles', 'r5_pmc_families.json')
+            cname = os.path.basename(cpath)
             if os.path.exists(cpath) and a.model == 'pspnet_pop' and a.backbone == 'resnet50' and a.batch == 16 and a.size == 512 and a.dtype == 'bf16':      # the counter passes are of this workload
                 try:
                     cj = json.load(open(cpath))
                     if cj.get('lib_sha256_16') != lib_sha:
-                        csrc = 'null: profiles/r5_pmc_families.json was collected with another build of the library (%s, loaded %s)' % (cj.get('lib_sha256_16'), lib_sha)
+                        csrc = 'null: profiles/%s was collected with another build of the library (%s, loaded %s)' % (cname, cj.get('lib_sha256_16'), lib_sha)
                     else:
                         base = e['family'].split('<')[0]
                         cands = [(v['ms_per_step'], v) for k_, v in cj.get('kernels', {}).items() if k_.split('<')[0].split('(')[0] == base]
@@ -533,8 +536,8 @@ def main():
                             v = max(cands, key=lambda t: t[0])[1]
                             clock, mfma_busy = v.get('clock_ghz'), v.get('mfma_busy_over_sq_busy')
                             csrc = ('NOT measured in this run: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass of this command (kernel by kernel) with this '
-                                    'library (sha256 %s), committed as profiles/r5_pmc_families.json (tools/collect_profiles.sh pmc): clock = GRBM_GUI_ACTIVE / kernel duration, '
-                                    'mfma_busy = MFMA_BUSY / (32 x SQ_BUSY_CYCLES)' % lib_sha)
+                                    'library (sha256 %s), committed as profiles/%s (tools/collect_profiles.sh pmc): clock = GRBM_GUI_ACTIVE / kernel duration, '
+                                    'mfma_busy = MFMA_BUSY / (32 x SQ_BUSY_CYCLES)' % (lib_sha, cname))
                 except Exception:
                     pass
             # what north_star asks: MFMA utilisation "in the backbone convs" -- ALL conv / GEMM launches of the instrumented step, not the best kernel

@@ -188,6 +188,9 @@ __device__ __forceinline__ float sk_sum_8_16_32(float v) {
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
 
+#ifndef SL_SK_ABL
+#define SL_SK_ABL 0      // ablation builds (tools/sk_ablation.sh; never in the product): 1 = no global stores, 2 = no addend / BN-input loads, 4 = no column-sum arithmetic, 8 = no MFMAs
+#endif
 template <int KS, int MODE, bool SKEW>       // MODE 1: store (+ statistics), 2: + (bit-gated) addend, 5: + addend, result gated with the ReLU bits of its own positions + BN-backward column sums (ConvGemmParams::gate)
 __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm_sk_kernel(ConvGemmParams p) {      // MODE 5 holds 81 KiB of LDS at KS = 4: one block per CU whatever the registers allow
   using G = SkGeom<KS>;
@@ -273,10 +276,10 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
     if constexpr (MODE == 2 || MODE == 5) {
       const int ncol = s * 64 + sch * 8;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) addv[it] = arow[it] >= 0 ? *(const uint4*)((const T*)p.addend + arow[it] * p.N + ncol) : make_uint4(0, 0, 0, 0);
+      for (int it = 0; it < 4; ++it) addv[it] = (arow[it] >= 0 && !(SL_SK_ABL & 2)) ? *(const uint4*)((const T*)p.addend + arow[it] * p.N + ncol) : make_uint4(0, 0, 0, 0);
       if constexpr (MODE == 5) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) cxv[it] = *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
+        for (int it = 0; it < 4; ++it) cxv[it] = (SL_SK_ABL & 2) ? make_uint4(0, 0, 0, 0) : *(const uint4*)((const T*)p.bn_x + (orow + it * 8) * p.N + ncol);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bmu[e] = p.bn_mean[ncol + e]; bis[e] = p.bn_invstd[ncol + e]; }
         if (dual) {
@@ -296,8 +299,10 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const uint4 b0 = *(const uint4*)(bb + foff[ks]), b1 = *(const uint4*)(bb + 32 * G::RB + foff[ks]);
+      if constexpr (!(SL_SK_ABL & 8)) {
       Mma<T>::run(b0, a[ks], acc[0]);
       Mma<T>::run(b1, a[ks], acc[1]);
+      } else { acc[0][0] += __uint_as_float(b0.x); acc[1][0] += __uint_as_float(b1.x); }
     }
     // D layout: lane = pixel (l31), register r = column (r & 3) + 8 (r >> 2) + 4 fh of column half j
 #pragma unroll
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
           const unsigned xw[4] = {cxv[it].x, cxv[it].y, cxv[it].z, cxv[it].w};
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
+            if constexpr (SL_SK_ABL & 4) { sa[2 * c] += __uint_as_float(ow[c] ^ xw[c]); continue; }
             const float glo = __uint_as_float(ow[c] << 16), ghi = __uint_as_float(ow[c] & 0xffff0000u);
             const float xlo = __uint_as_float(xw[c] << 16), xhi = __uint_as_float(xw[c] & 0xffff0000u);
             sa[2 * c] += glo; sq[2 * c] += glo * ((xlo - bmu[2 * c]) * bis[2 * c]);
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(512, (KS == 4 && MODE != 5) ? 4 : 2) void conv_gemm
             }
           }
         }
-        st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
+        if constexpr (SL_SK_ABL & 1) { if (ow[0] == 0x12345678u && ow[1] == 0x9abcdef0u) st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3])); }
+        else st16(o, make_uint4(ow[0], ow[1], ow[2], ow[3]));
       }
     }
     if ((MODE == 1 || MODE == 5) && p.stat_partial) {                  // lanes 8 apart share the column octet
@@ -468,6 +475,9 @@ int slconv::launch_sk(ConvGemmParams& p, hipStream_t st) {
   // memory traffic (data gradient 1024 -> 256: 41 -> 47 us, with addend 58 -> 67 us).  bit 0: statistics, bit 1: plain store, bit 2: addend
   constexpr int skew = 1;
   p.gridM = p.M / 256; p.gridN = 1;
+  // MODE 5 (gate + BatchNorm-backward column sums in the store loop) stays un-skewed: round 6's ablation (profiles/r6_sk_ablation.txt) shows the launch bound by its own
+  // instruction streams, not by HBM -- 80 of 115 us remain with NO global loads or stores; MFMAs and column-sum arithmetic are worth 26 us each -- but putting one wave
+  // group's MFMAs under the other's store loop (SKEW) measured 126 vs 117 us (profiles/r6_ab_sk_skew5.txt): the second barrier per step costs more than the overlap buys.
   if (p.gate) return launch_sk_k<5, false>(p, st);
   if (p.addend) return (skew & 4) ? launch_sk_k<2, true>(p, st) : launch_sk_k<2, false>(p, st);
   return (skew & (p.stat_partial ? 1 : 2)) ? launch_sk_k<1, true>(p, st) : launch_sk_k<1, false>(p, st);

@@ -15,7 +15,7 @@
 #   soak      tools/soak.py (drivers for 30 epochs each in one process)
 #   odd       bench.py on other batch / tile sizes and modes
 set -u
-ROUND=r5
+ROUND=r6
 if [ "${1:-}" = "-r" ]; then ROUND=$2; shift 2; fi
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

@@ -21,12 +21,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int ROWS, int NST, int FLY, int MODE, int CONSUME>
-__global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const unsigned char* B, size_t pitch, int ksteps, int mtiles, float* sink, unsigned long long* ticks) {
+// NW: waves per block (8, or 4 for two independent blocks per CU: each wave then issues twice the LDS-DMA and twice the MFMAs per stage, same bytes per FLOP per CU)
+template <int ROWS, int NST, int FLY, int MODE, int CONSUME, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void fill_kernel(const unsigned char* A, const unsigned char* B, size_t pitch, int ksteps, int mtiles, float* sink, unsigned long long* ticks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int RB = 128, HALF = ROWS * RB;       // bytes per operand and stage (ROWS = 256: 32 KiB, a whole K-tile of a 256 x 256 tile; 128: half of one)
   constexpr int STAGE = 2 * HALF;
-  constexpr int LH = ROWS / 64;                   // 1 KiB wave-instructions per wave, operand and stage (ROWS rows / 8 rows per instruction / 8 waves)
+  constexpr int LH = ROWS / (8 * NW);             // 1 KiB wave-instructions per wave, operand and stage (ROWS rows / 8 rows per instruction / NW waves)
   constexpr int LA = (MODE == 1 || MODE == 3) ? 0 : LH, LB_DMA = (MODE == 0 || MODE >= 4) ? LH : 0;     // LDS-DMA instructions per wave and stage
   constexpr int VA = MODE == 1 ? LH : 0, VB = (MODE == 0 || MODE >= 3) ? 0 : LH;         // register-path loads per wave and stage
   constexpr int NV = VA + VB, ND = LA + LB_DMA;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
       } else if constexpr (CONSUME) {
         const unsigned char* st = smem + slot * STAGE;
 #pragma unroll
-        for (int q = 0; q < ROWS / 64; ++q) {
+        for (int q = 0; q < ROWS / 64 * (8 / NW); ++q) {
           u32x4 fr[6];
 #pragma unroll
           for (int i = 0; i < 6; ++i) fr[i] = *(const u32x4*)(st + ((wave * 6 + i + q * 7) % (2 * ROWS / 8)) * 1024 + lane * 16);
@@ -172,21 +173,21 @@ __global__ __launch_bounds__(512) void fill_kernel(const unsigned char* A, const
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < (CONSUME == 2 ? 8 : 4); ++i) s += acc[i][0];
-  if (lane == 0) sink[blockIdx.x * 8 + wave] = s + (float)((unsigned*)smem)[wave];
+  if (lane == 0) sink[(blockIdx.x * 8 + wave) % 8192] = s + (float)((unsigned*)smem)[wave];
   if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
-template <int ROWS, int NST, int FLY, int MODE, int CONSUME>
-void run(const char* name, const unsigned char* A, const unsigned char* B, size_t pitch, int mtiles, int nblocks, float* sink, unsigned long long* ticks) {
+template <int ROWS, int NST, int FLY, int MODE, int CONSUME, int NW = 8>
+void run(const char* name, const unsigned char* A, const unsigned char* B, size_t pitch, int mtiles, int nblocks, float* sink, unsigned long long* ticks, size_t lds_pad = 0) {
   const int ksteps = (int)(pitch / 128) / FLY * FLY - 2 * FLY;           // the loop issues up to FLY + 1 stages past its last one: keep them inside the rows
-  const size_t lds = (size_t)NST * ROWS * 256;
-  auto kern = fill_kernel<ROWS, NST, FLY, MODE, CONSUME>;
+  const size_t lds = (size_t)NST * ROWS * 256 + lds_pad;      // lds_pad: unused bytes that keep a second block off the CU
+  auto kern = fill_kernel<ROWS, NST, FLY, MODE, CONSUME, NW>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, 0, A, B, pitch, ksteps, mtiles, sink, ticks);
+  for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * NW), lds, 0, A, B, pitch, ksteps, mtiles, sink, ticks);
   hipEventRecord(e0);
   const int it = 10;
-  for (int w = 0; w < it; ++w) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(512), lds, 0, A, B, pitch, ksteps, mtiles, sink, ticks);
+  for (int w = 0; w < it; ++w) hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * NW), lds, 0, A, B, pitch, ksteps, mtiles, sink, ticks);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= it;
   unsigned long long* h = (unsigned long long*)malloc(nblocks * 8);
@@ -194,7 +195,7 @@ void run(const char* name, const unsigned char* A, const unsigned char* B, size_
   double tk = 0; for (int i = 0; i < nblocks; ++i) tk += (double)h[i]; tk /= nblocks; free(h);
   const double bytes = (double)nblocks * ksteps * ROWS * 256;
   // s_memtime ticks at 100 MHz on gfx950: convert with the wall time of the launch instead -- B/clk/CU = bytes per block / (block time in 2.4 GHz clocks); blocks run `rounds` deep per CU
-  const double rounds = (double)nblocks / 256.0;
+  const double rounds = (double)nblocks / 256.0;      // (two blocks per CU: the per-CU figure counts both)
   printf("%-58s %8.3f ms  %6.2f TB/s into LDS  %5.1f B/clk/CU at 2.4 GHz  (%.0f memtime ticks per block; %s)\n", name, ms, bytes / ms / 1e9,
          bytes / nblocks * rounds / (ms * 1e-3 * 2.4e9), tk, hipGetErrorString(hipGetLastError()));
 }
@@ -204,7 +205,7 @@ int main(int argc, char** argv) {
   const int mtiles = argc > 2 ? atoi(argv[2]) : 256;           // distinct A row-tiles (A bytes = mtiles * 256 * pitch)
   const int nblocks = argc > 3 ? atoi(argv[3]) : 1024;
   unsigned char *A, *B; float* sink; unsigned long long* ticks;
-  hipMalloc(&A, (size_t)mtiles * 256 * pitch + 65536); hipMalloc(&B, 256 * pitch + 65536); hipMalloc(&sink, nblocks * 8 * 4); hipMalloc(&ticks, nblocks * 8);
+  hipMalloc(&A, (size_t)mtiles * 256 * pitch + 65536); hipMalloc(&B, 256 * pitch + 65536); hipMalloc(&sink, 8192 * 4); hipMalloc(&ticks, 2 * nblocks * 8);
   hipMemset(A, 0x3c, (size_t)mtiles * 256 * pitch + 65536); hipMemset(B, 0x3c, 256 * pitch + 65536);
   printf("pitch %zu B, %d A tiles (%.1f MB), %d blocks of 512 threads, one per CU (64-128 KiB of LDS)\n", pitch, mtiles, mtiles * 256.0 * pitch / 1e6, nblocks);
   const char* nm[6] = {"all LDS-DMA           ", "all through registers ", "A LDS-DMA, B registers", "NO fill (loop only)   ", "LDS-DMA by waves 0-3  ", "LDS-DMA by waves 0-1  "};
@@ -222,6 +223,13 @@ int main(int argc, char** argv) {
   RUN3(256, 2, 1, 1)
   RUN3(128, 4, 2, 1)
   RUN3(128, 4, 3, 1)
+  printf("-- one block of 8 waves per CU vs two independent blocks per CU (same bytes and MFMAs per CU; 128-row stages, 2 slots = 64 KiB per block, 1 in flight)\n");
+  run<128, 2, 1, 0, 1, 8>("with MFMA all LDS-DMA   ONE 8-wave block per CU (LDS padded)          ", A, B, pitch, mtiles, nblocks, sink, ticks, 40 * 1024);
+  run<128, 2, 1, 0, 1, 8>("with MFMA all LDS-DMA   TWO 8-wave blocks per CU                      ", A, B, pitch, mtiles, nblocks, sink, ticks);
+  run<128, 2, 1, 0, 1, 4>("with MFMA all LDS-DMA   TWO 4-wave blocks per CU (2x work per wave)   ", A, B, pitch, mtiles, 2 * nblocks, sink, ticks);
+  run<128, 2, 1, 3, 1, 8>("with MFMA NO fill       ONE 8-wave block per CU (LDS padded)          ", A, B, pitch, mtiles, nblocks, sink, ticks, 40 * 1024);
+  run<128, 2, 1, 3, 1, 8>("with MFMA NO fill       TWO 8-wave blocks per CU                      ", A, B, pitch, mtiles, nblocks, sink, ticks);
+  run<128, 2, 1, 3, 1, 4>("with MFMA NO fill       TWO 4-wave blocks per CU (2x work per wave)   ", A, B, pitch, mtiles, 2 * nblocks, sink, ticks);
   printf("-- the same with the weight-gradient kernel's transpose reads (24 ds_read_b64_tr_b16 per wave and stage instead of 12 ds_read_b128)\n");
   RUN3(128, 4, 2, 2)
   RUN3(128, 4, 3, 2)
