@@ -65,9 +65,35 @@ def confusion_of_batch(logits, label, num_classes, ignore_label, pad_to_longside
     return pred, ops.confusion_matrix(pred, label.contiguous(), num_classes, ignore_label)
 
 
-def dump_probabilities(logits, size, pred, ids, out_dir):
-    """eval_base.py:168,180-190 without the GeoTIFF profile (rasterio): per tile `<id>.mat` = {'outputs': [1,K,H,W] logits upsampled with
-    align_corners=True} (the input of fusemat.py) and `<id>.png`, the argmax as a palette image."""
+def write_prediction_tiff(path, pred_hw, source_tif=None):
+    """eval_base.py:180-188: the label map of one tile as a single-band uint8 TIFF with the class colormap.  With rasterio installed and the tile's source image at hand
+    the file is the reference's GeoTIFF (the source's profile -- CRS, transform -- with driver GTiff, dtype uint8, count 1, nodata 0, + write_colormap); without rasterio
+    (the build image) Pillow writes the same pixels and the same palette as a baseline palette TIFF, without georeferencing.  Returns 'rasterio' or 'PIL'."""
+    from .fusemat import COLORMAP
+    pred_hw = np.ascontiguousarray(pred_hw, dtype=np.uint8)
+    try:
+        import rasterio
+    except ImportError:
+        rasterio = None
+    if rasterio is not None and source_tif is not None and osp.exists(source_tif):
+        with rasterio.open(source_tif) as src:
+            profile = src.profile.copy()
+        profile.update(driver='GTiff', dtype='uint8', count=1, nodata=0)
+        with rasterio.open(path, 'w', **profile) as f:
+            f.write(pred_hw, 1)
+            f.write_colormap(1, {i: tuple(int(v) for v in COLORMAP[i % len(COLORMAP)]) for i in range(256)})
+        return 'rasterio'
+    from PIL import Image
+    img = Image.fromarray(pred_hw, 'P')
+    img.putpalette(np.resize(COLORMAP, (256, 3)).astype(np.uint8).tobytes())
+    img.save(path, format='TIFF')
+    return 'PIL'
+
+
+def dump_probabilities(logits, size, pred, ids, out_dir, data_dir=None):
+    """eval_base.py:168,180-190: per tile `<id>.mat` = {'outputs': [1,K,H,W] logits upsampled with align_corners=True} (the input of fusemat.py), `<id>.tif` = the
+    argmax as a colormapped single-band TIFF next to the .mat directory (write_prediction_tiff: the reference's GeoTIFF when rasterio and the source tile
+    <data_dir>/image/<id>.tif exist), and `<id>.png`, the same as a palette image."""
     import scipy.io
     from . import ops
     from .fusemat import COLORMAP
@@ -77,6 +103,12 @@ def dump_probabilities(logits, size, pred, ids, out_dir):
     for b in range(up.shape[0]):
         name = str(ids[b].item() if hasattr(ids[b], 'item') else ids[b])
         scipy.io.savemat(osp.join(out_dir, name + '.mat'), {'outputs': up[b:b + 1]})
+        try:
+            os.makedirs(out_dir + '_tif', exist_ok=True)
+            write_prediction_tiff(osp.join(out_dir + '_tif', name + '.tif'), pred[b][:size[0], :size[1]],
+                                  osp.join(data_dir, 'image', name + '.tif') if data_dir else None)
+        except ImportError:
+            pass
         try:
             from PIL import Image
             img = Image.fromarray(pred[b][:size[0], :size[1]], 'P')
@@ -141,7 +173,7 @@ def main(argv=None, ft=False):
                     pred, cmb = confusion_of_batch(logits, label, args.num_classes, args.ignore_label, pad_to_longside=ft)
                     cm += cmb
                 if args.save_prob and args.save_path:
-                    dump_probabilities(logits, size, pred, ids, osp.join(args.save_path, 'prob_%d' % seed))
+                    dump_probabilities(logits, size, pred, ids, osp.join(args.save_path, 'prob_%d' % seed), data_dir=getattr(args, 'data_dir', None))
             if engine.distributed:
                 cm = engine.all_reduce_tensor(cm, norm=False)
             cmn = cm.cpu().numpy().astype(np.float64)

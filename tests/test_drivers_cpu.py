@@ -470,3 +470,22 @@ def test_bucket_step_agree_mismatched_signatures_and_bounded_wait(case):
         rank, took, _, err = res[0]
         assert err is not None and 'did not all reach a capture attempt' in err, err
         assert took < 30.0, took
+
+
+def test_prediction_tiff_writer(tmp_path):
+    """eval_base.py:180-188 (the label map of a tile as a single-band uint8 TIFF with the class colormap): without rasterio (this image) Pillow writes a palette TIFF with
+    the same pixels and the same colours; read back through the product's own tile decoder and through Pillow."""
+    import numpy as np
+    from segland_amd.eval_base import write_prediction_tiff
+    from segland_amd.fusemat import COLORMAP
+    rng = np.random.default_rng(3)
+    pred = rng.integers(0, 12, size=(96, 130), dtype=np.uint8)
+    path = str(tmp_path / 'tile.tif')
+    how = write_prediction_tiff(path, pred, source_tif=None)
+    assert how in ('PIL', 'rasterio')
+    from PIL import Image
+    img = Image.open(path)
+    assert img.mode == 'P' and img.size == (130, 96)
+    assert np.array_equal(np.asarray(img), pred)
+    pal = np.asarray(img.getpalette()[:3 * 12], dtype=np.uint8).reshape(12, 3)
+    assert np.array_equal(pal, np.resize(COLORMAP, (256, 3))[:12].astype(np.uint8))

@@ -27,7 +27,7 @@ for target in "$@"; do
   bench)
     python bench.py 2>$O/bench_err.txt | json_line > $O/${ROUND}_bench_default.json
     python bench.py --no-cpu-baseline --no-other-configs --no-step-graph --profile-table $O/${ROUND}_conv_shapes.txt 2>/dev/null | json_line > $O/${ROUND}_bench_kernel_by_kernel.json
-    python bench.py --backbone resnet101 --no-cpu-baseline 2>/dev/null | json_line > $O/${ROUND}_bench_r101.json
+    python bench.py --backbone resnet101 --no-cpu-baseline --profile-table $O/${ROUND}_conv_shapes_r101.txt 2>/dev/null | json_line > $O/${ROUND}_bench_r101.json
     python bench.py --model swin_pop 2>/dev/null | json_line > $O/${ROUND}_bench_swin.json
     for a in "--dtype bf16" "--dtype bf16 --model swin_pop" "--dtype bf16 --pairs 8" "--dtype bf16 --no-step-graph"; do python tools/bench_ft.py $a 2>/dev/null | grep '^{'; done > $O/${ROUND}_bench_ft.txt
     head -c 900 $O/${ROUND}_bench_default.json; echo ;;
