@@ -2,7 +2,7 @@
  *
  * Every hook writes one process-wide record (SlDebugState, segland_amd/csrc/common.h) that the dispatch reads; the record is at its defaults unless a hook
  * was called, and sl_debug_reset() puts it back.  The hooks are NOT thread-safe and must not be called while launches of other threads are being issued.
- * Users: tests/ (route A vs route B bit-identity tests; tests/conftest.py resets the record after every GPU test, also when the test failed), tools/*_trace.py
+ * Users: tests/ (route A vs route B bit-identity tests; tests/conftest.py resets the record after every GPU test, also when the test failed), the tools/ trace scripts
  * (s_memtime phase stamps), tools/with_hook.py (same-box A/B of a whole bench run with one route switched).
  */
 #ifndef SEGLAND_HIP_DEBUG_H
@@ -20,6 +20,7 @@ void sl_debug_conv_p9(int on);             /* 3x3 patch kernel (conv_gemm_p9_ker
 void sl_debug_conv_ring192(int on);        /* 128 x 192 ring tiles for 192-multiple output widths vs the two-stage 256 x 64 kernel */
 void sl_debug_conv_ringn64(int on);        /* 128 x 64 ring tiles for 64-column inference layers vs the two-stage kernel */
 void sl_debug_conv_rows_small(int on);     /* <= 32-row launches on conv_rows_small_kernel vs the tile kernels */
+void sl_debug_ppm_fact_walk(int on);       /* factorised PPM prior path: sliding-window scatter / gather kernels vs the general two-stage kernels */
 void sl_debug_conv_parity(int on);         /* stride-2 3x3 data gradients as four parity-plane launches vs one launch over all nine taps */
 void sl_debug_ring64_max_tiles(int tiles); /* 64 x 128 ring tiles up to this many 128 x 128 tiles (default 256, 0: never) */
 void sl_debug_wgrad3(int on);              /* nine-tap 3x3 weight gradient (conv_wgrad3_kernel) vs the per-tap kernels */

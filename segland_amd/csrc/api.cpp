@@ -28,6 +28,7 @@ extern "C" void sl_debug_conv_ring192(int v) { g_sl_debug.conv_ring192 = v ? 1 :
 extern "C" void sl_debug_conv_ringn64(int v) { g_sl_debug.conv_ringn64 = v ? 1 : 0; }
 extern "C" void sl_debug_conv_rows_small(int v) { g_sl_debug.conv_rows_small = v ? 1 : 0; }
 extern "C" void sl_debug_conv_parity(int v) { g_sl_debug.conv_parity = v ? 1 : 0; }
+extern "C" void sl_debug_ppm_fact_walk(int v) { g_sl_debug.ppm_fact_walk = v ? 1 : 0; }
 extern "C" void sl_debug_ring64_max_tiles(int v) { g_sl_debug.ring64_max_tiles = v; }
 extern "C" void sl_debug_wgrad3(int v) { g_sl_debug.wgrad3 = v ? 1 : 0; }
 extern "C" void sl_debug_wgrad_bias(int v) { g_sl_debug.wgrad_bias = v ? 1 : 0; }

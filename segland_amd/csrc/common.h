@@ -94,6 +94,7 @@ struct SlDebugState {
   int conv_ring192 = 1;            // 128 x 192 ring tile for 192-multiple output widths
   int conv_ringn64 = 1;            // 128 x 64 ring tile for 64-column inference layers
   int conv_rows_small = 1;         // <= 32-row launches on conv_rows_small_kernel
+  int ppm_fact_walk = 1;           // factorised PPM prior path: sliding-window scatter / gather kernels (0: the general two-stage kernels they replace)
   int conv_parity = 1;             // stride-2 3x3 data gradients as four parity-plane launches (0: one launch over all nine taps per pixel)
   long long ring64_max_tiles = 256;   // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks (0: never)
   int wgrad3 = 1;                  // nine-tap 3x3 weight gradient (0: per-tap kernels)

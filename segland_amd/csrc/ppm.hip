@@ -491,6 +491,134 @@ __global__ void ppm_fact_scatterB_kernel(PpmGeom g, int N, const float* __restri
   }
 }
 
+
+// ---- Round 6: the same two stages as sliding windows.  u_tap(pos; cell) = W(pos + k - 1; cell) with W the bilinear weight of a destination index on a source cell: walking
+// the SHIFTED index p = pos + k - 1 instead of pos, the cell pair (c(p), c(p) + 1) and its weights are the same for all three taps of the axis and the taps differ only in
+// which datum they multiply (pos = p + 1, p, p - 1).  c(p) is non-decreasing and advances by at most one per step (levels no finer than the map), so a thread keeps two
+// open accumulators per (level, tap) -- the cell being left and the cell being entered -- and writes a cell out when the walk leaves it: every input element is read ONCE
+// (stage A re-read each map row 36 times from the L2, stage B each intermediate row ~6 times: 131 + 100 us per ResNet-50 step), no weight is evaluated per element.
+struct FactWalk { int c; float a, b; };                       // position p touches cell c with weight a and cell c + 1 with weight b
+__device__ __forceinline__ FactWalk fact_walk(int p, int s, int size) {
+  int i0, i1; float l1;
+  src_index_ac0(p, s, size, i0, i1, l1);
+  FactWalk w; w.c = i0;
+  if (i1 == i0) { w.a = (1.f - l1) + l1; w.b = 0.f; } else { w.a = 1.f - l1; w.b = l1; }      // (the sum as tap_weight forms it: bit-identical to the general kernels)
+  return w;
+}
+template <typename T> __device__ __forceinline__ float2 ld_pair(const T* p);
+template <> __device__ __forceinline__ float2 ld_pair<float>(const float* p) { return *(const float2*)p; }
+template <> __device__ __forceinline__ float2 ld_pair<bf16_t>(const bf16_t* p) { const unsigned v = *(const unsigned*)p; return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u)); }
+
+// stage A: sa[b][y][kx][lj][n] = sum_x W_l(x + kx - 1; j) * dcb[b][y][x][n].  One block per map row (b, y), a thread per channel PAIR.
+template <typename T>
+__global__ __launch_bounds__(256) void ppm_fact_scatterA2_kernel(PpmGeom g, int N, const T* __restrict__ dcb, float* __restrict__ sa, int nlj) {
+  __shared__ FactWalk tab[4][64];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < g.nlevels * g.W; e += 256) { const int l = e / g.W, p = e - l * g.W; tab[l][p] = fact_walk(p, g.sizes[l], g.W); }
+  __syncthreads();
+  const int by = blockIdx.x;                                  // b * H + y
+  const T* row = dcb + (size_t)by * g.W * N;
+  float* out = sa + (size_t)by * 3 * nlj * N;
+  for (int pr = tid; pr < N / 2; pr += 256) {
+    const int n = 2 * pr;
+    float2 acc[4][3][2];
+    int cur[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) { cur[l] = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { acc[l][k][0] = make_float2(0.f, 0.f); acc[l][k][1] = make_float2(0.f, 0.f); } }
+    float2 dm = make_float2(0.f, 0.f), d0 = ld_pair<T>(row + n), dp = g.W > 1 ? ld_pair<T>(row + (size_t)N + n) : make_float2(0.f, 0.f);      // pixels p - 1, p, p + 1
+    int ljoff_[4]; { int o = 0;
+#pragma unroll
+      for (int l = 0; l < 4; ++l) { ljoff_[l] = o; o += g.sizes[l]; } }
+    for (int p = 0; p < g.W; ++p) {
+      const float2 dn = p + 2 < g.W ? ld_pair<T>(row + (size_t)(p + 2) * N + n) : make_float2(0.f, 0.f);      // next step's pixel p + 1
+#pragma unroll
+      for (int l = 0; l < 4; ++l) {
+        if (l < g.nlevels) {
+          const FactWalk w = tab[l][p];
+          if (w.c != cur[l]) {                                   // the walk left cell cur: it is complete (block-uniform branch)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              *(float2*)(out + ((size_t)k * nlj + ljoff_[l] + cur[l]) * N + n) = acc[l][k][0];
+              acc[l][k][0] = acc[l][k][1]; acc[l][k][1] = make_float2(0.f, 0.f);
+            }
+            cur[l] = w.c;
+          }
+          // tap kx multiplies pixel p - kx + 1: kx = 0 -> dp, 1 -> d0, 2 -> dm
+          acc[l][0][0].x += w.a * dp.x; acc[l][0][0].y += w.a * dp.y; acc[l][0][1].x += w.b * dp.x; acc[l][0][1].y += w.b * dp.y;
+          acc[l][1][0].x += w.a * d0.x; acc[l][1][0].y += w.a * d0.y; acc[l][1][1].x += w.b * d0.x; acc[l][1][1].y += w.b * d0.y;
+          acc[l][2][0].x += w.a * dm.x; acc[l][2][0].y += w.a * dm.y; acc[l][2][1].x += w.b * dm.x; acc[l][2][1].y += w.b * dm.y;
+        }
+      }
+      dm = d0; d0 = dp; dp = dn;
+    }
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+      if (l < g.nlevels) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          *(float2*)(out + ((size_t)k * nlj + ljoff_[l] + cur[l]) * N + n) = acc[l][k][0];
+          for (int c = cur[l] + 1; c < g.sizes[l]; ++c)          // the cell being entered (and, on a map narrower than the level's support, cells never reached: zero)
+            *(float2*)(out + ((size_t)k * nlj + ljoff_[l] + c) * N + n) = c == cur[l] + 1 ? acc[l][k][1] : make_float2(0.f, 0.f);
+        }
+      }
+  }
+}
+
+// stage B: gq[row_l(b,i,j)][(ky*3+kx)*N + n] = sum_y W_l(y + ky - 1; i) * sa[b][y][kx][lj][n].  A thread per (b, kx, lj, channel pair) column of sa, walking y.
+__global__ __launch_bounds__(256) void ppm_fact_scatterB2_kernel(PpmGeom g, int N, const float* __restrict__ sa, float* __restrict__ gq, int nlj) {
+  const int np = N / 2;
+  const long long total = (long long)g.B * 3 * nlj * np;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int pr = (int)(e % np); long long r = e / np;
+    int lj = (int)(r % nlj); r /= nlj;
+    const int kx = (int)(r % 3); const int b = (int)(r / 3);
+    const int ljall = lj;
+    int l = 0;
+    while (lj >= g.sizes[l]) { lj -= g.sizes[l]; ++l; }
+    const int s = g.sizes[l], j = lj, n = 2 * pr;
+    const float* col = sa + (((size_t)b * g.H * 3 + kx) * nlj + ljall) * N + n;      // row y at col + y * 3 * nlj * N
+    const size_t ystep = (size_t)3 * nlj * N;
+    float2 acc[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { acc[k][0] = make_float2(0.f, 0.f); acc[k][1] = make_float2(0.f, 0.f); }
+    int cur = 0;
+    auto flush = [&](int i, int slot) {
+      float* o = gq + ((size_t)g.rowoff[l] + ((size_t)b * s + i) * s + j) * 9 * N + (size_t)kx * N + n;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) *(float2*)(o + (size_t)k * 3 * N) = acc[k][slot];
+    };
+    float2 dm = make_float2(0.f, 0.f), d0 = *(const float2*)col, dp = g.H > 1 ? *(const float2*)(col + ystep) : make_float2(0.f, 0.f);
+    float2 dq = g.H > 2 ? *(const float2*)(col + 2 * ystep) : make_float2(0.f, 0.f);       // one more row in flight
+    for (int p = 0; p < g.H; ++p) {
+      const float2 dn = p + 3 < g.H ? *(const float2*)(col + (size_t)(p + 3) * ystep) : make_float2(0.f, 0.f);
+      const FactWalk w = fact_walk(p, s, g.H);
+      if (w.c != cur) {
+        flush(cur, 0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { acc[k][0] = acc[k][1]; acc[k][1] = make_float2(0.f, 0.f); }
+        cur = w.c;
+      }
+      acc[0][0].x += w.a * dp.x; acc[0][0].y += w.a * dp.y; acc[0][1].x += w.b * dp.x; acc[0][1].y += w.b * dp.y;
+      acc[1][0].x += w.a * d0.x; acc[1][0].y += w.a * d0.y; acc[1][1].x += w.b * d0.x; acc[1][1].y += w.b * d0.y;
+      acc[2][0].x += w.a * dm.x; acc[2][0].y += w.a * dm.y; acc[2][1].x += w.b * dm.x; acc[2][1].y += w.b * dm.y;
+      dm = d0; d0 = dp; dp = dq; dq = dn;
+    }
+    flush(cur, 0);
+    for (int c = cur + 1; c < s; ++c) {
+      if (c == cur + 1) flush(c, 1);
+      else { float* o = gq + ((size_t)g.rowoff[l] + ((size_t)b * s + c) * s + j) * 9 * N + (size_t)kx * N + n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) *(float2*)(o + (size_t)k * 3 * N) = make_float2(0.f, 0.f); }
+    }
+  }
+}
+
+// (Round 6, gather stage 2: two forms that serve the operand rows from registers / the LDS instead of the L2 were built and measured against ppm_fact_gather2_kernel's
+// 113 us per ResNet-50 step -- a sliding window per channel pair (64 dependent steps per thread on 8 waves per CU): 170 us; the general body reading a row staged in the
+// LDS (32-byte lane accesses, bank conflicts): 340 us.  Neither kept; profiles/r6_ab_ppm_fact.txt.)
+
 inline int gs_blocks(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
 inline int sum_sizes(const PpmGeom& g) { int n = 0; for (int l = 0; l < g.nlevels; ++l) n += g.sizes[l]; return n; }
 
@@ -748,6 +876,72 @@ extern "C" int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x
   return (int)hipGetLastError();
 }
 
+// ---- weight gradients of the grouped row GEMMs (round 6): dw[l][n][k] = sum over the rows r of level l of a[r][n] * x[r][k].  The reduction has 16 ... 576 rows per level:
+// the generic weight-gradient tile kernel ran each level as a launch of its own with split-K slabs and a reduce launch (eight launches, 0.24 ms per ResNet-50 step for
+// 5.5 GFLOP).  Here one launch covers all levels: a block owns a 64 x 64 tile of one level's gradient, walks that level's rows in chunks of 32 (the MFMA k index is the row)
+// and writes the tile itself -- no slabs, fixed summation order (ascending rows).  fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 products).
+struct RowsWgrad {
+  const float* a; const float* x; float* dw[SL_PPM_MAX_LEVELS];
+  int N, K, nl;
+  int row_off[5];
+};
+constexpr int RW_LD = 68;            // LDS row pitch in floats (64 + 4: the float4 stores of the 16 threads of a row do not collide with the next row's)
+__global__ __launch_bounds__(256) void ppm_rows_wgrad_kernel(RowsWgrad p) {
+  __shared__ __attribute__((aligned(16))) float As[2][32][RW_LD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][32][RW_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l = blockIdx.z, n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int r0 = p.row_off[l], r1 = p.row_off[l + 1];
+  const int lr = tid >> 4, lc = (tid & 15) * 4;                  // this thread loads rows lr and lr + 16 of a chunk, floats lc .. lc + 3
+  float4 ra[2], rx[2];
+  auto gload = [&](int r) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = r + lr + 16 * h;
+      const bool ok = row < r1;
+      ra[h] = ok ? *reinterpret_cast<const float4*>(p.a + (size_t)row * p.N + n0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rx[h] = ok ? *reinterpret_cast<const float4*>(p.x + (size_t)row * p.K + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int wn = (wave & 1) * 32, wk = (wave >> 1) * 32, li = lane & 31, lh = lane >> 5;
+  gload(r0);
+  int buf = 0;
+  for (int r = r0; r < r1; r += 32, buf ^= 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      *reinterpret_cast<float4*>(&As[buf][lr + 16 * h][lc]) = ra[h];
+      *reinterpret_cast<float4*>(&Xs[buf][lr + 16 * h][lc]) = rx[h];
+    }
+    __syncthreads();                                   // one barrier per chunk: the other buffer was last read a full iteration ago
+    if (r + 32 < r1) gload(r + 32);
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk)                    // k = row 2 kk + (lane >> 5) of the chunk
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * kk + lh][wn + li], Xs[buf][2 * kk + lh][wk + li], acc, 0, 0, 0);
+  }
+  // D layout: register r = row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the first operand (n), lane & 31 = column of the second (k)
+  float* o = p.dw[l] + (size_t)(n0 + wn) * p.K + k0 + wk + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * p.K] = acc[r];
+}
+
+extern "C" int sl_ppm_rows_wgrad(const SlPpmDesc* d, int N, int K, const float* a, const float* x, float* const* dw, sl_stream_t stream) {
+  SL_REQUIRE(d && d->nlevels >= 1 && d->nlevels <= SL_PPM_MAX_LEVELS && d->B > 0, "ppm_rows_wgrad: bad descriptor");
+  SL_REQUIRE(a && x && dw && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, "ppm_rows_wgrad: N % 64 == 0 and K % 64 == 0 required");
+  RowsWgrad p{};
+  p.a = a; p.x = x; p.N = N; p.K = K; p.nl = d->nlevels;
+  for (int l = 0; l < d->nlevels; ++l) {
+    SL_REQUIRE(dw[l] && d->sizes[l] > 0, "ppm_rows_wgrad: null output / bad level size");
+    p.dw[l] = dw[l];
+    p.row_off[l + 1] = p.row_off[l] + d->B * d->sizes[l] * d->sizes[l];
+  }
+  hipLaunchKernelGGL(ppm_rows_wgrad_kernel, dim3(N / 64, K / 64, d->nlevels), dim3(256), 0, (hipStream_t)stream, p);
+  SL_LAUNCH_CHECK("ppm_rows_wgrad_kernel");
+  return 0;
+}
+
 extern "C" size_t sl_ppm_fact_workspace(const SlPpmDesc* d, int N) {
   PpmGeom g;
   if (make_geom(d, g)) return 0;
@@ -780,6 +974,18 @@ extern "C" int sl_ppm_fact_scatter(const SlPpmDesc* d, int N, const void* dcb, f
   if (workspace_bytes < need) { sl_set_error("ppm_fact_scatter: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
   hipStream_t st = (hipStream_t)stream;
   float* sa = (float*)workspace;
+  // the sliding-window kernels (round 6) need every level no finer than the map (the cell index advances by at most one per step) and rows of at most 64 pixels for the
+  // weight table; anything else takes the two general kernels.  Test hook: sl_debug_ppm_fact_walk(0).
+  bool walk = g_sl_debug.ppm_fact_walk && g.W <= 64 && g.H >= 1 && N % 2 == 0;
+  for (int l = 0; l < g.nlevels; ++l) walk = walk && g.sizes[l] <= g.W && g.sizes[l] <= g.H;
+  if (walk) {
+    if (d->dtype == SL_BF16) hipLaunchKernelGGL(ppm_fact_scatterA2_kernel<bf16_t>, dim3(g.B * g.H), dim3(256), 0, st, g, N, (const bf16_t*)dcb, sa, nlj);
+    else if (d->dtype == SL_F32) hipLaunchKernelGGL(ppm_fact_scatterA2_kernel<float>, dim3(g.B * g.H), dim3(256), 0, st, g, N, (const float*)dcb, sa, nlj);
+    else SL_REQUIRE(false, "ppm_fact_scatter: bad dtype");
+    hipLaunchKernelGGL(ppm_fact_scatterB2_kernel, dim3(gs_blocks((long long)g.B * 3 * nlj * (N / 2))), dim3(256), 0, st, g, N, sa, gq, nlj);
+    SL_LAUNCH_CHECK("ppm_fact_scatter (walk)");
+    return 0;
+  }
   if (d->dtype == SL_BF16) hipLaunchKernelGGL(ppm_fact_scatterA_kernel<bf16_t>, dim3(gs_blocks((long long)g.B * g.H * 3 * nlj * N / 8)), dim3(256), 0, st, g, N, (const bf16_t*)dcb, sa, nlj);
   else if (d->dtype == SL_F32) hipLaunchKernelGGL(ppm_fact_scatterA_kernel<float>, dim3(gs_blocks((long long)g.B * g.H * 3 * nlj * N / 4)), dim3(256), 0, st, g, N, (const float*)dcb, sa, nlj);
   else SL_REQUIRE(false, "ppm_fact_scatter: bad dtype");

@@ -244,6 +244,7 @@ def _frozen(ctx, *bns):
     return not any(ctx.needs_input_grad) and not any(b.training for b in bns)
 
 
+_PPM_WGRAD_GROUPED = True  # test hook: the pyramid's eight row-GEMM weight gradients as two grouped launches (ops.ppm_rows_wgrad); False: one generic weight-gradient launch + slab reduce per level
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
 _BASE_CHAIN_CACHE = True   # test hook: ft mode, the frozen base classifier's rows are computed once (False: every iteration)
@@ -578,12 +579,15 @@ class PPMFn(torch.autograd.Function):
                 dwb = gwb if gwb is not None else torch.empty_like(bt[0].weight, dtype=torch.float32)
                 ops.conv2d_bwd_weight(x4, dcb, spec4, out=dwb, out_ci_off=nl * Cs)
                 dwq = torch.empty((nl, 9 * N, Cs), dtype=torch.float32, device=x4.device)
-                qspec, off = ConvSpec(Cs, 9 * N, 1), 0
-                for k, s in enumerate(sizes):
-                    n = B * s * s
-                    ops.conv2d_bwd_weight(stage_act[off:off + n].view(B, s, s, Cs), gq[off:off + n].view(B, s, s, 9 * N), qspec,
-                                          out=dwq[k].view(9 * N, Cs, 1, 1))
-                    off += n
+                if _PPM_WGRAD_GROUPED:
+                    ops.ppm_rows_wgrad(gq, stage_act, B, sizes, outs=[dwq[k] for k in range(nl)])      # all levels in one launch (round 6)
+                else:
+                    qspec, off = ConvSpec(Cs, 9 * N, 1), 0
+                    for k, s in enumerate(sizes):
+                        n = B * s * s
+                        ops.conv2d_bwd_weight(stage_act[off:off + n].view(B, s, s, Cs), gq[off:off + n].view(B, s, s, 9 * N), qspec,
+                                              out=dwq[k].view(9 * N, Cs, 1, 1))
+                        off += n
             if need_w:
                 ops.ppm_dwq_scatter(dwq, dwb, Cs, nl)
                 dwb = grad_alias(dwb, gwb)
@@ -603,6 +607,10 @@ class PPMFn(torch.autograd.Function):
             dbl = [d_[1] if d_[1] is not None else tmp[k, 1] for k, d_ in enumerate(dsts)]
             ops.ppm_stage_bn_bwd(dstage, stage_act, call, B, sizes, ml, il, [st[2].weight for st in dec.stages], [st[2].training for st in dec.stages], dgl, dbl, out=dc_all)
             grouped = [(grad_alias(dgl[k], dsts[k][0]), grad_alias(dbl[k], dsts[k][1])) for k in range(nl)]
+        dws_all = None
+        if need_w and _PPM_WGRAD_GROUPED and grouped is not None:
+            # the four stage convs' weight gradients in one launch (ops.ppm_rows_wgrad); dc_all is complete (the grouped BatchNorm backward wrote every level)
+            dws_all = ops.ppm_rows_wgrad(dc_all, pooled, B, sizes, outs=[grad_dst(st[1].weight) for st in dec.stages])
         for k, (s, st) in enumerate(zip(sizes, dec.stages)):
             n = B * s * s
             ggs, gbs, gws = (grad_dst(st[2].weight), grad_dst(st[2].bias), grad_dst(st[1].weight)) if need_w else (None, None, None)
@@ -612,7 +620,10 @@ class PPMFn(torch.autograd.Function):
                 _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], st[2].weight, train=st[2].training,
                                             out=dc_all[off:off + n], sync_world=sync_world(st[2]), dgamma_out=ggs, dbeta_out=gbs)
                 dgs, dbs = grad_alias(dgs, ggs), grad_alias(dbs, gbs)
-            dws = grad_alias(ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1]), out=gws), gws) if need_w else None
+            if dws_all is not None:
+                dws = grad_alias(dws_all[k] if dws_all[k] is gws else dws_all[k].view_as(st[1].weight), gws)
+            else:
+                dws = grad_alias(ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Cs), spec_of(st[1]), out=gws), gws) if need_w else None
             gstage += [dws, dgs, dbs]; off += n
         dpooled = ops.ppm_rows_gemm(dc_all, _stage_weights(dec)[1], B, sizes)[0] if need_x else None
         dx4 = ops.ppm_pool_bwd(dpooled, x4.shape, x4.dtype, sizes, dcat=dcat, cat_off=cat_off) if need_x else None

@@ -771,6 +771,22 @@ def ppm_rows_gemm(x, w, B, sizes, want_stats=False):
     return y, part
 
 
+def ppm_rows_wgrad(a, x, B, sizes, outs=None):
+    """Weight gradients of ppm_rows_gemm for all levels in ONE launch: dw[l] [N][K] = sum over level l's rows of a[r][:]^T x[r][:].  a [rows][N] (gradient wrt the GEMM's
+    output), x [rows][K] (its input), float.  outs: per level a float [N*K] destination (a parameter's gradient buffer) or None -> a fresh [nl][N][K] tensor's slices."""
+    assert a.dtype == torch.float32 and x.dtype == torch.float32 and a.is_contiguous() and x.is_contiguous() and a.shape[0] == x.shape[0] == ppm_rows(B, sizes)
+    nl, N, K = len(sizes), a.shape[1], x.shape[1]
+    fresh = _f32((nl, N, K), a.device) if (outs is None or any(o is None for o in outs)) else None
+    dws = [fresh[l] if (outs is None or outs[l] is None) else outs[l] for l in range(nl)]
+    for t in dws:
+        assert t.numel() == N * K and t.dtype == torch.float32 and t.is_contiguous()
+    d = SlPpmDesc(SL_F32, B, 1, 1, 8, nl, (C.c_int * 4)(*(list(sizes) + [0] * (4 - nl))))
+    tok = PROFILER.begin_bytes('ppm_rows_wgrad', (a.numel() + x.numel() + nl * N * K) * 4)
+    check(_lib.lib().sl_ppm_rows_wgrad(C.byref(d), N, K, _p(a), _p(x), (C.c_void_p * nl)(*[_p(t) for t in dws]), _s()), 'ppm_rows_wgrad')
+    PROFILER.end_bytes(tok)
+    return dws
+
+
 def ppm_stat_groups(B, sizes):
     """Prefix of the 128-row statistic groups per level in ppm_rows_gemm's partials."""
     off = [0]

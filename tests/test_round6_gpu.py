@@ -218,3 +218,76 @@ def test_stride2_data_gradient_as_parity_planes(hip, cin, cout, B, H):
     print('  gated statistics: column sums of the two routes differ by %.1e of scale' % rel)
     assert rel <= 1e-5
     assert t1 < t0, (t1, t0)
+
+
+def test_ppm_rows_weight_gradients_grouped(hip):
+    """The weight gradients of the pyramid's row GEMMs (four stage convs, pspnet_pop.py:12-16, and the four per-level GEMMs of the factorised prior path) as ONE launch each
+    (sl_ppm_rows_wgrad): against torch's fp32 einsum per level (1e-5 of scale: exact-fp32 MFMA products, ascending-row sums), into caller-provided destinations, and
+    at the model level -- every PSPModule parameter gradient of the grouped route against the per-level route it replaces."""
+    from segland_amd import functional as sf
+    from segland_amd import ops
+    from segland_amd.networks.pspnet_pop import PSPModule
+    torch.manual_seed(2)
+    B, sizes = 3, (1, 2, 3, 6)
+    rows = ops.ppm_rows(B, sizes)
+    for N, K in ((128, 64), (512, 2048), (576, 128)):
+        a, x = torch.randn(rows, N, device=DEV), torch.randn(rows, K, device=DEV)
+        dst = torch.zeros(N * K, device=DEV)
+        dws = ops.ppm_rows_wgrad(a, x, B, sizes, outs=[None, dst, None, None])
+        assert dws[1] is dst
+        off = 0
+        for l, s in enumerate(sizes):
+            n = B * s * s
+            ref = a[off:off + n].double().t() @ x[off:off + n].double()
+            err = float((dws[l].view(N, K).double() - ref).abs().max() / ref.abs().max())
+            assert err <= 1e-5, (N, K, l, err)
+            off += n
+    outs = {}
+    for grouped in (True, False):
+        old = sf._PPM_WGRAD_GROUPED
+        sf._PPM_WGRAD_GROUPED = grouped
+        try:
+            torch.manual_seed(4)
+            dec = PSPModule(256, out_features=128).to(DEV).train()
+            xg = torch.randn(2, 24, 24, 256, device=DEV).to(torch.bfloat16).requires_grad_(True)
+            y = dec(xg)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+            outs[grouped] = {k: p.grad.clone() for k, p in dec.named_parameters()} | {'x': xg.grad.float().clone()}
+        finally:
+            sf._PPM_WGRAD_GROUPED = old
+    for k in outs[True]:
+        e = rel_l2(outs[True][k], outs[False][k])
+        assert e <= 1e-4, (k, e)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('B,H,W,N', [(16, 64, 64, 512), (3, 24, 40, 128), (2, 7, 9, 64)])
+def test_ppm_factorised_scatter_gather_sliding_window(hip, B, H, W, N, dtype):
+    """The factorised prior path's scatter (the backward of pspnet_pop.py:19 applied to the bilinearly upsampled stage maps, ppm.hip) as sliding-window kernels: every input
+    element read once.  Bit-identical to the general two-stage kernels they replace (hook sl_debug_ppm_fact_walk(0): the same products summed in the same ascending order),
+    and the scatter is the exact transpose of the gather (<gather(q), d> == <q, scatter(d)> to fp32 accuracy).  (The gather keeps its general kernels: the hook changes
+    nothing there, the comparison stays as a guard.)"""
+    from segland_amd import ops
+    torch.manual_seed(9)
+    sizes = (1, 2, 3, 6)
+    rows = ops.ppm_rows(B, sizes)
+    q = torch.randn(rows, 9 * N, device=DEV)
+    dcb = torch.randn(B, H, W, N, device=DEV).to(dtype)
+    shape = (B, H, W, 2048)
+
+    def both(fn):
+        r1 = fn()
+        hip.sl_debug_ppm_fact_walk(0)
+        try:
+            r0 = fn()
+        finally:
+            hip.sl_debug_ppm_fact_walk(1)
+        return r1, r0
+    s1, s0 = both(lambda: ops.ppm_fact_scatter(dcb, shape, sizes))
+    assert torch.equal(s1, s0), 'scatter: sliding window vs general kernels: max diff %g' % float((s1 - s0).abs().max())
+    g1, g0 = both(lambda: ops.ppm_fact_gather(q, shape, sizes, N, dtype))
+    assert torch.equal(g1, g0), 'gather: sliding window vs general kernels: max diff %g' % float((g1.float() - g0.float()).abs().max())
+    if dtype == torch.float32:
+        lhs = float((g1.double() * dcb.double()).sum())
+        rhs = float((q.double() * s1.double()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
