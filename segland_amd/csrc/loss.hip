@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_kernel(UpGeom g, const fl
 // Sums run in a fixed order (deterministic); they are associated differently from the gather kernel (last-bit differences).
 constexpr int CT = 4;
 struct UpTile { int NYmax, NXmax; };
-__global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, UpTile ut, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
+template <int NT>
+__global__ __launch_bounds__(NT) void upsample_ce_bwd_tiled_kernel(UpGeom g, UpTile ut, const float* __restrict__ lg, const int64_t* __restrict__ tgt,
                                                                     const float* __restrict__ loss_cnt, const float* __restrict__ gscale,
                                                                     int ignore, float* __restrict__ dlg) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -167,18 +168,18 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, Up
   const int Xhi = g.sx > 0.f ? min(g.W - 1, (int)ceilf((float)(j1 + 1) / g.sx)) : g.W - 1;
   const int NY = Yhi - Ylo + 1, NX = Xhi - Xlo + 1;
   const float* lb = lg + (size_t)b * K * g.h * g.w;
-  for (int e = tid; e < (CT + 2) * (CT + 2) * K; e += 256) {
+  for (int e = tid; e < (CT + 2) * (CT + 2) * K; e += NT) {
     const int k = e % K, c = e / K, cy = c / (CT + 2), cx = c - cy * (CT + 2);
     const int yy = min(max(i0 - 1 + cy, 0), g.h - 1), xx = min(max(j0 - 1 + cx, 0), g.w - 1);
     lgt[e] = lb[((size_t)k * g.h + yy) * g.w + xx];
   }
-  for (int e = tid; e < NY; e += 256) {
+  for (int e = tid; e < NY; e += NT) {
     int y0, y1; float ly; src_index_ac1(Ylo + e, g.h, g.sy, y0, y1, ly);
     wy0[3 * e] = __int_as_float(y0); wy0[3 * e + 1] = __int_as_float(y1); wy0[3 * e + 2] = ly;
 #pragma unroll
     for (int r = 0; r < CT; ++r) wyi[e * CT + r] = (y0 == i0 + r ? 1.f - ly : 0.f) + (y1 == i0 + r ? ly : 0.f);
   }
-  for (int e = tid; e < NX; e += 256) {
+  for (int e = tid; e < NX; e += NT) {
     int x0, x1; float lx; src_index_ac1(Xlo + e, g.w, g.sx, x0, x1, lx);
     wx0[3 * e] = __int_as_float(x0); wx0[3 * e + 1] = __int_as_float(x1); wx0[3 * e + 2] = lx;
 #pragma unroll
@@ -187,17 +188,17 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, Up
   __syncthreads();
   // ---- pass 1: softmax - onehot of every footprint pixel, once
   // the thread's labels first, all loads in flight (a load at the top of every iteration was a chain of ~8 memory round trips per block)
-  constexpr int TPF = 8;
+  constexpr int TPF = 2048 / NT;
   long long tpre[TPF];
 #pragma unroll
   for (int u = 0; u < TPF; ++u) {
-    const int pix = tid + 256 * u;
+    const int pix = tid + NT * u;
     const int yr = pix / NX, xr = pix - yr * NX;
     tpre[u] = pix < NY * NX ? tgt[((size_t)b * g.H + Ylo + yr) * g.W + Xlo + xr] : (long long)ignore;
   }
 #pragma unroll 1
-  for (int u = 0; tid + 256 * u < NY * NX; ++u) {
-    const int pix = tid + 256 * u;
+  for (int u = 0; tid + NT * u < NY * NX; ++u) {
+    const int pix = tid + NT * u;
     const int yr = pix / NX, xr = pix - yr * NX;
     float* out = G + (size_t)pix * K;
     long long t;
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, Up
   }
   __syncthreads();
   // ---- pass 2a: along X
-  for (int e = tid; e < NY * CT * K; e += 256) {
+  for (int e = tid; e < NY * CT * K; e += NT) {
     const int k = e % K, r = e / K, jr = r % CT, yr = r / CT;
     const int j = j0 + jr;
     float acc = 0.f;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_tiled_kernel(UpGeom g, Up
   __syncthreads();
   // ---- pass 2b: along Y, scale, store
   const float f = gscale[0] / loss_cnt[1];
-  for (int e = tid; e < CT * CT * K; e += 256) {
+  for (int e = tid; e < CT * CT * K; e += NT) {
     const int k = e % K, c = e / K, ir = c / CT, jr = c - ir * CT;
     const int i = i0 + ir, j = j0 + jr;
     if (i > i1 || j > j1) continue;
@@ -426,8 +427,11 @@ extern "C" int sl_upsample_ce_bwd(const float* logits, const int64_t* target, co
     const size_t lds = ((size_t)(CT + 2) * (CT + 2) * K + (3 + CT) * (ut.NYmax + ut.NXmax) + (size_t)ut.NYmax * CT * K + (size_t)ut.NYmax * ut.NXmax * K) * sizeof(float);
     if (lds <= 150 * 1024) {
       static size_t attr = 0;
-      if (lds > attr) { (void)hipFuncSetAttribute((const void*)upsample_ce_bwd_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = 150 * 1024; }
-      hipLaunchKernelGGL(upsample_ce_bwd_tiled_kernel, dim3((unsigned)(B * cdiv(h, CT) * cdiv(w, CT))), dim3(256), lds, (hipStream_t)stream, g, ut, logits, target, loss_and_count, gscale, ignore_index, dlogits);
+#ifndef SL_UPCE_NT
+#define SL_UPCE_NT 512      // threads per block of the tiled kernel (A/B build: 256)
+#endif
+      if (lds > attr) { (void)hipFuncSetAttribute((const void*)upsample_ce_bwd_tiled_kernel<SL_UPCE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = 150 * 1024; }
+      hipLaunchKernelGGL(upsample_ce_bwd_tiled_kernel<SL_UPCE_NT>, dim3((unsigned)(B * cdiv(h, CT) * cdiv(w, CT))), dim3(SL_UPCE_NT), lds, (hipStream_t)stream, g, ut, logits, target, loss_and_count, gscale, ignore_index, dlogits);
       SL_LAUNCH_CHECK("upsample_ce_bwd_tiled_kernel");
       return 0;
     }
