@@ -281,6 +281,9 @@ int sl_ppm_rows_gemm_stat_rows(const SlPpmDesc* d);
 size_t sl_ppm_rows_gemm_workspace(const SlPpmDesc* d, int K, int N);
 int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x, const float* w, float* y, float* stat_partial,
                      void* workspace, size_t workspace_bytes, sl_stream_t stream);
+/* The same with one [N][K] weight tensor per level (w_levels: d->nlevels pointers): the stage convs' own prepared weight copies, no stacked copy per step. */
+int sl_ppm_rows_gemm_levels(const SlPpmDesc* d, int K, int N, const float* x, const float* const* w_levels, float* y, float* stat_partial,
+                            void* workspace, size_t workspace_bytes, sl_stream_t stream);
 /* Weight gradients of those grouped GEMMs, all levels in one launch (the backward of pspnet_pop.py:12-16 wrt the stage conv weights, and of the per-level
  * GEMMs of the factorised prior path):  dw[l][n][k] = sum over the rows r of level l of a[r][n] * x[r][k]  with a [rows][N] (the gradient wrt y), x [rows][K], all
  * float; dw: d->nlevels pointers to float [N][K] tensors (the parameters' own gradient buffers).  N % 64 == 0, K % 64 == 0.  Fixed summation order, no workspace. */

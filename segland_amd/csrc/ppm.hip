@@ -726,7 +726,7 @@ extern "C" int sl_ppm_dwq_scatter(const float* dwq, int N, int Ctot, int Cs, int
 // output tiles, and K is split across blockIdx.z (slabs summed in a fixed order by the finish kernel -> deterministic).
 // The MFMA operand roles are swapped (A = weight rows, B = x rows) so that a lane ends up with 4 consecutive n of one row.
 struct RowsGemm {
-  const float* x; const float* w; float* out;
+  const float* x; const float* w[SL_PPM_MAX_LEVELS]; float* out;        // w[l]: level l's [N][K] weights
   int K, N, nl, kslice;
   int row_off[5], tile_off[5];
   long long slab_stride;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void ppm_rows_gemm_kernel(RowsGemm p) {
   const int m0 = p.row_off[l] + ((int)blockIdx.y - p.tile_off[l]) * 64, mend = p.row_off[l + 1];
   const int n0 = blockIdx.x * 64;
   const int kbeg = blockIdx.z * p.kslice, kend = min(p.K, kbeg + p.kslice);
-  const float* wl = p.w + (size_t)l * p.N * p.K;
+  const float* wl = p.w[l];
   const int lr = tid >> 3, lc = (tid & 7) * 4;             // this thread loads rows lr, lr+32; floats lc..lc+3 of the k tile
   float4 rx[2], rw[2];
   auto gload = [&](int k0) {
@@ -862,19 +862,30 @@ extern "C" size_t sl_ppm_rows_gemm_workspace(const SlPpmDesc* d, int K, int N) {
   return ks > 1 ? (size_t)ks * mm.slab_stride * sizeof(float) : 0;
 }
 
-extern "C" int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x, const float* w, float* y, float* stat_partial,
-                                void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+// w_levels: one [N][K] weight tensor per level (the parameters' own prepared copies: no stacked copy per step)
+extern "C" int sl_ppm_rows_gemm_levels(const SlPpmDesc* d, int K, int N, const float* x, const float* const* w_levels, float* y, float* stat_partial,
+                                       void* workspace, size_t workspace_bytes, sl_stream_t stream) {
   RowsGemm mm{}, fin{}; int ks, mtiles, groups;
   if (int e = rows_gemm_plan(d, K, N, mm, fin, ks, mtiles, groups)) return e;
-  SL_REQUIRE(x && w && y, "ppm_rows_gemm: null buffer");
+  SL_REQUIRE(x && w_levels && y, "ppm_rows_gemm: null buffer");
+  for (int l = 0; l < d->nlevels; ++l) { SL_REQUIRE(w_levels[l], "ppm_rows_gemm: null weight of a level"); mm.w[l] = w_levels[l]; }
   SL_REQUIRE(ks == 1 || (workspace && workspace_bytes >= (size_t)ks * mm.slab_stride * sizeof(float)), "ppm_rows_gemm: workspace too small");
-  mm.x = x; mm.w = w; mm.out = ks > 1 ? (float*)workspace : y;
+  mm.x = x; mm.out = ks > 1 ? (float*)workspace : y;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ppm_rows_gemm_kernel, dim3(N / 64, mtiles, ks), dim3(256), 0, st, mm);
   if (ks > 1 || stat_partial)
     hipLaunchKernelGGL(ppm_rows_finish_kernel, dim3(N / 64, groups), dim3(256), 0, st, (const float*)mm.out, ks, mm.slab_stride, y, N, fin, stat_partial);
   return (int)hipGetLastError();
 }
+
+extern "C" int sl_ppm_rows_gemm(const SlPpmDesc* d, int K, int N, const float* x, const float* w, float* y, float* stat_partial,
+                                void* workspace, size_t workspace_bytes, sl_stream_t stream) {
+  SL_REQUIRE(d && d->nlevels >= 1 && d->nlevels <= SL_PPM_MAX_LEVELS && w, "ppm_rows_gemm: bad descriptor / null weights");
+  const float* lv[SL_PPM_MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr};
+  for (int l = 0; l < d->nlevels; ++l) lv[l] = w + (size_t)l * N * K;
+  return sl_ppm_rows_gemm_levels(d, K, N, x, lv, y, stat_partial, workspace, workspace_bytes, stream);
+}
+
 
 // ---- weight gradients of the grouped row GEMMs (round 6): dw[l][n][k] = sum over the rows r of level l of a[r][n] * x[r][k].  The reduction has 16 ... 576 rows per level:
 // the generic weight-gradient tile kernel ran each level as a launch of its own with split-K slabs and a reduce launch (eight launches, 0.24 ms per ResNet-50 step for
@@ -1004,24 +1015,36 @@ struct PpmStageBn {
   float* dgamma[SL_PPM_MAX_LEVELS]; float* dbeta[SL_PPM_MAX_LEVELS];
   int row0[SL_PPM_MAX_LEVELS + 1]; int train[SL_PPM_MAX_LEVELS];
 };
-__global__ __launch_bounds__(256) void ppm_stage_bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ dx,
-                                                               int C, PpmStageBn q) {
-  __shared__ double red[2][8][32];
+// (round 6: 32 row lanes per channel instead of 8, four rows in flight per thread -- the 576-row level was a chain of 72 dependent row reads per thread, twice: 83 -> ~20 us)
+constexpr int SBN_RL = 32;
+__global__ __launch_bounds__(32 * SBN_RL) void ppm_stage_bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ x, float* __restrict__ dx,
+                                                                      int C, PpmStageBn q) {
+  __shared__ double red[2][SBN_RL][32];
   __shared__ float co[3][32];
   const int cg = C / 32, lvl = blockIdx.x / cg, c = (blockIdx.x % cg) * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
   const int r0 = q.row0[lvl], r1 = q.row0[lvl + 1];
   const float mu = q.mean[lvl][c], is = q.invstd[lvl][c];
   float s1 = 0.f, s2 = 0.f;
-  for (int r = r0 + rl; r < r1; r += 8) {
-    const size_t o = (size_t)r * C + c;
-    const float g = y[o] > 0.f ? dy[o] : 0.f;
-    s1 += g; s2 += g * ((x[o] - mu) * is);
+  for (int r = r0 + rl; r < r1; r += 4 * SBN_RL) {
+    float gy[4], gd[4], gx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * SBN_RL;
+      const size_t o = (size_t)(rr < r1 ? rr : r) * C + c;
+      gy[u] = y[o]; gd[u] = dy[o]; gx[u] = x[o];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + u * SBN_RL < r1) {                       // rows in ascending order per lane, as before
+        const float g = gy[u] > 0.f ? gd[u] : 0.f;
+        s1 += g; s2 += g * ((gx[u] - mu) * is);
+      }
   }
   red[0][rl][threadIdx.x & 31] = (double)s1; red[1][rl][threadIdx.x & 31] = (double)s2;
   __syncthreads();
   if (rl == 0) {
     double a = 0.0, b = 0.0;
-    for (int j = 0; j < 8; ++j) { a += red[0][j][threadIdx.x]; b += red[1][j][threadIdx.x]; }
+    for (int j = 0; j < SBN_RL; ++j) { a += red[0][j][threadIdx.x]; b += red[1][j][threadIdx.x]; }
     if (q.dgamma[lvl]) q.dgamma[lvl][c] = (float)b;
     if (q.dbeta[lvl]) q.dbeta[lvl][c] = (float)a;
     const double gm = q.gamma[lvl] ? (double)q.gamma[lvl][c] : 1.0, isd = (double)is, count = (double)(r1 - r0);
@@ -1031,7 +1054,7 @@ __global__ __launch_bounds__(256) void ppm_stage_bn_bwd_kernel(const float* __re
   }
   __syncthreads();
   const float cA = co[0][threadIdx.x & 31], cB = co[1][threadIdx.x & 31], cC = co[2][threadIdx.x & 31];
-  for (int r = r0 + rl; r < r1; r += 8) {
+  for (int r = r0 + rl; r < r1; r += SBN_RL) {
     const size_t o = (size_t)r * C + c;
     const float g = y[o] > 0.f ? dy[o] : 0.f;
     dx[o] = cA * g + cB * (x[o] - mu) + cC;
@@ -1050,7 +1073,7 @@ extern "C" int sl_ppm_stage_bn_bwd(const SlPpmDesc* d, int C, const float* dy, c
     q.row0[l] = row; row += d->B * d->sizes[l] * d->sizes[l];
   }
   q.row0[d->nlevels] = row;
-  hipLaunchKernelGGL(ppm_stage_bn_bwd_kernel, dim3(d->nlevels * (C / 32)), dim3(256), 0, (hipStream_t)stream, dy, y, x, dx, C, q);
+  hipLaunchKernelGGL(ppm_stage_bn_bwd_kernel, dim3(d->nlevels * (C / 32)), dim3(32 * SBN_RL), 0, (hipStream_t)stream, dy, y, x, dx, C, q);
   SL_LAUNCH_CHECK("ppm_stage_bn_bwd_kernel");
   return 0;
 }

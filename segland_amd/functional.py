@@ -641,15 +641,14 @@ def set_ppm_factorised(flag):
 
 
 def _stage_weights(dec):
-    """Stage 1x1 weights stacked for the grouped GEMM: ([nl][Cs][Cf] forward, [nl][Cf][Cs] data gradient), float, cached per version."""
-    ws = [st[1].weight for st in dec.stages]
-    key = tuple((_wver(w), w.data_ptr()) for w in ws)
-    ent = getattr(dec, '_sl_stage_w', None)
-    if ent is None or ent[0] != key:
-        f = torch.stack([w.detach().view(w.shape[0], w.shape[1]) for w in ws]).float().contiguous()
-        ent = (key, f, f.transpose(1, 2).contiguous())
-        dec._sl_stage_w = ent
-    return ent[1], ent[2]
+    """The stage 1x1 weights for the grouped GEMMs: (per level [Cs][Cf] forward, per level [Cf][Cs] data gradient) -- the float copies weight preparation makes anyway
+    (refresh_weights: the stage convs are in the plan with float32), handed to ops.ppm_rows_gemm as per-level pointers.  (Until round 6 they were stacked and transposed
+    with two torch launches per step: 37 us.)"""
+    fs, bs = [], []
+    for st in dec.stages:
+        wf, wb = prepared(st[1].weight, torch.float32)
+        fs.append(wf); bs.append(wb)
+    return fs, bs
 
 
 def _ppm_weights(w, Cs, nl, dtype):

@@ -757,17 +757,26 @@ def _ppm_d(dtype, x_shape, sizes):
 
 
 def ppm_rows_gemm(x, w, B, sizes, want_stats=False):
-    """y[r] = w[level(r)] @ x[r] over the pyramid rows; x [rows][K] float, w [nl][N][K] float.  Returns (y, stat partials or None)."""
-    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    """y[r] = w[level(r)] @ x[r] over the pyramid rows; x [rows][K] float, w [nl][N][K] float -- or a list of nl float tensors of N * K elements each (the levels' own
+    weight copies, row-major [N][K]) with N given by the first one's leading dimension.  Returns (y, stat partials or None)."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
     rows, K = x.shape
-    nl, N, K2 = w.shape
-    assert K2 == K and nl == len(sizes) and rows == ppm_rows(B, sizes)
+    if isinstance(w, (list, tuple)):
+        nl, N = len(w), w[0].numel() // K
+        for t in w:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == N * K
+    else:
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        nl, N, K2 = w.shape
+        assert K2 == K
+        w = [w[l] for l in range(nl)]
+    assert nl == len(sizes) and rows == ppm_rows(B, sizes)
     d = SlPpmDesc(SL_F32, B, 1, 1, 8, nl, (C.c_int * 4)(*(list(sizes) + [0] * (4 - nl))))
     L = _lib.lib()
     ws = workspace(L.sl_ppm_rows_gemm_workspace(C.byref(d), K, N), x.device)
     y = _f32((rows, N), x.device)
     part = _f32((L.sl_ppm_rows_gemm_stat_rows(C.byref(d)), 2, N), x.device) if want_stats else None
-    check(L.sl_ppm_rows_gemm(C.byref(d), K, N, _p(x), _p(w), _p(y), _p(part), _p(ws), ws.numel(), _s()), 'ppm_rows_gemm')
+    check(L.sl_ppm_rows_gemm_levels(C.byref(d), K, N, _p(x), (C.c_void_p * nl)(*[_p(t) for t in w]), _p(y), _p(part), _p(ws), ws.numel(), _s()), 'ppm_rows_gemm')
     return y, part
 
 
