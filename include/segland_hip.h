@@ -422,6 +422,15 @@ int sl_adamw_multi(const void* table_dev, int n, long long total_chunks, float b
  * parameter group }; a record's `group` selects its pair and the record's own lr / wd are ignored. */
 int sl_adamw_multi_dev(const void* table_dev, int n, long long total_chunks, float beta1, float beta2, float eps,
                        const float* hyper_dev, int repeat, const float* grad_scale, sl_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_'s total norm and clip coefficient (train_base.py:258-261 through utils/pyt_utils.py:327-347; ft_pop.py:250) over a list of contiguous
+ * float gradient tensors: sl_grad_sqnorm_multi (up to SL_NORM_MAX tensors per launch; the addresses are kernel arguments, so a captured step carries them) writes one
+ * partial sum of squares per 4096-element chunk to partial[batch->chunk_base + chunk]; sl_grad_norm_finalize sums the nchunks partials in a fixed order and writes
+ * out[0] = norm = sqrt(sum) * inv_div and out[1] = min(1, max_norm / (norm + 1e-6)) * inv_div (inv_div = 1 / world size when the gradients hold the sum over ranks).
+ * chunk0[i] = first chunk of tensor i within this batch (chunk0[0] = 0, chunk0[n] = the batch's chunk count). */
+#define SL_NORM_MAX 64
+typedef struct SlNormBatch { const void* grad[SL_NORM_MAX]; long long numel[SL_NORM_MAX]; int chunk0[SL_NORM_MAX + 1]; int n; int chunk_base; } SlNormBatch;
+int sl_grad_sqnorm_multi(const SlNormBatch* batch, float* partial, sl_stream_t stream);
+int sl_grad_norm_finalize(const float* partial, int nchunks, float max_norm, float inv_div, float* out, sl_stream_t stream);
 /* torch.optim.SGD (momentum, weight decay; dampening 0, nesterov off) over all parameters in one launch: ft_pop.py:205-209,252.  Table records as for sl_adamw_multi
  * (64 bytes: p, g, momentum buffer or NULL, unused, numel, lr, weight_decay, chunk start, group, pad); hyper_dev = (lr, weight_decay) per parameter group in device
  * memory or NULL (the records' own values): with it the launch is capturable while the driver changes the learning rate every iteration.  grad_scale: optional

@@ -35,6 +35,13 @@ class SlResizeDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('dtype', 'B', 'h', 'w', 'H', 'W', 'C', 'src_pitch', 'src_off', 'dst_pitch', 'dst_off', 'align_corners', 'accumulate', 'src_f32')]
 
 
+SL_NORM_MAX = 64
+
+
+class SlNormBatch(C.Structure):
+    _fields_ = [('grad', C.c_void_p * SL_NORM_MAX), ('numel', C.c_longlong * SL_NORM_MAX), ('chunk0', C.c_int * (SL_NORM_MAX + 1)), ('n', C.c_int), ('chunk_base', C.c_int)]
+
+
 SL_COLSUM_MAX = 12
 
 

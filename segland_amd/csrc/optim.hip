@@ -189,3 +189,58 @@ extern "C" int sl_relpos_gather_multi(const void* table_dev, int n, sl_stream_t 
   SL_LAUNCH_CHECK("relpos_gather_multi_kernel");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// clip_grad_norm_'s total norm over a list of gradient tensors and the clip coefficient, without torch's ~12 launches (fill, four multi-tensor norm kernels, clean-up,
+// two concatenations, a reduce, reciprocal, clamp, copy: 130 us of a ResNet-50 step).  The gradient addresses travel as KERNEL ARGUMENTS (up to SL_NORM_MAX per launch), so
+// a captured step bakes them in like every other launch; partial sums of squares per 4096-element chunk, summed in a fixed order by the finalize launch (deterministic).
+//   norm = sqrt(sum g^2) * inv_div,   coef = min(1, max_norm / (norm + 1e-6)) * inv_div          (inv_div = 1 / world size when the gradients hold the SUM over ranks)
+namespace {
+__global__ __launch_bounds__(256) void grad_sqnorm_multi_kernel(SlNormBatch b, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int chunk = blockIdx.x;
+  int lo = 0, hi = b.n - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (b.chunk0[mid] <= chunk) lo = mid; else hi = mid - 1; }
+  const float* g = (const float*)b.grad[lo];
+  const long long base = (long long)(chunk - b.chunk0[lo]) * 4096, n = b.numel[lo];
+  float s = 0.f;
+  if (base + 4096 <= n && (((size_t)(g + base)) & 15) == 0) {
+    const float4* q = (const float4*)(g + base);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const float4 v = q[u * 256 + threadIdx.x]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+  } else {
+    for (int u = 0; u < 16; ++u) { const long long e = base + u * 256 + threadIdx.x; if (e < n) { const float v = g[e]; s += v * v; } }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[b.chunk_base + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(1024) void grad_norm_finalize_kernel(const float* __restrict__ partial, int nchunks, float max_norm, float inv_div, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nchunks; i += 1024) s += (double)partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0]) * inv_div;
+    float coef = max_norm / (norm + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    out[0] = norm; out[1] = coef * inv_div;
+  }
+}
+}  // namespace
+
+extern "C" int sl_grad_sqnorm_multi(const SlNormBatch* batch, float* partial, sl_stream_t stream) {
+  SL_REQUIRE(batch && partial && batch->n > 0 && batch->n <= SL_NORM_MAX && batch->chunk0[0] == 0 && batch->chunk0[batch->n] > 0, "grad_sqnorm_multi: bad batch");
+  hipLaunchKernelGGL(grad_sqnorm_multi_kernel, dim3(batch->chunk0[batch->n]), dim3(256), 0, (hipStream_t)stream, *batch, partial);
+  SL_LAUNCH_CHECK("grad_sqnorm_multi_kernel");
+  return 0;
+}
+extern "C" int sl_grad_norm_finalize(const float* partial, int nchunks, float max_norm, float inv_div, float* out, sl_stream_t stream) {
+  SL_REQUIRE(partial && out && nchunks > 0 && max_norm > 0.f && inv_div > 0.f, "grad_norm_finalize: bad args");
+  hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, nchunks, max_norm, inv_div, out);
+  SL_LAUNCH_CHECK("grad_norm_finalize_kernel");
+  return 0;
+}

@@ -1021,6 +1021,30 @@ def sgd_multi(table, n, total_chunks, momentum, hyper=None, grad_scale=None):
     check(_lib.lib().sl_sgd_multi(_p(table), n, int(total_chunks), float(momentum), _p(hyper), _p(grad_scale), _s()), 'sgd_multi')
 
 
+def grad_norm_coef(grads, max_norm, grad_div=1):
+    """(norm, coef) of clip_grad_norm_(max_norm) over a list of contiguous float32 GPU gradient tensors: ceil(n / 64) norm launches + one finalize (csrc/optim.hip).
+    Both results are views of one 2-element float tensor.  grad_div > 1: the gradients hold the SUM over that many ranks (see optim.clip_coefficient)."""
+    L = _lib.lib()
+    dev = grads[0].device
+    chunks = [(g.numel() + 4095) // 4096 for g in grads]
+    total = sum(chunks)
+    partial = _f32((total,), dev)
+    base = 0
+    for i0 in range(0, len(grads), _lib.SL_NORM_MAX):
+        part = grads[i0:i0 + _lib.SL_NORM_MAX]
+        b = _lib.SlNormBatch()
+        b.n, b.chunk_base, c = len(part), base, 0
+        for i, g in enumerate(part):
+            b.grad[i], b.numel[i], b.chunk0[i] = _p(g), g.numel(), c
+            c += chunks[i0 + i]
+        b.chunk0[len(part)] = c
+        check(L.sl_grad_sqnorm_multi(C.byref(b), _p(partial), _s()), 'grad_sqnorm_multi')
+        base += c
+    out = _f32((2,), dev)
+    check(L.sl_grad_norm_finalize(_p(partial), total, float(max_norm), 1.0 / float(grad_div), _p(out), _s()), 'grad_norm_finalize')
+    return out[0], out[1:2]
+
+
 def store_floats(dst, values):
     """values (<= 16 python floats) -> the first len(values) elements of the float32 GPU tensor dst, as kernel arguments (no host -> device copy)."""
     arr = (C.c_float * len(values))(*[float(v) for v in values])
