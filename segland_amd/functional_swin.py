@@ -15,6 +15,7 @@ from .functional import _nbt_pending, _wver
 from .ops import ConvSpec
 from .ops_swin import pad_to
 
+_PSP_GROUPED = True    # test hook: the UperNet pyramid's stage BatchNorm backward + stage weight gradients as two grouped launches (False: a per-level chain)
 _GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
 
 
@@ -569,7 +570,7 @@ class PspSwinFn(torch.autograd.Function):
             y = osw.scale_add(y, drop, None, per_channel=True, Cn=bnb.num_features)
         if any(ctx.needs_input_grad):
             ctx.psp = psp
-            ctx.save_for_backward(x, pooled, stage_act, priors, cb, mb, ib, bits, drop, wst, *cl, *ml, *il)
+            ctx.save_for_backward(x, pooled, stage_act, priors, cb, mb, ib, bits, drop, wst, *cl, *ml, *il, call)
         return y
 
     @staticmethod
@@ -599,16 +600,32 @@ class PspSwinFn(torch.autograd.Function):
         dstage = torch.empty_like(stage_act)
         dc_all = torch.empty_like(stage_act)
         gstage, off = [], 0
-        for k, (s, st) in enumerate(zip(sizes, psp.stages)):
-            n = B * s * s
-            osw.bilinear_bwd(dcat, (s, s), True, out=dstage[off:off + n].view(B, s, s, Ps), Cn=Ps, dy_off=k * Ps)
-            gwk = _bn_padded(st[2], Ps)[0]
-            _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], gwk, train=st[2].training, out=dc_all[off:off + n])
-            dws = None
-            if need_w:
-                dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Ps), ConvSpec(Cf, Ps, 1))[:Cs].contiguous()
-            gstage += [dws, dgs[:Cs].contiguous() if need_w else None, dbs[:Cs].contiguous() if need_w else None]
-            off += n
+        call = sv[10 + 3 * nl]
+        if _PSP_GROUPED:
+            # round 6: the four levels' BatchNorm + ReLU backward in one launch and their stage-conv weight gradients in one launch (the PSPNet-POP pyramid's kernels:
+            # ops.ppm_stage_bn_bwd, ops.ppm_rows_wgrad) instead of four (reduce, finalize, apply, weight gradient, slab reduce) chains: 16 launches less per step
+            for k, s in enumerate(sizes):
+                n = B * s * s
+                osw.bilinear_bwd(dcat, (s, s), True, out=dstage[off:off + n].view(B, s, s, Ps), Cn=Ps, dy_off=k * Ps)
+                off += n
+            dgb_l = torch.empty((nl, 2, Ps), dtype=torch.float32, device=x.device)
+            ops.ppm_stage_bn_bwd(dstage, stage_act, call, B, sizes, ml, il, [_bn_padded(st[2], Ps)[0] for st in psp.stages], [st[2].training for st in psp.stages],
+                                 [dgb_l[k, 0] for k in range(nl)], [dgb_l[k, 1] for k in range(nl)], out=dc_all)
+            dws_l = ops.ppm_rows_wgrad(dc_all, pooled, B, sizes) if need_w else None
+            for k in range(nl):
+                gstage += [dws_l[k].view(Ps, Cf)[:Cs].view_as(psp.stages[k][1].weight) if need_w else None,
+                           dgb_l[k, 0, :Cs] if need_w else None, dgb_l[k, 1, :Cs] if need_w else None]
+        else:
+            for k, (s, st) in enumerate(zip(sizes, psp.stages)):
+                n = B * s * s
+                osw.bilinear_bwd(dcat, (s, s), True, out=dstage[off:off + n].view(B, s, s, Ps), Cn=Ps, dy_off=k * Ps)
+                gwk = _bn_padded(st[2], Ps)[0]
+                _, _, dgs, dbs = ops.bn_bwd(dstage[off:off + n], stage_act[off:off + n], cl[k], ml[k], il[k], gwk, train=st[2].training, out=dc_all[off:off + n])
+                dws = None
+                if need_w:
+                    dws = ops.conv2d_bwd_weight(pooled[off:off + n].view(B, s, s, Cf), dc_all[off:off + n].view(B, s, s, Ps), ConvSpec(Cf, Ps, 1))[:Cs].contiguous()
+                gstage += [dws, dgs[:Cs].contiguous() if need_w else None, dbs[:Cs].contiguous() if need_w else None]
+                off += n
         dx = None
         if need_x:
             dpooled = ops.ppm_rows_gemm(dc_all, wst.transpose(1, 2).contiguous(), B, sizes)[0]
