@@ -185,6 +185,12 @@ int sl_weight_prep_batched(const void* table_dev, int n, long long total_tiles, 
 int sl_bn_finalize_train(const float* stat_partial, int stat_rows, int C, long long count, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                          float* mean, float* invstd, float* scale, float* shift, sl_stream_t stream);
+/* The same behind a BIASED conv (swin_pop.py:112-131: Conv2d(bias=True) + BatchNorm2d): stat_partial are the statistics of the raw conv output, the bias
+ * (bias_n <= C entries, the rest of a padded channel pitch has none) shifts only the mean that enters running_mean; mean / invstd / scale / shift stay those of
+ * the raw output (the bias cancels in the normalised result).  Replaces a separate running_mean += momentum * bias pass. */
+int sl_bn_finalize_train_bias(const float* stat_partial, int stat_rows, int C, long long count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              float* mean, float* invstd, float* scale, float* shift, const float* conv_bias, int bias_n, sl_stream_t stream);
 /* Eval mode: scale/shift (and mean/invstd) from the running statistics. */
 int sl_bn_finalize_eval(int C, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
@@ -484,6 +490,11 @@ int sl_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
 int sl_layernorm_bwd_rows(int dtype, long long rows, int C, int dx_pitch);
 int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
                      float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream);
+/* The same with a second result dx_scaled = dx (as rounded to dtype) * row_scale[row / rows_per_sample]: the gradient that enters the next residual branch behind
+ * DropPath's per-sample factor (swintransformer.py:246-249 backward) -- one launch and one pass over dx less than sl_scale_add on the result, same bits. */
+int sl_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                            void* dx_scaled, const float* row_scale, long long rows_per_sample,
+                            float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream);
 /* exact GELU on n contiguous elements (n % 8 == 0) */
 int sl_gelu_fwd(int dtype, const void* h, void* y, long long n, sl_stream_t stream);
 int sl_gelu_bwd(int dtype, const void* h, const void* dy, void* dh, long long n, sl_stream_t stream);
@@ -493,6 +504,9 @@ int sl_patch_merge_scatter(int dtype, const void* dxm, void* dx, int B, int H, i
 /* bilinear resize of a channel window, NHWC; the backward (d(dst) -> d(src)) is a gather over the destination pixels (bit-stable) */
 int sl_bilinear_fwd(const SlResizeDesc* d, const void* src, void* dst, sl_stream_t stream);
 int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* dsrc, sl_stream_t stream);
+/* dst = base + bilinear(src): the top-down sum of swin_pop.py:150-153 / the level-head sum of :167-169 without a copy of base first (base and dst share
+ * d's dst_pitch / dst_off; d->accumulate must be 0) */
+int sl_bilinear_fwd_add(const SlResizeDesc* d, const void* src, const void* base, void* dst, sl_stream_t stream);
 /* out = (addend ? addend : 0) + x * scale[b] (per_channel 0: DropPath) or x * scale[b][c] (per_channel 1: Dropout2d; pad channels -> 0) */
 int sl_scale_add(int dtype, const void* x, const float* scale, const void* addend, void* out, int B, long long rows_per_sample, int C,
                  int pitch, int per_channel, sl_stream_t stream);

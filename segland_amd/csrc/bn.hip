@@ -39,7 +39,7 @@ template <int FIN_CH, int FIN_RL>
 __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_finalize_train_kernel(const float* __restrict__ part, int rows, int C, double count,
                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                          float* rmean, float* rvar, float momentum, float eps,
-                                         float* mean, float* invstd, float* scale, float* shift) {
+                                         float* mean, float* invstd, float* scale, float* shift, const float* __restrict__ cbias, int nbias) {
   __shared__ double red[2][FIN_RL][FIN_CH];
   const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, rl = threadIdx.x / FIN_CH;
   double s, q;
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_RL) void bn_finalize_train_kernel(cons
   shift[c] = (float)(b - mu * g * is);
   if (rmean) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+    // cbias: the statistics are those of the RAW conv output; the conv's bias shifts the mean only (it cancels in the normalised output) and enters the running mean here
+    const double mb = (cbias && c < nbias) ? mu + (double)cbias[c] : mu;
+    rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mb);
     rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unbiased);
   }
 }
@@ -305,7 +307,18 @@ extern "C" int sl_bn_finalize_train(const float* stat_partial, int stat_rows, in
   SL_REQUIRE(stat_partial && mean && invstd && scale && shift && C > 0 && stat_rows > 0 && count > 0, "bn_finalize_train: bad args");
   SL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize_train: running stats must come in pairs");
   hipLaunchKernelGGL((bn_finalize_train_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partial, stat_rows, C, (double)count, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const float*)nullptr, 0);
+  SL_LAUNCH_CHECK("bn_finalize_train_kernel");
+  return 0;
+}
+
+extern "C" int sl_bn_finalize_train_bias(const float* stat_partial, int stat_rows, int C, long long count, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                         float* mean, float* invstd, float* scale, float* shift, const float* conv_bias, int bias_n, sl_stream_t stream) {
+  SL_REQUIRE(stat_partial && mean && invstd && scale && shift && C > 0 && stat_rows > 0 && count > 0, "bn_finalize_train_bias: bad args");
+  SL_REQUIRE(running_mean && running_var && conv_bias && bias_n > 0 && bias_n <= C, "bn_finalize_train_bias: running stats and bias_n in 1..C conv bias entries are required");
+  hipLaunchKernelGGL((bn_finalize_train_kernel<32, 32>), dim3(cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, stat_partial, stat_rows, C, (double)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, conv_bias, bias_n);
   SL_LAUNCH_CHECK("bn_finalize_train_kernel");
   return 0;
 }

@@ -197,7 +197,10 @@ template <int LPR> __device__ __forceinline__ float grp_across(float v) {      /
 template <typename T, int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ stats, const T* __restrict__ addend, T* __restrict__ dx,
-                                                            float* __restrict__ part, long long rows, int C, int pdy, int px, int pdx) {
+                                                            float* __restrict__ part, long long rows, int C, int pdy, int px, int pdx,
+                                                            T* __restrict__ dx2, const float* __restrict__ rscale, long long rps) {
+  // dx2 (optional): the ROUNDED dx times rscale[row / rps] -- DropPath's per-sample factor for the branch this gradient enters next (what a scale_add launch over dx
+  // would write, bit for bit)
   constexpr int V = Vec16<T>::N, RPW = 64 / LPR, NA = NV > 0 ? NV : 1;
   extern __shared__ __attribute__((aligned(16))) float red[];           // [4][2][C] when NV > 0
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane % LPR, grp = lane / LPR;
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     s2 = grp_sum<LPR>(s2) / (float)C;
     if (!live) continue;
     T* dxr = dx + (size_t)r * pdx;
+    const float rs = dx2 ? rscale[r / rps] : 0.f;
     auto emit = [&](int j) {
       const int v = sub + j * LPR;
       if (v >= pdx / V) return;
@@ -267,7 +271,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < V; ++e) o[e] = 0.f;
       }
-      *(uint4*)(dxr + v * V) = pack16<T>(o);
+      const uint4 pk = pack16<T>(o);
+      *(uint4*)(dxr + v * V) = pk;
+      if (dx2) {
+        unpack16<T>(pk, o);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] *= rs;
+        *(uint4*)(dx2 + (size_t)r * pdx + v * V) = pack16<T>(o);
+      }
     };
     if constexpr (NV > 0) {
 #pragma unroll
@@ -401,10 +412,10 @@ template <typename TS, int V> __device__ __forceinline__ void stv(TS* p, const f
   } else *(uint4*)p = pack16<TS>(o);
 }
 
-// y[b][Y][X][yoff + c] (+)= bilinear(x[b][..][..][xoff + c]), c < C
+// y[b][Y][X][yoff + c] = bilinear(x[b][..][..][xoff + c]) (+ add[b][Y][X][yoff + c]), c < C; add may be y itself (accumulate in place)
 template <typename T, typename TS>
-__global__ void bilinear_fwd_kernel(const TS* __restrict__ x, T* __restrict__ y, int B, int h, int w, int H, int W, int C, int px, int xoff,
-                                    int py, int yoff, int align, int accumulate) {
+__global__ void bilinear_fwd_kernel(const TS* __restrict__ x, T* y, int B, int h, int w, int H, int W, int C, int px, int xoff,
+                                    int py, int yoff, int align, const T* add) {
   constexpr int V = Vec16<T>::N;
   const int nv = C / V;
   const float sy = src_scale(h, H, align), sx = src_scale(w, W, align);
@@ -424,10 +435,11 @@ __global__ void bilinear_fwd_kernel(const TS* __restrict__ x, T* __restrict__ y,
     ldv<TS, V>(base + ((size_t)y1 * w + x1) * px, d);
 #pragma unroll
     for (int e = 0; e < V; ++e) o[e] = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * c[e] + lx1 * d[e]);      // ATen's association
-    T* dst = y + ((size_t)(b * H + Y) * W + X) * py + yoff + v * V;
-    if (accumulate) {
+    const size_t doff = ((size_t)(b * H + Y) * W + X) * py + yoff + v * V;
+    T* dst = y + doff;
+    if (add) {
       float p[V];
-      unpack16<T>(*(const uint4*)dst, p);
+      unpack16<T>(*(const uint4*)(add + doff), p);
 #pragma unroll
       for (int e = 0; e < V; ++e) o[e] += p[e];
     }
@@ -1453,14 +1465,14 @@ static int ln_bwd_fused_blocks(long long rows, int nvp) {
 
 template <typename T>
 static int launch_ln_bwd(const void* dy, const void* x, const float* gamma, const float* stats, const void* addend, void* dx, float* part, long long rows, int C,
-                         int pdy, int px, int pdx, hipStream_t st) {
+                         int pdy, int px, int pdx, hipStream_t st, void* dx2 = nullptr, const float* rscale = nullptr, long long rps = 1) {
   constexpr int V = Vec16<T>::N;
   const int nvec = C / V, nvp = pdx / V;
   long long want = rows / 16 + 1;
   const bool fused = part != nullptr && nvp <= 192;
   const int grid = (int)(fused ? ln_bwd_fused_blocks(rows, nvp) : (want > 8192 ? 8192 : want));
   const size_t lds = fused ? (size_t)8 * C * sizeof(float) : 0;
-#define LN_BWD(LPR, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, NV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, part, rows, C, pdy, px, pdx)
+#define LN_BWD(LPR, NV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, LPR, NV>), dim3(grid), dim3(256), lds, st, (const T*)dy, (const T*)x, gamma, stats, (const T*)addend, (T*)dx, part, rows, C, pdy, px, pdx, (T*)dx2, rscale, rps)
   if (fused) {
     if (nvp <= 16) LN_BWD(16, 1); else if (nvp <= 32) LN_BWD(32, 1); else if (nvp <= 64) LN_BWD(64, 1); else if (nvp <= 128) LN_BWD(64, 2); else LN_BWD(64, 3);
   } else {
@@ -1477,16 +1489,17 @@ extern "C" int sl_layernorm_bwd_rows(int dtype, long long rows, int C, int dx_pi
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
-extern "C" int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
-                                float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream) {
+static int layernorm_bwd_run(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                             float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream,
+                             void* dx2, const float* rscale, long long rps) {
   SL_REQUIRE(dy && x && gamma && mean_rstd && dx && rows > 0 && C > 0, "layernorm_bwd: bad args");
   const int vb = dtype == SL_BF16 ? 8 : 4;
   SL_REQUIRE(dtype == SL_BF16 || dtype == SL_F32, "layernorm_bwd: bad dtype");
   SL_REQUIRE(C % vb == 0 && dy_pitch >= C && x_pitch >= C && dx_pitch >= C && dy_pitch % vb == 0 && x_pitch % vb == 0 && dx_pitch % vb == 0, "layernorm_bwd: bad pitches");
   hipStream_t st = (hipStream_t)stream;
   const bool fused = dgamma_dbeta_partial && dx_pitch / vb <= 192;
-  if (dtype == SL_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st);
-  else launch_ln_bwd<float>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st);
+  if (dtype == SL_BF16) launch_ln_bwd<bf16_t>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st, dx2, rscale, rps);
+  else launch_ln_bwd<float>(dy, x, gamma, mean_rstd, addend, dx, fused ? dgamma_dbeta_partial : nullptr, rows, C, dy_pitch, x_pitch, dx_pitch, st, dx2, rscale, rps);
   SL_LAUNCH_CHECK("layernorm_bwd_kernel");
   if (dgamma_dbeta_partial && !fused) {
     const int nblk = sl_layernorm_bwd_rows(dtype, rows, C, dx_pitch);
@@ -1498,6 +1511,18 @@ extern "C" int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const 
     SL_LAUNCH_CHECK("layernorm_bwd_cols_kernel");
   }
   return 0;
+}
+
+extern "C" int sl_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                                float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream) {
+  return layernorm_bwd_run(dtype, dy, x, gamma, mean_rstd, addend, dx, dgamma_dbeta_partial, rows, C, dy_pitch, x_pitch, dx_pitch, stream, nullptr, nullptr, 1);
+}
+
+extern "C" int sl_layernorm_bwd_scaled(int dtype, const void* dy, const void* x, const float* gamma, const float* mean_rstd, const void* addend, void* dx,
+                                       void* dx_scaled, const float* row_scale, long long rows_per_sample,
+                                       float* dgamma_dbeta_partial, long long rows, int C, int dy_pitch, int x_pitch, int dx_pitch, sl_stream_t stream) {
+  SL_REQUIRE(dx_scaled && row_scale && rows_per_sample > 0 && rows % rows_per_sample == 0, "layernorm_bwd_scaled: dx_scaled, row_scale and rows_per_sample | rows are required");
+  return layernorm_bwd_run(dtype, dy, x, gamma, mean_rstd, addend, dx, dgamma_dbeta_partial, rows, C, dy_pitch, x_pitch, dx_pitch, stream, dx_scaled, row_scale, rows_per_sample);
 }
 
 extern "C" int sl_gelu_fwd(int dtype, const void* h, void* y, long long n, sl_stream_t stream) {
@@ -1547,17 +1572,27 @@ static int check_resize(const SlResizeDesc* d) {
   return 0;
 }
 
+static int bilinear_fwd_launch(const SlResizeDesc* d, const void* src, const void* add, void* dst, hipStream_t st) {
+  const long long n = (long long)d->B * d->H * d->W * d->C;
+#define BL_ARGS d->B, d->h, d->w, d->H, d->W, d->C, d->src_pitch, d->src_off, d->dst_pitch, d->dst_off, d->align_corners
+  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, BL_ARGS, (const bf16_t*)add);
+  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, BL_ARGS, (const bf16_t*)add);
+  else hipLaunchKernelGGL((bilinear_fwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)src, (float*)dst, BL_ARGS, (const float*)add);
+  SL_LAUNCH_CHECK("bilinear_fwd_kernel");
+  return 0;
+}
+
 extern "C" int sl_bilinear_fwd(const SlResizeDesc* d, const void* src, void* dst, sl_stream_t stream) {
   if (int e = check_resize(d)) return e;
   SL_REQUIRE(src && dst, "bilinear_fwd: null buffer");
-  hipStream_t st = (hipStream_t)stream;
-  const long long n = (long long)d->B * d->H * d->W * d->C;
-#define BL_ARGS d->B, d->h, d->w, d->H, d->W, d->C, d->src_pitch, d->src_off, d->dst_pitch, d->dst_off, d->align_corners, d->accumulate
-  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, BL_ARGS);
-  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, BL_ARGS);
-  else hipLaunchKernelGGL((bilinear_fwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)src, (float*)dst, BL_ARGS);
-  SL_LAUNCH_CHECK("bilinear_fwd_kernel");
-  return 0;
+  return bilinear_fwd_launch(d, src, d->accumulate ? dst : nullptr, dst, (hipStream_t)stream);
+}
+
+extern "C" int sl_bilinear_fwd_add(const SlResizeDesc* d, const void* src, const void* base, void* dst, sl_stream_t stream) {
+  if (int e = check_resize(d)) return e;
+  SL_REQUIRE(src && base && dst, "bilinear_fwd_add: null buffer");
+  SL_REQUIRE(!d->accumulate, "bilinear_fwd_add: accumulate is the in-place form of sl_bilinear_fwd");
+  return bilinear_fwd_launch(d, src, base, dst, (hipStream_t)stream);
 }
 
 extern "C" int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* dsrc, sl_stream_t stream) {
@@ -1567,15 +1602,15 @@ extern "C" int sl_bilinear_bwd(const SlResizeDesc* d, const void* ddst, void* ds
   const long long n = (long long)d->B * d->h * d->w * d->C;
   const int nsrc = d->B * d->h * d->w, nv = d->C / (d->dtype == SL_BF16 ? 8 : 4);
   if (nsrc <= 2048 && (long long)d->H * d->W >= 4LL * d->h * d->w && nv <= 128 && 256 % nv == 0) {       // few source pixels under a large map: a block per source pixel
-    if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, float>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS);
-    else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, bf16_t>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS);
-    else hipLaunchKernelGGL((bilinear_bwd_small_kernel<float, float>), dim3(nsrc), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS);
+    if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, float>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS, d->accumulate);
+    else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_small_kernel<bf16_t, bf16_t>), dim3(nsrc), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS, d->accumulate);
+    else hipLaunchKernelGGL((bilinear_bwd_small_kernel<float, float>), dim3(nsrc), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS, d->accumulate);
     SL_LAUNCH_CHECK("bilinear_bwd_small_kernel");
     return 0;
   }
-  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS);
-  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS);
-  else hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS);
+  if (d->dtype == SL_BF16 && d->src_f32) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (float*)dsrc, BL_ARGS, d->accumulate);
+  else if (d->dtype == SL_BF16) hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t, bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)ddst, (bf16_t*)dsrc, BL_ARGS, d->accumulate);
+  else hipLaunchKernelGGL((bilinear_bwd_kernel<float, float>), dim3(ew_grid(n / 4)), dim3(256), 0, st, (const float*)ddst, (float*)dsrc, BL_ARGS, d->accumulate);
   SL_LAUNCH_CHECK("bilinear_bwd_kernel");
   return 0;
 }

@@ -559,8 +559,11 @@ class PPMFn(torch.autograd.Function):
         if dab is None:
             dab = ops.conv2d_bwd_data(dfeat, wbf, spec_f, (H, W))
         gwf = grad_dst(bt[3].weight) if need_w else None
-        dwf = grad_alias(ops.conv2d_bwd_weight(ab, dfeat, spec_f, out=gwf), gwf) if need_w else None
-        dbias = ops.colsum_rows(dfeat) if need_w else None
+        dwf = dbias = None
+        if need_w:
+            # weight + bias gradient of the biased 1x1 conv in one kernel (the bias column sums come out of the weight-gradient kernel's dy fragments: round 6, one pass over dfeat less)
+            dwf, dbias = ops.conv2d_bwd_weight_bias(ab, dfeat, spec_f, out=gwf)
+            dwf = grad_alias(dwf, gwf)
         if ctx.fact:
             N = bt[0].out_channels
             wq_f, wq_b, wf4, wb4 = _ppm_weights(bt[0].weight, Cs, nl, x4.dtype)

@@ -17,6 +17,10 @@ from .ops_swin import pad_to
 
 _PSP_GROUPED = True    # test hook: the UperNet pyramid's stage BatchNorm backward + stage weight gradients as two grouped launches (False: a per-level chain)
 _GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
+_BN_BIAS_ZERO = True   # test hook: the exact-zero bias gradient of a conv in front of a train-mode BatchNorm is written as zero (False: the column sum of the BN-input gradient)
+_LN_SCALE = True       # test hook: DropPath's per-sample factor on a branch's incoming gradient comes out of the LayerNorm backward that produced the gradient (False: a scale_add launch)
+_RESIZE_ADD = True     # test hook: AddResizedFn as one launch (False: clone + accumulate)
+_BN_BIAS_FOLD = True   # test hook: a biased conv's bias enters running_mean inside bn_finalize_train (False: a torch add_ launch per BatchNorm)
 
 
 # ------------------------------------------------------------------------------------------------ prepared (padded) weights
@@ -275,13 +279,23 @@ class PatchEmbedFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ Swin block
+class SwinLink:
+    """What two consecutive blocks of ONE forward pass hand each other in the backward: the block behind (it runs first) produces this block's incoming gradient in its
+    LayerNorm-1 backward and leaves the copy scaled with this block's MLP DropPath factor s2 here (pre = (address, shape, tensor)) -- this block's scale_add launch disappears."""
+    __slots__ = ('s2', 'pre')
+
+    def __init__(self, s2):
+        self.s2, self.pre = s2, None
+
+
 class SwinBlockFn(torch.autograd.Function):
     """swintransformer.py:195-250 on a token map x [B,H,W,P]:
         x1 = x + s1 * proj(W-MSA(qkv(LN1(x))));   out = x1 + s2 * fc2(GELU(fc1(LN2(x1))))
-    s1, s2: per-sample DropPath scales (0 or 1/keep, timm) or None."""
+    s1, s2: per-sample DropPath scales (0 or 1/keep, timm) or None.  plink: the SwinLink of the block that produced x (None: not a block, or no DropPath there);
+    link: this block's own (None when s2 is None)."""
 
     @staticmethod
-    def forward(ctx, x, blk, s1, s2, *params):
+    def forward(ctx, x, blk, s1, s2, plink, link, *params):
         n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = params
         a = blk.attn
         Cn, heads, shift = blk.dim, blk.num_heads, blk.shift_size
@@ -300,7 +314,7 @@ class SwinBlockFn(torch.autograd.Function):
         h, g = lin_fwd(xn2, L1, want_gelu=True)                     # pre-activation (for the backward) and GELU from one epilogue
         out = lin_fwd(g, L2, residual=x1, row_scale=s2)
         if any(ctx.needs_input_grad):
-            ctx.blk = blk
+            ctx.blk, ctx.plink, ctx.link = blk, plink, link
             # g ([B,H,W,4C], the largest tensor of the block) is kept rather than recomputed: 0.6 GB over a Swin-T at 8 tiles of 512x512
             ctx.save_for_backward(x, st1, xn, qkv, att, x1, st2, xn2, h, g, rel, s1, s2, *params)
         return out
@@ -314,13 +328,22 @@ class SwinBlockFn(torch.autograd.Function):
         n1w, n1b, table, qw, qb, pw, pb, n2w, n2b, f1w, f1b, f2w, f2b = sv[13:]
         Cn, heads, shift = blk.dim, blk.num_heads, blk.shift_size
         dtp, P = x.dtype, x.shape[-1]
-        need_w = ctx.needs_input_grad[4]               # parameters of a block are frozen or trainable together
+        need_w = ctx.needs_input_grad[6]               # parameters of a block are frozen or trainable together
         Lq = lin_prep(qw, qb, dtp, Kp=P, Np=pad_to(3 * Cn))
         Lp = lin_prep(pw, pb, dtp, Kp=P, Np=P)
         L1 = lin_prep(f1w, f1b, dtp, Kp=P)
         L2 = lin_prep(f2w, f2b, dtp, Np=P)
         dout = dout.contiguous()
-        dz = dout if s2 is None else osw.scale_add(dout, s2)
+        link, plink = ctx.link, ctx.plink
+        pre = None
+        if link is not None:
+            pre, link.pre = link.pre, None
+        if s2 is None:
+            dz = dout
+        elif pre is not None and pre[0] == dout.data_ptr() and pre[1] == tuple(dout.shape):
+            dz = pre[2]                                # the block behind wrote dout AND s2 * dout (autograd handed over exactly that tensor: no second consumer summed into a new one)
+        else:
+            dz = osw.scale_add(dout, s2)
         # the eight column sums of this backward (four bias gradients, two LayerNorm (dgamma, dbeta) pairs, the attention bias and the pad-token
         # bias) are finalised by ONE launch at the end
         batch = ops.ColsumBatch() if need_w else None
@@ -330,12 +353,19 @@ class SwinBlockFn(torch.autograd.Function):
             dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch)
             dh = osw.gelu_bwd(h, dg)
         dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w, batch=batch)
-        dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch)
-        dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)
+        if s1 is not None and _LN_SCALE:
+            (dx1, dpr), dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch, row_scale=s1)
+        else:
+            dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch)
+            dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)
         datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w, batch=batch)
         dqkv, drel, dpad = osw.window_attention_bwd(qkv, qb.detach().contiguous(), rel, datt, Cn, heads, shift, batch=batch)
         dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w, batch=batch)
-        dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch)
+        if plink is not None and plink.s2 is not None and _LN_SCALE:
+            (dx, dxs), dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch, row_scale=plink.s2)
+            plink.pre = (dx.data_ptr(), tuple(dx.shape), dxs)
+        else:
+            dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch)
         dtable = None
         if need_w:
             batch.run()
@@ -343,7 +373,7 @@ class SwinBlockFn(torch.autograd.Function):
             # table row t collects the (query, key) pairs with relative offset t: a fixed-order gather instead of index_add_ (atomics,
             # last-bit differences from run to run) -- the step stays bit-reproducible like the rest of the path
             dtable = osw.relpos_table_grad(drel.view(heads, -1), _rel_pairs(blk.attn, table.shape[0]), table.shape[0])
-        return (dx, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
+        return (dx, None, None, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
 
 
 def _rel_pairs(attn, rows):
@@ -455,8 +485,9 @@ def _bn_forward(bn, c, part, conv_bias, P):
         count = c.numel() // P
         if count <= 1:
             raise ValueError('Expected more than 1 value per channel when training, got %d' % count)
-        mean, invstd, scale, shift = ops.bn_finalize_train(part, count, gw.contiguous(), gb.contiguous(), rm, rv, bn.momentum, bn.eps)
-        if conv_bias is not None:
+        cb = conv_bias.detach() if (conv_bias is not None and _BN_BIAS_FOLD and conv_bias.dtype == torch.float32 and conv_bias.is_contiguous()) else None
+        mean, invstd, scale, shift = ops.bn_finalize_train(part, count, gw.contiguous(), gb.contiguous(), rm, rv, bn.momentum, bn.eps, conv_bias=cb)
+        if conv_bias is not None and cb is None:
             with torch.no_grad():
                 bn.running_mean.add_(conv_bias.detach(), alpha=bn.momentum)
         _nbt_pending.append(bn.num_batches_tracked)
@@ -496,7 +527,13 @@ class ConvBnReluFn(torch.autograd.Function):
         gw = _bn_padded(bn, L.Np)[0]
         dc, _, dgam, dbet = ops.bn_bwd(dy.contiguous(), None, c, mean, invstd, gw, train=bn.training, mask=bits)
         dx, dw, _ = lin_bwd(x, dc, L, need_dx=ctx.needs_input_grad[0], need_w=need_w)
-        dbias = ops.colsum_rows(dc)[:Cn].contiguous() if need_w else None
+        dbias = None
+        if need_w and bn.training and _BN_BIAS_ZERO:
+            # a conv bias in front of a train-mode BatchNorm: the gradient is EXACTLY zero (the normalisation removes the mean; the column sum of the BN-input gradient is
+            # rounding noise -- 2e-2 of the weight gradient's scale in bf16, 5e-6 in the reference's fp32): written as zero instead of summed (two launches less per layer)
+            dbias = torch.zeros(Cn, dtype=torch.float32, device=dc.device)
+        elif need_w:
+            dbias = ops.colsum_rows(dc)[:Cn].contiguous()
         return dx, None, dw, dbias, (dgam[:Cn].contiguous() if need_w else None), (dbet[:Cn].contiguous() if need_w else None)
 
 
@@ -522,6 +559,8 @@ class AddResizedFn(torch.autograd.Function):
         ctx.hw, ctx.align, ctx.same = tuple(x.shape[1:3]), align, tuple(x.shape[1:3]) == tuple(base.shape[1:3])
         if ctx.same:
             return osw.scale_add(x, _ones(x.shape[0], x.device), base)
+        if _RESIZE_ADD and base.is_contiguous():
+            return osw.bilinear_fwd(x, tuple(base.shape[1:3]), align, base=base)      # base + resize(x) in one pass (round 6: no clone of base first)
         out = base.clone()
         return osw.bilinear_fwd(x, tuple(base.shape[1:3]), align, out=out, accumulate=True)
 
@@ -546,7 +585,11 @@ class PspSwinFn(torch.autograd.Function):
         wkey = tuple((_wver(st[1].weight), st[1].weight.data_ptr()) for st in psp.stages)
         went = psp.__dict__.get('_sl_wst')
         if went is None or went[0] != wkey:
-            went = psp.__dict__['_sl_wst'] = (wkey, torch.stack([_padded(st[1].weight.view(Cs, Cf), (Ps, Cf)) for st in psp.stages]).contiguous())
+            # the padded stack lives in one buffer (pad rows stay zero); a new optimizer step refills it with ONE multi-tensor copy (was: zeros + copy per level + stack)
+            buf = went[1] if (went is not None and went[1].shape == (nl, Ps, Cf) and went[1].device == x.device) else torch.zeros((nl, Ps, Cf), dtype=torch.float32, device=x.device)
+            with torch.no_grad():
+                torch._foreach_copy_([buf[k, :Cs] for k in range(nl)], [st[1].weight.detach().view(Cs, Cf) for st in psp.stages])
+            went = psp.__dict__['_sl_wst'] = (wkey, buf)
         wst = went[1]
         call, part = ops.ppm_rows_gemm(pooled, wst, B, sizes, want_stats=any(st[2].training for st in psp.stages))
         stage_act = torch.empty_like(call)

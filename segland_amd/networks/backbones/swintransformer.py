@@ -12,7 +12,7 @@ torch.rand on the GPU; `drop_path_hook(block_index, B, p) -> tensor | None` on t
 import torch
 import torch.nn as nn
 
-from ...functional_swin import LayerNormFn, PatchEmbedFn, PatchMergeFn, SwinBlockFn, block_params
+from ...functional_swin import LayerNormFn, PatchEmbedFn, PatchMergeFn, SwinBlockFn, SwinLink, block_params
 
 CONFIGS = {'swin-t': (96, (2, 2, 6, 2), (3, 6, 12, 24)), 'swin-s': (96, (2, 2, 18, 2), (3, 6, 12, 24)),
            'swin-b': (128, (2, 2, 18, 2), (4, 8, 16, 32)), 'swin-l': (192, (2, 2, 18, 2), (6, 12, 24, 48))}      # :485-507
@@ -138,8 +138,12 @@ class SwinTransformer(nn.Module):
         scales = self._drop_scales(B, x.device)
         for i, layer in enumerate(self.layers):
             Cn = self.filters[i]
+            plink = None                      # DropPath hand-over between consecutive blocks of a stage (functional_swin.SwinLink)
             for blk in layer.blocks:
-                x = SwinBlockFn.apply(x, blk, scales[2 * blk.index], scales[2 * blk.index + 1], *block_params(blk))
+                s2 = scales[2 * blk.index + 1]
+                link = SwinLink(s2) if s2 is not None else None
+                x = SwinBlockFn.apply(x, blk, scales[2 * blk.index], s2, plink, link, *block_params(blk))
+                plink = link
             nm = getattr(self, 'norm%d' % i)
             outs.append(LayerNormFn.apply(x, Cn, nm.weight, nm.bias))
             if layer.downsample is not None:

@@ -61,7 +61,8 @@ class UperNet_Decoder_Plus(nn.Module):
             return None if m is None else m.to(device=device, dtype=torch.float32).contiguous()
         if not self.psp.bottleneck[3].training or p <= 0.0:
             return None
-        return (torch.rand(B, Cn, device=device) >= p).float() / (1.0 - p)
+        # ATen's feature_dropout (F.dropout2d): noise.bernoulli_(1 - p).div_(1 - p) -- two launches, the reference's own draw
+        return torch.empty(B, Cn, dtype=torch.float32, device=device).bernoulli_(1.0 - p).div_(1.0 - p)
 
     @staticmethod
     def _cbr_apply(seq, x):

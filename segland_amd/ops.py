@@ -428,14 +428,15 @@ def _bias_rows(d, n_valid, c_valid):
     return r
 
 
-def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None):
-    """(dw float OIHW, db): weight and bias gradient of a biased 1x1 conv / nn.Linear; the column sums of dy ride in the weight gradient's slab-reduce launch.
-    batch (ColsumBatch): db is filled by batch.run()."""
+def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None, out=None):
+    """(dw float OIHW, db): weight and bias gradient of a biased 1x1 conv / nn.Linear; the column sums of dy ride in the weight-gradient kernel (or its slab-reduce launch).
+    batch (ColsumBatch): db is filled by batch.run().  out: the weight gradient's destination (same shape, float, contiguous)."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     L = _lib.lib()
     ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
-    dw = torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
+    assert dw.numel() == spec.cout * spec.cin * spec.k * spec.k and dw.dtype == torch.float32 and dw.is_contiguous()
     Cn = dy.shape[-1]
     rows = dy.numel() // Cn
     assert Cn == spec.cout and dy.is_contiguous()
@@ -468,9 +469,15 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
 
 
 # --------------------------------------------------------------------------------------------- batch norm
-def bn_finalize_train(part, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5):
+def bn_finalize_train(part, count, gamma, beta, rmean, rvar, momentum=0.1, eps=1e-5, conv_bias=None):
+    """conv_bias: the conv in front has a bias that is NOT in the statistics (they are of the raw output): it enters running_mean only."""
     Cn = part.shape[-1]
     o = _f32((4, Cn), part.device)
+    if conv_bias is not None:
+        assert conv_bias.dtype == torch.float32 and conv_bias.is_contiguous() and conv_bias.numel() <= Cn
+        check(_lib.lib().sl_bn_finalize_train_bias(_p(part), part.shape[0], Cn, int(count), _p(gamma), _p(beta), _p(rmean), _p(rvar), momentum, eps,
+                                                   _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(conv_bias), conv_bias.numel(), _s()), 'bn_finalize_train_bias')
+        return o[0], o[1], o[2], o[3]
     check(_lib.lib().sl_bn_finalize_train(_p(part), part.shape[0], Cn, int(count), _p(gamma), _p(beta), _p(rmean), _p(rvar),
                                           momentum, eps, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _s()), 'bn_finalize_train')
     return o[0], o[1], o[2], o[3]          # mean, invstd, scale, shift

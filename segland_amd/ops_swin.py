@@ -48,15 +48,22 @@ def layernorm_fwd(x, gamma, beta, Cn, out_pitch=None, eps=1e-5, want_stats=True)
     return y, stats
 
 
-def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, dx_pitch=None, batch=None):
-    """(dx, dgamma, dbeta); dx gets `addend` added (the gradient that bypasses the norm through the residual connection)."""
+def layernorm_bwd(dy, x, gamma, stats, Cn, addend=None, want_param_grads=True, dx_pitch=None, batch=None, row_scale=None):
+    """(dx, dgamma, dbeta); dx gets `addend` added (the gradient that bypasses the norm through the residual connection).
+    row_scale [B] float: dx is returned as the pair (dx, dx * row_scale[b]) -- the second is what scale_add(dx, row_scale) would make, from the same launch."""
     pdy, px = dy.shape[-1], x.shape[-1]
     pdx = px if dx_pitch is None else dx_pitch
     rows = x.numel() // px
     dx = torch.empty(x.shape[:-1] + (pdx,), dtype=x.dtype, device=x.device)
     L = _lib.lib()
     part = _f32((L.sl_layernorm_bwd_rows(dt(x), rows, Cn, pdx), 2, Cn), x.device) if want_param_grads else None
-    check(L.sl_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(stats), _p(addend), _p(dx), _p(part), rows, Cn, pdy, px, pdx, _s()), 'layernorm_bwd')
+    if row_scale is not None:
+        dx2 = torch.empty_like(dx)
+        check(L.sl_layernorm_bwd_scaled(dt(x), _p(dy), _p(x), _p(gamma), _p(stats), _p(addend), _p(dx), _p(dx2), _p(row_scale), rows // x.shape[0], _p(part), rows, Cn,
+                                        pdy, px, pdx, _s()), 'layernorm_bwd_scaled')
+        dx = (dx, dx2)
+    else:
+        check(L.sl_layernorm_bwd(dt(x), _p(dy), _p(x), _p(gamma), _p(stats), _p(addend), _p(dx), _p(part), rows, Cn, pdy, px, pdx, _s()), 'layernorm_bwd')
     if not want_param_grads:
         return dx, None, None
     tot = batch.add(part) if batch is not None else ops.colsum(part)       # batch: filled by batch.run()
@@ -103,13 +110,18 @@ def _rd(dtype, B, h, w, H, W, Cn, sp, so, dp, do, align, acc, src_f32=False):
     return SlResizeDesc(dt(dtype), B, h, w, H, W, Cn, sp, so, dp, do, int(align), int(acc), int(src_f32))
 
 
-def bilinear_fwd(x, size, align, out=None, out_off=0, Cn=None, src_off=0, accumulate=False):
-    """F.interpolate(x, size, mode='bilinear', align_corners=align) on an NHWC map (channel window [src_off, src_off+Cn) -> [out_off, ...))."""
+def bilinear_fwd(x, size, align, out=None, out_off=0, Cn=None, src_off=0, accumulate=False, base=None):
+    """F.interpolate(x, size, mode='bilinear', align_corners=align) on an NHWC map (channel window [src_off, src_off+Cn) -> [out_off, ...)).
+    base: out = base + interpolate(x) (same shape as out; no copy of base first)."""
     B, h, w, P = x.shape
     Cn = P if Cn is None else Cn
     if out is None:
         out = torch.empty((B, size[0], size[1], Cn), dtype=x.dtype, device=x.device)
     d = _rd(out.dtype, B, h, w, size[0], size[1], Cn, P, src_off, out.shape[-1], out_off, align, accumulate, src_f32=(x.dtype == torch.float32))
+    if base is not None:
+        assert not accumulate and base.shape == out.shape and base.dtype == out.dtype and base.is_contiguous()
+        check(_lib.lib().sl_bilinear_fwd_add(C.byref(d), _p(x), _p(base), _p(out), _s()), 'bilinear_fwd_add')
+        return out
     check(_lib.lib().sl_bilinear_fwd(C.byref(d), _p(x), _p(out), _s()), 'bilinear_fwd')
     return out
 

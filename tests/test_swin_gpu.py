@@ -146,7 +146,7 @@ def test_g13_swin_stage(hip, tag, dim, heads, H, W, dtype):
     xg = to_tokens(x, H, W, dtype, P).requires_grad_(True)
     y = xg
     for blk in st.blocks:
-        y = SwinBlockFn.apply(y, blk, None, None, *block_params(blk))
+        y = SwinBlockFn.apply(y, blk, None, None, None, None, *block_params(blk))
     ds = st.downsample
     yd = PatchMergeFn.apply(y, dim, ds.reduction.weight, ds.norm.weight, ds.norm.bias)
     c1 = fm.sym('g13%s/c1' % tag, (2, H * W, dim), 1.0).view(2, H, W, dim).to(DEV)
@@ -182,7 +182,7 @@ def test_drop_path_scales_in_block(hip):
     yo = so.block_forward(holder, ob, xo, 9, 8, so.shift_mask(14, 14, 7, 3))
     yo.square().sum().backward()
     xg = to_tokens(x, 9, 8, torch.float32, 128).requires_grad_(True)
-    y = SwinBlockFn.apply(xg, blk, s1.to(DEV), s2.to(DEV), *block_params(blk))
+    y = SwinBlockFn.apply(xg, blk, s1.to(DEV), s2.to(DEV), None, None, *block_params(blk))
     y.float()[..., :96].square().sum().backward()
     assert rel(y[..., :96].reshape(3, 72, 96), yo) <= 1e-5
     assert l2(xg.grad[..., :96].reshape(3, 72, 96), xo.grad) <= 1e-5
