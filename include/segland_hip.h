@@ -163,6 +163,18 @@ int sl_conv2d_bwd_weight_bias(const SlConvDesc* d, const void* x, const void* x2
  * PARAMETER's shape [n_valid][c_valid][KH][KW] -- the slab reduce writes only the channels that exist (no slicing copy behind it).  colsum_partial may be NULL. */
 int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
                               size_t workspace_bytes, float* colsum_partial, sl_stream_t stream);
+/* The slab reduces of several layers in ONE launch (a transformer block's four nn.Linear weight gradients, swintransformer.py:195-250 backward): sl_conv2d_bwd_weight_defer
+ * is sl_conv2d_bwd_weight_clip (n_valid / c_valid 0 = all; colsum_partial may be NULL) that runs the split-K kernel and leaves its flat slab reduce -- and the bias
+ * column sums that would ride in it -- in *item; sl_wgrad_reduce_multi runs up to SL_WGRAD_BATCH_MAX items at once (same summation order, same bits as the single
+ * launches).  item->splits == 0: the shape's path reduced by itself, nothing is deferred.  Every deferred layer needs a workspace of its own until the multi launch. */
+#define SL_WGRAD_BATCH_MAX 8
+typedef struct SlWgradReduce {
+  const float* ws; float* dw; long long total; int splits, Cin, dw_cin_total, dw_ci_off, n_valid, c_valid, dtype, Cout, ncol;
+  const void* dy; long long rows, rows_per_block; float* colsum_part;
+} SlWgradReduce;
+int sl_conv2d_bwd_weight_defer(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
+                               size_t workspace_bytes, float* colsum_partial, SlWgradReduce* item, sl_stream_t stream);
+int sl_wgrad_reduce_multi(const SlWgradReduce* items, int n, sl_stream_t stream);
 /* OIHW float master weight -> w_fwd [Cout][KH][KW][Cin] and/or w_bwd [Cin][KH][KW][Cout] in dtype (either may be NULL) */
 int sl_weight_prep(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_fwd, void* w_bwd,
                    sl_stream_t stream);

@@ -42,6 +42,15 @@ class SlNormBatch(C.Structure):
     _fields_ = [('grad', C.c_void_p * SL_NORM_MAX), ('numel', C.c_longlong * SL_NORM_MAX), ('chunk0', C.c_int * (SL_NORM_MAX + 1)), ('n', C.c_int), ('chunk_base', C.c_int)]
 
 
+SL_WGRAD_BATCH_MAX = 8
+
+
+class SlWgradReduce(C.Structure):
+    _fields_ = ([('ws', C.c_void_p), ('dw', C.c_void_p), ('total', C.c_longlong)]
+                + [(n, C.c_int) for n in ('splits', 'Cin', 'dw_cin_total', 'dw_ci_off', 'n_valid', 'c_valid', 'dtype', 'Cout', 'ncol')]
+                + [('dy', C.c_void_p), ('rows', C.c_longlong), ('rows_per_block', C.c_longlong), ('colsum_part', C.c_void_p)])
+
+
 SL_COLSUM_MAX = 12
 
 

@@ -581,6 +581,35 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_colsum_kernel(const flo
   }
 }
 
+// The flat slab reduces (+ bias column sums) of up to SL_WGRAD_BATCH_MAX layers in ONE launch (sl_wgrad_reduce_multi): a transformer block has four nn.Linear weight
+// gradients whose reduces are ~5 us launches each.  Block ranges per item: [start[i], start[i] + nred_i) reduce, then ncol_i column-sum blocks; per element the sums run
+// in the order of the single-layer kernels (same bits).
+struct WgradReduceBatch { SlWgradReduce it[SL_WGRAD_BATCH_MAX]; int start[SL_WGRAD_BATCH_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const WgradReduceBatch b) {
+  __shared__ float red[256 * 8];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.start[i + 1]) ++i;
+  const SlWgradReduce& t = b.it[i];
+  const int blk = (int)blockIdx.x - b.start[i];
+  const int nred = (int)((t.total + 255) / 256);
+  if (blk >= nred) {
+    if (t.dtype == SL_BF16) sl_colsum_rows_block<bf16_t>((const bf16_t*)t.dy, t.rows, t.Cout, t.rows_per_block, t.colsum_part, blk - nred, red);
+    else sl_colsum_rows_block<float>((const float*)t.dy, t.rows, t.Cout, t.rows_per_block, t.colsum_part, blk - nred, red);
+    return;
+  }
+  const long long e = blk * 256LL + threadIdx.x;
+  if (e >= t.total) return;
+  const float* __restrict__ ws = t.ws;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < t.splits; k += 4) {
+    s0 += ws[(size_t)k * t.total + e]; s1 += ws[(size_t)(k + 1) * t.total + e];
+    s2 += ws[(size_t)(k + 2) * t.total + e]; s3 += ws[(size_t)(k + 3) * t.total + e];
+  }
+  for (; k < t.splits; ++k) s0 += ws[(size_t)k * t.total + e];
+  if (e / t.Cin < t.n_valid && e % t.Cin < t.c_valid) t.dw[(e / t.Cin) * t.dw_cin_total + t.dw_ci_off + (e % t.Cin)] = (s0 + s1) + (s2 + s3);
+}
+
 // paired rows (plan(): 64-channel layers): slab = [2*Cout][taps][2*Cin]; the weight gradient is the sum of the two parity-diagonal blocks
 __global__ void wgrad_reduce_pair_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps, int splits, int dw_cin_total, int dw_ci_off, int n_valid, int c_valid) {
   const long long total = (long long)Cout * Cin * taps, slab = 4 * total;
@@ -993,7 +1022,8 @@ extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const vo
 }
 // dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid = 0, int c_valid = 0);
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid = 0, int c_valid = 0,
+                           SlWgradReduce* defer = nullptr);
 
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
@@ -1015,6 +1045,34 @@ extern "C" int sl_conv2d_bwd_weight_clip(const SlConvDesc* d, const void* x, con
   return bwd_weight_impl(d, x, x2, dy, dw, c_valid, 0, workspace, workspace_bytes, stream, colsum_partial, n_valid, c_valid);
 }
 
+// sl_conv2d_bwd_weight_clip with the slab reduce DEFERRED: item receives what is left to do (item->splits == 0: nothing -- this shape's path reduced by itself); the workspace
+// must stay untouched until sl_wgrad_reduce_multi has run (one workspace per deferred layer).
+extern "C" int sl_conv2d_bwd_weight_defer(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int n_valid, int c_valid, void* workspace,
+                                          size_t workspace_bytes, float* colsum_partial, SlWgradReduce* item, sl_stream_t stream) {
+  SL_REQUIRE(d && item && n_valid >= 0 && c_valid >= 0 && n_valid <= d->Cout && c_valid <= d->Cin, "conv bwd_weight_defer: bad arguments");
+  return bwd_weight_impl(d, x, x2, dy, dw, c_valid > 0 ? c_valid : d->Cin, 0, workspace, workspace_bytes, stream, colsum_partial, n_valid, c_valid, item);
+}
+
+extern "C" int sl_wgrad_reduce_multi(const SlWgradReduce* items, int n, sl_stream_t stream) {
+  SL_REQUIRE(items && n > 0 && n <= SL_WGRAD_BATCH_MAX, "wgrad_reduce_multi: 1..%d items", SL_WGRAD_BATCH_MAX);
+  WgradReduceBatch b{};
+  int blocks = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    const SlWgradReduce& t = items[i];
+    if (t.splits == 0) continue;
+    SL_REQUIRE(t.ws && t.dw && t.total > 0 && t.splits > 0 && t.Cin > 0 && t.total % t.Cin == 0, "wgrad_reduce_multi: item %d is not a deferred reduce", i);
+    SL_REQUIRE(t.ncol == 0 || (t.dy && t.colsum_part && t.rows > 0 && t.rows_per_block > 0 && (t.dtype == SL_BF16 || t.dtype == SL_F32)), "wgrad_reduce_multi: item %d: bad column-sum part", i);
+    b.it[m] = t; b.start[m] = blocks;
+    blocks += (int)((t.total + 255) / 256) + t.ncol;
+    ++m;
+  }
+  if (m == 0) return 0;
+  b.start[m] = blocks; b.n = m;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b);
+  SL_LAUNCH_CHECK("wgrad_reduce_multi_kernel");
+  return 0;
+}
+
 // Does the weight-gradient kernel of this shape carry the bias-gradient partials itself (BIAS instantiation: one row per split, two for pixel pairs)?
 static bool wgrad_bias_fused(const SlConvDesc* d, const WgradPlan& pl) {      // test hook sl_debug_wgrad_bias(0): the column sums of dy back in the reduce launch
   return g_sl_debug.wgrad_bias && pl.glds && pl.taps == 1 && !(pl.bnn == 256 && pl.bcc == 256) && use_tr();
@@ -1031,8 +1089,9 @@ extern "C" int sl_conv2d_bwd_weight_bias_rows(const SlConvDesc* d, int n_valid, 
 }
 
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid) {
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid, SlWgradReduce* defer) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
+  if (defer) defer->splits = 0;           // 0 = nothing left to do (this path ran its own reduce)
   const int nv = n_valid > 0 ? n_valid : d->Cout, cv = c_valid > 0 ? c_valid : d->Cin;
   SL_REQUIRE(nv <= d->Cout && cv <= d->Cin, "conv bwd_weight: valid channel counts exceed the (padded) problem");
   // column sums of dy by the stand-alone kernel: every path below that does not carry them in its reduce launch
@@ -1121,6 +1180,19 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   } else if (pl.taps == 1) {
     const long long total = (long long)d->Cout * d->Cin;
     const int nred = (int)((total + 255) / 256);
+    if (defer) {
+      // the flat slab reduce (and the column sums of dy that would ride in it) joins the caller's batch: sl_wgrad_reduce_multi runs it with the other layers' reduces
+      defer->ws = (const float*)workspace; defer->dw = dw; defer->total = total; defer->splits = pl.splits; defer->Cin = d->Cin; defer->dw_cin_total = dw_cin_total;
+      defer->dw_ci_off = dw_ci_off; defer->n_valid = nv; defer->c_valid = cv; defer->dtype = d->dtype; defer->dy = nullptr; defer->colsum_part = nullptr; defer->ncol = 0;
+      defer->rows = 0; defer->Cout = d->Cout; defer->rows_per_block = 0;
+      if (colsum_partial) {
+        const long long rows = (long long)d->B * d->Ho * d->Wo, ch = sl_colsum_rows_chunk(rows, d->Cout, d->dtype == SL_BF16 ? 2 : 4);
+        const int ncol = (int)((rows + ch - 1) / ch);
+        SL_REQUIRE(ncol == promised_rows, "conv bwd_weight: bias partial rows (deferred reduce) != sl_conv2d_bwd_weight_bias_rows (%d)", promised_rows);
+        defer->dy = dy; defer->rows = rows; defer->rows_per_block = ch; defer->colsum_part = colsum_partial; defer->ncol = ncol;
+      }
+      return 0;
+    }
     if (colsum_partial) {
       const long long rows = (long long)d->B * d->Ho * d->Wo, ch = sl_colsum_rows_chunk(rows, d->Cout, d->dtype == SL_BF16 ? 2 : 4);
       const int ncol = (int)((rows + ch - 1) / ch);

@@ -17,6 +17,7 @@ from .ops_swin import pad_to
 
 _PSP_GROUPED = True    # test hook: the UperNet pyramid's stage BatchNorm backward + stage weight gradients as two grouped launches (False: a per-level chain)
 _GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
+_WGRAD_BATCH = True    # test hook: the slab reduces of a block's four nn.Linear weight gradients in one launch (ops.WgradBatch); False: one reduce launch behind every weight gradient
 _BN_BIAS_ZERO = True   # test hook: the exact-zero bias gradient of a conv in front of a train-mode BatchNorm is written as zero (False: the column sum of the BN-input gradient)
 _LN_SCALE = True       # test hook: DropPath's per-sample factor on a branch's incoming gradient comes out of the LayerNorm backward that produced the gradient (False: a scale_add launch)
 _RESIZE_ADD = True     # test hook: AddResizedFn as one launch (False: clone + accumulate)
@@ -199,9 +200,10 @@ def lin_fwd(x, L, residual=None, x2=None, row_scale=None, want_gelu=False):
     return ops.conv2d_fwd(x, L.wf, L.spec, bias=L.bias, pre_addend=residual, x2=x2)[0]
 
 
-def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=None, gelu_h=None):
+def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=None, gelu_h=None, wbatch=None):
     """(dx, dw in the parameter's shape, dbias) of lin_fwd.  batch (ops.ColsumBatch): dbias is filled by batch.run().
-    gelu_h: x = GELU(gelu_h) -- dx is then the gradient wrt gelu_h (the activation's backward in the data gradient's epilogue)."""
+    gelu_h: x = GELU(gelu_h) -- dx is then the gradient wrt gelu_h (the activation's backward in the data gradient's epilogue).
+    wbatch (ops.WgradBatch): dw is filled by wbatch.run() -- the slab reduces of a block's linears in one launch; wbatch.run() comes before batch.run()."""
     if need_dx and gelu_h is not None:
         dx = ops.conv2d_bwd_data_gelu(dy, L.wb, L.spec, x.shape[1:3], gelu_h)
     else:
@@ -209,6 +211,13 @@ def lin_bwd(x, dy, L, need_dx=True, need_w=True, col_map=None, x2=None, batch=No
     dw = db = None
     if need_w:
         clip = col_map is None and x2 is None and L.K < L.spec.cin          # zero-padded input channels: the reduce writes the parameter's shape, no slicing copy
+        if wbatch is not None and col_map is None and x2 is None and L.k == 1:
+            r = ops.conv2d_bwd_weight_clip(x, dy, L.spec, L.N, L.K, want_bias=L.bias is not None, batch=batch, defer=wbatch)
+            dwp, db = r if L.bias is not None else (r, None)
+            if db is not None:
+                db = db[:L.N]
+                db = db.contiguous() if batch is None else db
+            return dx, dwp.view(L.N, L.K), db
         if L.bias is not None:
             if clip:
                 dwp, db = ops.conv2d_bwd_weight_clip(x, dy, L.spec, L.N, L.K, want_bias=True, batch=batch)
@@ -347,20 +356,21 @@ class SwinBlockFn(torch.autograd.Function):
         # the eight column sums of this backward (four bias gradients, two LayerNorm (dgamma, dbeta) pairs, the attention bias and the pad-token
         # bias) are finalised by ONE launch at the end
         batch = ops.ColsumBatch() if need_w else None
+        wbatch = ops.WgradBatch() if (need_w and _WGRAD_BATCH) else None       # the four linears' slab reduces: one launch at the end (round 6)
         if _GELU_FUSE:
-            dh, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch, gelu_h=h)       # fc2's data gradient * GELU'(h) in one launch
+            dh, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch, gelu_h=h, wbatch=wbatch)       # fc2's data gradient * GELU'(h) in one launch
         else:
-            dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch)
+            dg, dw2, db2 = lin_bwd(g, dz, L2, need_w=need_w, batch=batch, wbatch=wbatch)
             dh = osw.gelu_bwd(h, dg)
-        dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w, batch=batch)
+        dxn2, dw1, db1 = lin_bwd(xn2, dh, L1, need_w=need_w, batch=batch, wbatch=wbatch)
         if s1 is not None and _LN_SCALE:
             (dx1, dpr), dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch, row_scale=s1)
         else:
             dx1, dg2, dbt2 = osw.layernorm_bwd(dxn2, x1, n2w.detach(), st2, Cn, addend=dout, want_param_grads=need_w, batch=batch)
             dpr = dx1 if s1 is None else osw.scale_add(dx1, s1)
-        datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w, batch=batch)
+        datt, dwp, dbp = lin_bwd(att, dpr, Lp, need_w=need_w, batch=batch, wbatch=wbatch)
         dqkv, drel, dpad = osw.window_attention_bwd(qkv, qb.detach().contiguous(), rel, datt, Cn, heads, shift, batch=batch)
-        dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w, batch=batch)
+        dxn, dwq, dbq = lin_bwd(xn, dqkv, Lq, need_w=need_w, batch=batch, wbatch=wbatch)
         if plink is not None and plink.s2 is not None and _LN_SCALE:
             (dx, dxs), dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch, row_scale=plink.s2)
             plink.pre = (dx.data_ptr(), tuple(dx.shape), dxs)
@@ -368,6 +378,8 @@ class SwinBlockFn(torch.autograd.Function):
             dx, dg1, dbt1 = osw.layernorm_bwd(dxn, x, n1w.detach(), st1, Cn, addend=dx1, want_param_grads=need_w, batch=batch)
         dtable = None
         if need_w:
+            if wbatch is not None:
+                wbatch.run()
             batch.run()
             dbq = (dbq.view(3, heads, 32) + dpad).view(3 * Cn)         # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
             # table row t collects the (query, key) pairs with relative offset t: a fixed-order gather instead of index_add_ (atomics,

@@ -447,13 +447,13 @@ def conv2d_bwd_weight_bias(x, dy, spec, x2=None, batch=None, out=None):
     return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
 
 
-def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=False, batch=None):
+def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=False, batch=None, defer=None):
     """dw in the PARAMETER's shape [n_valid][c_valid][k][k] of a layer computed at zero-padded channel counts (spec.cout x spec.cin): the slab reduce writes only the
     channels that exist.  want_bias: also the bias gradient (padded length spec.cout; batch as in conv2d_bwd_weight_bias)."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
     L = _lib.lib()
-    ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
+    ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad' if defer is None else 'wgrad_d%d' % len(defer.items))
     dw = torch.empty((n_valid, c_valid, spec.k, spec.k), dtype=torch.float32, device=x.device)
     part = None
     if want_bias:
@@ -461,11 +461,35 @@ def conv2d_bwd_weight_clip(x, dy, spec, n_valid, c_valid, x2=None, want_bias=Fal
         assert Cn == spec.cout and dy.is_contiguous()
         part = _f32((_bias_rows(d, n_valid, c_valid), Cn), dy.device)
     tok = PROFILER.begin('conv_wgrad', d)
-    check(L.sl_conv2d_bwd_weight_clip(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_clip')
+    if defer is not None:          # defer (WgradBatch): the slab reduce (a flat 1x1 one) joins the batch's one launch; dw (and the bias partials) are filled by defer.run()
+        item = _lib.SlWgradReduce()
+        check(L.sl_conv2d_bwd_weight_defer(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), C.byref(item), _s()), 'conv2d_bwd_weight_defer')
+        if item.splits > 0:
+            defer.items.append(item)
+            defer.keep.append((ws, dy, dw, part))
+    else:
+        check(L.sl_conv2d_bwd_weight_clip(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), n_valid, c_valid, _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_clip')
     PROFILER.end(tok)
     if not want_bias:
         return dw
     return dw, (batch.add(part) if batch is not None else colsum(part).contiguous())
+
+
+class WgradBatch:
+    """The slab reduces of several weight gradients in ONE launch (sl_wgrad_reduce_multi): conv2d_bwd_weight_clip(..., defer=batch) runs the split-K kernel and hands out
+    dw right away; run() fills all of them (and the bias column-sum partials that ride in the reduce launch: run() comes BEFORE the ColsumBatch's).  Every deferred
+    layer keeps a workspace of its own until run()."""
+
+    def __init__(self):
+        self.items, self.keep = [], []
+
+    def run(self):
+        L = _lib.lib()
+        for i0 in range(0, len(self.items), _lib.SL_WGRAD_BATCH_MAX):
+            chunk = self.items[i0:i0 + _lib.SL_WGRAD_BATCH_MAX]
+            arr = (_lib.SlWgradReduce * len(chunk))(*chunk)
+            check(L.sl_wgrad_reduce_multi(arr, len(chunk), _s()), 'wgrad_reduce_multi')
+        self.items, self.keep = [], []
 
 
 # --------------------------------------------------------------------------------------------- batch norm

@@ -291,3 +291,67 @@ def test_ppm_factorised_scatter_gather_sliding_window(hip, B, H, W, N, dtype):
         lhs = float((g1.double() * dcb.double()).sum())
         rhs = float((q.double() * s1.double()).sum())
         assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+@pytest.mark.parametrize('dim,heads,H,W', [(96, 3, 14, 21), (192, 6, 14, 14)])
+def test_swin_stage_tail_fusions_are_bit_identical(hip, dim, heads, H, W):
+    """Round-6 launch fusions of the Swin block backward: (a) DropPath's per-sample factor on a branch's incoming gradient written by the LayerNorm backward that produced the
+    gradient (sl_layernorm_bwd_scaled; across blocks through functional_swin.SwinLink), (b) the four nn.Linear slab reduces + the bias column sums that ride in them in
+    one launch (sl_conv2d_bwd_weight_defer / sl_wgrad_reduce_multi).  Both promise the bits of the launches they replace: two DropPath blocks, every gradient torch.equal."""
+    from segland_amd import functional_swin as fs
+    from segland_amd.networks.backbones.swintransformer import BasicLayer
+    from segland_amd.ops_swin import pad_to
+    torch.manual_seed(11)
+    st = BasicLayer(dim, 2, heads, [0.1, 0.1], 0, False).to(DEV)
+    P = pad_to(dim)
+    B = 3
+    x0 = torch.zeros(B, H, W, P, device=DEV)
+    x0[..., :dim] = torch.randn(B, H, W, dim, device=DEV)
+    x0 = x0.to(torch.bfloat16)
+    sc = [torch.tensor(v, device=DEV) for v in ([0.0, 1 / 0.9, 1 / 0.9], [1 / 0.9, 0.0, 1 / 0.9], [1 / 0.9, 1 / 0.9, 0.0], [1 / 0.9, 1 / 0.9, 1 / 0.9])]
+    wgt = torch.linspace(-1, 1, B * H * W * dim, device=DEV).view(B, H, W, dim)
+
+    def run(ln_scale, wbatch):
+        old = fs._LN_SCALE, fs._WGRAD_BATCH
+        fs._LN_SCALE, fs._WGRAD_BATCH = ln_scale, wbatch
+        try:
+            st.zero_grad(set_to_none=True)
+            xg = x0.clone().requires_grad_(True)
+            y, plink = xg, None
+            for i, blk in enumerate(st.blocks):
+                link = fs.SwinLink(sc[2 * i + 1])
+                y = fs.SwinBlockFn.apply(y, blk, sc[2 * i], sc[2 * i + 1], plink, link, *fs.block_params(blk))
+                plink = link
+            (y.float()[..., :dim] * wgt).sum().backward()
+            assert all(l is None or l.pre is None for l in (plink,))
+            return {k: p.grad.clone() for k, p in st.named_parameters()} | {'x': xg.grad.clone()}
+        finally:
+            fs._LN_SCALE, fs._WGRAD_BATCH = old
+    ref = run(False, False)
+    for cfg in ((True, False), (False, True), (True, True)):
+        got = run(*cfg)
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), (cfg, k, float((got[k].float() - ref[k].float()).abs().max()))
+
+
+def test_bilinear_add_and_bn_finalize_bias_entries(hip):
+    """sl_bilinear_fwd_add == clone + accumulate (same bits); sl_bn_finalize_train_bias == sl_bn_finalize_train + running_mean += momentum * bias (1e-7)."""
+    from segland_amd import ops, ops_swin as osw
+    torch.manual_seed(12)
+    base = torch.randn(2, 24, 20, 128, device=DEV).to(torch.bfloat16)
+    x = torch.randn(2, 12, 10, 128, device=DEV).to(torch.bfloat16)
+    one = osw.bilinear_fwd(x, (24, 20), True, base=base)
+    two = osw.bilinear_fwd(x, (24, 20), True, out=base.clone(), accumulate=True)
+    assert torch.equal(one, two)
+    part = torch.randn(7, 2, 128, device=DEV).abs() * 50
+    part[:, 1] += 400.0
+    g, b = torch.rand(128, device=DEV) + 0.5, torch.randn(128, device=DEV)
+    cb = torch.randn(96, device=DEV)
+    rm0, rv0 = torch.randn(128, device=DEV), torch.rand(128, device=DEV) + 0.5
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    a = ops.bn_finalize_train(part, 1000, g, b, rm0, rv0, 0.1, 1e-5)
+    rm0[:96] += 0.1 * cb
+    c = ops.bn_finalize_train(part, 1000, g, b, rm1, rv1, 0.1, 1e-5, conv_bias=cb)
+    for u, v in zip(a, c):
+        assert torch.equal(u, v)
+    assert torch.equal(rv0, rv1) and float((rm0 - rm1).abs().max()) <= 1e-6
