@@ -532,6 +532,10 @@ int sl_window_attention_bwd_chunks(const SlWinDesc* d);
 /* d relative_position_bias_table [rows][heads] from d bias [heads][npair] (npair = 49*49): dtable[t][h] = sum_j dbias[h][pairs[t][j]] over the
  * pairs[t][0..m) >= 0 (constant lists of the (query, key) pairs with relative offset t; swintransformer.py:128-131 backward, fixed order) */
 int sl_relpos_table_grad(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, sl_stream_t stream);
+/* the same + the qkv bias gradient in the launch: dbq [3][heads][32] = dbq_colsum (column sums of dqkv, same layout) + dpad [heads][3][32] (the finalized pad_partial
+ * of sl_window_attention_bwd: the pad tokens' k / v are the bias itself, swintransformer.py:208-213) */
+int sl_relpos_table_grad_bias(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, const float* dbq_colsum,
+                              const float* dpad, float* dbq, sl_stream_t stream);
 int sl_window_attention_windows(const SlWinDesc* d);
 int sl_window_attention_bwd(const SlWinDesc* d, const void* qkv, const float* qkv_bias, const float* rel_bias, const void* dout, void* dqkv,
                             float* drel_partial, float* pad_partial, sl_stream_t stream);

@@ -1660,7 +1660,18 @@ static int win_wpw(const WinGeom& g) { return (win_wpb(g) + 3) / 4; }         //
 
 // d relative_position_bias_table[t][h] = sum over the (query, key) pairs with relative offset t of d bias[h][pair] (swintransformer.py:128-131 backward):
 // fixed-order gather through the constant pair lists (pairs[t][j], -1 padded) -- the index_add_ of an autograd gather is atomic, this is bit-stable.
-__global__ void relpos_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ pairs, int rows, int m, int heads, int npair, float* __restrict__ dtable) {
+__global__ void relpos_table_grad_kernel(const float* __restrict__ dbias, const int* __restrict__ pairs, int rows, int m, int heads, int npair, float* __restrict__ dtable,
+                                         int nrel, const float* __restrict__ dbq_in, const float* __restrict__ dpad, float* __restrict__ dbq_out) {
+  if ((int)blockIdx.x >= nrel) {
+    // the blocks behind the table's: d qkv.bias [3][heads][32] = the column sums of dqkv + what reached the bias through the pad tokens, dpad [heads][3][32]
+    // (swintransformer.py:208-213 backward) -- the add that followed this launch as a torch kernel
+    const int i = ((int)blockIdx.x - nrel) * blockDim.x + threadIdx.x;
+    if (i < 3 * heads * 32) {
+      const int j = i & 31, h = (i >> 5) % heads, sct = (i >> 5) / heads;
+      dbq_out[i] = dbq_in[i] + dpad[(h * 3 + sct) * 32 + j];
+    }
+    return;
+  }
   // eight lanes per table entry: lane `sub` adds pairs sub, sub + 8, ... (up to 49 per offset: one thread walked them as a chain of dependent loads, 21 us whatever the stage),
   // then a fixed xor tree over the eight partial sums
   const int gi = blockIdx.x * blockDim.x + threadIdx.x, i = gi >> 3, sub = gi & 7;
@@ -1678,7 +1689,19 @@ __global__ void relpos_table_grad_kernel(const float* __restrict__ dbias, const 
 
 extern "C" int sl_relpos_table_grad(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, sl_stream_t stream) {
   SL_REQUIRE(dbias && pairs && dtable && rows > 0 && m > 0 && heads > 0 && npair > 0, "relpos_table_grad: bad args");
-  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(cdiv(rows * heads * 8, 256)), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable);
+  const int nrel = cdiv(rows * heads * 8, 256);
+  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(nrel), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable, nrel, (const float*)nullptr,
+                     (const float*)nullptr, (float*)nullptr);
+  SL_LAUNCH_CHECK("relpos_table_grad_kernel");
+  return 0;
+}
+
+extern "C" int sl_relpos_table_grad_bias(const float* dbias, const int* pairs, int rows, int m, int heads, int npair, float* dtable, const float* dbq_colsum,
+                                         const float* dpad, float* dbq, sl_stream_t stream) {
+  SL_REQUIRE(dbias && pairs && dtable && rows > 0 && m > 0 && heads > 0 && npair > 0 && dbq_colsum && dpad && dbq, "relpos_table_grad_bias: bad args");
+  const int nrel = cdiv(rows * heads * 8, 256);
+  hipLaunchKernelGGL(relpos_table_grad_kernel, dim3(nrel + cdiv(3 * heads * 32, 256)), dim3(256), 0, (hipStream_t)stream, dbias, pairs, rows, m, heads, npair, dtable, nrel,
+                     dbq_colsum, dpad, dbq);
   SL_LAUNCH_CHECK("relpos_table_grad_kernel");
   return 0;
 }

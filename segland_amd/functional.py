@@ -246,6 +246,7 @@ def _frozen(ctx, *bns):
 
 _PPM_WGRAD_GROUPED = True  # test hook: the pyramid's eight row-GEMM weight gradients as two grouped launches (ops.ppm_rows_wgrad); False: one generic weight-gradient launch + slab reduce per level
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
+_WGRAD_BATCH = False       # test hook: the flat slab reduces of a bottleneck's 1x1 weight gradients in one launch (ops.WgradBatch).  Measured NEGATIVE on the ResNet-50 step (691.1 vs 693.2 tiles/s, profiles/r6_ab_r50_wbatch.txt: the deferred reduce reads cold slabs); kept for the Swin blocks, whose slabs are small
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
 _BASE_CHAIN_CACHE = True   # test hook: ft mode, the frozen base classifier's rows are computed once (False: every iteration)
 # The ONE environment switch of the BatchNorm-backward fusions (A/B of the whole feature against stand-alone reduce passes): SEGLAND_BN_FUSE=0 switches all three off.
@@ -255,7 +256,7 @@ _BN_CROSS = _BN_FUSE       # test hook: bn3's column sums from the NEXT block's 
 
 
 def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want_dres=False, addend=None, x2=None, dx_out=None,
-                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None, prevd=None, dx_half=False, addend_half=False):
+                bits=None, addend_bits=None, pre_partial=None, below=None, bn_done=None, prev3=None, prevd=None, dx_half=False, addend_half=False, wbatch=None):
     """Backward of y = act(bn(conv(x))).  Returns (dx, dw, dgamma, dbeta, dres, partial_below).
     ReLU gate of dy: `bits` (bit mask from the forward) or `y_mask` (the activation itself).  `addend` (+ optional
     `addend_bits` gate) is accumulated into dx by the dgrad epilogue.
@@ -264,7 +265,8 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     store phase, its epilogue gates dx with those bits and emits that layer's column sums (partial_below is then not None and dx is gated).
     bn_done = (dc, dgamma, dbeta): the BatchNorm part was already done by the caller (ops.bn_bwd2: two BatchNorms behind one ReLU in one sweep).
     prev3 = (bits, c3, mean, invstd) of the PREVIOUS bottleneck's bn3 + output ReLU: dx (with its addend, which must be gated already) is that block's incoming
-    gradient; where the pixel-stationary kernel serves the shape it is gated there and reduced against c3 (partial_below = that block's bn3 column sums)."""
+    gradient; where the pixel-stationary kernel serves the shape it is gated there and reduced against c3 (partial_below = that block's bn3 column sums).
+    wbatch (ops.WgradBatch): a flat (1x1) slab reduce joins the caller's one reduce launch -- dw is filled by wbatch.run()."""
     gw, gg, gb = (grad_dst(conv.weight), grad_dst(bn.weight), grad_dst(bn.bias)) if need_dw else (None, None, None)
     if bn_done is not None:
         (dc, dgamma, dbeta), dres = bn_done, None
@@ -276,7 +278,7 @@ def conv_bn_bwd(dy, y_mask, c, x, conv, bn, mean, invstd, need_dx, need_dw, want
     spec = spec_of(conv)
     dx = dw = part_below = None
     if need_dw:
-        dw = grad_alias(ops.conv2d_bwd_weight(x, dc, spec, x2=x2, out=gw), gw)
+        dw = grad_alias(ops.conv2d_bwd_weight(x, dc, spec, x2=x2, out=gw, defer=wbatch), gw)
     if need_dx and dx_half:
         # a 1x1 stride-2 conv (a stage entry's downsample branch): its data gradient is non-zero at the even positions only -- return the DENSE gradient on the conv's own
         # output grid; the consumer adds it at the even positions (ops.conv2d_bwd_data_addend_half), the zero-filled tensor is never written
@@ -429,17 +431,18 @@ class BottleneckFn(torch.autograd.Function):
             prev3 = None
         prevd = plink.bnd if prev3 is not None else None
         want_dres = prev3 is not None and not ctx.has_ds and k3 is not None and p3 is None and done3 is None
+        wbatch = ops.WgradBatch() if (need_w and _WGRAD_BATCH) else None       # the 1x1 convs' slab reduces of this block: one launch at the end (round 6)
         da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,
-                                                   below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres)
+                                                   below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres, wbatch=wbatch)
         da1, dw2, dg2, db2, _, p1 = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=None if p2 is not None else k2, pre_partial=p2,
-                                                below=(k1, c1, m1, i1) if blk.bn1.training else None)
+                                                below=(k1, c1, m1, i1) if blk.bn1.training else None, wbatch=wbatch)
         grads_ds = ()
         if ctx.has_ds:
             cd, md, idd = sv[14:17]
             dsc = blk.downsample[0]
             half = (_DS_HALF and need_x and dsc.kernel_size == (1, 1) and dsc.stride == (2, 2) and dsc.padding == (0, 0) and x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0
                     and ops.conv2d_bwd_data_addend_half_ok(x, spec_of(blk.conv1)))
-            dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, dsc, blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned, dx_half=half)
+            dxd, dwd, dgd, dbd, _, _ = conv_bn_bwd(dout, None, cd, x, dsc, blk.downsample[1], md, idd, need_x, need_w, bits=k3, bn_done=doned, dx_half=half, wbatch=wbatch)
             grads_ds = (dwd, dgd, dbd)
             addend, abits = dxd, None
         elif dres is not None:
@@ -450,7 +453,9 @@ class BottleneckFn(torch.autograd.Function):
             prev3 = None
         dx, dw1, dg1, db1, _, pp = conv_bn_bwd(da1, None, c1, x, blk.conv1, blk.bn1, m1, i1, need_x, need_w,
                                                addend=addend if need_x else None, addend_bits=abits if need_x else None, bits=None if p1 is not None else k1, pre_partial=p1,
-                                               prev3=prev3, prevd=prevd, addend_half=ctx.has_ds and half)
+                                               prev3=prev3, prevd=prevd, addend_half=ctx.has_ds and half, wbatch=wbatch)
+        if wbatch is not None:
+            wbatch.run()
         if pp is not None and prev3 is not None:
             plink.pre3 = (dx.data_ptr(), tuple(dx.shape), pp)
         return (dx, None, dw1, dg1, db1, dw2, dg2, db2, dw3, dg3, db3) + grads_ds

@@ -17,6 +17,7 @@ from .ops_swin import pad_to
 
 _PSP_GROUPED = True    # test hook: the UperNet pyramid's stage BatchNorm backward + stage weight gradients as two grouped launches (False: a per-level chain)
 _GELU_FUSE = True      # test hook: fc2's data gradient lands behind the GELU in its epilogue (sl_conv2d_bwd_data_gelu); False: + a gelu_bwd launch (profiles/r5_ab_swin_gelu.txt)
+_BIAS_TAIL = True      # test hook: d qkv.bias = column sums + pad-token share inside the relative-position table launch (False: a torch add)
 _WGRAD_BATCH = True    # test hook: the slab reduces of a block's four nn.Linear weight gradients in one launch (ops.WgradBatch); False: one reduce launch behind every weight gradient
 _BN_BIAS_ZERO = True   # test hook: the exact-zero bias gradient of a conv in front of a train-mode BatchNorm is written as zero (False: the column sum of the BN-input gradient)
 _LN_SCALE = True       # test hook: DropPath's per-sample factor on a branch's incoming gradient comes out of the LayerNorm backward that produced the gradient (False: a scale_add launch)
@@ -381,10 +382,15 @@ class SwinBlockFn(torch.autograd.Function):
             if wbatch is not None:
                 wbatch.run()
             batch.run()
-            dbq = (dbq.view(3, heads, 32) + dpad).view(3 * Cn)         # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213)
             # table row t collects the (query, key) pairs with relative offset t: a fixed-order gather instead of index_add_ (atomics,
             # last-bit differences from run to run) -- the step stays bit-reproducible like the rest of the path
-            dtable = osw.relpos_table_grad(drel.view(heads, -1), _rel_pairs(blk.attn, table.shape[0]), table.shape[0])
+            praw = dpad.permute(1, 0, 2)                               # back to the kernel's own [heads, 3, 32]
+            if _BIAS_TAIL and praw.is_contiguous() and dbq.is_contiguous() and dbq.numel() == 3 * Cn:
+                # the zero-padded tokens' k / v are the bias itself (swintransformer.py:208-213): their share joins the column sums inside the table launch
+                dtable, dbq = osw.relpos_table_grad(drel.view(heads, -1), _rel_pairs(blk.attn, table.shape[0]), table.shape[0], qkv_bias=(dbq, praw))
+            else:
+                dbq = (dbq.view(3, heads, 32) + dpad).view(3 * Cn)
+                dtable = osw.relpos_table_grad(drel.view(heads, -1), _rel_pairs(blk.attn, table.shape[0]), table.shape[0])
         return (dx, None, None, None, None, None, dg1, dbt1, dtable, dwq, dbq, dwp, dbp, dg2, dbt2, dw1, db1, dw2, db2)
 
 

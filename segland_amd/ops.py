@@ -406,14 +406,26 @@ def workspace(nbytes, dev, tag=None):
     return w
 
 
-def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0):
+def conv2d_bwd_weight(x, dy, spec, x2=None, out=None, out_ci_off=0, defer=None):
     """dw (float OIHW).  `out`: a wider [Cout][Ctot][k][k] gradient tensor; this conv's channels land at input-channel offset out_ci_off.  The fixed-order slab
-    reduce follows the MFMA kernel on the same stream."""
+    reduce follows the MFMA kernel on the same stream -- or, with defer (WgradBatch), joins the batch's one reduce launch where the shape has a flat (1x1) reduce:
+    dw is then filled by defer.run()."""
     B, H, W, C1 = x.shape
     d = conv_desc(x.dtype, B, H, W, spec, C1 if x2 is not None else None)
-    ws = workspace(_lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
     dw = out if out is not None else torch.empty((spec.cout, spec.cin, spec.k, spec.k), dtype=torch.float32, device=x.device)
     tot = dw.shape[1]
+    if defer is not None and out_ci_off == 0 and tot == spec.cin and dw.is_contiguous():
+        L = _lib.lib()
+        ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad_d%d' % len(defer.items))
+        item = _lib.SlWgradReduce()
+        tok = PROFILER.begin('conv_wgrad', d)
+        check(L.sl_conv2d_bwd_weight_defer(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), 0, 0, _p(ws), ws.numel(), None, C.byref(item), _s()), 'conv2d_bwd_weight_defer')
+        PROFILER.end(tok)
+        if item.splits > 0:
+            defer.items.append(item)
+            defer.keep.append((ws, dy, dw))
+        return dw
+    ws = workspace(_lib.lib().sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
     tok = PROFILER.begin('conv_wgrad', d)
     check(_lib.lib().sl_conv2d_bwd_weight_ex(C.byref(d), _p(x), _p(x2), _p(dy), _p(dw), tot, out_ci_off, _p(ws), ws.numel(), _s()), 'conv2d_bwd_weight')
     PROFILER.end(tok)

@@ -150,10 +150,18 @@ def window_attention_fwd(qkv, qkv_bias, rel_bias, Cn, heads, shift, out_pitch):
     return out
 
 
-def relpos_table_grad(dbias, pairs, rows):
-    """d relative_position_bias_table [rows, heads] from d bias [heads, 49*49] through the constant pair lists `pairs` [rows, m] (int32, -1 padded)."""
+def relpos_table_grad(dbias, pairs, rows, qkv_bias=None):
+    """d relative_position_bias_table [rows, heads] from d bias [heads, 49*49] through the constant pair lists `pairs` [rows, m] (int32, -1 padded).
+    qkv_bias = (dbq_colsum [3*C], dpad [heads, 3, 32] contiguous): also returns d qkv.bias [3*C] = dbq_colsum + dpad in the bias' (3, heads, 32) order, same launch."""
     heads = dbias.shape[0]
     out = _f32((rows, heads), dbias.device)
+    if qkv_bias is not None:
+        dbq_in, dpad = qkv_bias
+        assert dbq_in.is_contiguous() and dpad.is_contiguous() and dbq_in.numel() == 3 * heads * 32 == dpad.numel() and dbq_in.dtype == dpad.dtype == torch.float32
+        dbq = torch.empty_like(dbq_in)
+        check(_lib.lib().sl_relpos_table_grad_bias(_p(dbias), _p(pairs), rows, pairs.shape[1], heads, dbias[0].numel(), _p(out), _p(dbq_in), _p(dpad), _p(dbq), _s()),
+              'relpos_table_grad_bias')
+        return out, dbq
     check(_lib.lib().sl_relpos_table_grad(_p(dbias), _p(pairs), rows, pairs.shape[1], heads, dbias[0].numel(), _p(out), _s()), 'relpos_table_grad')
     return out
 

@@ -297,7 +297,8 @@ def test_ppm_factorised_scatter_gather_sliding_window(hip, B, H, W, N, dtype):
 def test_swin_stage_tail_fusions_are_bit_identical(hip, dim, heads, H, W):
     """Round-6 launch fusions of the Swin block backward: (a) DropPath's per-sample factor on a branch's incoming gradient written by the LayerNorm backward that produced the
     gradient (sl_layernorm_bwd_scaled; across blocks through functional_swin.SwinLink), (b) the four nn.Linear slab reduces + the bias column sums that ride in them in
-    one launch (sl_conv2d_bwd_weight_defer / sl_wgrad_reduce_multi).  Both promise the bits of the launches they replace: two DropPath blocks, every gradient torch.equal."""
+    one launch (sl_conv2d_bwd_weight_defer / sl_wgrad_reduce_multi), (c) the pad tokens' share of d qkv.bias added inside the relative-position table launch
+    (sl_relpos_table_grad_bias).  All promise the bits of the launches they replace: two DropPath blocks, every gradient torch.equal."""
     from segland_amd import functional_swin as fs
     from segland_amd.networks.backbones.swintransformer import BasicLayer
     from segland_amd.ops_swin import pad_to
@@ -311,9 +312,9 @@ def test_swin_stage_tail_fusions_are_bit_identical(hip, dim, heads, H, W):
     sc = [torch.tensor(v, device=DEV) for v in ([0.0, 1 / 0.9, 1 / 0.9], [1 / 0.9, 0.0, 1 / 0.9], [1 / 0.9, 1 / 0.9, 0.0], [1 / 0.9, 1 / 0.9, 1 / 0.9])]
     wgt = torch.linspace(-1, 1, B * H * W * dim, device=DEV).view(B, H, W, dim)
 
-    def run(ln_scale, wbatch):
-        old = fs._LN_SCALE, fs._WGRAD_BATCH
-        fs._LN_SCALE, fs._WGRAD_BATCH = ln_scale, wbatch
+    def run(ln_scale, wbatch, tail=False):
+        old = fs._LN_SCALE, fs._WGRAD_BATCH, fs._BIAS_TAIL
+        fs._LN_SCALE, fs._WGRAD_BATCH, fs._BIAS_TAIL = ln_scale, wbatch, tail
         try:
             st.zero_grad(set_to_none=True)
             xg = x0.clone().requires_grad_(True)
@@ -326,9 +327,9 @@ def test_swin_stage_tail_fusions_are_bit_identical(hip, dim, heads, H, W):
             assert all(l is None or l.pre is None for l in (plink,))
             return {k: p.grad.clone() for k, p in st.named_parameters()} | {'x': xg.grad.clone()}
         finally:
-            fs._LN_SCALE, fs._WGRAD_BATCH = old
+            fs._LN_SCALE, fs._WGRAD_BATCH, fs._BIAS_TAIL = old
     ref = run(False, False)
-    for cfg in ((True, False), (False, True), (True, True)):
+    for cfg in ((True, False), (False, True), (False, False, True), (True, True, True)):
         got = run(*cfg)
         for k in ref:
             assert torch.equal(got[k], ref[k]), (cfg, k, float((got[k].float() - ref[k].float()).abs().max()))
@@ -355,3 +356,34 @@ def test_bilinear_add_and_bn_finalize_bias_entries(hip):
     for u, v in zip(a, c):
         assert torch.equal(u, v)
     assert torch.equal(rv0, rv1) and float((rm0 - rm1).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize('inp,pl,stride,B,H', [(256, 128, 2, 4, 64), (1024, 256, 1, 4, 32), (64, 64, 1, 2, 64)])
+def test_bottleneck_weight_gradient_reduces_in_one_launch_are_bit_identical(hip, inp, pl, stride, B, H):
+    """The flat slab reduces of a bottleneck's 1x1 weight gradients (conv1, conv3, the downsample conv) joined in one launch (ops.WgradBatch, functional._WGRAD_BATCH):
+    same summation order -> every gradient torch.equal to the one-reduce-per-layer form; a stage's first block (stride 2 / downsample branch) and identity blocks."""
+    from segland_amd import functional as sf
+    from segland_amd.functional import flush_num_batches_tracked
+    from segland_amd.networks.backbones.resnet import Bottleneck
+    torch.manual_seed(5)
+    ds = None
+    if stride != 1 or inp != pl * 4:
+        ds = nn.Sequential(nn.Conv2d(inp, pl * 4, kernel_size=1, stride=stride, bias=False), nn.BatchNorm2d(pl * 4))
+    blocks = nn.Sequential(Bottleneck(inp, pl, stride=stride, dilation=1, downsample=ds), Bottleneck(pl * 4, pl, stride=1, dilation=1)).to(DEV).train()
+    blocks[1].__dict__['_sl_prev'] = blocks[0]
+    x = torch.randn(B, H, H, inp, device=DEV).relu_().to(torch.bfloat16)
+    outs = {}
+    for on in (True, False):
+        old = sf._WGRAD_BATCH
+        sf._WGRAD_BATCH = on
+        try:
+            blocks.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            y = blocks(xg)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+            flush_num_batches_tracked()
+            outs[on] = {k: p.grad.clone() for k, p in blocks.named_parameters()} | {'x': xg.grad.clone()}
+        finally:
+            sf._WGRAD_BATCH = old
+    for k in outs[True]:
+        assert torch.equal(outs[True][k], outs[False][k]), (k, float((outs[True][k].float() - outs[False][k].float()).abs().max()))
