@@ -30,6 +30,7 @@ extern "C" void sl_debug_conv_rows_small(int v) { g_sl_debug.conv_rows_small = v
 extern "C" void sl_debug_conv_parity(int v) { g_sl_debug.conv_parity = v ? 1 : 0; }
 extern "C" void sl_debug_ppm_fact_walk(int v) { g_sl_debug.ppm_fact_walk = v ? 1 : 0; }
 extern "C" void sl_debug_ring64_max_tiles(int v) { g_sl_debug.ring64_max_tiles = v; }
+extern "C" void sl_debug_ring_small_k(int v) { g_sl_debug.ring_small_k = v; }
 extern "C" void sl_debug_wgrad3(int v) { g_sl_debug.wgrad3 = v ? 1 : 0; }
 extern "C" void sl_debug_wgrad_bias(int v) { g_sl_debug.wgrad_bias = v ? 1 : 0; }
 extern "C" void sl_debug_wgrad_tr(int v) { g_sl_debug.wgrad_tr = v ? 1 : 0; }

@@ -62,6 +62,10 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
   // 64-column inference layers (a fine-tune pair's frozen layer1: 256 -> 64 and 3x3 64 -> 64 on 32 768 rows): 128 x 64 tiles of the ring kernel, four waves of 32 rows x 64
   // columns, three blocks per CU -- 256 blocks where the two-stage 256 x 64 kernel has 128.  Launches without BN statistic partials only (the partial rows' granularity).
   if (dtype == SL_BF16 && ringn64_on() && !n128 && p.N % 192 != 0 && !p.stat_partial && !p.gate && p.M >= 128LL * RING128_MIN) return 4128064;
+  // short reductions on many rows (Swin stage 1: 128 -> 384 on 131 072 tokens): a 256 x 128 tile's ring holds the whole reduction (96 KiB, one block per CU), so load, MFMA
+  // and store phases of a CU run one after the other; two 64 KiB blocks of 128 x 128 tiles overlap one block's store phase with the other's loads (hook: sl_debug_ring_small_k)
+  if (big && dtype == SL_BF16 && n128 && !n256 && g_sl_debug.ring_small_k > 0 && (long long)p.KH * p.KW * (p.C1 + p.C2) <= g_sl_debug.ring_small_k && !p.stat_partial && !p.gate)
+    return 4128128;
   if (big) {
     // fp32 stages hold 16 (64-byte rows) or 32 K elements; channel counts are multiples of 64, so both divide
     if (n256) return 4256256;

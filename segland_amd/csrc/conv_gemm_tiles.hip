@@ -151,6 +151,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_glds_kernel(ConvGemmPa
   conv_epilogue_lds<T, BM, BN, WM, WN>(p, acc, bm, bn, wm, wn, lane, tid, smem);
 }
 
+#ifndef SL_RING_LATE
+#define SL_RING_LATE 1          // 0: the round-3..5 schedule (A/B builds: tools/ab_libs.sh)
+#endif
+
 template <typename T, int BM, int BN, int WM, int WN, int RBYTES, int NST>
 struct RingGeom {
   static constexpr int STAGE = (BM + BN) * RBYTES;
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
   constexpr int D = NST - 1;                    // stages issued ahead of the one being consumed
   // wait until at most `fl` of the most recently issued stages are still in flight (fl is block-uniform)
   auto wait_stages = [&](int fl) {
-    if constexpr (D >= 5) { if (fl >= 3) { wait_vmcnt<3 * L>(); return; } }
-    if constexpr (D >= 4) { if (fl == 2) { wait_vmcnt<2 * L>(); return; } }
+    if constexpr (D >= 4 && 3 * L <= 63) { if (fl >= 3) { wait_vmcnt<3 * L>(); return; } }
+    if constexpr (D >= 3 && 2 * L <= 63) { if (fl >= 2) { wait_vmcnt<2 * L>(); return; } }
     if (fl >= 1) wait_vmcnt<L>(); else wait_vmcnt<0>();
   };
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -319,6 +323,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
 #pragma unroll
   for (int st = 0; st < D; ++st)
     if (st < nk) issue(st);
+#if SL_RING_LATE
+  // Round 6 schedule: a stage is waited for where its first fragments are read -- before the LAST k-step of the iteration in front of it -- not one iteration earlier.
+  // Invariant at the top of iteration i: stage i is complete and visible to every wave, the fragments of (stage i, k-step 0) are in registers, stages i+1 .. i+D-1 fly;
+  // the slot stage i+D goes to (the one of stage i-1) was released by the barrier inside iteration i-1, behind that iteration's last fragment reads of it.  Same MFMA
+  // order, same results; a stage's latency budget grows from D - 1 to D - 1/KS iterations with the same LDS (small-M layers -- 8 192 tokens on 64 x 128 tiles with a
+  // three-slot ring -- were bound by exactly that: one iteration of 256 MFMA clocks against ~2 000 clocks of load latency).
+  wait_stages(min(nk, D) - 1);                            // stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  ldfrag(afA, bfA, 0, 0);
+
+  int slot = 0;
+  for (int i = 0; i < nk; ++i) {
+    if (i + D < nk) { int ns = slot + D; if (ns >= NST) ns -= NST; issue(ns); }
+    int nslot = slot + 1; if (nslot == NST) nslot = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; s2 += 2) {
+      ldfrag(afB, bfB, slot, s2 + 1);
+      mma(afA, bfA);
+      if (s2 + 2 < KS) ldfrag(afA, bfA, slot, s2 + 2);
+      else if (i + 1 < nk) {
+        wait_stages(min(i + D, nk - 1) - (i + 1));         // stage i+1 landed; i+2 .. i+D may stay in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's last fragment reads of slot i are done: behind the barrier the slot may be refilled
+        __builtin_amdgcn_s_barrier();
+        ldfrag(afA, bfA, nslot, 0);                        // first k-step of the next stage
+      }
+      mma(afB, bfB);
+    }
+    slot = nslot;
+  }
+#else
   wait_stages(min(nk, D) - 2);                            // stages 0 and 1 landed (later ones may still fly)
   __builtin_amdgcn_s_barrier();
   ldfrag(afA, bfA, 0, 0);
@@ -340,6 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_ring_kernel(ConvGemmPa
     __builtin_amdgcn_s_barrier();
     slot = nslot;
   }
+#endif
   __syncthreads();
   if constexpr (BN == 192) {
     // 192-column tile (a wave owns 32 rows x all 192 columns): the store phases map a 64 * WM * WN-thread block onto power-of-two row widths, so the tile leaves as three

@@ -452,11 +452,14 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
     if (st < nit) issue(st, st);
   // stages 0 and 1 complete; later ones may stay in flight.  fl = issued stages that need not have landed yet (block-uniform)
   auto wait_fl = [&](int fl) {
-    if constexpr (D >= 5) { if (fl >= 3) { wg_wait_vmcnt<3 * L>(); return; } }
-    if constexpr (D >= 4) { if (fl == 2) { wg_wait_vmcnt<2 * L>(); return; } }
+    if constexpr (D >= 4 && 3 * L <= 63) { if (fl >= 3) { wg_wait_vmcnt<3 * L>(); return; } }
+    if constexpr (D >= 3 && 2 * L <= 63) { if (fl >= 2) { wg_wait_vmcnt<2 * L>(); return; } }
     if (fl >= 1) wg_wait_vmcnt<L>(); else wg_wait_vmcnt<0>();
   };
-  wait_fl(min(nit, D) - 2);
+#ifndef SL_WG_LATE
+#define SL_WG_LATE 0       // 1: a stage is waited for where its first fragments are read (the ring kernel's round-6 schedule, conv_gemm_tiles.hip SL_RING_LATE).  Measured NEGATIVE here: ResNet-50 256 x 256 tiles 1.15 -> 1.23 ms per step, Swin-T neutral (profiles/r6_ab_wg_late.txt) -- these launches are fill-bound, and the barrier in front of the last k-step holds the MFMA queue back
+#endif
+  wait_fl(min(nit, D) - (SL_WG_LATE ? 1 : 2));
   __builtin_amdgcn_s_barrier();
   if (p.trace) tr1 = __builtin_amdgcn_s_memtime();
   ldfrag(afA, bfA, 0, 0);
@@ -479,12 +482,21 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
       if (!(SL_WG_ABL & 1) && ks == 0 && late && it + D < nit) issue(it + D, ns3);
       if constexpr (!(SL_WG_ABL & 2)) {
         if (ks + 2 < KS) ldfrag(afA, bfA, slot, ks + 2);
-        else             ldfrag(afA, bfA, nslot, 0);
+        else if (SL_WG_LATE) {
+          if (it + 1 < nit) {
+            wait_fl(min(it + D, nit - 1) - (it + 1));          // stage it + 1 landed; it + 2 .. it + D may stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this wave's fragment reads of the slot are done: behind the barrier it may be refilled
+            __builtin_amdgcn_s_barrier();
+            ldfrag(afA, bfA, nslot, 0);
+          }
+        } else ldfrag(afA, bfA, nslot, 0);
       }
       mma(afB, bfB);
     }
-    wait_fl(min(it + D, nit - 1) - (it + 2));                  // stage it + 2 complete before anyone starts iteration it + 1; it + 3 .. it + D may stay in flight
-    __builtin_amdgcn_s_barrier();
+    if (!SL_WG_LATE) {
+      wait_fl(min(it + D, nit - 1) - (it + 2));                // stage it + 2 complete before anyone starts iteration it + 1; it + 3 .. it + D may stay in flight
+      __builtin_amdgcn_s_barrier();
+    }
     slot = nslot;
   }
   if (p.trace) tr2 = __builtin_amdgcn_s_memtime();
