@@ -22,7 +22,7 @@ void sl_debug_conv_ringn64(int on);        /* 128 x 64 ring tiles for 64-column 
 void sl_debug_conv_rows_small(int on);     /* <= 32-row launches on conv_rows_small_kernel vs the tile kernels */
 void sl_debug_ppm_fact_walk(int on);       /* factorised PPM prior path: sliding-window scatter / gather kernels vs the general two-stage kernels */
 void sl_debug_conv_parity(int on);         /* stride-2 3x3 data gradients as four parity-plane launches vs one launch over all nine taps */
-void sl_debug_ring_small_k(int k);        /* big-M layers with N % 128 == 0 and at most k reduction elements on 128 x 128 ring tiles, two blocks per CU (default 0: 256 x 128) */
+void sl_debug_ring_small_k(int k);        /* big-M layers with N % 128 == 0 and at most k reduction elements on 128 x 128 ring tiles, two blocks per CU (default 128; 0: 256 x 128 tiles) */
 void sl_debug_ring64_max_tiles(int tiles); /* 64 x 128 ring tiles up to this many 128 x 128 tiles (default 256, 0: never) */
 void sl_debug_wgrad3(int on);              /* nine-tap 3x3 weight gradient (conv_wgrad3_kernel) vs the per-tap kernels */
 void sl_debug_wgrad_bias(int on);          /* bias-gradient column sums inside the weight-gradient kernel vs in the slab-reduce launch */

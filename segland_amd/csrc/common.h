@@ -96,7 +96,7 @@ struct SlDebugState {
   int conv_rows_small = 1;         // <= 32-row launches on conv_rows_small_kernel
   int ppm_fact_walk = 1;           // factorised PPM prior path: sliding-window scatter / gather kernels (0: the general two-stage kernels they replace)
   int conv_parity = 1;             // stride-2 3x3 data gradients as four parity-plane launches (0: one launch over all nine taps per pixel)
-  int ring_small_k = 0;               // > 0: big-M layers with N % 128 == 0 and a reduction of at most this many elements run on 128 x 128 ring tiles (two blocks per CU) instead of 256 x 128
+  int ring_small_k = 128;             // > 0: big-M layers with N % 128 == 0 and a reduction of at most this many elements run on 128 x 128 ring tiles (two blocks per CU) instead of 256 x 128
   long long ring64_max_tiles = 256;   // 64 x 128 ring tiles when the 128 x 128 grid would have at most this many blocks (0: never)
   int wgrad3 = 1;                  // nine-tap 3x3 weight gradient (0: per-tap kernels)
   int wgrad_bias = 1;              // bias-gradient column sums out of the weight-gradient kernel's dy fragments (0: blocks of the slab-reduce launch)
