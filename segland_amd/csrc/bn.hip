@@ -450,3 +450,107 @@ extern "C" int sl_bn_bwd_apply2(int dtype, const void* dy, const uint8_t* relu_m
   SL_REQUIRE(false, "bn_bwd_apply2: bad dtype");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ bn3 apply pass folded into conv3's gradients (round 6)
+// y = bn(conv1x1(x, W)): with dc = cA g + cB (c - mean) + cC (sl_bn_bwd_finalize) and c = x W^T,
+//   dx = dc W      = [g | x] [diag(cA) W ; W^T diag(cB) W] + (cC - cB mean) W          (sl_bn_fold_weights -> sl_conv2d_bwd_data_bnstat_folded)
+//   dW = dc^T x    = diag(cA) (g^T x) + diag(cB) W (x^T x) + (cC - cB mean) (x) colsum(x)   (sl_bn_fold_wgrad on the raw products g^T x, x^T x)
+// W is the bf16 weight the forward multiplied (c was produced with it).  Both kernels are small GEMMs on 16 x 16 output tiles staged through the LDS.
+namespace {
+constexpr int FT = 16, FK = 64;
+
+// wt_ext [Cin][Cout + Cin] (bf16), bias [Cin].  grid (Cin / 16, Cin / 16 + Cout / 256 + 1):
+//   y <  Cin / 16           : the tile (n0, j0) of W^T diag(cB) W
+//   y <  Cin / 16 + Cout/256: columns [256 (y - Cin/16), +256) of diag(cA) W, rows n0 .. n0 + 15 (from the transposed weight w_bwd: coalesced both ways)
+__global__ __launch_bounds__(256) void bn_fold_weights_kernel(const bf16_t* __restrict__ wf, const bf16_t* __restrict__ wb, const float* __restrict__ cA, const float* __restrict__ cB,
+                                                              bf16_t* __restrict__ wext, int Cout, int Cin) {
+  __shared__ float ta[FK][FT + 1], tb[FK][FT + 1];
+  const int n0 = blockIdx.x * FT, ny = Cin / FT, nsc = Cout / 256;
+  const int KE = Cout + Cin;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  if ((int)blockIdx.y < ny) {
+    const int j0 = blockIdx.y * FT;
+    float acc = 0.f;
+    for (int k0 = 0; k0 < Cout; k0 += FK) {
+      for (int e = threadIdx.x; e < FK * FT; e += 256) {
+        const int kk = e / FT, c = e % FT;
+        ta[kk][c] = bf2f(wf[(size_t)(k0 + kk) * Cin + n0 + c]) * cB[k0 + kk];
+        tb[kk][c] = bf2f(wf[(size_t)(k0 + kk) * Cin + j0 + c]);
+      }
+      __syncthreads();
+#pragma unroll 16
+      for (int kk = 0; kk < FK; ++kk) acc = fmaf(ta[kk][ty], tb[kk][tx], acc);
+      __syncthreads();
+    }
+    wext[(size_t)(n0 + ty) * KE + Cout + j0 + tx] = f2bf(acc);
+  } else if ((int)blockIdx.y < ny + nsc) {
+    const int k0 = ((int)blockIdx.y - ny) * 256;
+    for (int e = threadIdx.x; e < FT * 256; e += 256) {
+      const int r = e >> 8, k = k0 + (e & 255);
+      wext[(size_t)(n0 + r) * KE + k] = f2bf(cA[k] * bf2f(wb[(size_t)(n0 + r) * Cout + k]));
+    }
+  }
+}
+
+// bias[n] = - sum_K avg[K] wt_ext[n][K], avg = [colsum(g) / rows (Cout) | colsum(x) / rows (Cin)]: the constant terms of the apply pass are the MEANS of the two virtual-concat
+// inputs against the ROUNDED extended weight (cC = -cA mean(g), cB mean = cB mean(x) W^T), so a rounding error of a weight multiplies a centred input, as in the unfolded
+// pass -- formed from the unrounded (cC - cB mean) W the bias left the bf16 rounding of W^T diag(cB) W against the uncentred x (bn2's gradients: cosine 0.978 vs the oracle).
+// One wave per output channel, fixed-order tree.
+__global__ __launch_bounds__(64) void bn_fold_bias_kernel(const bf16_t* __restrict__ wext, const float* __restrict__ gsum, const float* __restrict__ xsum, float inv_rows,
+                                                          float* __restrict__ bias, int Cout, int Cin) {
+  const int n = blockIdx.x, KE = Cout + Cin;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < KE; k += 64) s = fmaf((k < Cout ? gsum[k] : xsum[k - Cout]) * inv_rows, bf2f(wext[(size_t)n * KE + k]), s);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) bias[n] = -s;
+}
+
+// dw [Cout][Cin] in: G1 = g^T x, out: diag(cA) G1 + diag(cB) W G2 + (cC - cB mean) (x) s.   grid (Cin / 16, Cout / 16)
+__global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(float* __restrict__ dw, const float* __restrict__ G2, const float* __restrict__ s, const bf16_t* __restrict__ wf,
+                                                            const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, const float* __restrict__ mean,
+                                                            int Cout, int Cin) {
+  __shared__ float tw[FT][FK + 1], tg[FK][FT + 1];
+  const int j0 = blockIdx.x * FT, k0 = blockIdx.y * FT;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc = 0.f;
+  for (int i0 = 0; i0 < Cin; i0 += FK) {
+    for (int e = threadIdx.x; e < FT * FK; e += 256) {
+      const int r = e / FK, c = e % FK;
+      tw[r][c] = bf2f(wf[(size_t)(k0 + r) * Cin + i0 + c]);
+    }
+    for (int e = threadIdx.x; e < FK * FT; e += 256) {
+      const int r = e / FT, c = e % FT;
+      tg[r][c] = G2[(size_t)(i0 + r) * Cin + j0 + c];
+    }
+    __syncthreads();
+#pragma unroll 16
+    for (int ii = 0; ii < FK; ++ii) acc = fmaf(tw[ty][ii], tg[ii][tx], acc);
+    __syncthreads();
+  }
+  const int k = k0 + ty, j = j0 + tx;
+  const size_t o = (size_t)k * Cin + j;
+  dw[o] = cA[k] * dw[o] + cB[k] * acc + (cC[k] - cB[k] * mean[k]) * s[j];
+}
+}  // namespace
+
+extern "C" int sl_bn_fold_weights(int Cout, int Cin, const void* w_fwd, const void* w_bwd, const float* cA, const float* cB, const float* g_colsum, const float* x_colsum,
+                                  long long rows, void* wt_ext, float* bias, sl_stream_t stream) {
+  SL_REQUIRE(w_fwd && w_bwd && cA && cB && g_colsum && x_colsum && wt_ext && bias && rows > 0, "bn_fold_weights: null buffer");
+  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % 256 == 0 && Cin % 16 == 0, "bn_fold_weights: Cout must be a multiple of 256 and Cin of 16 (got %d, %d)", Cout, Cin);
+  hipLaunchKernelGGL(bn_fold_weights_kernel, dim3(Cin / FT, Cin / FT + Cout / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (const bf16_t*)w_bwd, cA, cB,
+                     (bf16_t*)wt_ext, Cout, Cin);
+  SL_LAUNCH_CHECK("bn_fold_weights_kernel");
+  hipLaunchKernelGGL(bn_fold_bias_kernel, dim3(Cin), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)wt_ext, g_colsum, x_colsum, (float)(1.0 / (double)rows), bias, Cout, Cin);
+  SL_LAUNCH_CHECK("bn_fold_bias_kernel");
+  return 0;
+}
+
+extern "C" int sl_bn_fold_wgrad(int Cout, int Cin, float* dw, const float* xtx, const float* x_colsum, const void* w_fwd, const float* cA, const float* cB, const float* cC,
+                                const float* mean, sl_stream_t stream) {
+  SL_REQUIRE(dw && xtx && x_colsum && w_fwd && cA && cB && cC && mean, "bn_fold_wgrad: null buffer");
+  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 64 == 0, "bn_fold_wgrad: Cout must be a multiple of 16 and Cin of 64 (got %d, %d)", Cout, Cin);
+  hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(Cin / FT, Cout / FT), dim3(256), 0, (hipStream_t)stream, dw, xtx, x_colsum, (const bf16_t*)w_fwd, cA, cB, cC, mean, Cout, Cin);
+  SL_LAUNCH_CHECK("bn_fold_wgrad_kernel");
+  return 0;
+}

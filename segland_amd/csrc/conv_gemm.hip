@@ -325,6 +325,37 @@ extern "C" int sl_conv2d_bwd_data_bnstat(const SlConvDesc* d, const void* dy, co
   return run_gemm(d->dtype, p, (hipStream_t)stream);
 }
 
+// The same with the BatchNorm-backward APPLY pass of the conv's own output folded into the data gradient (resnet.py:66-70 backward of conv3 -> bn3, 1x1 convs):
+//   dc3 = cA g + cB (c3 - mean) + cC  and  c3 = a2 W3^T   =>   da2 = dc3 W3 = [g | a2] [diag(cA) W3 ; W3^T diag(cB) W3] + (cC - cB mean) W3
+// i.e. the data gradient reads the GATED incoming gradient g (Cout channels) and the conv's own input a2 (Cin channels) as one virtual concat against an extended
+// weight wt_ext [Cin][Cout + Cin] (sl_bn_fold_weights) plus a per-column bias; the apply pass over (g, c3) -- 6 bytes per element of the Cout-channel tensor -- and
+// the tensor dc3 disappear.  Served: the half-tile kernel's shapes (Cin % 256 == 0, whole 256-row tiles); rows of stat_partial as sl_conv2d_bwd_data_bnstat_rows(d).
+extern "C" int sl_conv2d_bwd_data_bnstat_folded_rows(const SlConvDesc* d) {
+  if (!d || d->dtype != SL_BF16 || d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad != 0 || d->H != d->Ho || d->W != d->Wo) return 0;
+  const long long M = (long long)d->B * d->H * d->W;
+  if (d->Cin % 256 || d->Cout % 64 || M % 256 || block_rows((int)M) != 256) return 0;
+  ConvGemmParams p{};
+  p.src1 = p.src2 = p.wt = p.out = (void*)g_cfg_dummy;
+  p.C1 = d->Cout; p.C2 = d->Cin; p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W; p.N = d->Cin; p.M = (int)M;
+  p.KH = p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.mode = 1; p.ksplit = 1;
+  p.gate = (const unsigned char*)g_cfg_dummy; p.bn_x = g_cfg_dummy; p.bn_mean = p.bn_invstd = p.bias = (const float*)g_cfg_dummy; p.stat_partial = (float*)g_cfg_dummy;
+  return choose_kernel(p, d->dtype) == 5256256 ? (int)(M / 256) : 0;
+}
+
+extern "C" int sl_conv2d_bwd_data_bnstat_folded(const SlConvDesc* d, const void* g, const void* x, const void* wt_ext, const float* bias, const uint8_t* gate, const void* bn_x,
+                                                const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream) {
+  if (int e = check_desc(d)) return e;
+  SL_REQUIRE(g && x && wt_ext && bias && dx && gate && bn_x && bn_mean && bn_invstd && stat_partial, "conv bwd_data_bnstat_folded: null buffer");
+  SL_REQUIRE(sl_conv2d_bwd_data_bnstat_folded_rows(d) > 0, "conv bwd_data_bnstat_folded: shape not served (sl_conv2d_bwd_data_bnstat_folded_rows == 0)");
+  ConvGemmParams p{};
+  p.src1 = g; p.src2 = x; p.C1 = d->Cout; p.C2 = d->Cin; p.wt = wt_ext; p.out = dx;
+  p.B = d->B; p.Hs = d->Ho; p.Ws = d->Wo; p.Hd = d->H; p.Wd = d->W;
+  p.N = d->Cin; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.dil = 1; p.mode = 1;
+  p.bias = bias; p.gate = gate; p.bn_x = bn_x; p.bn_mean = bn_mean; p.bn_invstd = bn_invstd; p.stat_partial = stat_partial;
+  p.M = d->B * d->H * d->W;
+  return run_gemm(d->dtype, p, (hipStream_t)stream);
+}
+
 // The same across a block boundary (resnet.py:71-78 backward): the data gradient of conv1 plus the shortcut gradient `addend` IS the gradient wrt the previous block's
 // output relu(bn3(c3) + res); gated with that ReLU's bits and reduced against c3 it hands the previous block its bn3 backward column sums -- its reduce pass over
 // (dout, c3) disappears, and dout arrives gated.  Served: the shapes of the pixel-stationary kernel (1x1, K = 64 / 128 / 256, N % 128 == 0, N <= 1024, M % 256 == 0).

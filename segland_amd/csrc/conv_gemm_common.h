@@ -465,7 +465,7 @@ __device__ __forceinline__ void conv_epilogue_generic(const ConvGemmParams& p, f
 // step, A/B/A/B on one box (profiles/r3_ab_gate_split.txt).
 // AFF: this instantiation carries the branch-free affine store phases (bias / folded BatchNorm / residual / GELU side output); the tile kernels always, the half-tile
 // kernel in an instantiation of its own (conv_gemm_p8_kernel<2>: inference convs and biased Linears with N % 256 == 0 on >= 24 576 rows).
-template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true, bool AFF = !SPLIT, bool SUBP = false>
+template <typename T, int BM, int BN, int WM, int WN, bool SPLIT = false, bool GATE = true, bool AFF = !SPLIT, bool SUBP = false, bool GATEB = false>
 __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16_t (&acc)[BM / WM / 32][BN / WN / 32], int bm, int bn, int wm, int wn,
                                                   int lane, int tid, unsigned char* smem) {
   const bool full = (bm + 1) * BM <= p.M;
@@ -485,6 +485,12 @@ __device__ __forceinline__ int conv_epilogue_lds(const ConvGemmParams& p, f32x16
     else if (p.addend) conv_epilogue_fast<T, BM, BN, WM, WN, 2, SPLIT, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     else conv_epilogue_fast<T, BM, BN, WM, WN, 1, SPLIT, true>(p, acc, bm, bn, wm, wn, lane, tid, smem);
     return -1;
+  }
+  if constexpr (GATEB) {
+    // conv_gemm_p8_kernel<3>: launched only for a gated data gradient with a bias (sl_conv2d_bwd_data_bnstat_folded) on whole tiles; the kernel has added the bias to the
+    // accumulators (one rounding of the centred value), the store phase is the plain gated-statistics one
+    conv_epilogue_fast<T, BM, BN, WM, WN, 3, SPLIT>(p, acc, bm, bn, wm, wn, lane, tid, smem);
+    return SPLIT ? 49 : -1;
   }
   if constexpr (GATE) {
     if (full && !shaped && !p.addend && p.gate) {

@@ -98,9 +98,9 @@ __device__ __forceinline__ int p8_slot_a1(int par) { return (par ? 2 : 7) * P8_S
 __device__ __forceinline__ int p8_slot_b1(int par) { return (par ? 3 : 8) * P8_SLOT; }
 __device__ __forceinline__ int p8_slot_b0(int j) { return (j == 0 ? 9 : j + 3) * P8_SLOT; }
 
-template <int EPI>       // 0: the store phases without MODE 3, 1: with the gated-statistics store phase (MODE 3), 2: with the affine store phases (inference convs, biased Linears)
+template <int EPI>       // 0: the store phases without MODE 3, 1: with the gated-statistics store phase (MODE 3), 2: with the affine store phases (inference convs, biased Linears), 3: MODE 3 + bias only
 __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
-  constexpr bool GATE = EPI == 1, AFF = EPI == 2;
+  constexpr bool GATE = EPI == 1, AFF = EPI == 2, GATEB = EPI == 3;
   using T = bf16_t;
   constexpr int BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -259,6 +259,19 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       s3 = s3 == 2 ? 0 : s3 + 1;
     }
     if (p.trace && tile == (int)blockIdx.x) tr2 = __builtin_amdgcn_s_memtime();
+    if constexpr (GATEB) {
+      // the per-column bias joins the fp32 accumulators (accumulator block [.][j], registers 4 q + e = columns j 128 + wn 32 + 8 q + 4 (lane >> 5) + e, as epi_stage_acc stages
+      // them): loaded HERE, in front of the next tile's first LDS-DMA, so the counted waits of the next prologue are unchanged
+      const int fh = lane >> 5;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b4 = *(const float4*)(p.bias + bn * BN + j * (BN / 2) + wn * (BN / 8) + 8 * q + 4 * fh);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc[i][j][4 * q + 0] += b4.x; acc[i][j][4 * q + 1] += b4.y; acc[i][j][4 * q + 2] += b4.z; acc[i][j][4 * q + 3] += b4.w; }
+        }
+    }
     lds_barrier();
     // every slot is idle: the next tile's row map, weight rows and first K-tile go out now and land under the epilogue (slots 6-9; the staging passes use 0-5)
     const int cbm = bm, cbn = bn;
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(512) void conv_gemm_p8_kernel(ConvGemmParams p) {
       setup(bm, bn);
       issue_first();
     }
-    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE, AFF>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
+    younger = conv_epilogue_lds<T, BM, BN, 2, 4, true, GATE, AFF, false, GATEB>(p, acc, cbm, cbn, wm, wn, lane, tid, smem);
     if (!counted) younger = 0;
     lds_barrier();                              // statistic partials are read from the staging area: the next tile's second K-tile goes to slots inside it
   }
@@ -297,11 +310,15 @@ int slconv::launch_p8(ConvGemmParams& p, hipStream_t st) {
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_p8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P8_LDS);
     attr_set = true;
   }
   const int ntiles = p.gridM * p.gridN;
   // persistent: min(tiles, 256) blocks walk over the tiles; the instantiation with the gated-statistics store phase only where it is used
-  if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<1>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  if (p.gate && p.bias) {
+    if (p.M % 256 || p.addend || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) { sl_set_error("conv p8: gated data gradient with a bias: whole 256-row tiles and no other store-phase operand"); return SL_EINVAL; }
+    hipLaunchKernelGGL(conv_gemm_p8_kernel<3>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
+  } else if (p.gate) hipLaunchKernelGGL(conv_gemm_p8_kernel<1>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   else if ((p.bias || p.scale) && !p.stat_partial) hipLaunchKernelGGL(conv_gemm_p8_kernel<2>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   else        hipLaunchKernelGGL(conv_gemm_p8_kernel<0>, dim3(ntiles > 256 ? 256 : ntiles), dim3(512), P8_LDS, st, p);
   SL_LAUNCH_CHECK("conv_gemm_p8_kernel");

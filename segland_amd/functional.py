@@ -246,6 +246,7 @@ def _frozen(ctx, *bns):
 
 _PPM_WGRAD_GROUPED = True  # test hook: the pyramid's eight row-GEMM weight gradients as two grouped launches (ops.ppm_rows_wgrad); False: one generic weight-gradient launch + slab reduce per level
 _STAGE_BN_GROUPED = True   # test hook: the pyramid stages' BatchNorm backward in one launch (ops.ppm_stage_bn_bwd); SyncBatchNorm stages always take the per-level chain
+_BN3_FOLD = False          # test hook (default OFF: built and measured 678.3 vs 679.7 tiles/s, profiles/r6_ab_bn3_fold.txt): bn3's backward apply pass folded into conv3's data and weight gradient where the incoming gradient arrived gated and reduced
 _WGRAD_BATCH = False       # test hook: the flat slab reduces of a bottleneck's 1x1 weight gradients in one launch (ops.WgradBatch).  Measured NEGATIVE on the ResNet-50 step (691.1 vs 693.2 tiles/s, profiles/r6_ab_r50_wbatch.txt: the deferred reduce reads cold slabs); kept for the Swin blocks, whose slabs are small
 _DS_HALF = True            # test hook: the data gradient of a stride-2 1x1 downsample conv stays on its own grid (conv2d_bwd_data_addend_half)
 _BASE_CHAIN_CACHE = True   # test hook: ft mode, the frozen base classifier's rows are computed once (False: every iteration)
@@ -432,8 +433,26 @@ class BottleneckFn(torch.autograd.Function):
         prevd = plink.bnd if prev3 is not None else None
         want_dres = prev3 is not None and not ctx.has_ds and k3 is not None and p3 is None and done3 is None
         wbatch = ops.WgradBatch() if (need_w and _WGRAD_BATCH) else None       # the 1x1 convs' slab reduces of this block: one launch at the end (round 6)
-        da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,
-                                                   below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres, wbatch=wbatch)
+        fold = (_BN3_FOLD and p3 is not None and not ctx.has_ds and need_w and blk.bn3.training and blk.bn2.training and not sync_world(blk.bn3) and k2 is not None
+                and ops.conv2d_bwd_data_bnstat_folded_ok(a2, spec_of(blk.conv3)))
+        if fold:
+            # bn3's apply pass folded into conv3's two gradients: dout arrived gated with its column sums; dc3 is never formed
+            spec3 = spec_of(blk.conv3)
+            g3_, b3_ = grad_dst(blk.bn3.weight), grad_dst(blk.bn3.bias)
+            rows3 = c3.numel() // c3.shape[-1]
+            cA, cB, cC, dg3, db3 = ops.bn_bwd_coeffs(p3, rows3, blk.bn3.weight, m3, i3, dgamma_out=g3_, dbeta_out=b3_)
+            wf3, wb3 = prepared(blk.conv3.weight, c3.dtype)
+            xtx, xsum = ops.conv2d_bwd_weight_bias(a2, a2, ConvSpec(spec3.cin, spec3.cin, 1, 1, 0, 1))      # x^T x and colsum(x) of conv3's input
+            wext, vbias = ops.bn_fold_weights(wf3, wb3, cA, cB, db3, xsum, rows3)
+            dg3, db3 = grad_alias(dg3, g3_), grad_alias(db3, b3_)
+            da2, p2 = ops.conv2d_bwd_data_bnstat_folded(dout, a2, wext, vbias, spec3, k2, c2, m2, i2)
+            gw3 = grad_dst(blk.conv3.weight)
+            dw3 = ops.conv2d_bwd_weight(a2, dout, spec3, out=gw3)
+            dw3 = grad_alias(ops.bn_fold_wgrad(dw3, xtx, xsum, wf3, cA, cB, cC, m3), gw3)
+            dres = None
+        else:
+            da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,
+                                                       below=(k2, c2, m2, i2) if blk.bn2.training else None, bn_done=done3, want_dres=want_dres, wbatch=wbatch)
         da1, dw2, dg2, db2, _, p1 = conv_bn_bwd(da2, None, c2, a1, blk.conv2, blk.bn2, m2, i2, True, need_w, bits=None if p2 is not None else k2, pre_partial=p2,
                                                 below=(k1, c1, m1, i1) if blk.bn1.training else None, wbatch=wbatch)
         grads_ds = ()

@@ -45,4 +45,5 @@ class OrthLoss(nn.Module):
             aux_loss = self.seg_loss(aux_preds, target)
             total = seg_loss + orth_loss * self.w + 0.4 * aux_loss
             return {'total_loss': total, 'seg_loss': seg_loss, 'aux_loss': aux_loss, 'orth_loss': orth_loss}
-        return {'total_loss': seg_loss + orth_loss * self.w, 'seg_loss': seg_loss, 'orth_loss': orth_loss}
+        # one launch each way (add with alpha; its backward is one scale) instead of mul + add
+        return {'total_loss': torch.add(seg_loss, orth_loss, alpha=self.w), 'seg_loss': seg_loss, 'orth_loss': orth_loss}

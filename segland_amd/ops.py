@@ -581,6 +581,63 @@ def bn_bwd(dy, y, x, mean, invstd, gamma, train=True, want_dres=False, mask=None
     return dx, dres, dg, db
 
 
+def bn_bwd_coeffs(part, rows, gamma, mean, invstd, dgamma_out=None, dbeta_out=None):
+    """Train-mode BatchNorm backward up to the coefficients: (cA, cB, cC, dgamma, dbeta) with dx = cA dy + cB (x - mean) + cC, from the column-sum partials a data-gradient
+    epilogue produced (no reduce pass, no apply pass: the caller folds the apply into the next kernels, bn_fold_weights / bn_fold_wgrad)."""
+    Cn = part.shape[-1]
+    o = _f32((5, Cn), part.device)
+    dg = o[0] if dgamma_out is None else dgamma_out
+    db = o[1] if dbeta_out is None else dbeta_out
+    check(_lib.lib().sl_bn_bwd_finalize(_p(part), part.shape[0], Cn, int(rows), _p(gamma), _p(mean), _p(invstd), 1, _p(dg), _p(db), _p(o[2]), _p(o[3]), _p(o[4]), _s()),
+          'bn_bwd_finalize')
+    return o[2], o[3], o[4], dg, db
+
+
+def conv2d_bwd_data_bnstat_folded_ok(x, spec):
+    """Would conv2d_bwd_data_bnstat_folded serve the data gradient of the 1x1 conv `spec` on input x [B,H,W,Cin]?"""
+    if x.dtype != torch.bfloat16 or spec.k != 1:
+        return False
+    B, H, W, _ = x.shape
+    return _lib.lib().sl_conv2d_bwd_data_bnstat_folded_rows(C.byref(conv_desc(x.dtype, B, H, W, spec, None))) > 0
+
+
+def bn_fold_weights(wf, wb, cA, cB, gsum, xsum, rows):
+    """(wt_ext [Cin][Cout + Cin] bf16, bias [Cin]) of conv2d_bwd_data_bnstat_folded from the layer's prepared weights wf [Cout][Cin], wb [Cin][Cout], the BatchNorm-backward
+    coefficients of its output (bn_bwd_coeffs) and the column sums of the two inputs (gsum = dbeta, xsum = colsum(x))."""
+    Cout, Cin = cA.numel(), xsum.numel()
+    assert wf.numel() == Cout * Cin == wb.numel() and wf.dtype == torch.bfloat16 and gsum.numel() == Cout and gsum.is_contiguous() and xsum.is_contiguous()
+    wext = torch.empty((Cin, Cout + Cin), dtype=torch.bfloat16, device=wf.device)
+    bias = _f32((Cin,), wf.device)
+    check(_lib.lib().sl_bn_fold_weights(Cout, Cin, _p(wf), _p(wb), _p(cA), _p(cB), _p(gsum), _p(xsum), int(rows), _p(wext), _p(bias), _s()), 'bn_fold_weights')
+    return wext, bias
+
+
+def bn_fold_wgrad(dw, xtx, xsum, wf, cA, cB, cC, mean):
+    """In place on dw = g^T x [Cout][Cin]: the weight gradient of a 1x1 conv whose output BatchNorm's apply pass was folded (xtx = x^T x, xsum = colsum(x))."""
+    Cout, Cin = cA.numel(), xsum.numel()
+    assert dw.numel() == Cout * Cin and dw.is_contiguous() and xtx.numel() == Cin * Cin and xtx.is_contiguous() and dw.dtype == torch.float32 == xtx.dtype
+    check(_lib.lib().sl_bn_fold_wgrad(Cout, Cin, _p(dw), _p(xtx), _p(xsum), _p(wf), _p(cA), _p(cB), _p(cC), _p(mean), _s()), 'bn_fold_wgrad')
+    return dw
+
+
+def conv2d_bwd_data_bnstat_folded(g, x, wext, bias, spec, gate, bn_x, mean, invstd):
+    """Data gradient of the 1x1 conv `spec` (input x, gated incoming gradient g of its BatchNorm's output) with that BatchNorm's backward apply pass folded into the weights
+    (bn_fold_weights); the result is gated with `gate` and reduced against bn_x as in conv2d_bwd_data_bnstat.  -> (dx, partial)."""
+    B, H, W, _ = x.shape
+    d = conv_desc(x.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    rows = L.sl_conv2d_bwd_data_bnstat_folded_rows(C.byref(d))
+    assert rows > 0
+    dx = torch.empty((B, H, W, spec.cin), dtype=x.dtype, device=x.device)
+    part = _f32((rows, 2, spec.cin), x.device)
+    tok = PROFILER.begin('conv_dgrad', d, EPI_GATE)
+    check(L.sl_conv2d_bwd_data_bnstat_folded(C.byref(d), _p(g), _p(x), _p(wext), _p(bias), _p(gate), _p(bn_x), _p(mean), _p(invstd), _p(dx), _p(part), _s()),
+          'conv2d_bwd_data_bnstat_folded')
+    if tok is not None:
+        PROFILER.end(tok, bn_x.numel() * bn_x.element_size() + gate.numel() + x.numel() * x.element_size())
+    return dx, part
+
+
 def bn_bwd2(dy, mask, x1, mean1, invstd1, gamma1, x2, mean2, invstd2, gamma2, outs1=(None, None), outs2=(None, None), pre_partials=None):
     """Train-mode backward of TWO BatchNorms whose outputs were added before one ReLU (bn3 + downsample BN, resnet.py:71-76): both see the gradient
     dy gated by `mask`; dy and the bits are swept once per pass for both.  -> (dx1, dgamma1, dbeta1, dx2, dgamma2, dbeta2).

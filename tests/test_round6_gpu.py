@@ -387,3 +387,69 @@ def test_bottleneck_weight_gradient_reduces_in_one_launch_are_bit_identical(hip,
             sf._WGRAD_BATCH = old
     for k in outs[True]:
         assert torch.equal(outs[True][k], outs[False][k]), (k, float((outs[True][k].float() - outs[False][k].float()).abs().max()))
+
+
+def test_bn3_apply_pass_folded_into_conv3_gradients(hip):
+    """BatchNorm-backward apply pass of bn3 folded into conv3's data and weight gradient (functional._BN3_FOLD): three identity bottlenecks at a layer3-like
+    shape (1024 / 256 channels, 65 536 rows, dilation 2) -- the two upper blocks receive their incoming gradient gated and reduced by the block behind (MODE 5) and take
+    the folded path.  (1) it engages (bn_bwd_apply launches drop by two, the half-tile kernel serves the K = 1280 data gradient); (2) output gradient and every parameter
+    gradient agree with the unfolded path to bf16 rounding of the tensor that is no longer formed (relative L2 <= 1.5e-2, cosine >= 0.9998)."""
+    from segland_amd import functional as sf, ops
+    from segland_amd.functional import flush_num_batches_tracked
+    from segland_amd.networks.backbones.resnet import Bottleneck
+    torch.manual_seed(21)
+    blocks = nn.Sequential(*[Bottleneck(1024, 256, stride=1, dilation=2) for _ in range(3)]).to(DEV).train()
+    with torch.no_grad():
+        for m in blocks.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.2, 0.2)
+    for i in (1, 2):
+        blocks[i].__dict__['_sl_prev'] = blocks[i - 1]
+    x = torch.randn(16, 64, 64, 1024, device=DEV).relu_().to(torch.bfloat16)      # 65 536 rows: the pixel-stationary kernel's cross-block statistics need them
+    coef = torch.randn(16, 64, 64, 1024, device=DEV)
+    outs, applies = {}, {}
+    for on in (True, False):
+        old = sf._BN3_FOLD
+        sf._BN3_FOLD = on
+        try:
+            blocks.zero_grad(set_to_none=True)
+            xg = x.clone().requires_grad_(True)
+            ops.PROFILER.start()
+            y = blocks(xg)
+            (y.float() * coef).sum().backward()
+            table = ops.PROFILER.stop()
+            tb = ops.PROFILER.stop_bytes()
+            flush_num_batches_tracked()
+            applies[on] = tb.get('bn_bwd_apply', {}).get('calls', 0)
+            outs[on] = {k: p.grad.clone() for k, p in blocks.named_parameters()} | {'x': xg.grad.clone()}
+        finally:
+            sf._BN3_FOLD = old
+    assert applies[False] - applies[True] == 2, applies
+    # against the fp32 CPU oracle of the same three blocks: the folded path must be about as close to it as the unfolded one (within 25 %: it skips a bf16 rounding of dc3, but rounds the
+    # folded weights; the bias is formed from the input means so that weight rounding meets centred inputs)
+    from oracle import pop_oracle as po
+    oracles = [po.make_bottleneck(1024, 256, 1, 2, False) for _ in range(3)]
+    for b_, o in zip(blocks, oracles):
+        sd = {k: v.detach().float().cpu() for k, v in b_.state_dict().items()}
+        for k in list(sd):
+            if k.endswith('conv1.weight') or k.endswith('conv2.weight') or k.endswith('conv3.weight'):
+                sd[k] = sd[k].to(torch.bfloat16).float()
+        o.load_state_dict(sd); o.train()
+    xo = x.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    yo = xo
+    for o in oracles:
+        yo = po.bottleneck_forward(o, yo)
+    (yo * coef.cpu().permute(0, 3, 1, 2)).sum().backward()
+    ref = {'x': xo.grad.permute(0, 2, 3, 1)}
+    for i, o in enumerate(oracles):
+        for k, p_ in o.named_parameters():
+            ref['%d.%s' % (i, k)] = p_.grad
+    worst, bad = (0.0, None), []
+    for k in outs[True]:
+        r = ref[k].double().reshape(-1)
+        ef, eu = (float((outs[v][k].double().cpu().reshape(-1) - r).norm() / r.norm()) for v in (True, False))
+        worst = max(worst, (ef / max(eu, 1e-6), k))
+        print('   %-22s folded %.4f unfolded %.4f' % (k, ef, eu))
+        bad = bad + [(k, ef, eu)] if ef > 1.25 * eu + 2e-3 else bad
+    assert not bad, bad
+    print('folded vs unfolded error against the oracle: worst ratio %.3f (%s)' % worst)

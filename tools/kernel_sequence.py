@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Kernels of ONE step in launch order, with the idle time in front of each, from a rocprofv3 --kernel-trace database.  Steps are told apart
-by their optimizer kernel (adamw_multi_kernel ends a step).  usage: kernel_sequence.py <rocprof dir> <step index, negative from the end> <out.txt>"""
+by their optimizer kernel (adamw_multi_kernel / sgd_multi_kernel ends a step).  usage: kernel_sequence.py <rocprof dir> <step index, negative from the end> <out.txt>"""
 import glob, re, sqlite3, sys
 path, which, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 db = sqlite3.connect(glob.glob(path + '/**/*.db', recursive=True)[0])
@@ -8,7 +8,7 @@ rows = list(db.execute("select name, start, end from kernels order by start"))
 steps, cur = [], []
 for r in rows:
     cur.append(r)
-    if 'adamw_multi_kernel' in r[0]:
+    if 'adamw_multi_kernel' in r[0] or 'sgd_multi_kernel' in r[0]:
         steps.append(cur); cur = []
 # the requested step, unless the profiler stalled inside it (a trace flush shows up as gaps of tens of microseconds to milliseconds between graph nodes): then the step with the
 # shortest wall time among the graph-replayed steps (the second half of the run) is shown instead and the header says so
