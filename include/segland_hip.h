@@ -141,16 +141,20 @@ int sl_conv2d_bwd_data_addend_half(const SlConvDesc* d, const void* dy, const vo
  * gradient g arrived gated and reduced): with dc = cA g + cB (c - mean) + cC (sl_bn_bwd_finalize) and c = x W^T,
  *   dx = [g | x] wt_ext^T + bias,  wt_ext [Cin][Cout + Cin] = [diag(cA) W ; W^T diag(cB) W]^T, bias = (cC - cB mean) W = -[mean(g) | mean(x)] wt_ext^T      (sl_bn_fold_weights; w_fwd [Cout][Cin] /
  *        w_bwd [Cin][Cout] are the layer's prepared bf16 weights), gated with the ReLU bits of x's own BatchNorm + its column sums as in sl_conv2d_bwd_data_bnstat;
- *   dW = diag(cA) (g^T x) + diag(cB) W (x^T x) + (cC - cB mean) (x) colsum(x)      (sl_bn_fold_wgrad, in place on dw = g^T x; xtx = x^T x [Cin][Cin], both from
- *        sl_conv2d_bwd_weight(_bias)).
+ *   dW = diag(cA) (g^T x) + diag(cB) W (x^T x) + (cC - cB mean) (x) colsum(x)      (sl_bn_fold_wgrad; g^T x, x^T x [Cin][Cin] and colsum(x) from ONE launch of
+ *        sl_conv2d_bwd_weight_dy2).
  * The pass over (g, c) and the tensor dc never exist.  Served (rows > 0): bf16 1x1 stride-1 layers with Cin % 256 == 0 on whole 256-row tiles (the half-tile kernel). */
 int sl_conv2d_bwd_data_bnstat_folded_rows(const SlConvDesc* d);
 int sl_conv2d_bwd_data_bnstat_folded(const SlConvDesc* d, const void* g, const void* x, const void* wt_ext, const float* bias, const uint8_t* gate, const void* bn_x,
                                      const float* bn_mean, const float* bn_invstd, void* dx, float* stat_partial, sl_stream_t stream);
 int sl_bn_fold_weights(int Cout, int Cin, const void* w_fwd, const void* w_bwd, const float* cA, const float* cB, const float* g_colsum, const float* x_colsum,
                        long long rows, void* wt_ext, float* bias, sl_stream_t stream);       /* g_colsum = dbeta of the BatchNorm, x_colsum = colsum(x): the bias is formed from the two means */
-int sl_bn_fold_wgrad(int Cout, int Cin, float* dw, const float* xtx, const float* x_colsum, const void* w_fwd, const float* cA, const float* cB, const float* cC,
-                     const float* mean, sl_stream_t stream);
+int sl_bn_fold_wgrad(int Cout, int Cin, const float* gtx, float* dw, const float* xtx, const float* x_colsum, const void* w_fwd, const float* cA, const float* cB,
+                     const float* cC, const float* mean, sl_stream_t stream);       /* gtx = g^T x [Cout][Cin] (may be dw itself) */
+/* [dy1 | dy2]^T x in one launch: dw [d->Cout][d->Cin], d->Cout = Cout1 + the channels of dy2 (g^T x and x^T x of the fold above from one pass over x); colsum_partial
+ * [sl_conv2d_bwd_weight_bias_rows(d, 0, 0)][d->Cout] or NULL.  1x1 stride-1 bf16 layers on the LDS-DMA tile kernel, Cout1 a multiple of its row tile. */
+int sl_conv2d_bwd_weight_dy2(const SlConvDesc* d, const void* x, const void* dy1, const void* dy2, int Cout1, float* dw, void* workspace, size_t workspace_bytes,
+                             float* colsum_partial, sl_stream_t stream);
 
 /* The dual form: the previous block is the FIRST bottleneck of a stage, whose output ReLU sits behind bn3 AND the downsample BatchNorm (resnet.py:71-76): the gated
  * gradient is reduced against both BatchNorm inputs in one store loop.  stat_partial / stat_partial2: [rows][2][Cin] each, (sum g, sum g * xhat) per BatchNorm

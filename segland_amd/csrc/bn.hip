@@ -457,37 +457,50 @@ extern "C" int sl_bn_bwd_apply2(int dtype, const void* dy, const uint8_t* relu_m
 //   dW = dc^T x    = diag(cA) (g^T x) + diag(cB) W (x^T x) + (cC - cB mean) (x) colsum(x)   (sl_bn_fold_wgrad on the raw products g^T x, x^T x)
 // W is the bf16 weight the forward multiplied (c was produced with it).  Both kernels are small GEMMs on 16 x 16 output tiles staged through the LDS.
 namespace {
-constexpr int FT = 16, FK = 64;
+constexpr int FT = 16;
+constexpr int FKW = 512;          // reduction elements staged per round trip (global -> LDS -> barrier): the kernels are bound by the NUMBER of round trips, not by their FLOPs
+constexpr int FKG = 256;
 
-// wt_ext [Cin][Cout + Cin] (bf16), bias [Cin].  grid (Cin / 16, Cin / 16 + Cout / 256 + 1):
-//   y <  Cin / 16           : the tile (n0, j0) of W^T diag(cB) W
-//   y <  Cin / 16 + Cout/256: columns [256 (y - Cin/16), +256) of diag(cA) W, rows n0 .. n0 + 15 (from the transposed weight w_bwd: coalesced both ways)
+// wt_ext [Cin][Cout + Cin] (bf16).  grid (Cin / 16, Cin / 16 + Cout / 256):
+//   y <  Cin / 16 : the tile (n0, j0) of W^T diag(cB) W
+//   else          : columns [256 (y - Cin/16), +256) of diag(cA) W, rows n0 .. n0 + 15 (from the transposed weight w_bwd: coalesced both ways)
 __global__ __launch_bounds__(256) void bn_fold_weights_kernel(const bf16_t* __restrict__ wf, const bf16_t* __restrict__ wb, const float* __restrict__ cA, const float* __restrict__ cB,
                                                               bf16_t* __restrict__ wext, int Cout, int Cin) {
-  __shared__ float ta[FK][FT + 1], tb[FK][FT + 1];
-  const int n0 = blockIdx.x * FT, ny = Cin / FT, nsc = Cout / 256;
+  extern __shared__ float fsm[];                       // ta [FKW][17], tb [FKW][17]
+  float (*ta)[FT + 1] = (float (*)[FT + 1])fsm;
+  float (*tb)[FT + 1] = (float (*)[FT + 1])(fsm + FKW * (FT + 1));
+  const int n0 = blockIdx.x * FT, ny = Cin / FT;
   const int KE = Cout + Cin;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   if ((int)blockIdx.y < ny) {
     const int j0 = blockIdx.y * FT;
     float acc = 0.f;
-    for (int k0 = 0; k0 < Cout; k0 += FK) {
-      for (int e = threadIdx.x; e < FK * FT; e += 256) {
-        const int kk = e / FT, c = e % FT;
-        ta[kk][c] = bf2f(wf[(size_t)(k0 + kk) * Cin + n0 + c]) * cB[k0 + kk];
-        tb[kk][c] = bf2f(wf[(size_t)(k0 + kk) * Cin + j0 + c]);
+    for (int k0 = 0; k0 < Cout; k0 += FKW) {
+      // a thread loads 8 consecutive bf16 (16 bytes) of one weight row per tile and step: FKW rows x 2 x 16 bytes per tile, all loads of the chunk in flight together
+#pragma unroll
+      for (int u = 0; u < FKW * 2 / 256; ++u) {
+        const int e = threadIdx.x + 256 * u, kk = e >> 1, h = e & 1;
+        const float cb = cB[k0 + kk];
+        const uint4 va = *(const uint4*)(wf + (size_t)(k0 + kk) * Cin + n0 + 8 * h), vb = *(const uint4*)(wf + (size_t)(k0 + kk) * Cin + j0 + 8 * h);
+        const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wbv[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ta[kk][8 * h + 2 * q] = __uint_as_float(wa[q] << 16) * cb; ta[kk][8 * h + 2 * q + 1] = __uint_as_float(wa[q] & 0xffff0000u) * cb;
+          tb[kk][8 * h + 2 * q] = __uint_as_float(wbv[q] << 16);     tb[kk][8 * h + 2 * q + 1] = __uint_as_float(wbv[q] & 0xffff0000u);
+        }
       }
       __syncthreads();
 #pragma unroll 16
-      for (int kk = 0; kk < FK; ++kk) acc = fmaf(ta[kk][ty], tb[kk][tx], acc);
+      for (int kk = 0; kk < FKW; ++kk) acc = fmaf(ta[kk][ty], tb[kk][tx], acc);
       __syncthreads();
     }
     wext[(size_t)(n0 + ty) * KE + Cout + j0 + tx] = f2bf(acc);
-  } else if ((int)blockIdx.y < ny + nsc) {
+  } else {
     const int k0 = ((int)blockIdx.y - ny) * 256;
-    for (int e = threadIdx.x; e < FT * 256; e += 256) {
-      const int r = e >> 8, k = k0 + (e & 255);
-      wext[(size_t)(n0 + r) * KE + k] = f2bf(cA[k] * bf2f(wb[(size_t)(n0 + r) * Cout + k]));
+#pragma unroll
+    for (int u = 0; u < FT; ++u) {
+      const int k = k0 + threadIdx.x;
+      wext[(size_t)(n0 + u) * KE + k] = f2bf(cA[k] * bf2f(wb[(size_t)(n0 + u) * Cout + k]));
     }
   }
 }
@@ -495,50 +508,63 @@ __global__ __launch_bounds__(256) void bn_fold_weights_kernel(const bf16_t* __re
 // bias[n] = - sum_K avg[K] wt_ext[n][K], avg = [colsum(g) / rows (Cout) | colsum(x) / rows (Cin)]: the constant terms of the apply pass are the MEANS of the two virtual-concat
 // inputs against the ROUNDED extended weight (cC = -cA mean(g), cB mean = cB mean(x) W^T), so a rounding error of a weight multiplies a centred input, as in the unfolded
 // pass -- formed from the unrounded (cC - cB mean) W the bias left the bf16 rounding of W^T diag(cB) W against the uncentred x (bn2's gradients: cosine 0.978 vs the oracle).
-// One wave per output channel, fixed-order tree.
+// One wave per output channel (8 elements per lane and step, all loads in flight), fixed-order tree.
 __global__ __launch_bounds__(64) void bn_fold_bias_kernel(const bf16_t* __restrict__ wext, const float* __restrict__ gsum, const float* __restrict__ xsum, float inv_rows,
                                                           float* __restrict__ bias, int Cout, int Cin) {
   const int n = blockIdx.x, KE = Cout + Cin;
   float s = 0.f;
-  for (int k = threadIdx.x; k < KE; k += 64) s = fmaf((k < Cout ? gsum[k] : xsum[k - Cout]) * inv_rows, bf2f(wext[(size_t)n * KE + k]), s);
+  for (int k = threadIdx.x * 8; k < KE; k += 512) {
+    const uint4 v = *(const uint4*)(wext + (size_t)n * KE + k);
+    const float* av = k < Cout ? gsum + k : xsum + (k - Cout);            // Cout % 8 == 0: a vector lies on one side
+    const float4 a0 = *(const float4*)av, a1 = *(const float4*)(av + 4);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s = fmaf(a[2 * q], __uint_as_float(w[q] << 16), s); s = fmaf(a[2 * q + 1], __uint_as_float(w[q] & 0xffff0000u), s); }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (threadIdx.x == 0) bias[n] = -s;
+  if (threadIdx.x == 0) bias[n] = -s * inv_rows;
 }
 
-// dw [Cout][Cin] in: G1 = g^T x, out: diag(cA) G1 + diag(cB) W G2 + (cC - cB mean) (x) s.   grid (Cin / 16, Cout / 16)
-__global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(float* __restrict__ dw, const float* __restrict__ G2, const float* __restrict__ s, const bf16_t* __restrict__ wf,
+// dw [Cout][Cin] = diag(cA) G1 + diag(cB) W G2 + (cC - cB mean) (x) s, G1 = g^T x (may be dw itself).   grid (Cin / 16, Cout / 16)
+__global__ __launch_bounds__(256) void bn_fold_wgrad_kernel(const float* G1, float* dw, const float* __restrict__ G2, const float* __restrict__ s, const bf16_t* __restrict__ wf,
                                                             const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cC, const float* __restrict__ mean,
                                                             int Cout, int Cin) {
-  __shared__ float tw[FT][FK + 1], tg[FK][FT + 1];
+  __shared__ float tw[FT][FKG + 1], tg[FKG][FT + 1];
   const int j0 = blockIdx.x * FT, k0 = blockIdx.y * FT;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   float acc = 0.f;
-  for (int i0 = 0; i0 < Cin; i0 += FK) {
-    for (int e = threadIdx.x; e < FT * FK; e += 256) {
-      const int r = e / FK, c = e % FK;
+  for (int i0 = 0; i0 < Cin; i0 += FKG) {
+#pragma unroll
+    for (int u = 0; u < FT * FKG / 256; ++u) {
+      const int e = threadIdx.x + 256 * u, r = e / FKG, c = e % FKG;
       tw[r][c] = bf2f(wf[(size_t)(k0 + r) * Cin + i0 + c]);
     }
-    for (int e = threadIdx.x; e < FK * FT; e += 256) {
-      const int r = e / FT, c = e % FT;
+#pragma unroll
+    for (int u = 0; u < FKG * FT / 256; ++u) {
+      const int e = threadIdx.x + 256 * u, r = e / FT, c = e % FT;
       tg[r][c] = G2[(size_t)(i0 + r) * Cin + j0 + c];
     }
     __syncthreads();
 #pragma unroll 16
-    for (int ii = 0; ii < FK; ++ii) acc = fmaf(tw[ty][ii], tg[ii][tx], acc);
+    for (int ii = 0; ii < FKG; ++ii) acc = fmaf(tw[ty][ii], tg[ii][tx], acc);
     __syncthreads();
   }
   const int k = k0 + ty, j = j0 + tx;
   const size_t o = (size_t)k * Cin + j;
-  dw[o] = cA[k] * dw[o] + cB[k] * acc + (cC[k] - cB[k] * mean[k]) * s[j];
+  dw[o] = cA[k] * G1[o] + cB[k] * acc + (cC[k] - cB[k] * mean[k]) * s[j];
 }
 }  // namespace
 
 extern "C" int sl_bn_fold_weights(int Cout, int Cin, const void* w_fwd, const void* w_bwd, const float* cA, const float* cB, const float* g_colsum, const float* x_colsum,
                                   long long rows, void* wt_ext, float* bias, sl_stream_t stream) {
   SL_REQUIRE(w_fwd && w_bwd && cA && cB && g_colsum && x_colsum && wt_ext && bias && rows > 0, "bn_fold_weights: null buffer");
-  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % 256 == 0 && Cin % 16 == 0, "bn_fold_weights: Cout must be a multiple of 256 and Cin of 16 (got %d, %d)", Cout, Cin);
-  hipLaunchKernelGGL(bn_fold_weights_kernel, dim3(Cin / FT, Cin / FT + Cout / 256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_fwd, (const bf16_t*)w_bwd, cA, cB,
+  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % FKW == 0 && Cin % 16 == 0, "bn_fold_weights: Cout must be a multiple of %d and Cin of 16 (got %d, %d)", FKW, Cout, Cin);
+  const size_t lds = (size_t)2 * FKW * (FT + 1) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)bn_fold_weights_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+  hipLaunchKernelGGL(bn_fold_weights_kernel, dim3(Cin / FT, Cin / FT + Cout / 256), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)w_fwd, (const bf16_t*)w_bwd, cA, cB,
                      (bf16_t*)wt_ext, Cout, Cin);
   SL_LAUNCH_CHECK("bn_fold_weights_kernel");
   hipLaunchKernelGGL(bn_fold_bias_kernel, dim3(Cin), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)wt_ext, g_colsum, x_colsum, (float)(1.0 / (double)rows), bias, Cout, Cin);
@@ -546,11 +572,11 @@ extern "C" int sl_bn_fold_weights(int Cout, int Cin, const void* w_fwd, const vo
   return 0;
 }
 
-extern "C" int sl_bn_fold_wgrad(int Cout, int Cin, float* dw, const float* xtx, const float* x_colsum, const void* w_fwd, const float* cA, const float* cB, const float* cC,
-                                const float* mean, sl_stream_t stream) {
-  SL_REQUIRE(dw && xtx && x_colsum && w_fwd && cA && cB && cC && mean, "bn_fold_wgrad: null buffer");
-  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % 64 == 0, "bn_fold_wgrad: Cout must be a multiple of 16 and Cin of 64 (got %d, %d)", Cout, Cin);
-  hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(Cin / FT, Cout / FT), dim3(256), 0, (hipStream_t)stream, dw, xtx, x_colsum, (const bf16_t*)w_fwd, cA, cB, cC, mean, Cout, Cin);
+extern "C" int sl_bn_fold_wgrad(int Cout, int Cin, const float* gtx, float* dw, const float* xtx, const float* x_colsum, const void* w_fwd, const float* cA, const float* cB,
+                                const float* cC, const float* mean, sl_stream_t stream) {
+  SL_REQUIRE(gtx && dw && xtx && x_colsum && w_fwd && cA && cB && cC && mean, "bn_fold_wgrad: null buffer");
+  SL_REQUIRE(Cout > 0 && Cin > 0 && Cout % 16 == 0 && Cin % FKG == 0, "bn_fold_wgrad: Cout must be a multiple of 16 and Cin of %d (got %d, %d)", FKG, Cout, Cin);
+  hipLaunchKernelGGL(bn_fold_wgrad_kernel, dim3(Cin / FT, Cout / FT), dim3(256), 0, (hipStream_t)stream, gtx, dw, xtx, x_colsum, (const bf16_t*)w_fwd, cA, cB, cC, mean, Cout, Cin);
   SL_LAUNCH_CHECK("bn_fold_wgrad_kernel");
   return 0;
 }

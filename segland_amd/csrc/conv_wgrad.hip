@@ -22,6 +22,7 @@ namespace {
 struct WgradParams {
   const void* src1; const void* src2; int C1, C2;   // x (virtual concat)
   const void* dy;
+  const void* dy2; int Cout1;                       // conv_wgrad_glds_kernel only: output rows [Cout1, Cout) come from a SECOND gradient tensor dy2 of pitch Cout - Cout1 (sl_conv2d_bwd_weight_dy2); null: one tensor
   float* ws;                                        // [splits][Cout][taps][Cin]
   int B, H, W, Ho, Wo, Cout;
   int KH, KW, stride, pad, dil;
@@ -299,7 +300,10 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
   const T* xbase; int xpitch, xoff;
   if (c0 < p.C1) { xbase = (const T*)p.src1; xpitch = p.C1; xoff = c0; }
   else           { xbase = (const T*)p.src2; xpitch = p.C2; xoff = c0 - p.C1; }
-  const T* dyb = (const T*)p.dy + bn * BNN;
+  // two gradient tensors side by side (block-uniform: a tile never straddles Cout1, the entry point checks)
+  const bool dsec = p.dy2 && bn * BNN >= p.Cout1;
+  const T* dyb = dsec ? (const T*)p.dy2 + (bn * BNN - p.Cout1) : (const T*)p.dy + bn * BNN;
+  const int dpitch = p.dy2 ? (dsec ? p.Cout - p.Cout1 : p.Cout1) : p.Cout;
   const bool ident = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0);
 
   const int m_begin = split * p.rows_per_split;
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(64 * WNN * WCC) void conv_wgrad_glds_kernel(WgradPa
 #pragma unroll
     for (int j = 0; j < IA; ++j) {
       const int ins = wave * IA + j, r = ins * RPI_A + a_rin, m = m0 + r;
-      const void* src = (m < m_end) ? (const void*)(dyb + (size_t)m * p.Cout + (a_pos ^ ((r & 3) << 2)) * EPC) : (const void*)zsrc;
+      const void* src = (m < m_end) ? (const void*)(dyb + (size_t)m * dpitch + (a_pos ^ ((r & 3) << 2)) * EPC) : (const void*)zsrc;
       wglds16_asm(src, la + ins * 1024);
     }
 #pragma unroll
@@ -923,7 +927,8 @@ WgradPlan plan_shape(const SlConvDesc* d, long long M) {
     // few output tiles (a 256 x 1024 gradient is FOUR 256 x 256 tiles: 64 splits over the pixels, 64 MB of slabs for 1 MB of gradient): with at most four
     // 256 x 256 tiles (x taps) the n side drops to 128 rows, i.e. twice the tiles, half the splits and slab bytes.  Measured (profiles/r3_ab_wgrad_tiles.txt):
     // -0.16 ms per ResNet-50 step (the 1x1 256 <-> 1024 and 512 -> 512 gradients); with the 3x3 256 -> 256 layers included (nine tiles) +0.03, both sides at 128 slower
-    if (pl.bnn == 256 && pl.bcc == 256 && (long long)(d->Cout / 256) * (d->Cin / 256) * d->KH * d->KW <= 4) pl.bnn = 128;
+    // (<= 5 since round 6: the 1280 x 256 product [g | x]^T x of a folded BatchNorm apply pass, sl_conv2d_bwd_weight_dy2, needs the 128-row tile's in-kernel column sums)
+    if (pl.bnn == 256 && pl.bcc == 256 && (long long)(d->Cout / 256) * (d->Cin / 256) * d->KH * d->KW <= 5) pl.bnn = 128;
   } else {
     pl.bnn = d->Cout % 128 == 0 ? 128 : 64;
     pl.bcc = (d->C1 % 128 == 0 && c2 % 128 == 0) ? 128 : 64;
@@ -1035,7 +1040,7 @@ extern "C" int sl_conv2d_bwd_weight(const SlConvDesc* d, const void* x, const vo
 // dw may be a wider OIHW tensor [Cout][dw_cin_total][KH][KW]; this conv's Cin channels land at input-channel offset dw_ci_off
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                            int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid = 0, int c_valid = 0,
-                           SlWgradReduce* defer = nullptr);
+                           SlWgradReduce* defer = nullptr, const void* dy2 = nullptr, int cout1 = 0);
 
 extern "C" int sl_conv2d_bwd_weight_ex(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
                                        int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream) {
@@ -1085,6 +1090,14 @@ extern "C" int sl_wgrad_reduce_multi(const SlWgradReduce* items, int n, sl_strea
   return 0;
 }
 
+// Two gradient tensors side by side: dw [d->Cout][d->Cin] = [dy1 | dy2]^T x with dy1 [rows][Cout1], dy2 [rows][d->Cout - Cout1] (1x1 layers on the LDS-DMA tile kernel) --
+// g^T x and x^T x of a folded BatchNorm apply pass (sl_bn_fold_wgrad) from ONE pass over x.  colsum_partial as in sl_conv2d_bwd_weight_bias (may be NULL).
+extern "C" int sl_conv2d_bwd_weight_dy2(const SlConvDesc* d, const void* x, const void* dy1, const void* dy2, int Cout1, float* dw, void* workspace, size_t workspace_bytes,
+                                        float* colsum_partial, sl_stream_t stream) {
+  SL_REQUIRE(d && dy2 && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0, "conv bwd_weight_dy2: 1x1 stride-1 layers");
+  return bwd_weight_impl(d, x, nullptr, dy1, dw, d->Cin, 0, workspace, workspace_bytes, stream, colsum_partial, 0, 0, nullptr, dy2, Cout1);
+}
+
 // Does the weight-gradient kernel of this shape carry the bias-gradient partials itself (BIAS instantiation: one row per split, two for pixel pairs)?
 static bool wgrad_bias_fused(const SlConvDesc* d, const WgradPlan& pl) {      // test hook sl_debug_wgrad_bias(0): the column sums of dy back in the reduce launch
   return g_sl_debug.wgrad_bias && pl.glds && pl.taps == 1 && !(pl.bnn == 256 && pl.bcc == 256) && use_tr();
@@ -1101,7 +1114,8 @@ extern "C" int sl_conv2d_bwd_weight_bias_rows(const SlConvDesc* d, int n_valid, 
 }
 
 static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, const void* dy, float* dw, int dw_cin_total,
-                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid, SlWgradReduce* defer) {
+                           int dw_ci_off, void* workspace, size_t workspace_bytes, sl_stream_t stream, float* colsum_partial, int n_valid, int c_valid, SlWgradReduce* defer,
+                           const void* dy2, int cout1) {
   SL_REQUIRE(d && x && dy && dw && workspace, "conv bwd_weight: null buffer");
   if (defer) defer->splits = 0;           // 0 = nothing left to do (this path ran its own reduce)
   const int nv = n_valid > 0 ? n_valid : d->Cout, cv = c_valid > 0 ? c_valid : d->Cin;
@@ -1140,7 +1154,7 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
     SL_LAUNCH_CHECK("wgrad_reduce_kernel");
     return colsum_separately();
   }
-  if (c64p_eligible(d) && use_tr()) {
+  if (c64p_eligible(d) && use_tr() && !dy2) {
     const int nblk = c64p_blocks(d), nslab = c64p_slabs(d), ntiles = (int)((long long)d->B * d->H * d->W / CP_T);
     const size_t need = (size_t)(nslab + 1) * d->Cout * d->Cin * sizeof(float);       // the slabs + their sum
     if (workspace_bytes < need) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, need); return SL_EWORKSPACE; }
@@ -1169,6 +1183,12 @@ static int bwd_weight_impl(const SlConvDesc* d, const void* x, const void* x2, c
   if (workspace_bytes < pl.ws_bytes) { sl_set_error("conv bwd_weight: workspace %zu < %zu", workspace_bytes, pl.ws_bytes); return SL_EWORKSPACE; }
   WgradParams p{};
   p.src1 = x; p.src2 = x2; p.C1 = d->C1; p.C2 = c2; p.dy = dy; p.ws = (float*)workspace;
+  if (dy2) {
+    SL_REQUIRE(pl.glds && !pl.pair && pl.taps == 1 && use_tr() && d->dtype == SL_BF16 && cout1 > 0 && cout1 < d->Cout && cout1 % pl.bnn == 0 && (d->Cout - cout1) % 8 == 0,
+               "conv bwd_weight_dy2: served by the LDS-DMA tile kernel only, Cout1 (%d) a multiple of its %d-row tile", cout1, pl.bnn);
+    SL_REQUIRE(!colsum_partial || wgrad_bias_fused(d, pl), "conv bwd_weight_dy2: column sums only where the kernel forms them itself (two gradient tensors have no common pitch for a separate pass)");
+    p.dy2 = dy2; p.Cout1 = cout1;
+  }
   p.B = d->B; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
   p.M = d->B * d->Ho * d->Wo; p.rows_per_split = pl.rows_per_split;

@@ -442,13 +442,15 @@ class BottleneckFn(torch.autograd.Function):
             rows3 = c3.numel() // c3.shape[-1]
             cA, cB, cC, dg3, db3 = ops.bn_bwd_coeffs(p3, rows3, blk.bn3.weight, m3, i3, dgamma_out=g3_, dbeta_out=b3_)
             wf3, wb3 = prepared(blk.conv3.weight, c3.dtype)
-            xtx, xsum = ops.conv2d_bwd_weight_bias(a2, a2, ConvSpec(spec3.cin, spec3.cin, 1, 1, 0, 1))      # x^T x and colsum(x) of conv3's input
+            gx, gsum = ops.conv2d_bwd_weight_dy2(a2, dout, a2)      # [g | a2]^T a2 and the column sums of both from one pass over a2
+            n3 = spec3.cout
+            xtx, xsum = gx[n3:], gsum[n3:]
             wext, vbias = ops.bn_fold_weights(wf3, wb3, cA, cB, db3, xsum, rows3)
             dg3, db3 = grad_alias(dg3, g3_), grad_alias(db3, b3_)
             da2, p2 = ops.conv2d_bwd_data_bnstat_folded(dout, a2, wext, vbias, spec3, k2, c2, m2, i2)
             gw3 = grad_dst(blk.conv3.weight)
-            dw3 = ops.conv2d_bwd_weight(a2, dout, spec3, out=gw3)
-            dw3 = grad_alias(ops.bn_fold_wgrad(dw3, xtx, xsum, wf3, cA, cB, cC, m3), gw3)
+            dw3 = ops.bn_fold_wgrad(gx[:n3], xtx, xsum, wf3, cA, cB, cC, m3, out=gw3 if gw3 is not None else torch.empty((n3, spec3.cin, 1, 1), dtype=torch.float32, device=a2.device))
+            dw3 = grad_alias(dw3, gw3)
             dres = None
         else:
             da2, dw3, dg3, db3, dres, p2 = conv_bn_bwd(dout, None, c3, a2, blk.conv3, blk.bn3, m3, i3, True, need_w, bits=k3, pre_partial=p3,

@@ -612,12 +612,31 @@ def bn_fold_weights(wf, wb, cA, cB, gsum, xsum, rows):
     return wext, bias
 
 
-def bn_fold_wgrad(dw, xtx, xsum, wf, cA, cB, cC, mean):
-    """In place on dw = g^T x [Cout][Cin]: the weight gradient of a 1x1 conv whose output BatchNorm's apply pass was folded (xtx = x^T x, xsum = colsum(x))."""
+def bn_fold_wgrad(gtx, xtx, xsum, wf, cA, cB, cC, mean, out=None):
+    """The weight gradient [Cout][Cin] of a 1x1 conv whose output BatchNorm's apply pass was folded, from gtx = g^T x, xtx = x^T x, xsum = colsum(x); out: its destination
+    (default: in place on gtx)."""
     Cout, Cin = cA.numel(), xsum.numel()
-    assert dw.numel() == Cout * Cin and dw.is_contiguous() and xtx.numel() == Cin * Cin and xtx.is_contiguous() and dw.dtype == torch.float32 == xtx.dtype
-    check(_lib.lib().sl_bn_fold_wgrad(Cout, Cin, _p(dw), _p(xtx), _p(xsum), _p(wf), _p(cA), _p(cB), _p(cC), _p(mean), _s()), 'bn_fold_wgrad')
+    dw = gtx if out is None else out
+    assert gtx.numel() == Cout * Cin == dw.numel() and gtx.is_contiguous() and dw.is_contiguous() and xtx.numel() == Cin * Cin and xtx.is_contiguous()
+    assert gtx.dtype == torch.float32 == xtx.dtype == dw.dtype and xsum.is_contiguous()
+    check(_lib.lib().sl_bn_fold_wgrad(Cout, Cin, _p(gtx), _p(dw), _p(xtx), _p(xsum), _p(wf), _p(cA), _p(cB), _p(cC), _p(mean), _s()), 'bn_fold_wgrad')
     return dw
+
+
+def conv2d_bwd_weight_dy2(x, dy1, dy2):
+    """[dy1 | dy2]^T x [C1 + C2][Cin] (float) and the column sums of [dy1 | dy2] from ONE weight-gradient launch (1x1 layers; conv_wgrad.hip: two gradient tensors)."""
+    B, H, W, Cin = x.shape
+    c1, c2 = dy1.shape[-1], dy2.shape[-1]
+    spec = ConvSpec(Cin, c1 + c2, 1, 1, 0, 1)
+    d = conv_desc(x.dtype, B, H, W, spec, None)
+    L = _lib.lib()
+    ws = workspace(L.sl_conv2d_bwd_weight_workspace(C.byref(d)), x.device, 'wgrad')
+    dw = torch.empty((c1 + c2, Cin), dtype=torch.float32, device=x.device)
+    part = _f32((_bias_rows(d, 0, 0), c1 + c2), x.device)
+    tok = PROFILER.begin('conv_wgrad', d)
+    check(L.sl_conv2d_bwd_weight_dy2(C.byref(d), _p(x), _p(dy1), _p(dy2), c1, _p(dw), _p(ws), ws.numel(), _p(part), _s()), 'conv2d_bwd_weight_dy2')
+    PROFILER.end(tok)
+    return dw, colsum(part).contiguous()
 
 
 def conv2d_bwd_data_bnstat_folded(g, x, wext, bias, spec, gate, bn_x, mean, invstd):
