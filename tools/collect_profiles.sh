@@ -57,6 +57,8 @@ for target in "$@"; do
         IFS=: read needle label file <<< "$k"
         python3 tools/collect_traffic.py /tmp/pmcC /tmp/pmcD "$needle" "$label" $O/${ROUND}_$file > /dev/null 2>&1
       done
+      # a `bench` target behind this one in the same call reads the counters from profiles/ (sha-gated on the library): give it this box's fresh ones
+      cp $O/${ROUND}_pmc_families.json $O/${ROUND}_traffic*.json $R/profiles/ 2>/dev/null
     fi
     head -30 $O/${ROUND}_pmc_families$TAG.txt ;;
   wgrad)
