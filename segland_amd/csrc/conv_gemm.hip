@@ -8,6 +8,9 @@ namespace {
 // rows per block of the kernel that will run for an M-row problem (also the granularity of the BN partial statistics): 256-row tiles need enough row blocks
 // to fill 256 CUs; the 4-stage ring replaces the 2-stage kernel from 16 blocks of 128 rows (Swin-T stage 3 / 4 GEMMs of 8 192 / 2 048 tokens: +4 %)
 constexpr int MIN_TILES256 = 96, RING128_MIN = 16;
+#ifndef SL_C64K3_GATE
+#define SL_C64K3_GATE 1       // 0: the gated 64 -> 64 3x3 data gradient back on the two-stage 256 x 64 tile kernel (A/B builds, tools/build_variant.sh)
+#endif
 static int block_rows(long long M) { return M >= 256LL * MIN_TILES256 ? 256 : 128; }
 // (Measured and dropped, tools/ft_shapes.py: 256 x 256 tiles by TILE count on short M -- 8 192 rows x 1024 / 2048 channels are 128 / 256 tiles -- lose to the 128 x 128
 // ring kernel with two blocks per CU on three of four shapes: 256 -> 1024 25.0 vs 11.2 us, 512 -> 1024 29.4 vs 16.3, 512 -> 2048 35.1 vs 32.7, 1024 -> 2048 44.9 vs 51.0.)
@@ -45,8 +48,8 @@ static int choose_kernel(const ConvGemmParams& p, int dtype) {
       return 3032032;
     if (p.ksplit > 1) return 18256256;                                                // planned by splitk_parts: the shape is served by the patch kernel
     if (c64k3_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.dil, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
-        !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2 || p.gate))
-      return 7016016;
+        !(p.bias || p.scale || p.relu || p.addend || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (!p.gate || (SL_C64K3_GATE && p.stat_partial && p.bn_x)))
+      return 7016016;                                                                  // (round 6: also the gated data gradient with BN-backward column sums)
     if (sk_shape(SL_BF16, p.KH, p.KW, p.stride, p.pad, p.C1 + p.C2, p.C1, p.N, p.M) && p.Hs == p.Hd && p.Ws == p.Wd &&
         !(p.bias || p.scale || p.relu || p.mask_src || p.pre_addend || p.row_scale || p.out2) && (p.gate || !(p.addend && p.stat_partial)) && (p.addend || !p.addend_mask) &&
         (!p.gate || (p.addend && !p.addend_mask && p.stat_partial)) && (!(p.addend_mask || p.gate) || (p.N % 128 == 0 && p.N <= 1024)))
@@ -306,6 +309,7 @@ extern "C" int sl_conv2d_bwd_data_bnstat_rows(const SlConvDesc* d) {
   const int cfg = sl_conv2d_tile_config_ex(d, 1, SL_EPI_GATE);
   const int fam = cfg / 1000000, bm = (cfg / 1000) % 1000;
   const long long M = (long long)d->B * d->H * d->W;
+  if (cfg == 7016016) return d->B * cdiv(d->H, C64_T) * cdiv(d->W, C64_T);      // conv_c64k3_kernel: one row per 16 x 16 tile (as the forward's statistics)
   if (!(fam == 5 || fam == 8 || fam == 4 || fam == 2) || bm <= 0 || M % bm != 0) return 0;
   if (cfg % 1000 == 192) return 0;      // the 128 x 192 ring tile's gated-statistics store phase is not exercised by any BatchNorm model (192-multiple widths are Swin's LayerNorm layers): not offered
   return (int)(M / bm);

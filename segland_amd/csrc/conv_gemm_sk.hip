@@ -104,6 +104,46 @@ __global__ __launch_bounds__(256) void conv_c64k3_kernel(ConvGemmParams p, int n
     float sa[8], sq[8];                                               // this thread's 8 channels (tid & 7) over its 8 pixels: column sums of the stored (rounded) tile
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sa[c] = 0.f; sq[c] = 0.f; }
+    if (p.gate) {
+      // data gradient into relu(bn(c)) (round 6): gate with the ReLU bits of these positions, store, accumulate (sum g, sum g * xhat) against the BatchNorm's input c --
+      // the store phase MODE 3 of the tile kernels (conv_gemm_common.h), same arithmetic; layer1.conv2's gated data gradient ran on the two-stage 256 x 64 tile kernel at
+      // 79 us where this kernel's forward takes 43
+      float mu[8], is[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { mu[c] = p.bn_mean[(tid & 7) * 8 + c]; is[c] = p.bn_invstd[(tid & 7) * 8 + c]; }
+      uint4 xv[8]; unsigned bits[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * 256, pidx = e >> 3, ch8 = e & 7;
+        const int oy = by * C64_T + (pidx >> 4), ox = bx * C64_T + (pidx & 15);
+        const bool in = oy < H && ox < W;
+        const size_t pix = in ? (size_t)(b * H + oy) * W + ox : 0;
+        xv[u] = *(const uint4*)((const bf16_t*)p.bn_x + pix * 64 + ch8 * 8);
+        bits[u] = p.gate[pix * 8 + ch8];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = tid + u * 256, pidx = e >> 3, ch8 = e & 7;
+        const int oy = by * C64_T + (pidx >> 4), ox = bx * C64_T + (pidx & 15);
+        if (oy < H && ox < W) {
+          uint4 v = *(const uint4*)(outt + pidx * C64_PITCH + ch8 * 16);
+          const unsigned bb = bits[u];
+          v.x &= ((unsigned)__builtin_amdgcn_sbfe(bb, 0, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(bb, 1, 1) & 0xffff0000u);
+          v.y &= ((unsigned)__builtin_amdgcn_sbfe(bb, 2, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(bb, 3, 1) & 0xffff0000u);
+          v.z &= ((unsigned)__builtin_amdgcn_sbfe(bb, 4, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(bb, 5, 1) & 0xffff0000u);
+          v.w &= ((unsigned)__builtin_amdgcn_sbfe(bb, 6, 1) & 0xffffu) | ((unsigned)__builtin_amdgcn_sbfe(bb, 7, 1) & 0xffff0000u);
+          st16(out + ((size_t)(b * H + oy) * W + ox) * 64 + ch8 * 8, v);
+          const unsigned wv[4] = {v.x, v.y, v.z, v.w}, xw[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float lo = __uint_as_float(wv[c] << 16), hi = __uint_as_float(wv[c] & 0xffff0000u);
+            const float xl = __uint_as_float(xw[c] << 16), xh = __uint_as_float(xw[c] & 0xffff0000u);
+            sa[2 * c] += lo; sq[2 * c] += lo * ((xl - mu[2 * c]) * is[2 * c]);
+            sa[2 * c + 1] += hi; sq[2 * c + 1] += hi * ((xh - mu[2 * c + 1]) * is[2 * c + 1]);
+          }
+        }
+      }
+    } else
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int e = tid + u * 256;

@@ -453,3 +453,36 @@ def test_bn3_apply_pass_folded_into_conv3_gradients(hip):
         bad = bad + [(k, ef, eu)] if ef > 1.25 * eu + 2e-3 else bad
     assert not bad, bad
     print('folded vs unfolded error against the oracle: worst ratio %.3f (%s)' % worst)
+
+
+def test_gated_data_gradient_of_the_64_channel_3x3_conv_on_the_patch_kernel(hip):
+    """layer1.conv2's data gradient (resnet.py:46 backward at 64 channels, 128 x 128 maps) with the ReLU gate of bn1's output and bn1's backward column sums in the store
+    phase now runs on conv_c64k3_kernel (round 6; it ran on the two-stage 256 x 64 tile kernel at 79 us, the kernel's forward takes 43): the dispatch says so, the gated
+    result is bit-identical to the kernel's plain data gradient with the bits applied afterwards, and the column sums match a float64 reduction of the stored tensor."""
+    import ctypes
+    from segland_amd import ops
+    from segland_amd.ops import ConvSpec
+    torch.manual_seed(31)
+    B, H, W, Cn = 4, 128, 128, 64
+    spec = ConvSpec(Cn, Cn, 3, 1, 1, 1)
+    w = torch.randn(Cn, Cn, 3, 3, device=DEV) / 24.0
+    wf = torch.empty((Cn, 3, 3, Cn), dtype=torch.bfloat16, device=DEV); wb = torch.empty((Cn, 3, 3, Cn), dtype=torch.bfloat16, device=DEV)
+    ops.check(hip.sl_weight_prep(1, ops._p(w), Cn, Cn, 3, 3, ops._p(wf), ops._p(wb), ops._s()), 'weight_prep')
+    dy = torch.randn(B, H, W, Cn, device=DEV).to(torch.bfloat16)
+    c = torch.randn(B, H, W, Cn, device=DEV).to(torch.bfloat16)
+    mean, invstd = torch.randn(Cn, device=DEV) * 0.1, torch.rand(Cn, device=DEV) + 0.5
+    gate = torch.randint(0, 256, (B * H * W * Cn // 8,), dtype=torch.uint8, device=DEV)
+    d = ops.conv_desc(torch.bfloat16, B, H, W, spec, None)
+    assert hip.sl_conv2d_tile_config_ex(ctypes.byref(d), 1, ops.EPI_GATE) == 7016016
+    r = ops.conv2d_bwd_data_bnstat(dy, wb, spec, (H, W), gate, c, mean, invstd)
+    assert r is not None
+    g, part = r
+    assert part.shape == (B * (H // 16) * (W // 16), 2, Cn)
+    plain = ops.conv2d_bwd_data(dy, wb, spec, (H, W))
+    mask = ((gate.view(-1, 1).int() >> torch.arange(8, device=DEV).view(1, 8)) & 1).bool().view(B, H, W, Cn)
+    want = torch.where(mask, plain, torch.zeros_like(plain))
+    assert torch.equal(g, want), float((g.float() - want.float()).abs().max())
+    s1 = want.double().sum((0, 1, 2))
+    s2 = (want.double() * ((c.double() - mean.double()) * invstd.double())).sum((0, 1, 2))
+    got = part.double().sum(0)
+    assert float((got[0] - s1).abs().max() / s1.abs().max()) <= 1e-5 and float((got[1] - s2).abs().max() / s2.abs().max()) <= 1e-5
